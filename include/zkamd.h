@@ -1,0 +1,182 @@
+/* zkamd.h - C ABI of the MI355X-native Groth16 prover hot path (libzkamd.so).
+ *
+ * Drop-in boundary for the ONE call LayerXcom/zero-chain makes into bellman on the proving
+ * path:   create_random_proof(instance, &self.proving_key, rng)
+ *           /root/reference/core/proofs/src/confidential.rs:149  (and anonymous.rs:165)
+ * plus the Parameters load next to it (confidential.rs:95-103, Parameters::read(.., true)).
+ *
+ * The reference has no FFI today (the seam is a Rust generic call into the un-vendored bellman
+ * 0.1.0 crate).  The entry points below are what a Rust `core/proofs` would bind with
+ * `extern "C"` (see INTEGRATION.md for the stub): the Rust side keeps Circuit::synthesize and
+ * its ProvingAssignment (host, witness generation) and hands the assignment to zk_prove*, which
+ * replaces bellman's EvaluationDomain pipeline, its eight multiexp calls and the final fold.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every byte buffer; the library owns device
+ *     memory behind the opaque handles; no exceptions or panics cross the ABI.
+ *   - scalars (Fr) are 32 bytes little-endian.  By default they are PLAIN integers < r
+ *     (FrRepr::write_le order, core/pairing/src/bls12_381/fr.rs:57-58); with ZK_FR_MONTGOMERY they
+ *     are the raw in-memory Montgomery limbs of `Fr` (fr.rs:246-247), i.e. a Rust Vec<Fr> can be
+ *     passed without conversion.
+ *   - points use the reference's encodings: uncompressed G1 96 B / G2 192 B big-endian
+ *     (core/pairing/src/bls12_381/ec.rs:666-753, :1303-1427) in Parameters, and a Proof is the
+ *     192 bytes of Proof::write (core/bellman-verifier/src/lib.rs:55-65): A (G1 compressed 48 B)
+ *     || B (G2 compressed 96 B) || C (G1 compressed 48 B).
+ *   - status codes 1..8 map 1:1 onto bellman's SynthesisError variants
+ *     (mirrored in-tree at core/bellman-verifier/src/lib.rs:359-383).
+ *   - one handle may be used from one host thread at a time (the reference caller is
+ *     single-threaded).
+ */
+#ifndef ZKAMD_H
+#define ZKAMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t zk_status;
+
+enum {
+    ZK_OK = 0,
+    ZK_ERR_ASSIGNMENT_MISSING = 1,          /* SynthesisError::AssignmentMissing */
+    ZK_ERR_DIVISION_BY_ZERO = 2,            /* SynthesisError::DivisionByZero */
+    ZK_ERR_UNSATISFIABLE = 3,               /* SynthesisError::Unsatisfiable */
+    ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE = 4, /* SynthesisError::PolynomialDegreeTooLarge */
+    ZK_ERR_UNEXPECTED_IDENTITY = 5,         /* SynthesisError::UnexpectedIdentity */
+    ZK_ERR_IO = 6,                          /* SynthesisError::IoError (malformed / short pk) */
+    ZK_ERR_MALFORMED_VERIFYING_KEY = 7,     /* SynthesisError::MalformedVerifyingKey */
+    ZK_ERR_UNCONSTRAINED_VARIABLE = 8,      /* SynthesisError::UnconstrainedVariable */
+    ZK_ERR_INVALID_ARGUMENT = 16,
+    ZK_ERR_DEVICE = 17,                     /* HIP runtime error; see zk_last_error() */
+    ZK_ERR_NO_DEVICE = 18,
+    ZK_ERR_OUT_OF_MEMORY = 19
+};
+
+#define ZK_FR_MONTGOMERY 1u /* flag: scalars are raw Montgomery-form Fr limbs */
+
+const char* zk_strerror(zk_status st);
+/* Human-readable detail of the last failure on this thread (HIP error string, offending index). */
+const char* zk_last_error(void);
+zk_status zk_device_count(int* count);
+
+/* ------------------------------------------------------------------------------------------
+ * Parameters  (bellman groth16::Parameters<Bls12>)
+ * replaces: Parameters::read(reader, checked)   reference call: confidential.rs:99
+ * Byte format (bellman Parameters::write): vk = alpha_g1 | beta_g1 | beta_g2 |
+ * gamma_g2 | delta_g1 | delta_g2 | u32be n_ic | ic[] ; then u32be len | points for h, l, a,
+ * b_g1 (G1) and b_g2 (G2).  checked != 0 additionally verifies on-curve and subgroup membership
+ * of every point (on the GPU); both modes reject the point at infinity, as bellman does.
+ * The bases are uploaded once, expanded into per-window tables and stay resident in HBM.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zk_params zk_params;
+
+typedef struct {
+    uint32_t n_ic, n_h, n_l, n_a, n_b_g1, n_b_g2;
+    uint32_t log_domain;  /* m = 2^log_domain = n_h + 1 */
+    uint32_t window_bits; /* Pippenger window c used for this key */
+    uint32_t n_windows;
+    uint32_t device;
+    uint64_t device_bytes; /* HBM held by the handle (tables + twiddles) */
+} zk_params_info;
+
+zk_status zk_params_load(const uint8_t* pk_bytes, size_t len, int checked, int device, zk_params** out);
+zk_status zk_params_get_info(const zk_params* p, zk_params_info* info);
+void zk_params_free(zk_params* p);
+
+/* ------------------------------------------------------------------------------------------
+ * Proving  (bellman groth16::create_proof(circuit, params, r, s) after synthesis)
+ * replaces: create_random_proof / create_proof   reference call: confidential.rs:149
+ * The assignment is exactly bellman's ProvingAssignment after `circuit.synthesize` and the
+ * per-input `Input(i) * 0 = 0` rows: the row evaluations a, b, c (n_rows each), the input and
+ * aux assignments, and the three density trackers (one byte per variable, 0 / 1).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t n_rows;   /* constraints + n_inputs */
+    uint32_t n_inputs; /* including ONE */
+    uint32_t n_aux;
+    uint32_t flags;    /* ZK_FR_MONTGOMERY */
+    const uint8_t* a;  /* n_rows x 32 */
+    const uint8_t* b;
+    const uint8_t* c;
+    const uint8_t* inputs;          /* n_inputs x 32 */
+    const uint8_t* aux;             /* n_aux x 32 */
+    const uint8_t* a_aux_density;   /* n_aux bytes */
+    const uint8_t* b_input_density; /* n_inputs bytes */
+    const uint8_t* b_aux_density;   /* n_aux bytes */
+} zk_assignment;
+
+/* r, s: 32-byte little-endian PLAIN scalars (the two Fr::rand draws of create_random_proof). */
+zk_status zk_prove(zk_params* p, const zk_assignment* asg, const uint8_t r[32], const uint8_t s[32],
+                   uint8_t proof_out[192]);
+
+/* n independent proofs of the same circuit (same shape and densities).  rs: n x 64 bytes
+ * (r then s per proof).  proofs_out: n x 192 bytes. */
+zk_status zk_prove_batch(zk_params* p, size_t n, const zk_assignment* asgs, const uint8_t* rs,
+                         uint8_t* proofs_out);
+
+/* Same, with the assignments already resident in HBM (device pointers, plain scalars unless
+ * ZK_FR_MONTGOMERY): a, b, c are [n][n_rows][32]; wit is [n][n_inputs + n_aux][32];
+ * rs is a HOST pointer.  Densities are host byte arrays shared by the whole batch. */
+typedef struct {
+    uint32_t n_rows, n_inputs, n_aux, flags;
+    const void* d_a;
+    const void* d_b;
+    const void* d_c;
+    const void* d_wit;
+    const uint8_t* a_aux_density;
+    const uint8_t* b_input_density;
+    const uint8_t* b_aux_density;
+} zk_batch_dev;
+zk_status zk_prove_batch_dev(zk_params* p, size_t n, const zk_batch_dev* batch, const uint8_t* rs,
+                             uint8_t* proofs_out);
+
+/* ------------------------------------------------------------------------------------------
+ * Stand-alone kernels (micro-benchmark / test entries)
+ * ------------------------------------------------------------------------------------------ */
+/* multiexp over G1 / G2: sum_i scalars[i] * bases[i].   replaces bellman multiexp (FullDensity).
+ * bases: n x 96 (G1) / n x 192 (G2) uncompressed; scalars: n x 32 plain LE; out: uncompressed. */
+typedef struct zk_msm zk_msm;
+zk_status zk_msm_create(int group /*1 = G1, 2 = G2*/, const uint8_t* bases, size_t n, int window_bits /*0 = auto*/,
+                        int checked, int device, zk_msm** out);
+zk_status zk_msm_run(zk_msm* m, const uint8_t* scalars, uint32_t flags, uint8_t* out);
+/* scalars already in HBM (device pointer, n x 32 bytes); out is a host buffer */
+zk_status zk_msm_run_dev(zk_msm* m, const void* d_scalars, uint32_t flags, uint8_t* out);
+void zk_msm_free(zk_msm* m);
+zk_status zk_msm_g1(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]);
+zk_status zk_msm_g2(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]);
+
+/* EvaluationDomain transforms over Fr, n = 2^log_n.
+ * zk_ntt_fr: in-place on a HOST buffer of plain LE scalars, natural order in and out, the four
+ * bellman operations: inverse = 0, coset = 0 -> fft ; 1, 0 -> ifft ; 0, 1 -> coset_fft ;
+ * 1, 1 -> icoset_fft. */
+zk_status zk_ntt_fr(uint8_t* data, uint32_t log_n, int inverse, int coset);
+
+typedef struct zk_ntt zk_ntt;
+#define ZK_NTT_INVERSE 1u
+#define ZK_NTT_COSET 2u
+#define ZK_NTT_IN_BITREV 4u   /* input is in bit-reversed order (skips the permutation) */
+#define ZK_NTT_OUT_BITREV 8u  /* leave the output in bit-reversed order */
+zk_status zk_ntt_create(uint32_t log_n, int device, zk_ntt** out);
+/* d_data: device pointer, batch x 2^log_n x 32 bytes, Montgomery-form Fr, transformed in place */
+zk_status zk_ntt_run_dev(zk_ntt* t, void* d_data, uint32_t batch, uint32_t flags);
+void zk_ntt_free(zk_ntt* t);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (used by bench.py): HIP-event timing of named kernels on the library's
+ * stream.  zk_profile_begin() arms it, zk_profile_get() synchronises and reports.
+ * ------------------------------------------------------------------------------------------ */
+void zk_profile_begin(void);
+/* returns the number of launches of `kernel` recorded since begin; *total_ms their summed time */
+int zk_profile_get(const char* kernel, double* total_ms);
+void zk_profile_end(void);
+/* the HIP stream (hipStream_t) all work of this library is enqueued on */
+void* zk_stream(void);
+zk_status zk_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKAMD_H */

@@ -1,0 +1,60 @@
+// TEST-ONLY host emulation of the handful of HIP runtime features the kernels use
+// (see zero-chain_amd/csrc/gpu_rt.h).  Blocks run one after another; kernels that call
+// __syncthreads() get one OS thread per GPU thread and a real barrier, the rest are run as a
+// plain loop over thread indices.
+#define ZK_EMU 1
+#include "../../zero-chain_amd/csrc/gpu_rt.h"
+
+thread_local emu_dim3 threadIdx, blockIdx;
+emu_dim3 blockDim, gridDim;
+unsigned char* emu_dyn_shared = nullptr;
+
+namespace {
+std::mutex g_mu;
+std::condition_variable g_cv;
+unsigned g_count = 0, g_gen = 0, g_parties = 1;
+}  // namespace
+
+void emu_barrier_wait() {
+    std::unique_lock<std::mutex> lk(g_mu);
+    unsigned gen = g_gen;
+    if (++g_count == g_parties) {
+        g_count = 0;
+        g_gen++;
+        g_cv.notify_all();
+    } else {
+        g_cv.wait(lk, [&] { return gen != g_gen; });
+    }
+}
+
+void emu_launch(emu_dim3 grid, emu_dim3 block, size_t shmem, bool needs_sync, const std::function<void()>& body) {
+    blockDim = block;
+    gridDim = grid;
+    std::vector<unsigned char> dyn(shmem + 64);
+    emu_dyn_shared = dyn.data();
+    const unsigned nthreads = block.x * block.y * block.z;
+    for (unsigned bz = 0; bz < grid.z; bz++)
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                if (!needs_sync) {
+                    blockIdx = emu_dim3(bx, by, bz);
+                    for (unsigned t = 0; t < nthreads; t++) {
+                        threadIdx = emu_dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                        body();
+                    }
+                } else {
+                    g_parties = nthreads;
+                    g_count = 0;
+                    std::vector<std::thread> ths;
+                    ths.reserve(nthreads);
+                    for (unsigned t = 0; t < nthreads; t++)
+                        ths.emplace_back([&, t] {
+                            blockIdx = emu_dim3(bx, by, bz);
+                            threadIdx = emu_dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                            body();
+                        });
+                    for (auto& th : ths) th.join();
+                }
+            }
+    emu_dyn_shared = nullptr;
+}

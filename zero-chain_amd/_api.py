@@ -1,0 +1,317 @@
+"""Host-side mirror of the bellman surface LayerXcom/zero-chain consumes on its proving path,
+over the C ABI of libzkamd.so (include/zkamd.h).
+
+Reference surface being mirrored (all in the un-vendored bellman 0.1.0 crate,
+called from /root/reference/core/proofs/src/confidential.rs):
+    Parameters::read(reader, checked)      confidential.rs:99     -> Parameters.read
+    Parameters::write(writer)              confidential.rs:83     -> Parameters.write
+    create_random_proof(circuit, &pk, rng) confidential.rs:149    -> create_random_proof
+    create_proof(circuit, &pk, r, s)                              -> create_proof
+    Proof::write / Proof::read (192 B)     confidential.rs:294-297 -> Proof.write / Proof.read
+    SynthesisError                         confidential.rs:171,272 -> ZkError.variant
+
+The circuit itself (Circuit::synthesize + ProvingAssignment) stays on the host side of the
+boundary, exactly as in the reference; what crosses it is the finished assignment
+(`ProvingAssignment`: row evaluations a/b/c, input and aux assignments, density trackers).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSET, ZK_NTT_IN_BITREV,
+                   ZK_NTT_OUT_BITREV)
+
+__all__ = ["Parameters", "Proof", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
+           "multiexp", "MultiexpContext", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
+           "scalars_to_bytes", "bytes_to_scalars", "load_library"]
+
+FR_MODULUS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+_FR_R_INV = pow(1 << 256, -1, FR_MODULUS)
+PROOF_SIZE = 192  # core/proofs/src/constants.rs:3
+
+
+def load_library():
+    return _lib.load()
+
+
+def scalars_to_bytes(values):
+    """ints -> n x 32 bytes, plain little-endian (FrRepr::write_le)."""
+    return np.frombuffer(b"".join(int(v % FR_MODULUS).to_bytes(32, "little") for v in values), dtype=np.uint8).copy()
+
+
+def bytes_to_scalars(buf):
+    b = bytes(buf)
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+def _u8(x, n=None):
+    a = np.ascontiguousarray(np.frombuffer(x, dtype=np.uint8) if isinstance(x, (bytes, bytearray)) else x, dtype=np.uint8)
+    if n is not None and a.size != n:
+        raise ValueError("expected %d bytes, got %d" % (n, a.size))
+    return a
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ----------------------------------------------------------------------------------------------
+# rand 0.4 XorShiftRng + Fr::rand, so that create_random_proof draws the same (r, s) as the
+# reference for a given seed (core/pairing/src/bls12_381/fr.rs:255-267; seeds as in
+# core/proofs/src/confidential.rs:511-513).
+# ----------------------------------------------------------------------------------------------
+class XorShiftRng:
+    def __init__(self, seed):
+        self.x, self.y, self.z, self.w = [int(s) & 0xFFFFFFFF for s in seed]
+
+    @classmethod
+    def from_seed(cls, seed):
+        return cls(seed)
+
+    def next_u32(self):
+        t = (self.x ^ (self.x << 11)) & 0xFFFFFFFF
+        self.x, self.y, self.z = self.y, self.z, self.w
+        self.w = (self.w ^ (self.w >> 19) ^ (t ^ (t >> 8))) & 0xFFFFFFFF
+        return self.w
+
+    def next_u64(self):
+        hi = self.next_u32()
+        return (hi << 32) | self.next_u32()
+
+
+def fr_rand(rng):
+    """Fr::rand: 4 x next_u64 limbs, top bit shaved, rejected unless < r; the accepted limbs ARE the
+    Montgomery representation.  Returns the plain integer."""
+    while True:
+        limbs = [rng.next_u64() for _ in range(4)]
+        limbs[3] &= 0xFFFFFFFFFFFFFFFF >> 1
+        v = sum(l << (64 * i) for i, l in enumerate(limbs))
+        if v < FR_MODULUS:
+            return v * _FR_R_INV % FR_MODULUS
+
+
+# ----------------------------------------------------------------------------------------------
+class Proof:
+    """groth16::Proof<Bls12>: A (G1) | B (G2) | C (G1), compressed (bellman-verifier/src/lib.rs:55-65)."""
+
+    def __init__(self, data):
+        data = bytes(data)
+        if len(data) != PROOF_SIZE:
+            raise ValueError("a proof is exactly 192 bytes")
+        self.bytes = data
+
+    @property
+    def a(self):
+        return self.bytes[:48]
+
+    @property
+    def b(self):
+        return self.bytes[48:144]
+
+    @property
+    def c(self):
+        return self.bytes[144:]
+
+    def write(self, writer=None):
+        if writer is not None:
+            writer.write(self.bytes)
+        return self.bytes
+
+    @classmethod
+    def read(cls, reader):
+        data = reader if isinstance(reader, (bytes, bytearray)) else reader.read(PROOF_SIZE)
+        return cls(data)
+
+    def __eq__(self, other):
+        return isinstance(other, Proof) and other.bytes == self.bytes
+
+    def __repr__(self):
+        return "Proof(%s)" % self.bytes.hex()
+
+
+class Parameters:
+    """groth16::Parameters<Bls12>, resident on one GPU.  `read` parses bellman's Parameters::write
+    format, uploads the query bases once and expands the per-window tables."""
+
+    def __init__(self, lib, handle, pk_bytes):
+        self._lib = lib
+        self._h = handle
+        self._pk = pk_bytes
+        info = _lib.ParamsInfo()
+        lib.check(lib.zk_params_get_info(handle, C.byref(info)))
+        self.info = {f[0]: getattr(info, f[0]) for f in info._fields_}
+
+    @classmethod
+    def read(cls, reader, checked=True, device=0, lib=None):
+        lib = lib or _lib.load()
+        data = bytes(reader if isinstance(reader, (bytes, bytearray)) else reader.read())
+        buf = _u8(data)
+        h = C.c_void_p()
+        lib.check(lib.zk_params_load(_ptr(buf), buf.size, 1 if checked else 0, device, C.byref(h)))
+        return cls(lib, h, data)
+
+    def write(self, writer=None):
+        if writer is not None:
+            writer.write(self._pk)
+        return self._pk
+
+    @property
+    def vk(self):
+        """The VerifyingKey section of the parameter file (uncompressed points)."""
+        n_ic = self.info["n_ic"]
+        b = self._pk
+        return {"alpha_g1": b[0:96], "beta_g1": b[96:192], "beta_g2": b[192:384], "gamma_g2": b[384:576],
+                "delta_g1": b[576:672], "delta_g2": b[672:864],
+                "ic": [b[868 + 96 * i: 868 + 96 * (i + 1)] for i in range(n_ic)]}
+
+    def close(self):
+        if self._h:
+            self._lib.zk_params_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ProvingAssignment:
+    """What bellman's ProvingAssignment holds after synthesis and the per-input rows."""
+
+    def __init__(self, a, b, c, inputs, aux, a_aux_density, b_input_density, b_aux_density, montgomery=False):
+        self.a, self.b, self.c = _u8(a), _u8(b), _u8(c)
+        self.inputs, self.aux = _u8(inputs), _u8(aux)
+        self.n_rows = self.a.size // 32
+        self.n_inputs = self.inputs.size // 32
+        self.n_aux = self.aux.size // 32
+        if self.b.size != self.a.size or self.c.size != self.a.size:
+            raise ValueError("a, b, c must have the same length")
+        self.a_aux_density = _u8(np.asarray(a_aux_density, dtype=np.uint8), self.n_aux)
+        self.b_input_density = _u8(np.asarray(b_input_density, dtype=np.uint8), self.n_inputs)
+        self.b_aux_density = _u8(np.asarray(b_aux_density, dtype=np.uint8), self.n_aux)
+        self.flags = ZK_FR_MONTGOMERY if montgomery else 0
+
+    @classmethod
+    def from_ints(cls, a, b, c, inputs, aux, a_aux_density, b_input_density, b_aux_density):
+        return cls(scalars_to_bytes(a), scalars_to_bytes(b), scalars_to_bytes(c), scalars_to_bytes(inputs),
+                   scalars_to_bytes(aux), a_aux_density, b_input_density, b_aux_density)
+
+    def _struct(self):
+        s = _lib.Assignment()
+        s.n_rows, s.n_inputs, s.n_aux, s.flags = self.n_rows, self.n_inputs, self.n_aux, self.flags
+        for name in ("a", "b", "c", "inputs", "aux", "a_aux_density", "b_input_density", "b_aux_density"):
+            setattr(s, name, getattr(self, name).ctypes.data)
+        return s
+
+
+def create_proof(assignment, params, r, s):
+    """bellman create_proof(circuit, params, r, s) after synthesis; r, s plain integers."""
+    lib = params._lib
+    rb, sb = scalars_to_bytes([r]), scalars_to_bytes([s])
+    out = np.zeros(PROOF_SIZE, dtype=np.uint8)
+    st = assignment._struct()
+    lib.check(lib.zk_prove(params._h, C.byref(st), _ptr(rb), _ptr(sb), _ptr(out)))
+    return Proof(out.tobytes())
+
+
+def create_random_proof(assignment, params, rng):
+    """bellman create_random_proof: r = Fr::rand(rng); s = Fr::rand(rng); create_proof(.., r, s)."""
+    r = fr_rand(rng)
+    s = fr_rand(rng)
+    return create_proof(assignment, params, r, s)
+
+
+def create_proofs(assignments, params, rs):
+    """Batch of independent proofs of one circuit; rs = [(r, s), ...]."""
+    lib = params._lib
+    n = len(assignments)
+    arr = (_lib.Assignment * n)(*[a._struct() for a in assignments])
+    rsb = scalars_to_bytes([x for pair in rs for x in pair])
+    out = np.zeros(PROOF_SIZE * n, dtype=np.uint8)
+    lib.check(lib.zk_prove_batch(params._h, n, arr, _ptr(rsb), _ptr(out)))
+    ob = out.tobytes()
+    return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
+
+
+# ----------------------------------------------------------------------------------------------
+class MultiexpContext:
+    """Bases resident on the GPU (window tables built once); run() = bellman multiexp, FullDensity."""
+
+    def __init__(self, group, bases, window_bits=0, checked=False, device=0, lib=None):
+        self._lib = lib or _lib.load()
+        self.group = {"g1": 1, "g2": 2, 1: 1, 2: 2}[group]
+        self.point_size = 96 if self.group == 1 else 192
+        b = _u8(bases)
+        self.n = b.size // self.point_size
+        h = C.c_void_p()
+        self._lib.check(self._lib.zk_msm_create(self.group, _ptr(b), self.n, window_bits, 1 if checked else 0, device,
+                                                C.byref(h)))
+        self._h = h
+
+    def run(self, scalars, montgomery=False):
+        s = _u8(scalars, self.n * 32) if not isinstance(scalars, (list, tuple)) else scalars_to_bytes(scalars)
+        out = np.zeros(self.point_size, dtype=np.uint8)
+        self._lib.check(self._lib.zk_msm_run(self._h, _ptr(s), ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
+        return out.tobytes()
+
+    def run_dev(self, d_scalars_ptr, montgomery=False):
+        out = np.zeros(self.point_size, dtype=np.uint8)
+        self._lib.check(self._lib.zk_msm_run_dev(self._h, C.c_void_p(d_scalars_ptr),
+                                                 ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
+        return out.tobytes()
+
+    def close(self):
+        if self._h:
+            self._lib.zk_msm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def multiexp(group, bases, scalars, lib=None):
+    """One-shot multiexp over uncompressed bases; returns the uncompressed result."""
+    ctx = MultiexpContext(group, bases, lib=lib)
+    try:
+        return ctx.run(scalars)
+    finally:
+        ctx.close()
+
+
+class EvaluationDomain:
+    """bellman EvaluationDomain over Fr: fft / ifft / coset_fft / icoset_fft on lists of ints."""
+
+    def __init__(self, coeffs, lib=None):
+        self._lib = lib or _lib.load()
+        n = len(coeffs)
+        m, exp = 1, 0
+        while m < n:
+            m *= 2
+            exp += 1
+        self.exp = exp
+        self.coeffs = [c % FR_MODULUS for c in coeffs] + [0] * (m - n)
+
+    def _run(self, inverse, coset):
+        buf = scalars_to_bytes(self.coeffs)
+        self._lib.check(self._lib.zk_ntt_fr(_ptr(buf), self.exp, inverse, coset))
+        self.coeffs = bytes_to_scalars(buf)
+
+    def fft(self):
+        self._run(0, 0)
+
+    def ifft(self):
+        self._run(1, 0)
+
+    def coset_fft(self):
+        self._run(0, 1)
+
+    def icoset_fft(self):
+        self._run(1, 1)
+
+    def into_coeffs(self):
+        return list(self.coeffs)

@@ -1,0 +1,112 @@
+"""ctypes binding of libzkamd.so (the C ABI declared in include/zkamd.h).
+
+The product loader only ever opens the gfx950 library built in-tree next to this file and
+raises if it is missing: there is no CPU fallback.  (The CPU test-suite opens the TEST-ONLY
+emulation build itself, by explicit path, through `ZkLib(path)`.)
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzkamd.so")
+
+ZK_OK = 0
+ZK_FR_MONTGOMERY = 1
+ZK_NTT_INVERSE, ZK_NTT_COSET, ZK_NTT_IN_BITREV, ZK_NTT_OUT_BITREV = 1, 2, 4, 8
+
+STATUS_NAMES = {
+    0: "Ok", 1: "AssignmentMissing", 2: "DivisionByZero", 3: "Unsatisfiable",
+    4: "PolynomialDegreeTooLarge", 5: "UnexpectedIdentity", 6: "IoError",
+    7: "MalformedVerifyingKey", 8: "UnconstrainedVariable", 16: "InvalidArgument",
+    17: "DeviceError", 18: "NoDevice", 19: "OutOfMemory",
+}
+
+
+class ZkError(Exception):
+    """A non-OK zk_status.  `.status` is the code, `.variant` the bellman SynthesisError name."""
+
+    def __init__(self, status, detail):
+        self.status = status
+        self.variant = STATUS_NAMES.get(status, "Unknown")
+        super().__init__("%s (%d): %s" % (self.variant, status, detail))
+
+
+class ParamsInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_ic", "n_h", "n_l", "n_a", "n_b_g1", "n_b_g2", "log_domain",
+                                          "window_bits", "n_windows", "device")] + [("device_bytes", C.c_uint64)]
+
+
+class Assignment(C.Structure):
+    _fields_ = [("n_rows", C.c_uint32), ("n_inputs", C.c_uint32), ("n_aux", C.c_uint32), ("flags", C.c_uint32),
+                ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("inputs", C.c_void_p), ("aux", C.c_void_p),
+                ("a_aux_density", C.c_void_p), ("b_input_density", C.c_void_p), ("b_aux_density", C.c_void_p)]
+
+
+class BatchDev(C.Structure):
+    _fields_ = [("n_rows", C.c_uint32), ("n_inputs", C.c_uint32), ("n_aux", C.c_uint32), ("flags", C.c_uint32),
+                ("d_a", C.c_void_p), ("d_b", C.c_void_p), ("d_c", C.c_void_p), ("d_wit", C.c_void_p),
+                ("a_aux_density", C.c_void_p), ("b_input_density", C.c_void_p), ("b_aux_density", C.c_void_p)]
+
+
+_PROTOS = {
+    "zk_strerror": (C.c_char_p, [C.c_int32]),
+    "zk_last_error": (C.c_char_p, []),
+    "zk_device_count": (C.c_int32, [C.POINTER(C.c_int)]),
+    "zk_params_load": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_params_get_info": (C.c_int32, [C.c_void_p, C.POINTER(ParamsInfo)]),
+    "zk_params_free": (None, [C.c_void_p]),
+    "zk_prove": (C.c_int32, [C.c_void_p, C.POINTER(Assignment), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "zk_prove_batch": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(Assignment), C.c_void_p, C.c_void_p]),
+    "zk_prove_batch_dev": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(BatchDev), C.c_void_p, C.c_void_p]),
+    "zk_msm_create": (C.c_int32, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_msm_run": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "zk_msm_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "zk_msm_free": (None, [C.c_void_p]),
+    "zk_msm_g1": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zk_msm_g2": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zk_ntt_fr": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
+    "zk_ntt_create": (C.c_int32, [C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_ntt_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "zk_ntt_free": (None, [C.c_void_p]),
+    "zk_profile_begin": (None, []),
+    "zk_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
+    "zk_profile_end": (None, []),
+    "zk_stream": (C.c_void_p, []),
+    "zk_synchronize": (C.c_int32, []),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+
+class ZkLib:
+    """The C ABI, with prototypes attached and statuses turned into exceptions."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise ImportError(
+                "%s is missing: build it with `python zero-chain_amd/build.py` (hipcc --offload-arch=gfx950). "
+                "The prover has no CPU fallback." % path)
+        self.path = path
+        self.dll = C.CDLL(path)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(self.dll, name)
+            fn.restype = res
+            fn.argtypes = args
+
+    def check(self, status):
+        if status != ZK_OK:
+            detail = self.dll.zk_last_error() or self.dll.zk_strerror(status) or b""
+            raise ZkError(status, detail.decode("utf-8", "replace"))
+
+    def __getattr__(self, name):
+        return getattr(self.dll, name)
+
+
+_lib = None
+
+
+def load():
+    """Open the in-tree gfx950 library (and nothing else)."""
+    global _lib
+    if _lib is None:
+        _lib = ZkLib(LIB_PATH)
+    return _lib

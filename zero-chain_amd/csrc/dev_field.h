@@ -1,0 +1,278 @@
+// Device-side prime-field arithmetic for gfx950 (CDNA4): Montgomery form, 32-bit limbs.
+//
+// Spec followed: the reference's vendored arithmetic crate
+//   Fr: core/pairing/src/bls12_381/fr.rs:341-571  (4 x u64, R = 2^256)
+//   Fq: core/pairing/src/bls12_381/fq.rs:749-1127 (6 x u64, R = 2^384)
+//   Fq2: core/pairing/src/bls12_381/fq2.rs:90-182
+// Same values, same Montgomery radix; a little-endian array of 2k u32 limbs is byte-identical
+// to the reference's k u64 limbs, so device buffers can be compared word-for-word with the
+// literal KATs in fr.rs / fq.rs.
+//
+// CDNA4 has no 64x64 multiplier in the VALU: the unit of work is v_mad_u64_u32
+// (32x32+64 -> 64).  mont_mul is a CIOS loop arranged so that every limb product is ONE
+// v_mad_u64_u32 whose 64-bit addend carries the accumulator limb, followed by ONE
+// v_addc_co_u32 in a carry chain: 2N^2 + N multiplier ops and ~2N^2 adds per product.
+#pragma once
+#include <stdint.h>
+#include "gpu_rt.h"
+#include "consts.h"
+
+namespace zkdev {
+
+#define ZK_DI __device__ __forceinline__
+// The Montgomery product is ~1000 instructions (8 KB of code for Fq).  A point addition inlines
+// 10-14 of them (x3 for Fq2), which overflows the 64 KB instruction cache two CUs share, so the
+// product is a real function by default and the curve formulas call it.
+#ifndef ZK_MUL_ATTR
+#ifdef ZK_EMU
+#define ZK_MUL_ATTR inline
+#else
+#define ZK_MUL_ATTR __device__ __attribute__((noinline))
+#endif
+#endif
+
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x12 __attribute__((ext_vector_type(12)));
+
+struct FrCfg {
+    static constexpr int N = 8;
+    typedef u32x8 vec;
+    static constexpr uint32_t P[8] = ZK_FR_P_32;
+    static constexpr uint32_t R[8] = ZK_FR_R_32;     // Montgomery one
+    static constexpr uint32_t R2[8] = ZK_FR_R2_32;
+    static constexpr uint32_t INV = ZK_FR_INV32;
+};
+struct FqCfg {
+    static constexpr int N = 12;
+    typedef u32x12 vec;
+    static constexpr uint32_t P[12] = ZK_FQ_P_32;
+    static constexpr uint32_t R[12] = ZK_FQ_R_32;
+    static constexpr uint32_t R2[12] = ZK_FQ_R2_32;
+    static constexpr uint32_t INV = ZK_FQ_INV32;
+};
+
+template <class C>
+struct Fp {
+    static constexpr int N = C::N;
+    uint32_t l[N];
+
+    ZK_DI static Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = 0;
+        return r;
+    }
+    ZK_DI static Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = C::R[i];
+        return r;
+    }
+    ZK_DI static Fp r2() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; i++) r.l[i] = C::R2[i];
+        return r;
+    }
+    ZK_DI bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= l[i];
+        return o == 0;
+    }
+    ZK_DI bool operator==(const Fp& b) const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) o |= l[i] ^ b.l[i];
+        return o == 0;
+    }
+    ZK_DI bool operator!=(const Fp& b) const { return !(*this == b); }
+};
+
+// r = (a + b) mod p ; inputs < p (both moduli leave >= 1 spare bit, so a + b cannot carry out)
+template <class C>
+ZK_DI Fp<C> add(const Fp<C>& a, const Fp<C>& b) {
+    constexpr int N = C::N;
+    uint32_t t[N], s[N], cy = 0, co;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        t[i] = __builtin_addc(a.l[i], b.l[i], cy, &co);
+        cy = co;
+    }
+    uint32_t bo = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        s[i] = __builtin_subc(t[i], C::P[i], bo, &co);
+        bo = co;
+    }
+    Fp<C> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) r.l[i] = bo ? t[i] : s[i];
+    return r;
+}
+
+template <class C>
+ZK_DI Fp<C> sub(const Fp<C>& a, const Fp<C>& b) {
+    constexpr int N = C::N;
+    uint32_t t[N], bo = 0, co;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        t[i] = __builtin_subc(a.l[i], b.l[i], bo, &co);
+        bo = co;
+    }
+    uint32_t mask = 0u - bo, cy = 0;
+    Fp<C> r;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        r.l[i] = __builtin_addc(t[i], C::P[i] & mask, cy, &co);
+        cy = co;
+    }
+    return r;
+}
+
+template <class C>
+ZK_DI Fp<C> neg(const Fp<C>& a) {
+    return sub(Fp<C>::zero(), a);
+}
+
+template <class C>
+ZK_DI Fp<C> dbl(const Fp<C>& a) {
+    return add(a, a);
+}
+
+// Montgomery product a*b*R^-1 mod p (fr.rs:438-464 / fq.rs:915-1016 compute the same value).
+// Operands and result are passed as N-wide vector values so that the (non-inlined) call keeps
+// them in VGPRs v0..v(2N-1); an aggregate argument would be passed through scratch memory.
+template <class C>
+ZK_MUL_ATTR typename C::vec mul_raw(typename C::vec av, typename C::vec bv) {
+    constexpr int N = C::N;
+    struct { uint32_t l[C::N]; } a, b;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        a.l[j] = av[j];
+        b.l[j] = bv[j];
+    }
+    uint32_t t[N + 1];
+#pragma unroll
+    for (int j = 0; j <= N; j++) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        uint64_t pr[N];
+        uint32_t cy, co;
+        // t += a * b[i]   (t < 2p before, so the top word t[N] is zero on entry)
+#pragma unroll
+        for (int j = 0; j < N; j++) pr[j] = (uint64_t)a.l[j] * b.l[i] + t[j];
+        t[0] = (uint32_t)pr[0];
+        cy = 0;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            t[j] = __builtin_addc((uint32_t)pr[j], (uint32_t)(pr[j - 1] >> 32), cy, &co);
+            cy = co;
+        }
+        t[N] = (uint32_t)(pr[N - 1] >> 32) + cy;
+        // t = (t + m*p) >> 32 with m = t[0] * (-p^-1)
+        uint32_t m = t[0] * C::INV;
+#pragma unroll
+        for (int j = 0; j < N; j++) pr[j] = (uint64_t)m * C::P[j] + t[j];
+        cy = 0;
+#pragma unroll
+        for (int j = 1; j < N; j++) {
+            t[j - 1] = __builtin_addc((uint32_t)pr[j], (uint32_t)(pr[j - 1] >> 32), cy, &co);
+            cy = co;
+        }
+        t[N - 1] = __builtin_addc(t[N], (uint32_t)(pr[N - 1] >> 32), cy, &co);
+    }
+    uint32_t s[N], bo = 0, co;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        s[j] = __builtin_subc(t[j], C::P[j], bo, &co);
+        bo = co;
+    }
+    typename C::vec r;
+#pragma unroll
+    for (int j = 0; j < N; j++) r[j] = bo ? t[j] : s[j];
+    return r;
+}
+
+template <class C>
+ZK_DI Fp<C> mul(const Fp<C>& a, const Fp<C>& b) {
+    typename C::vec av, bv;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        av[j] = a.l[j];
+        bv[j] = b.l[j];
+    }
+    typename C::vec rv = mul_raw<C>(av, bv);
+    Fp<C> r;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) r.l[j] = rv[j];
+    return r;
+}
+
+template <class C>
+ZK_DI Fp<C> sqr(const Fp<C>& a) {
+    return mul(a, a);
+}
+
+template <class C>
+ZK_DI Fp<C> to_mont(const Fp<C>& a) {
+    return mul(a, Fp<C>::r2());
+}
+
+template <class C>
+ZK_DI Fp<C> from_mont(const Fp<C>& a) {
+    Fp<C> o = Fp<C>::zero();
+    o.l[0] = 1;
+    return mul(a, o);
+}
+
+// a^e for a (public) multi-limb exponent, MSB first; used only off the hot path (inversion).
+template <class C, int EN>
+ZK_DI Fp<C> pow_limbs(const Fp<C>& a, const uint32_t (&e)[EN]) {
+    Fp<C> r = Fp<C>::one();
+    bool started = false;
+    for (int i = EN - 1; i >= 0; i--) {
+        for (int b = 31; b >= 0; b--) {
+            if (started) r = sqr(r);
+            if ((e[i] >> b) & 1u) {
+                r = started ? mul(r, a) : a;
+                started = true;
+            }
+        }
+    }
+    return r;
+}
+
+typedef Fp<FrCfg> Fr;
+typedef Fp<FqCfg> Fq;
+
+// ---------------------------------------------------------------------------------------------
+// Fq2 = Fq[u]/(u^2 + 1)  (fq2.rs:90-182)
+// ---------------------------------------------------------------------------------------------
+struct Fq2 {
+    Fq c0, c1;
+    ZK_DI static Fq2 zero() { return Fq2{Fq::zero(), Fq::zero()}; }
+    ZK_DI static Fq2 one() { return Fq2{Fq::one(), Fq::zero()}; }
+    ZK_DI bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    ZK_DI bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
+    ZK_DI bool operator!=(const Fq2& b) const { return !(*this == b); }
+};
+ZK_DI Fq2 add(const Fq2& a, const Fq2& b) { return Fq2{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+ZK_DI Fq2 sub(const Fq2& a, const Fq2& b) { return Fq2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+ZK_DI Fq2 neg(const Fq2& a) { return Fq2{neg(a.c0), neg(a.c1)}; }
+ZK_DI Fq2 dbl(const Fq2& a) { return Fq2{dbl(a.c0), dbl(a.c1)}; }
+ZK_DI Fq2 mul(const Fq2& a, const Fq2& b) {
+    // Karatsuba, fq2.rs:133-158: 3 base-field products
+    Fq aa = mul(a.c0, b.c0);
+    Fq bb = mul(a.c1, b.c1);
+    Fq o = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    return Fq2{sub(aa, bb), sub(sub(o, aa), bb)};
+}
+ZK_DI Fq2 sqr(const Fq2& a) {
+    // complex squaring, fq2.rs:109-131: 2 base-field products
+    Fq ab = mul(a.c0, a.c1);
+    Fq s = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
+    return Fq2{s, dbl(ab)};
+}
+
+}  // namespace zkdev

@@ -1,0 +1,219 @@
+// Radix-2 NTT over the BLS12-381 scalar field Fr for gfx950, LDS-tiled.
+//
+// Replaces bellman 0.1.0's EvaluationDomain (domain.rs: fft / ifft / coset_fft / icoset_fft /
+// mul_assign / sub_assign / divide_by_z_on_coset) as used by create_proof for the H query
+// (call site: /root/reference/core/proofs/src/confidential.rs:149).  Field constants follow
+// core/pairing/src/bls12_381/fr.rs:38-55 (GENERATOR = 7, S = 32, ROOT_OF_UNITY).
+//
+// bellman bit-reverses and then runs an in-place DIT.  Here a forward/inverse *pair* never
+// permutes: a DIF pass chain maps natural order -> bit-reversed order, a DIT chain maps
+// bit-reversed -> natural, and everything between them (coset scaling, 1/m, pointwise ops,
+// Montgomery conversion) is fused into table multiplications at pass boundaries.
+//
+// One pass = up to NTT_MAX_G consecutive butterfly stages done inside LDS.  A workgroup owns a
+// tile of CW "columns" x 2^g rows; element (row m, column col) lives at global index
+//      hi * 2^(s+g) + m * 2^s + lo,     col = hi * 2^s + lo,
+// so for s >= log2(CW) every row of the tile is one contiguous CW*32-byte segment (coalesced),
+// and for s = 0 the whole tile is contiguous.  Twiddles are read from a table in HBM.
+#pragma once
+#include "dev_field.h"
+
+namespace zkdev {
+
+constexpr int NTT_MAX_G = 8;        // stages per pass
+constexpr int NTT_TILE_ELEMS = 2048;  // 64 KiB of LDS per workgroup
+constexpr int NTT_THREADS = 256;
+
+struct NttPass {
+    uint32_t log_n;    // transform size
+    uint32_t t0;       // first global stage of this pass
+    uint32_t g;        // stages in this pass
+    uint32_t log_cw;   // log2(columns per tile)
+    uint32_t dif;      // 1: decimation in frequency (natural -> bit-reversed), 0: DIT
+    uint32_t stride;   // elements between consecutive polynomials of the batch
+    uint32_t src_stride;  // when `src` is given: elements between polynomials in src ...
+    uint32_t src_valid;   // ... and how many leading elements exist (the rest read as zero)
+};
+
+ZK_DI Fr ld_fr(const uint32_t* p) {
+    Fr r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+ZK_DI void st_fr(uint32_t* p, const Fr& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// One pass over a batch of polynomials (blockIdx.y = polynomial).  `tw` holds w^e (Montgomery)
+// for e in [0, n/2).  `pre` / `post` (optional, n entries each) are multiplied into every
+// element at load / store, indexed by the element's global position.  `src` (optional) replaces
+// `data` as the load source for the first pass of a chain.
+__global__ void __launch_bounds__(NTT_THREADS)
+k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __restrict__ tw,
+           const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post, NttPass ps) {
+    ZK_DYN_SHARED(uint32_t, tile);   // [2^g][CW][8]
+    const uint32_t k = ps.log_n, g = ps.g, lcw = ps.log_cw;
+    const uint32_t rows = 1u << g, cw = 1u << lcw;
+    // s = log2 of the smallest butterfly half-distance (in elements) handled by this pass
+    const uint32_t s = ps.dif ? (k - ps.t0 - g) : ps.t0;
+    uint32_t* base = data + (size_t)blockIdx.y * ps.stride * 8;
+    const uint32_t col0 = blockIdx.x << lcw;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile_elems = rows << lcw;
+
+    // ---- load tile (row-major over m, columns fastest => coalesced segments)
+    for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
+        uint32_t c = e & (cw - 1), m = e >> lcw;
+        uint32_t col = col0 + c;
+        uint32_t hi = col >> s, lo = col & ((1u << s) - 1);
+        uint32_t idx = (hi << (s + g)) | (m << s) | lo;
+        Fr v;
+        if (src) {
+            // first pass of a chain: read the caller's (unpadded) array, zero-extend to n
+            v = idx < ps.src_valid ? ld_fr(src + ((size_t)blockIdx.y * ps.src_stride + idx) * 8) : Fr::zero();
+        } else {
+            v = ld_fr(base + (size_t)idx * 8);
+        }
+        if (pre) v = mul(v, ld_fr(pre + (size_t)idx * 8));
+        st_fr(tile + e * 8, v);
+    }
+    __syncthreads();
+
+    const uint32_t nbf = tile_elems >> 1;
+    for (uint32_t j = 0; j < g; j++) {
+        // position (within m) of the bit that separates the two butterfly inputs
+        const uint32_t pos = ps.dif ? (g - 1 - j) : j;
+        const uint32_t half = 1u << pos;
+        // global stage index and the shift that turns (i mod d) into a twiddle exponent
+        const uint32_t tsh = ps.dif ? (ps.t0 + j) : (k - 1 - ps.t0 - j);
+        for (uint32_t b = tid; b < nbf; b += NTT_THREADS) {
+            uint32_t c = b & (cw - 1), mm = b >> lcw;
+            uint32_t m = ((mm >> pos) << (pos + 1)) | (mm & (half - 1));
+            uint32_t col = col0 + c;
+            uint32_t lo = col & ((1u << s) - 1);
+            // i mod d, d = half * 2^s
+            uint32_t imod = ((m & (half - 1)) << s) | lo;
+            uint32_t e = imod << tsh;
+            uint32_t* px = tile + ((m << lcw) | c) * 8;
+            uint32_t* py = tile + (((m + half) << lcw) | c) * 8;
+            Fr x = ld_fr(px), y = ld_fr(py);
+            if (ps.dif) {
+                Fr u = add(x, y);
+                Fr v = sub(x, y);
+                if (e) v = mul(v, ld_fr(tw + (size_t)e * 8));
+                st_fr(px, u);
+                st_fr(py, v);
+            } else {
+                if (e) y = mul(y, ld_fr(tw + (size_t)e * 8));
+                st_fr(px, add(x, y));
+                st_fr(py, sub(x, y));
+            }
+        }
+        __syncthreads();
+    }
+
+    for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
+        uint32_t c = e & (cw - 1), m = e >> lcw;
+        uint32_t col = col0 + c;
+        uint32_t hi = col >> s, lo = col & ((1u << s) - 1);
+        uint32_t idx = (hi << (s + g)) | (m << s) | lo;
+        Fr v = ld_fr(tile + e * 8);
+        if (post) v = mul(v, ld_fr(post + (size_t)idx * 8));
+        st_fr(base + (size_t)idx * 8, v);
+    }
+}
+
+// h = (a*b - c) * zinv, element-wise over `count` elements (a, b, c Montgomery; result in a).
+// bellman: a.mul_assign(b); a.sub_assign(c); a.divide_by_z_on_coset()  
+__global__ void __launch_bounds__(256)
+k_h_pointwise(uint32_t* a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
+              const uint32_t* __restrict__ zinv, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fr z = ld_fr(zinv);
+    Fr x = mul(ld_fr(a + i * 8), ld_fr(b + i * 8));
+    x = sub(x, ld_fr(c + i * 8));
+    st_fr(a + i * 8, mul(x, z));
+}
+
+// out[i] = in[i] * tab[i]  (optional table) ; used by the stand-alone zk_ntt_fr entry
+__global__ void __launch_bounds__(256)
+k_fr_scale(uint32_t* data, const uint32_t* __restrict__ tab, size_t n, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    st_fr(data + i * 8, mul(ld_fr(data + i * 8), ld_fr(tab + (i % n) * 8)));
+}
+
+// out[bitrev(i)] = in[i] (out-of-place)
+__global__ void __launch_bounds__(256)
+k_fr_bitrev(uint32_t* out, const uint32_t* __restrict__ in, uint32_t log_n, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t n_mask = (1u << log_n) - 1;
+    uint32_t lo = (uint32_t)i & n_mask;
+    size_t poly = i >> log_n;
+    uint32_t r = log_n ? (__builtin_bitreverse32(lo) >> (32 - log_n)) : 0;
+    st_fr(out + ((poly << log_n) + r) * 8, ld_fr(in + i * 8));
+}
+
+ZK_DI Fr fr_pow_u32(Fr base, uint32_t e) {
+    Fr r = Fr::one();
+    while (e) {
+        if (e & 1u) r = mul(r, base);
+        base = sqr(base);
+        e >>= 1;
+    }
+    return r;
+}
+
+// Table generation.  mode 0: out[i] = base^i                     (twiddles, i < count)
+//                    mode 1: out[pos] = base^bitrev(pos) * scale   (coset tables, bit-reversed)
+//                    mode 2: out[i] = base^i * scale
+// `base`, `scale` are Montgomery; if raw_out the Montgomery factor is stripped from the result
+// (so that multiplying a Montgomery value by the table entry yields a PLAIN value).
+__global__ void __launch_bounds__(256)
+k_fr_pow_table(uint32_t* out, const uint32_t* __restrict__ base, const uint32_t* __restrict__ scale,
+               uint32_t log_n, uint32_t mode, uint32_t raw_out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t e = i;
+    if (mode == 1) e = log_n ? (__builtin_bitreverse32(i) >> (32 - log_n)) : 0;
+    Fr v = fr_pow_u32(ld_fr(base), e);
+    if (mode) v = mul(v, ld_fr(scale));
+    if (raw_out) v = from_mont(v);
+    st_fr(out + (size_t)i * 8, v);
+}
+
+// plain <-> Montgomery conversion of a scalar array (mode 0: to Montgomery, 1: from)
+__global__ void __launch_bounds__(256)
+k_fr_convert(uint32_t* out, const uint32_t* __restrict__ in, uint32_t from, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Fr v = ld_fr(in + i * 8);
+    st_fr(out + i * 8, from ? from_mont(v) : to_mont(v));
+}
+
+// Per-proof scalar vector for the multiexps: out[p] = [ wit[p][0..nv) | tail[p][0..3) ]
+// (tail = 1, r, s).  Witness scalars are converted out of Montgomery form when `mont` is set.
+__global__ void __launch_bounds__(256)
+k_build_scalars(uint32_t* out, const uint32_t* __restrict__ wit, const uint32_t* __restrict__ tail, uint32_t nv,
+                uint32_t mont) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nv + 3) return;
+    size_t p = blockIdx.y;
+    Fr v;
+    if (i < nv) {
+        v = ld_fr(wit + (p * nv + i) * 8);
+        if (mont) v = from_mont(v);
+    } else {
+        v = ld_fr(tail + (p * 3 + (i - nv)) * 8);
+    }
+    st_fr(out + (p * (nv + 3) + i) * 8, v);
+}
+
+}  // namespace zkdev

@@ -1,0 +1,1107 @@
+// libzkamd: host orchestration + C ABI (include/zkamd.h) of the MI355X Groth16 prover hot path.
+//
+// What it replaces in the reference (all behind core/proofs/src/confidential.rs:149, in the
+// un-vendored bellman 0.1.0 crate; restated in SURVEY.md Appendix A):
+//   create_proof step 3  (EvaluationDomain H pipeline)   -> ntt.h kernels, NttPlan below
+//   create_proof step 4  (8 x multiexp)                  -> msm.h kernels, MsmGroup below
+//   create_proof step 6  (final fold, into_affine)       -> fold_proof() below (host)
+//   Parameters::read                                     -> Params::load below
+//   Proof::write                                         -> host_math.h g1/g2_to_compressed
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <thread>
+#include <algorithm>
+#include <new>
+
+#include "../../include/zkamd.h"
+#include "gpu_rt.h"
+#include "host_math.h"
+#include "ntt.h"
+#include "msm.h"
+
+using zkdev::MsmJob;
+using zkdev::NttPass;
+
+namespace {
+
+thread_local std::string g_err;
+hipStream_t g_stream = nullptr;
+bool g_stream_init = false;
+int g_device = -1;
+
+zk_status fail(zk_status st, const std::string& msg) {
+    g_err = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ZK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+#define ZK_TRY(expr)                \
+    do {                            \
+        zk_status s_ = (expr);      \
+        if (s_ != ZK_OK) return s_; \
+    } while (0)
+
+zk_status use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ZK_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(ZK_ERR_INVALID_ARGUMENT, "device index out of range");
+    if (g_device != device) {
+        HIP_TRY(hipSetDevice(device));
+        if (g_stream_init) {
+            (void)hipStreamDestroy(g_stream);
+            g_stream_init = false;
+        }
+        g_device = device;
+    }
+    if (!g_stream_init) {
+        HIP_TRY(hipStreamCreate(&g_stream));
+        g_stream_init = true;
+    }
+    return ZK_OK;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    zk_status ensure(size_t bytes) {
+        if (bytes <= cap) return ZK_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            p = nullptr;
+            return fail(ZK_ERR_OUT_OF_MEMORY, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+        }
+        cap = bytes;
+        return ZK_OK;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// HIP-event profiling of named kernels (zk_profile_*)
+// ------------------------------------------------------------------------------------------
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+bool g_prof = false;
+std::vector<ProfRec> g_recs;
+
+struct ProfScope {
+    bool on;
+    ProfScope(const char* name) : on(g_prof) {
+        if (!on) return;
+        ProfRec r;
+        r.name = name;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, g_stream);
+        g_recs.push_back(r);
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(g_recs.back().b, g_stream);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// NTT plan: twiddles and fused scaling tables for one domain size, resident in HBM
+// ------------------------------------------------------------------------------------------
+using zkhost::Fr;
+
+Fr fr_from_u64(uint64_t v) {
+    Fr x = Fr::zero();
+    x.l[0] = v;
+    return x.to_mont();
+}
+Fr fr_const(const uint64_t (&v)[4]) {
+    Fr x;
+    for (int i = 0; i < 4; i++) x.l[i] = v[i];
+    return x;
+}
+
+struct NttPlan {
+    uint32_t log_n = 0;
+    size_t n = 0;
+    DevBuf tw_fwd, tw_inv;           // w^e, w^-e, e < n/2 (Montgomery)
+    DevBuf s1_plain, s1_mont, s2;    // prover tables, bit-reversed order (see prove_chunk)
+    DevBuf coset_fwd, coset_inv;     // g^i and g^-i / n, natural order (Montgomery)
+    DevBuf consts;                   // [0] = 1/n, [1] = 1/(g^n - 1)   (Montgomery)
+    DevBuf scratch;                  // permutation scratch for the stand-alone entry
+    size_t bytes = 0;
+
+    static std::vector<NttPass> passes(uint32_t k, bool dif, uint32_t stride) {
+        std::vector<NttPass> out;
+        if (k == 0) return out;
+        uint32_t np = (k + zkdev::NTT_MAX_G - 1) / zkdev::NTT_MAX_G;
+        uint32_t base = k / np, extra = k % np, t0 = 0;
+        for (uint32_t i = 0; i < np; i++) {
+            NttPass p;
+            p.log_n = k;
+            p.t0 = t0;
+            p.g = base + (i < extra ? 1 : 0);
+            uint32_t lcw = 11 - p.g;
+            if (lcw > k - p.g) lcw = k - p.g;
+            p.log_cw = lcw;
+            p.dif = dif ? 1 : 0;
+            p.stride = stride;
+            p.src_stride = 0;
+            p.src_valid = 0;
+            out.push_back(p);
+            t0 += p.g;
+        }
+        return out;
+    }
+
+    zk_status upload_fr(DevBuf& buf, const Fr* v, size_t count) {
+        ZK_TRY(buf.ensure(count * 32));
+        HIP_TRY(hipMemcpy(buf.p, v, count * 32, hipMemcpyHostToDevice));
+        return ZK_OK;
+    }
+
+    zk_status pow_table(DevBuf& out, const Fr& base, const Fr& scale, uint32_t mode, uint32_t raw, size_t count) {
+        DevBuf tmp;
+        Fr bs[2] = {base, scale};
+        ZK_TRY(upload_fr(tmp, bs, 2));
+        ZK_TRY(out.ensure(count * 32));
+        bytes += count * 32;
+        if (count == 0) return ZK_OK;
+        ZK_LAUNCH(zkdev::k_fr_pow_table, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, g_stream,
+                  out.as<uint32_t>(), tmp.as<uint32_t>(), tmp.as<uint32_t>() + 8, log_n, mode, raw, (uint32_t)count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return ZK_OK;
+    }
+
+    zk_status init(uint32_t k) {
+        if (k > 27) return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "domain larger than 2^27");
+        log_n = k;
+        n = (size_t)1 << k;
+        static const uint64_t root_v[4] = ZK_FR_ROOT_OF_UNITY_MONT_64;
+        static const uint64_t gen_v[4] = ZK_FR_GENERATOR_MONT_64;
+        static const uint64_t r2_v[4] = ZK_FR_R2_64;
+        Fr w = fr_const(root_v);
+        for (uint32_t i = k; i < ZK_FR_S; i++) w = w.sqr();   // w = ROOT^(2^(S-k))  (domain.rs)
+        Fr winv = zkhost::fr_inv(w);
+        Fr g = fr_const(gen_v), ginv = zkhost::fr_inv(g);
+        Fr ninv = zkhost::fr_inv(fr_from_u64((uint64_t)n));
+        Fr r_elem = fr_const(r2_v);   // Montgomery form of the field element R
+        Fr gn = g;
+        for (uint32_t i = 0; i < k; i++) gn = gn.sqr();
+        Fr zinv = zkhost::fr_inv(gn - Fr::one());   // divide_by_z_on_coset
+        Fr cs[2] = {ninv, zinv};
+        ZK_TRY(upload_fr(consts, cs, 2));
+        ZK_TRY(pow_table(tw_fwd, w, Fr::one(), 0, 0, n / 2));
+        ZK_TRY(pow_table(tw_inv, winv, Fr::one(), 0, 0, n / 2));
+        // after the first inverse transform: * g^i / n, and lift the (plain or Montgomery) input
+        // into Montgomery form in the same multiplication
+        ZK_TRY(pow_table(s1_plain, g, ninv * r_elem, 1, 0, n));
+        ZK_TRY(pow_table(s1_mont, g, ninv, 1, 0, n));
+        // after the last inverse transform: * g^-i / n and drop the Montgomery factor
+        ZK_TRY(pow_table(s2, ginv, ninv, 1, 1, n));
+        ZK_TRY(pow_table(coset_fwd, g, Fr::one(), 0, 0, n));
+        ZK_TRY(pow_table(coset_inv, ginv, ninv, 2, 0, n));
+        return ZK_OK;
+    }
+
+    // Run one chain of passes over `batch` polynomials laid out with `stride` elements.
+    zk_status chain(uint32_t* data, uint32_t batch, uint32_t stride, bool dif, bool inverse,
+                    const uint32_t* pre, const uint32_t* post, const uint32_t* src = nullptr,
+                    uint32_t src_stride = 0, uint32_t src_valid = 0) {
+        std::vector<NttPass> ps = passes(log_n, dif, stride);
+        const uint32_t* tw = inverse ? tw_inv.as<uint32_t>() : tw_fwd.as<uint32_t>();
+        for (size_t i = 0; i < ps.size(); i++) {
+            NttPass p = ps[i];
+            const uint32_t* s = nullptr;
+            if (i == 0 && src) {
+                s = src;
+                p.src_stride = src_stride;
+                p.src_valid = src_valid;
+            }
+            unsigned cols = (unsigned)(n >> p.g);
+            dim3 grid(cols >> p.log_cw, batch);
+            size_t shmem = ((size_t)1 << (p.g + p.log_cw)) * 32;
+            ProfScope ps_(dif ? "ntt_pass_dif" : "ntt_pass_dit");
+            ZK_LAUNCH_SYNC(zkdev::k_ntt_pass, grid, dim3(zkdev::NTT_THREADS), shmem, g_stream, data, s, tw,
+                           i == 0 ? pre : (const uint32_t*)nullptr,
+                           i + 1 == ps.size() ? post : (const uint32_t*)nullptr, p);
+        }
+        if (ps.empty() && (pre || post || src)) return fail(ZK_ERR_INVALID_ARGUMENT, "size-1 transform");
+        HIP_TRY(hipGetLastError());
+        return ZK_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// MSM group: window tables of a set of bases + the bucket pipeline over a list of jobs
+// ------------------------------------------------------------------------------------------
+uint32_t pick_window(size_t n) {
+    const char* env = getenv("ZKAMD_WINDOW_BITS");
+    if (env && atoi(env) >= 2 && atoi(env) <= 22) return (uint32_t)atoi(env);
+    uint32_t best = 2;
+    double best_cost = 1e300;
+    for (uint32_t c = 2; c <= 20; c++) {
+        uint32_t W = (256 + c - 1) / c;
+        double cost = (double)W * (double)(n ? n : 1) + 6.0 * (double)((size_t)1 << (c - 1));
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+// On-curve + subgroup validation of an array of decoded points (Parameters::read(checked = true):
+// core/pairing/src/bls12_381/ec.rs:675-688), one GPU thread per point.
+template <class HF, class DF>
+zk_status check_points_dev(const zkdev::Affine<DF>* d_pts, size_t n, const char* what) {
+    if (!n) return ZK_OK;
+    DevBuf flags;
+    ZK_TRY(flags.ensure(4 * n));
+    ZK_LAUNCH(zkdev::k_check_points<DF>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, g_stream, d_pts, (uint32_t)n, 1u,
+              flags.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> f(n);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(f.data(), flags.p, 4 * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++)
+        if (f[i])
+            return fail(ZK_ERR_IO, std::string(what) + ": point " + std::to_string(i) +
+                                       (f[i] & 1 ? " is not on the curve" : " is not in the correct subgroup"));
+    return ZK_OK;
+}
+template <class HF, class DF>
+zk_status check_points_host(const std::vector<zkhost::Affine<HF>>& pts, const char* what) {
+    if (pts.empty()) return ZK_OK;
+    DevBuf d;
+    ZK_TRY(d.ensure(pts.size() * sizeof(zkdev::Affine<DF>)));
+    HIP_TRY(hipMemcpy(d.p, pts.data(), pts.size() * sizeof(zkdev::Affine<DF>), hipMemcpyHostToDevice));
+    return check_points_dev<HF, DF>(d.as<zkdev::Affine<DF>>(), pts.size(), what);
+}
+
+template <class HF, class DF>
+struct MsmGroup {
+    typedef zkhost::Affine<HF> HAffine;
+    typedef zkhost::Point<HF> HPoint;
+    typedef zkdev::Affine<DF> DAffine;
+    typedef zkdev::XYZZ<DF> DPoint;
+    static_assert(sizeof(HAffine) == sizeof(DAffine), "host/device affine layout");
+    static_assert(sizeof(HPoint) == sizeof(DPoint), "host/device point layout");
+
+    uint32_t c = 0, W = 0, nb = 0;
+    size_t n_points = 0;
+    DevBuf table;
+    DevBuf jobs_d, cnt, off, rank, pairs, sums, part_a, part_b;
+    size_t bytes = 0;
+
+    zk_status build(const std::vector<HAffine>& pts, uint32_t c_, bool checked, const char* what) {
+        c = c_;
+        W = (256 + c - 1) / c;
+        nb = 1u << (c - 1);
+        n_points = pts.size();
+        if ((uint64_t)n_points * W >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "window table too large");
+        size_t tb = sizeof(DAffine) * n_points * W;
+        ZK_TRY(table.ensure(tb ? tb : 1));
+        bytes = tb;
+        if (!n_points) return ZK_OK;
+        HIP_TRY(hipMemcpy(table.p, pts.data(), sizeof(DAffine) * n_points, hipMemcpyHostToDevice));
+        unsigned blocks = (unsigned)((n_points + 127) / 128);
+        if (checked) ZK_TRY((check_points_dev<HF, DF>(table.as<DAffine>(), n_points, what)));
+        ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3(blocks), dim3(128), 0, g_stream, table.as<DAffine>(),
+                  (uint32_t)n_points, c, W);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return ZK_OK;
+    }
+
+    // jobs[i].pair_base is filled in here.  Results (one XYZZ per job) are copied to `out`.
+    zk_status run(std::vector<MsmJob>& jobs, std::vector<HPoint>& out) {
+        const size_t nj = jobs.size();
+        out.resize(nj);
+        if (!nj) return ZK_OK;
+        uint64_t total = 0;
+        uint32_t max_n = 0;
+        for (auto& j : jobs) {
+            j.pair_base = (uint32_t)total;
+            total += (uint64_t)j.n * W;
+            max_n = std::max(max_n, j.n);
+        }
+        if (total >= (1ull << 32)) return fail(ZK_ERR_INVALID_ARGUMENT, "too many (digit, point) pairs in one launch");
+        const size_t n_buckets = nj * (size_t)nb;
+        if (n_buckets >= (1ull << 32)) return fail(ZK_ERR_INVALID_ARGUMENT, "too many buckets in one launch");
+        ZK_TRY(jobs_d.ensure(nj * sizeof(MsmJob)));
+        ZK_TRY(cnt.ensure(n_buckets * 4));
+        ZK_TRY(off.ensure(n_buckets * 4));
+        ZK_TRY(rank.ensure((size_t)(total ? total : 1) * 4));
+        ZK_TRY(pairs.ensure((size_t)(total ? total : 1) * 4));
+        ZK_TRY(sums.ensure(n_buckets * sizeof(DPoint)));
+        const uint32_t L = nb < 64 ? nb : 64;
+        const uint32_t T = nb / L;
+        ZK_TRY(part_a.ensure(nj * (size_t)T * sizeof(DPoint)));
+        ZK_TRY(part_b.ensure(nj * (size_t)((T + 7) / 8) * sizeof(DPoint)));
+        HIP_TRY(hipMemcpyAsync(jobs_d.p, jobs.data(), nj * sizeof(MsmJob), hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, g_stream));
+        const MsmJob* dj = jobs_d.as<MsmJob>();
+        dim3 gridn((max_n + 255) / 256, (unsigned)nj);
+        if (max_n) {
+            ProfScope ps("msm_count");
+            ZK_LAUNCH(zkdev::k_msm_count, gridn, dim3(256), 0, g_stream, dj, c, W, cnt.as<uint32_t>(), rank.as<uint32_t>());
+        }
+        {
+            ProfScope ps("msm_scan");
+            ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < 1024 ? (nb < 64 ? 64 : nb) : 1024), 0, g_stream,
+                           dj, c, cnt.as<uint32_t>(), off.as<uint32_t>());
+        }
+        if (max_n) {
+            ProfScope ps("msm_scatter");
+            ZK_LAUNCH(zkdev::k_msm_scatter, gridn, dim3(256), 0, g_stream, dj, c, W, off.as<uint32_t>(),
+                      rank.as<uint32_t>(), pairs.as<uint32_t>());
+        }
+        {
+            ProfScope ps(sizeof(DF) > 48 ? "msm_accumulate_g2" : "msm_accumulate_g1");
+            ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((n_buckets + 127) / 128)), dim3(128), 0, g_stream,
+                      table.as<DAffine>(), pairs.as<uint32_t>(), off.as<uint32_t>(), cnt.as<uint32_t>(),
+                      sums.as<DPoint>(), (uint32_t)n_buckets);
+        }
+        {
+            ProfScope ps(sizeof(DF) > 48 ? "msm_reduce_g2" : "msm_reduce_g1");
+            ZK_LAUNCH(zkdev::k_msm_reduce<DF>, dim3((T + 63) / 64, (unsigned)nj), dim3(64), 0, g_stream,
+                      sums.as<DPoint>(), part_a.as<DPoint>(), nb, L);
+        }
+        DPoint* in = part_a.as<DPoint>();
+        DPoint* outp = part_b.as<DPoint>();
+        uint32_t seg = T;
+        while (seg > 1) {
+            uint32_t seg_out = (seg + 7) / 8;
+            ProfScope ps("msm_sum");
+            ZK_LAUNCH(zkdev::k_msm_sum<DF>, dim3((seg_out + 63) / 64, (unsigned)nj), dim3(64), 0, g_stream, in, outp, seg, 8u);
+            std::swap(in, outp);
+            seg = seg_out;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out.data(), in, nj * sizeof(DPoint), hipMemcpyDeviceToHost, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        return ZK_OK;
+    }
+};
+
+typedef MsmGroup<zkhost::Fq, zkdev::Fq> MsmG1;
+typedef MsmGroup<zkhost::Fq2, zkdev::Fq2> MsmG2;
+typedef zkhost::Affine<zkhost::Fq> HG1A;
+typedef zkhost::Affine<zkhost::Fq2> HG2A;
+typedef zkhost::Point<zkhost::Fq> HG1;
+typedef zkhost::Point<zkhost::Fq2> HG2;
+
+// ------------------------------------------------------------------------------------------
+// byte reader for the Parameters format
+// ------------------------------------------------------------------------------------------
+struct Reader {
+    const uint8_t* p;
+    size_t left;
+    bool take(size_t n, const uint8_t** out) {
+        if (left < n) return false;
+        *out = p;
+        p += n;
+        left -= n;
+        return true;
+    }
+    bool u32be(uint32_t* v) {
+        const uint8_t* b;
+        if (!take(4, &b)) return false;
+        *v = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+        return true;
+    }
+};
+
+zk_status read_g1(Reader& r, HG1A* out, const char* what) {
+    const uint8_t* b;
+    if (!r.take(96, &b)) return fail(ZK_ERR_IO, std::string("unexpected end of parameters in ") + what);
+    if (zkhost::g1_from_uncompressed(b, out) != zkhost::DEC_OK) return fail(ZK_ERR_IO, std::string("invalid G1 encoding in ") + what);
+    // bellman Parameters::read: "point at infinity" is an error in both modes
+    if (out->is_inf()) return fail(ZK_ERR_IO, std::string("point at infinity in ") + what);
+    return ZK_OK;
+}
+zk_status read_g2(Reader& r, HG2A* out, const char* what) {
+    const uint8_t* b;
+    if (!r.take(192, &b)) return fail(ZK_ERR_IO, std::string("unexpected end of parameters in ") + what);
+    if (zkhost::g2_from_uncompressed(b, out) != zkhost::DEC_OK) return fail(ZK_ERR_IO, std::string("invalid G2 encoding in ") + what);
+    if (out->is_inf()) return fail(ZK_ERR_IO, std::string("point at infinity in ") + what);
+    return ZK_OK;
+}
+
+void load_scalar_le(const uint8_t* b, uint64_t out[4]) {
+    for (int i = 0; i < 4; i++) {
+        uint64_t w = 0;
+        for (int j = 7; j >= 0; j--) w = (w << 8) | b[i * 8 + j];
+        out[i] = w;
+    }
+}
+bool scalar_lt_r(const uint64_t v[4]) { return !Fr::geq_p(v); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// zk_params
+// ------------------------------------------------------------------------------------------
+struct zk_params {
+    int device = 0;
+    uint32_t n_ic = 0, n_h = 0, n_l = 0, n_a = 0, n_b1 = 0, n_b2 = 0;
+    uint32_t log_m = 0;
+    size_t m = 0;
+    // offsets of each query inside the G1 group table (window slice 0)
+    uint32_t off_h = 0, off_l = 0, off_a = 0, off_b1 = 0;
+    MsmG1 g1;
+    MsmG2 g2;
+    NttPlan ntt;
+    // cached per-circuit index maps (keyed by the density bytes)
+    std::vector<uint8_t> dens_key;
+    DevBuf map_h, map_a, map_b1, map_b2;
+    uint32_t map_nv = 0;
+    // workspaces
+    DevBuf abc, wit, tail, stage_a, stage_b, stage_c, stage_w;
+    std::vector<MsmJob> jobs1, jobs2;
+    std::vector<HG1> res1;
+    std::vector<HG2> res2;
+};
+
+namespace {
+
+zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk_params** out) {
+    ZK_TRY(use_device(device));
+    zk_params* P = new (std::nothrow) zk_params();
+    if (!P) return fail(ZK_ERR_OUT_OF_MEMORY, "host allocation failed");
+    struct Guard {
+        zk_params* p;
+        ~Guard() { delete p; }
+    } guard{P};
+    P->device = device;
+    Reader r{pk, len};
+    HG1A alpha_g1, beta_g1, delta_g1, tmp1;
+    HG2A beta_g2, gamma_g2, delta_g2, tmp2;
+    ZK_TRY(read_g1(r, &alpha_g1, "vk.alpha_g1"));
+    ZK_TRY(read_g1(r, &beta_g1, "vk.beta_g1"));
+    ZK_TRY(read_g2(r, &beta_g2, "vk.beta_g2"));
+    ZK_TRY(read_g2(r, &gamma_g2, "vk.gamma_g2"));
+    ZK_TRY(read_g1(r, &delta_g1, "vk.delta_g1"));
+    ZK_TRY(read_g2(r, &delta_g2, "vk.delta_g2"));
+    if (!r.u32be(&P->n_ic)) return fail(ZK_ERR_IO, "unexpected end of parameters (ic length)");
+    std::vector<HG1A> ic(P->n_ic);
+    if ((size_t)P->n_ic * 96 > r.left) return fail(ZK_ERR_IO, "unexpected end of parameters in vk.ic");
+    for (uint32_t i = 0; i < P->n_ic; i++) ZK_TRY(read_g1(r, &ic[i], "vk.ic"));
+
+    std::vector<HG1A> pts1;
+    auto read_vec1 = [&](uint32_t* n, uint32_t* off, const char* what) -> zk_status {
+        if (!r.u32be(n)) return fail(ZK_ERR_IO, std::string("unexpected end of parameters (length of ") + what + ")");
+        if ((size_t)*n * 96 > r.left) return fail(ZK_ERR_IO, std::string("unexpected end of parameters in ") + what);
+        *off = (uint32_t)pts1.size();
+        pts1.reserve(pts1.size() + *n + 4);
+        for (uint32_t i = 0; i < *n; i++) {
+            ZK_TRY(read_g1(r, &tmp1, what));
+            pts1.push_back(tmp1);
+        }
+        return ZK_OK;
+    };
+    ZK_TRY(read_vec1(&P->n_h, &P->off_h, "h"));
+    ZK_TRY(read_vec1(&P->n_l, &P->off_l, "l"));
+    ZK_TRY(read_vec1(&P->n_a, &P->off_a, "a"));
+    pts1.push_back(alpha_g1);   // a-slice tail: [alpha_g1, delta_g1]  (scalars 1, r)
+    pts1.push_back(delta_g1);
+    ZK_TRY(read_vec1(&P->n_b1, &P->off_b1, "b_g1"));
+    pts1.push_back(beta_g1);    // b_g1-slice tail: [beta_g1]           (scalar 1)
+    std::vector<HG2A> pts2;
+    if (!r.u32be(&P->n_b2)) return fail(ZK_ERR_IO, "unexpected end of parameters (length of b_g2)");
+    if ((size_t)P->n_b2 * 192 > r.left) return fail(ZK_ERR_IO, "unexpected end of parameters in b_g2");
+    pts2.reserve(P->n_b2 + 2);
+    for (uint32_t i = 0; i < P->n_b2; i++) {
+        ZK_TRY(read_g2(r, &tmp2, "b_g2"));
+        pts2.push_back(tmp2);
+    }
+    pts2.push_back(beta_g2);    // tail: [beta_g2, delta_g2]            (scalars 1, s)
+    pts2.push_back(delta_g2);
+
+    // the evaluation domain: bellman writes h with m - 1 entries
+    size_t m = (size_t)P->n_h + 1;
+    if (m < 2 || (m & (m - 1))) return fail(ZK_ERR_IO, "h query length + 1 is not a power of two");
+    P->m = m;
+    while (((size_t)1 << P->log_m) < m) P->log_m++;
+    if (checked) {
+        // vk points that never enter a table are checked on the host side of the same kernel
+        ZK_TRY((check_points_host<zkhost::Fq, zkdev::Fq>(ic, "vk.ic")));
+        ZK_TRY((check_points_host<zkhost::Fq2, zkdev::Fq2>(std::vector<HG2A>{gamma_g2}, "vk.gamma_g2")));
+    }
+    uint32_t c = pick_window(std::max<size_t>(P->n_h, P->n_l));
+    ZK_TRY(P->g1.build(pts1, c, checked != 0, "parameters (G1)"));
+    ZK_TRY(P->g2.build(pts2, c, checked != 0, "parameters (G2)"));
+    ZK_TRY(P->ntt.init(P->log_m));
+    guard.p = nullptr;
+    *out = P;
+    return ZK_OK;
+}
+
+// Build (or reuse) the per-circuit index maps from the density trackers.
+zk_status ensure_maps(zk_params* P, uint32_t n_in, uint32_t n_aux, const uint8_t* a_aux_d, const uint8_t* b_in_d,
+                      const uint8_t* b_aux_d) {
+    std::vector<uint8_t> key;
+    key.reserve(8 + n_in + 2 * (size_t)n_aux);
+    for (int i = 0; i < 4; i++) key.push_back((uint8_t)(n_in >> (8 * i)));
+    for (int i = 0; i < 4; i++) key.push_back((uint8_t)(n_aux >> (8 * i)));
+    key.insert(key.end(), a_aux_d, a_aux_d + n_aux);
+    key.insert(key.end(), b_in_d, b_in_d + n_in);
+    key.insert(key.end(), b_aux_d, b_aux_d + n_aux);
+    if (key == P->dens_key) return ZK_OK;
+    const uint32_t nv = n_in + n_aux;
+    // scalar layout per proof: [inputs | aux | 1 | r | s]
+    std::vector<int32_t> ma(nv + 3, -1), mb1(nv + 3, -1), mb2(nv + 3, -1);
+    uint32_t pa = n_in;
+    for (uint32_t i = 0; i < n_in; i++) ma[i] = (int32_t)i;   // A inputs: full density
+    for (uint32_t j = 0; j < n_aux; j++)
+        if (a_aux_d[j]) ma[n_in + j] = (int32_t)pa++;
+    if (pa > P->n_a) return fail(ZK_ERR_IO, "a query shorter than the A density (unexpected EOF in bases)");
+    ma[nv] = (int32_t)P->n_a;         // 1 * alpha_g1
+    ma[nv + 1] = (int32_t)P->n_a + 1; // r * delta_g1
+    uint32_t pb = 0;
+    for (uint32_t i = 0; i < n_in; i++)
+        if (b_in_d[i]) mb1[i] = mb2[i] = (int32_t)pb++;
+    for (uint32_t j = 0; j < n_aux; j++)
+        if (b_aux_d[j]) mb1[n_in + j] = mb2[n_in + j] = (int32_t)pb++;
+    if (pb > P->n_b1 || pb > P->n_b2) return fail(ZK_ERR_IO, "b query shorter than the B density (unexpected EOF in bases)");
+    mb1[nv] = (int32_t)P->n_b1;       // 1 * beta_g1
+    mb2[nv] = (int32_t)P->n_b2;       // 1 * beta_g2
+    mb2[nv + 2] = (int32_t)P->n_b2 + 1;   // s * delta_g2
+    // h coefficients leave the last transform in bit-reversed order; the top coefficient
+    // (degree m - 1) is dropped exactly as bellman truncates it
+    std::vector<int32_t> mh(P->m);
+    for (size_t pos = 0; pos < P->m; pos++) {
+        uint32_t e = P->log_m ? (__builtin_bitreverse32((uint32_t)pos) >> (32 - P->log_m)) : 0;
+        mh[pos] = e < P->n_h ? (int32_t)e : -1;
+    }
+    ZK_TRY(P->map_a.ensure(ma.size() * 4));
+    ZK_TRY(P->map_b1.ensure(mb1.size() * 4));
+    ZK_TRY(P->map_b2.ensure(mb2.size() * 4));
+    ZK_TRY(P->map_h.ensure(mh.size() * 4));
+    HIP_TRY(hipMemcpy(P->map_a.p, ma.data(), ma.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->map_b1.p, mb1.data(), mb1.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->map_b2.p, mb2.data(), mb2.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->map_h.p, mh.data(), mh.size() * 4, hipMemcpyHostToDevice));
+    P->dens_key.swap(key);
+    P->map_nv = nv;
+    return ZK_OK;
+}
+
+// create_proof step 6, rearranged:  with A = alpha + sum_A + r*delta (already
+// complete, the alpha and r*delta terms rode along in the A multiexp) and B1 = beta_1 + sum_B1,
+//   C = s*A + r*B1 + h + l   ==  rs*delta + s*alpha + r*beta_1 + s*sum_A + r*sum_B1 + h + l.
+void fold_proof(const HG1& h, const HG1& l, const HG1& a, const HG1& b1, const HG2& b2, const uint64_t r[4],
+                const uint64_t s[4], uint8_t* out) {
+    HG1 c = zkhost::padd(zkhost::padd(zkhost::pmul(a, s), zkhost::pmul(b1, r)), zkhost::padd(h, l));
+    zkhost::g1_to_compressed(zkhost::to_affine(a), out);
+    zkhost::g2_to_compressed(zkhost::to_affine(b2), out + 48);
+    zkhost::g1_to_compressed(zkhost::to_affine(c), out + 144);
+}
+
+zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t first, const uint8_t* rs, uint8_t* proofs_out) {
+    const uint32_t n_in = bt->n_inputs, n_aux = bt->n_aux, nv = n_in + n_aux, n_rows = bt->n_rows;
+    const size_t m = P->m;
+    const bool mont = (bt->flags & ZK_FR_MONTGOMERY) != 0;
+    // ---- scalars [inputs | aux | 1 | r | s] per proof, plain
+    const size_t wstride = (size_t)(nv + 3);
+    ZK_TRY(P->wit.ensure(np * wstride * 32));
+    uint32_t* wit = P->wit.as<uint32_t>();
+    std::vector<uint8_t> tail(np * 96, 0);
+    std::vector<uint64_t> rsv(np * 8);
+    for (size_t p = 0; p < np; p++) {
+        const uint8_t* rr = rs + (first + p) * 64;
+        load_scalar_le(rr, &rsv[p * 8]);
+        load_scalar_le(rr + 32, &rsv[p * 8 + 4]);
+        if (!scalar_lt_r(&rsv[p * 8]) || !scalar_lt_r(&rsv[p * 8 + 4]))
+            return fail(ZK_ERR_INVALID_ARGUMENT, "r or s is not a canonical scalar (>= field modulus)");
+        tail[p * 96] = 1;
+        memcpy(&tail[p * 96 + 32], rr, 64);
+    }
+    ZK_TRY(P->tail.ensure(np * 96));
+    HIP_TRY(hipMemcpyAsync(P->tail.p, tail.data(), np * 96, hipMemcpyHostToDevice, g_stream));
+    ZK_LAUNCH(zkdev::k_build_scalars, dim3((nv + 3 + 255) / 256, (unsigned)np), dim3(256), 0, g_stream, wit,
+              (const uint32_t*)bt->d_wit + first * (size_t)nv * 8, P->tail.as<uint32_t>(), nv, mont ? 1u : 0u);
+    // ---- H pipeline (create_proof step 3)
+    ZK_TRY(P->abc.ensure(3 * np * m * 32));
+    uint32_t* A = P->abc.as<uint32_t>();
+    uint32_t* B = A + np * m * 8;
+    uint32_t* C = B + np * m * 8;
+    const uint32_t* s1 = mont ? P->ntt.s1_mont.as<uint32_t>() : P->ntt.s1_plain.as<uint32_t>();
+    const uint32_t* srcs[3] = {(const uint32_t*)bt->d_a + first * (size_t)n_rows * 8,
+                               (const uint32_t*)bt->d_b + first * (size_t)n_rows * 8,
+                               (const uint32_t*)bt->d_c + first * (size_t)n_rows * 8};
+    uint32_t* dsts[3] = {A, B, C};
+    for (int k = 0; k < 3; k++)   // ifft (natural -> bit-reversed), then * g^i / m  (coset shift)
+        ZK_TRY(P->ntt.chain(dsts[k], (uint32_t)np, (uint32_t)m, true, true, nullptr, s1, srcs[k], n_rows, n_rows));
+    // coset fft (bit-reversed -> natural) of all three at once
+    ZK_TRY(P->ntt.chain(A, (uint32_t)(3 * np), (uint32_t)m, false, false, nullptr, nullptr));
+    {
+        ProfScope ps("h_pointwise");
+        size_t count = np * m;
+        ZK_LAUNCH(zkdev::k_h_pointwise, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, g_stream, A, B, C,
+                  P->ntt.consts.as<uint32_t>() + 8, count);
+    }
+    // icoset fft: ifft (natural -> bit-reversed), * g^-i / m, Montgomery factor dropped
+    ZK_TRY(P->ntt.chain(A, (uint32_t)np, (uint32_t)m, true, true, nullptr, P->ntt.s2.as<uint32_t>()));
+    // ---- multiexps (create_proof step 4)
+    P->jobs1.clear();
+    P->jobs2.clear();
+    const uint32_t npts1 = (uint32_t)P->g1.n_points, npts2 = (uint32_t)P->g2.n_points;
+    for (size_t p = 0; p < np; p++) {
+        const uint32_t* w = wit + p * wstride * 8;
+        MsmJob jh = {A + p * m * 8, P->map_h.as<int32_t>(), (uint32_t)m, P->off_h, npts1, 0};
+        MsmJob jl = {w + (size_t)n_in * 8, nullptr, n_aux, P->off_l, npts1, 0};
+        MsmJob ja = {w, P->map_a.as<int32_t>(), nv + 3, P->off_a, npts1, 0};
+        MsmJob jb = {w, P->map_b1.as<int32_t>(), nv + 3, P->off_b1, npts1, 0};
+        MsmJob j2 = {w, P->map_b2.as<int32_t>(), nv + 3, 0, npts2, 0};
+        P->jobs1.push_back(jh);
+        P->jobs1.push_back(jl);
+        P->jobs1.push_back(ja);
+        P->jobs1.push_back(jb);
+        P->jobs2.push_back(j2);
+    }
+    ZK_TRY(P->g1.run(P->jobs1, P->res1));
+    ZK_TRY(P->g2.run(P->jobs2, P->res2));
+    // ---- final fold + encoding (host, one thread per slice of the chunk)
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > 32) nthreads = 32;
+    if (nthreads > np) nthreads = (unsigned)np;
+    auto work = [&](size_t lo, size_t hi) {
+        for (size_t p = lo; p < hi; p++)
+            fold_proof(P->res1[4 * p], P->res1[4 * p + 1], P->res1[4 * p + 2], P->res1[4 * p + 3], P->res2[p],
+                       &rsv[p * 8], &rsv[p * 8 + 4], proofs_out + (first + p) * 192);
+    };
+    if (nthreads <= 1) {
+        work(0, np);
+    } else {
+        std::vector<std::thread> ths;
+        for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, np * t / nthreads, np * (t + 1) / nthreads);
+        for (auto& th : ths) th.join();
+    }
+    return ZK_OK;
+}
+
+zk_status prove_batch_dev(zk_params* P, size_t n, const zk_batch_dev* bt, const uint8_t* rs, uint8_t* proofs_out) {
+    if (!P || !bt || !rs || !proofs_out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return ZK_OK;
+    ZK_TRY(use_device(P->device));
+    if (bt->n_inputs == 0) return fail(ZK_ERR_INVALID_ARGUMENT, "n_inputs must include ONE");
+    if (bt->n_rows > P->m) return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
+    if (bt->n_inputs != P->n_ic) return fail(ZK_ERR_MALFORMED_VERIFYING_KEY, "number of inputs differs from vk.ic");
+    if (bt->n_aux != P->n_l) return fail(ZK_ERR_IO, "number of aux variables differs from the l query");
+    if (!bt->d_a || !bt->d_b || !bt->d_c || !bt->d_wit || !bt->a_aux_density || !bt->b_input_density || !bt->b_aux_density)
+        return fail(ZK_ERR_ASSIGNMENT_MISSING, "assignment pointer is null");
+    ZK_TRY(ensure_maps(P, bt->n_inputs, bt->n_aux, bt->a_aux_density, bt->b_input_density, bt->b_aux_density));
+    size_t chunk = 128;
+    const char* env = getenv("ZKAMD_BATCH_CHUNK");
+    if (env && atoi(env) > 0) chunk = (size_t)atoi(env);
+    for (size_t first = 0; first < n; first += chunk) {
+        size_t np = std::min(chunk, n - first);
+        ZK_TRY(prove_chunk(P, np, bt, first, rs, proofs_out));
+    }
+    return ZK_OK;
+}
+
+bool same_circuit(const zk_assignment& x, const zk_assignment& y) {
+    return x.n_rows == y.n_rows && x.n_inputs == y.n_inputs && x.n_aux == y.n_aux && x.flags == y.flags &&
+           memcmp(x.a_aux_density, y.a_aux_density, x.n_aux) == 0 &&
+           memcmp(x.b_input_density, y.b_input_density, x.n_inputs) == 0 &&
+           memcmp(x.b_aux_density, y.b_aux_density, x.n_aux) == 0;
+}
+
+zk_status prove_batch_host(zk_params* P, size_t n, const zk_assignment* asgs, const uint8_t* rs, uint8_t* proofs_out) {
+    if (!P || !asgs || !rs || !proofs_out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return ZK_OK;
+    ZK_TRY(use_device(P->device));
+    const zk_assignment& z = asgs[0];
+    for (size_t i = 0; i < n; i++) {
+        const zk_assignment& x = asgs[i];
+        if (!x.a || !x.b || !x.c || !x.inputs || !x.aux || !x.a_aux_density || !x.b_input_density || !x.b_aux_density)
+            return fail(ZK_ERR_ASSIGNMENT_MISSING, "assignment pointer is null");
+        if (i && !same_circuit(z, x)) return fail(ZK_ERR_INVALID_ARGUMENT, "batch mixes different circuits");
+    }
+    const size_t rb = (size_t)z.n_rows * 32, nvb = (size_t)(z.n_inputs + z.n_aux) * 32;
+    ZK_TRY(P->stage_a.ensure(n * rb));
+    ZK_TRY(P->stage_b.ensure(n * rb));
+    ZK_TRY(P->stage_c.ensure(n * rb));
+    ZK_TRY(P->stage_w.ensure(n * nvb));
+    for (size_t i = 0; i < n; i++) {
+        const zk_assignment& x = asgs[i];
+        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_a.p + i * rb, x.a, rb, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_b.p + i * rb, x.b, rb, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_c.p + i * rb, x.c, rb, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_w.p + i * nvb, x.inputs, (size_t)z.n_inputs * 32, hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_w.p + i * nvb + (size_t)z.n_inputs * 32, x.aux, (size_t)z.n_aux * 32,
+                               hipMemcpyHostToDevice, g_stream));
+    }
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    zk_batch_dev bt;
+    bt.n_rows = z.n_rows;
+    bt.n_inputs = z.n_inputs;
+    bt.n_aux = z.n_aux;
+    bt.flags = z.flags;
+    bt.d_a = P->stage_a.p;
+    bt.d_b = P->stage_b.p;
+    bt.d_c = P->stage_c.p;
+    bt.d_wit = P->stage_w.p;
+    bt.a_aux_density = z.a_aux_density;
+    bt.b_input_density = z.b_input_density;
+    bt.b_aux_density = z.b_aux_density;
+    return prove_batch_dev(P, n, &bt, rs, proofs_out);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// stand-alone MSM / NTT handles
+// ------------------------------------------------------------------------------------------
+struct zk_msm {
+    int group = 1, device = 0;
+    size_t n = 0;
+    MsmG1 g1;
+    MsmG2 g2;
+    DevBuf map, scal, conv;
+    bool has_map = false;
+};
+struct zk_ntt {
+    int device = 0;
+    NttPlan plan;
+};
+
+namespace {
+
+zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
+    if (group != 1 && group != 2) return fail(ZK_ERR_INVALID_ARGUMENT, "group must be 1 (G1) or 2 (G2)");
+    if (!bases && n) return fail(ZK_ERR_INVALID_ARGUMENT, "null bases");
+    ZK_TRY(use_device(device));
+    zk_msm* M = new (std::nothrow) zk_msm();
+    if (!M) return fail(ZK_ERR_OUT_OF_MEMORY, "host allocation failed");
+    struct Guard {
+        zk_msm* p;
+        ~Guard() { delete p; }
+    } guard{M};
+    M->group = group;
+    M->device = device;
+    M->n = n;
+    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(n);
+    if (c < 2 || c > 22) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 22]");
+    // points at infinity are legal multiexp bases: they are mapped out (map = -1)
+    std::vector<int32_t> map(n);
+    bool any_inf = false;
+    if (group == 1) {
+        std::vector<HG1A> pts(n);
+        for (size_t i = 0; i < n; i++) {
+            if (zkhost::g1_from_uncompressed(bases + i * 96, &pts[i]) != zkhost::DEC_OK)
+                return fail(ZK_ERR_IO, "invalid G1 encoding at base " + std::to_string(i));
+            map[i] = pts[i].is_inf() ? -1 : (int32_t)i;
+            any_inf |= pts[i].is_inf();
+        }
+        ZK_TRY(M->g1.build(pts, c, checked != 0, "bases"));
+    } else {
+        std::vector<HG2A> pts(n);
+        for (size_t i = 0; i < n; i++) {
+            if (zkhost::g2_from_uncompressed(bases + i * 192, &pts[i]) != zkhost::DEC_OK)
+                return fail(ZK_ERR_IO, "invalid G2 encoding at base " + std::to_string(i));
+            map[i] = pts[i].is_inf() ? -1 : (int32_t)i;
+            any_inf |= pts[i].is_inf();
+        }
+        ZK_TRY(M->g2.build(pts, c, checked != 0, "bases"));
+    }
+    if (any_inf) {
+        ZK_TRY(M->map.ensure(n * 4));
+        HIP_TRY(hipMemcpy(M->map.p, map.data(), n * 4, hipMemcpyHostToDevice));
+        M->has_map = true;
+    }
+    guard.p = nullptr;
+    *out = M;
+    return ZK_OK;
+}
+
+zk_status msm_run_dev(zk_msm* M, const void* d_scalars, uint32_t flags, uint8_t* out) {
+    if (!M || (!d_scalars && M->n) || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    ZK_TRY(use_device(M->device));
+    const uint32_t* sc = (const uint32_t*)d_scalars;
+    if ((flags & ZK_FR_MONTGOMERY) && M->n) {
+        ZK_TRY(M->conv.ensure(M->n * 32));
+        ZK_LAUNCH(zkdev::k_fr_convert, dim3((unsigned)((M->n + 255) / 256)), dim3(256), 0, g_stream, M->conv.as<uint32_t>(), sc,
+                  1u, M->n);
+        sc = M->conv.as<uint32_t>();
+    }
+    std::vector<MsmJob> jobs;
+    if (M->n) {
+        MsmJob j = {sc, M->has_map ? M->map.as<int32_t>() : nullptr, (uint32_t)M->n, 0, (uint32_t)M->n, 0};
+        jobs.push_back(j);
+    }
+    if (M->group == 1) {
+        std::vector<HG1> res;
+        ZK_TRY(M->g1.run(jobs, res));
+        zkhost::g1_to_uncompressed(zkhost::to_affine(res.empty() ? HG1::inf() : res[0]), out);
+    } else {
+        std::vector<HG2> res;
+        ZK_TRY(M->g2.run(jobs, res));
+        zkhost::g2_to_uncompressed(zkhost::to_affine(res.empty() ? HG2::inf() : res[0]), out);
+    }
+    return ZK_OK;
+}
+
+zk_status check_scalars(const uint8_t* scalars, size_t n, uint32_t flags) {
+    if (flags & ZK_FR_MONTGOMERY) return ZK_OK;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t v[4];
+        load_scalar_le(scalars + i * 32, v);
+        if (!scalar_lt_r(v)) return fail(ZK_ERR_INVALID_ARGUMENT, "scalar " + std::to_string(i) + " is not < r");
+    }
+    return ZK_OK;
+}
+
+zk_status msm_run(zk_msm* M, const uint8_t* scalars, uint32_t flags, uint8_t* out) {
+    if (!M || (!scalars && M->n) || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    ZK_TRY(use_device(M->device));
+    ZK_TRY(check_scalars(scalars, M->n, flags));
+    ZK_TRY(M->scal.ensure(M->n * 32 + 32));
+    if (M->n) HIP_TRY(hipMemcpy(M->scal.p, scalars, M->n * 32, hipMemcpyHostToDevice));
+    return msm_run_dev(M, M->scal.p, flags, out);
+}
+
+zk_status ntt_run_dev(zk_ntt* T, void* d_data, uint32_t batch, uint32_t flags) {
+    if (!T || !d_data) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (batch == 0) return ZK_OK;
+    ZK_TRY(use_device(T->device));
+    NttPlan& pl = T->plan;
+    const bool inverse = flags & ZK_NTT_INVERSE, coset = flags & ZK_NTT_COSET;
+    const bool in_br = flags & ZK_NTT_IN_BITREV, out_br = flags & ZK_NTT_OUT_BITREV;
+    uint32_t* d = (uint32_t*)d_data;
+    const size_t n = pl.n, count = (size_t)batch * n;
+    const unsigned eb = (unsigned)((count + 255) / 256);
+    if (pl.log_n == 0) return ZK_OK;   // size-1 transform is the identity (bellman: exp = 0)
+    // coset_fft scales the (natural-order) input by g^i; icoset_fft scales the (natural-order)
+    // output by g^-i; plain ifft scales by 1/n.
+    const uint32_t* pre = nullptr;
+    const uint32_t* post = nullptr;
+    if (!inverse && coset) {
+        if (in_br) return fail(ZK_ERR_INVALID_ARGUMENT, "coset_fft needs natural-order input");
+        pre = pl.coset_fwd.as<uint32_t>();
+    }
+    if (inverse && coset) {
+        if (out_br) return fail(ZK_ERR_INVALID_ARGUMENT, "icoset_fft produces natural-order output");
+        post = pl.coset_inv.as<uint32_t>();
+    }
+    // DIF: natural -> bit-reversed.  DIT: bit-reversed -> natural.
+    const bool dif = !in_br;
+    bool post_fused = false;
+    if (post && !dif) post_fused = true;   // DIT ends in natural order: fuse the scaling
+    ZK_TRY(pl.chain(d, batch, (uint32_t)n, dif, inverse, pre, post_fused ? post : nullptr));
+    const bool have_br = dif;   // order after the chain
+    if (have_br != out_br) {
+        ZK_TRY(pl.scratch.ensure(count * 32));
+        ZK_LAUNCH(zkdev::k_fr_bitrev, dim3(eb), dim3(256), 0, g_stream, pl.scratch.as<uint32_t>(), d, pl.log_n, count);
+        HIP_TRY(hipMemcpyAsync(d, pl.scratch.p, count * 32, hipMemcpyDeviceToDevice, g_stream));
+    }
+    if (inverse) {
+        if (coset && !post_fused) {
+            ZK_LAUNCH(zkdev::k_fr_scale, dim3(eb), dim3(256), 0, g_stream, d, post, n, count);
+        } else if (!coset) {
+            ZK_LAUNCH(zkdev::k_fr_scale, dim3(eb), dim3(256), 0, g_stream, d, pl.consts.as<uint32_t>(), (size_t)1, count);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return ZK_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* zk_strerror(zk_status st) {
+    switch (st) {
+        case ZK_OK: return "ok";
+        case ZK_ERR_ASSIGNMENT_MISSING: return "an assignment for a variable could not be computed";
+        case ZK_ERR_DIVISION_BY_ZERO: return "division by zero";
+        case ZK_ERR_UNSATISFIABLE: return "unsatisfiable constraint system";
+        case ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE: return "polynomial degree is too large";
+        case ZK_ERR_UNEXPECTED_IDENTITY: return "encountered an identity element in the CRS";
+        case ZK_ERR_IO: return "encountered an I/O error";
+        case ZK_ERR_MALFORMED_VERIFYING_KEY: return "malformed verifying key";
+        case ZK_ERR_UNCONSTRAINED_VARIABLE: return "auxiliary variable was unconstrained";
+        case ZK_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case ZK_ERR_DEVICE: return "HIP runtime error";
+        case ZK_ERR_NO_DEVICE: return "no HIP device";
+        case ZK_ERR_OUT_OF_MEMORY: return "out of memory";
+    }
+    return "unknown status";
+}
+const char* zk_last_error(void) { return g_err.c_str(); }
+
+zk_status zk_device_count(int* count) {
+    if (!count) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return ZK_OK;
+}
+
+zk_status zk_params_load(const uint8_t* pk_bytes, size_t len, int checked, int device, zk_params** out) {
+    if (!pk_bytes || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    return params_load(pk_bytes, len, checked, device, out);
+}
+zk_status zk_params_get_info(const zk_params* p, zk_params_info* info) {
+    if (!p || !info) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    info->n_ic = p->n_ic;
+    info->n_h = p->n_h;
+    info->n_l = p->n_l;
+    info->n_a = p->n_a;
+    info->n_b_g1 = p->n_b1;
+    info->n_b_g2 = p->n_b2;
+    info->log_domain = p->log_m;
+    info->window_bits = p->g1.c;
+    info->n_windows = p->g1.W;
+    info->device = (uint32_t)p->device;
+    info->device_bytes = p->g1.bytes + p->g2.bytes + p->ntt.bytes;
+    return ZK_OK;
+}
+void zk_params_free(zk_params* p) { delete p; }
+
+zk_status zk_prove(zk_params* p, const zk_assignment* asg, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[192]) {
+    if (!r || !s) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    uint8_t rs[64];
+    memcpy(rs, r, 32);
+    memcpy(rs + 32, s, 32);
+    return prove_batch_host(p, 1, asg, rs, proof_out);
+}
+zk_status zk_prove_batch(zk_params* p, size_t n, const zk_assignment* asgs, const uint8_t* rs, uint8_t* proofs_out) {
+    return prove_batch_host(p, n, asgs, rs, proofs_out);
+}
+zk_status zk_prove_batch_dev(zk_params* p, size_t n, const zk_batch_dev* batch, const uint8_t* rs, uint8_t* proofs_out) {
+    return prove_batch_dev(p, n, batch, rs, proofs_out);
+}
+
+zk_status zk_msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
+    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    return msm_create(group, bases, n, window_bits, checked, device, out);
+}
+zk_status zk_msm_run(zk_msm* m, const uint8_t* scalars, uint32_t flags, uint8_t* out) { return msm_run(m, scalars, flags, out); }
+zk_status zk_msm_run_dev(zk_msm* m, const void* d_scalars, uint32_t flags, uint8_t* out) { return msm_run_dev(m, d_scalars, flags, out); }
+void zk_msm_free(zk_msm* m) { delete m; }
+
+static zk_status msm_oneshot(int group, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
+    zk_msm* m = nullptr;
+    int dev = g_device >= 0 ? g_device : 0;
+    zk_status st = zk_msm_create(group, bases, n, 0, 0, dev, &m);
+    if (st != ZK_OK) return st;
+    st = zk_msm_run(m, scalars, 0, out);
+    zk_msm_free(m);
+    return st;
+}
+zk_status zk_msm_g1(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+    return msm_oneshot(1, bases, scalars, n, out);
+}
+zk_status zk_msm_g2(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) {
+    return msm_oneshot(2, bases, scalars, n, out);
+}
+
+zk_status zk_ntt_create(uint32_t log_n, int device, zk_ntt** out) {
+    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    zk_status st = use_device(device);
+    if (st != ZK_OK) return st;
+    zk_ntt* t = new (std::nothrow) zk_ntt();
+    if (!t) return fail(ZK_ERR_OUT_OF_MEMORY, "host allocation failed");
+    t->device = device;
+    st = t->plan.init(log_n);
+    if (st != ZK_OK) {
+        delete t;
+        return st;
+    }
+    *out = t;
+    return ZK_OK;
+}
+zk_status zk_ntt_run_dev(zk_ntt* t, void* d_data, uint32_t batch, uint32_t flags) { return ntt_run_dev(t, d_data, batch, flags); }
+void zk_ntt_free(zk_ntt* t) { delete t; }
+
+zk_status zk_ntt_fr(uint8_t* data, uint32_t log_n, int inverse, int coset) {
+    if (!data) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    size_t n = (size_t)1 << log_n;
+    zk_status st = check_scalars(data, n, 0);
+    if (st != ZK_OK) return st;
+    zk_ntt* t = nullptr;
+    st = zk_ntt_create(log_n, g_device >= 0 ? g_device : 0, &t);
+    if (st != ZK_OK) return st;
+    DevBuf buf;
+    st = buf.ensure(n * 32);
+    if (st == ZK_OK) {
+        const unsigned eb = (unsigned)((n + 255) / 256);
+        if (hipMemcpy(buf.p, data, n * 32, hipMemcpyHostToDevice) != hipSuccess) st = fail(ZK_ERR_DEVICE, "upload failed");
+        if (st == ZK_OK) {
+            ZK_LAUNCH(zkdev::k_fr_convert, dim3(eb), dim3(256), 0, g_stream, buf.as<uint32_t>(), buf.as<uint32_t>(), 0u, n);
+            st = ntt_run_dev(t, buf.p, 1, (inverse ? ZK_NTT_INVERSE : 0u) | (coset ? ZK_NTT_COSET : 0u));
+        }
+        if (st == ZK_OK) {
+            ZK_LAUNCH(zkdev::k_fr_convert, dim3(eb), dim3(256), 0, g_stream, buf.as<uint32_t>(), buf.as<uint32_t>(), 1u, n);
+            if (hipStreamSynchronize(g_stream) != hipSuccess || hipMemcpy(data, buf.p, n * 32, hipMemcpyDeviceToHost) != hipSuccess)
+                st = fail(ZK_ERR_DEVICE, "download failed");
+        }
+    }
+    zk_ntt_free(t);
+    return st;
+}
+
+void zk_profile_begin(void) {
+    zk_profile_end();
+    g_prof = true;
+}
+int zk_profile_get(const char* kernel, double* total_ms) {
+    if (g_stream_init) (void)hipStreamSynchronize(g_stream);
+    int count = 0;
+    double tot = 0;
+    for (auto& r : g_recs)
+        if (!kernel || r.name == kernel) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+                tot += ms;
+                count++;
+            }
+        }
+    if (total_ms) *total_ms = tot;
+    return count;
+}
+void zk_profile_end(void) {
+    if (g_stream_init) (void)hipStreamSynchronize(g_stream);
+    for (auto& r : g_recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_recs.clear();
+    g_prof = false;
+}
+void* zk_stream(void) { return (void*)g_stream; }
+zk_status zk_synchronize(void) {
+    if (g_stream_init) HIP_TRY(hipStreamSynchronize(g_stream));
+    return ZK_OK;
+}
+
+}  // extern "C"
