@@ -164,6 +164,11 @@ zk_status zk_ntt_create(uint32_t log_n, int device, zk_ntt** out);
 zk_status zk_ntt_run_dev(zk_ntt* t, void* d_data, uint32_t batch, uint32_t flags);
 void zk_ntt_free(zk_ntt* t);
 
+/* Raw Montgomery products on the device multiplier (field 0 = Fr: 32-byte limbs, 1 = Fq: 48-byte
+ * limbs; little-endian limb arrays exactly as the reference stores Fr / Fq): out = a*b*R^-1.
+ * Exists so the reference's literal field KATs can be run through the kernels' arithmetic. */
+zk_status zk_debug_field_mul(int field, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py): HIP-event timing of named kernels on the library's
  * stream.  zk_profile_begin() arms it, zk_profile_get() synchronises and reports.

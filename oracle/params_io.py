@@ -45,3 +45,21 @@ def read_proof(data, checked=True):
     if a is None or b is None or c is None:
         raise bls.DecodeError("point at infinity")
     return a, b, c
+
+
+def write_parameters_from_scalars(sc, n_in, threads=8):
+    """Serialise a CRS given only the discrete logs of its elements (`Params.sc` of
+    groth16.generate_parameters(scalars_only=True)); the points are produced by the C port's
+    fixed-base multiplier.  Used to build Transfer-sized synthetic keys in seconds."""
+    from . import cport
+    le = lambda vals: b"".join(bls.fr_le(v) for v in vals)
+    g1 = lambda vals: cport.fixed_base_mul(1, le(vals), threads)
+    g2 = lambda vals: cport.fixed_base_mul(2, le(vals), threads)
+    out = [g1([sc["alpha"], sc["beta"]]), g2([sc["beta"], sc["gamma"]]), g1([sc["delta"]]), g2([sc["delta"]]),
+           struct.pack(">I", len(sc["ic"])), g1(sc["ic"])]
+    for name in ("h", "l", "a", "b"):
+        out.append(struct.pack(">I", len(sc[name])))
+        out.append(g1(sc[name]))
+    out.append(struct.pack(">I", len(sc["b"])))
+    out.append(g2(sc["b"]))
+    return b"".join(out)

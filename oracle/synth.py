@@ -62,3 +62,30 @@ def random_r1cs(seed, n_in, n_aux, n_con, r=bls.R_MOD, bool_frac=0.15):
         lc.append((fix, (va * vb - acc) * pow(z[fix], -1, r) % r))
         cons.append((la, lb, lc))
     return R1CS(n_in, n_aux, cons), inputs, aux
+
+
+class ChainCircuit:
+    """aux_j = A_j(z) * B_j(z) over earlier variables: any choice of inputs has a unique satisfying
+    witness, so a batch of *different* statements of one circuit can be produced (the shape of a
+    real prover batch: one R1CS, many witnesses)."""
+
+    def __init__(self, seed, n_in, n_aux, r=bls.R_MOD):
+        rng = SplitMix64(seed)
+        self.r, self.n_in, self.n_aux = r, n_in, n_aux
+        cons = []
+        for j in range(n_aux):
+            avail = n_in + j
+            pick = lambda ok: [v for v in (rng.below(avail) for _ in range(1 + rng.below(3)))
+                               if v < n_in or ok(v)] or [rng.below(n_in)]
+            la = [(v, rng.below(5) + 1) for v in pick(lambda v: v % 3 != 0)]
+            lb = [(v, rng.below(5) + 1) for v in pick(lambda v: v % 3 != 1)]
+            cons.append((la, lb, [(n_in + j, 1)]))
+        self.r1cs = R1CS(n_in, n_aux, cons)
+
+    def witness(self, seed):
+        rng = SplitMix64(seed)
+        inputs = [1] + [rng.field(self.r) if rng.below(4) else rng.below(2) for _ in range(self.n_in - 1)]
+        z = list(inputs)
+        for la, lb, _ in self.r1cs.constraints:
+            z.append(sum(z[v] * c for v, c in la) % self.r * (sum(z[v] * c for v, c in lb) % self.r) % self.r)
+        return inputs, z[self.n_in:]

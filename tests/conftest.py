@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """TEST-ONLY x86 emulation build of the kernel sources (csrc/gpu_rt.h, tests/emu/)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("zk_build_emu", os.path.join(ROOT, "tests", "emu", "build_emu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    path = mod.build_emu()
+    from zero_chain_amd._lib import ZkLib
+    return ZkLib(path)
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The product library on a real GPU; a missing library or device is a hard failure."""
+    import zero_chain_amd
+    lib = zero_chain_amd.load_library()
+    import ctypes
+    n = ctypes.c_int(0)
+    lib.check(lib.zk_device_count(ctypes.byref(n)))
+    assert n.value > 0, "no HIP device visible: -m gpu tests must run on the GPU box"
+    return lib

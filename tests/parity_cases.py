@@ -1,0 +1,248 @@
+"""Parity checks shared by the CPU (emulated kernels, small sizes) and GPU (real kernels, larger
+sizes) suites.  Every function takes `lib` (a ZkLib over one build of the C ABI) and compares
+the HIP path's bytes with the oracle's on the same seeded inputs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import zero_chain_amd as zk
+from oracle import bls12_381 as bls
+from oracle import cport
+from oracle import groth16 as g
+from oracle import params_io, synth
+import helpers
+
+
+def field_kats(lib):
+    """Reference literal KATs through the device multiplier (fr.rs:1239-1262, fq.rs:2563-2590)."""
+    k = helpers.kats()["kats"]
+    for field, name, n in ((0, "fr", 4), (1, "fq", 6)):
+        mod = bls.R_MOD if field == 0 else bls.Q_MOD
+        R = (1 << (64 * n)) % mod
+        rng = synth.SplitMix64(99 + field)
+        a = [bls.from_limbs64(k[name + "_mul"]["a"]), bls.from_limbs64(k[name + "_sqr"]["a"]), 0, 1, mod - 1]
+        b = [bls.from_limbs64(k[name + "_mul"]["b"]), bls.from_limbs64(k[name + "_sqr"]["a"]), 5, mod - 1, mod - 1]
+        for _ in range(123):
+            a.append(rng.field(mod) if field == 0 else (rng.field(1 << 255) * rng.field(1 << 255)) % mod)
+            b.append(rng.field(mod) if field == 0 else (rng.field(1 << 255) * rng.field(1 << 255)) % mod)
+        sz = 8 * n
+        pack = lambda v: np.frombuffer(b"".join(int(x).to_bytes(sz, "little") for x in v), dtype=np.uint8).copy()
+        A, B = pack(a), pack(b)
+        out = np.zeros_like(A)
+        lib.check(lib.zk_debug_field_mul(field, A.ctypes.data, B.ctypes.data, out.ctypes.data, len(a)))
+        got = [int.from_bytes(out[i * sz:(i + 1) * sz].tobytes(), "little") for i in range(len(a))]
+        Rinv = pow(R, -1, mod)
+        assert got == [x * y * Rinv % mod for x, y in zip(a, b)]
+        assert got[0] == bls.from_limbs64(k[name + "_mul"]["out"])
+        # squaring KAT is stated through from_repr: compare plain values
+        assert got[1] * Rinv % mod == bls.from_limbs64(k[name + "_sqr"]["out"])
+
+
+def ntt_against_oracle(lib, log_sizes, use_c_oracle=False):
+    E = g.Bls12Engine()
+    rng = synth.SplitMix64(3)
+    for logn in log_sizes:
+        n = 1 << logn
+        v = [rng.field(bls.R_MOD) for _ in range(n)]
+        if n > 2:
+            v[1], v[2] = 0, 1
+        om = g.omega_for(E, logn)
+        for inverse, coset in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            d = zk.EvaluationDomain(v, lib=lib)
+            assert d.exp == logn
+            d._run(inverse, coset)
+            if use_c_oracle:
+                want = zk.bytes_to_scalars(cport.fft(helpers.le(v), logn, bool(inverse), bool(coset), 4))
+            else:
+                f = {(0, 0): g.fft, (1, 0): g.ifft, (0, 1): g.coset_fft, (1, 1): g.icoset_fft}[(inverse, coset)]
+                want = f(E, v, om)
+            assert d.into_coeffs() == want, (logn, inverse, coset)
+
+
+def ntt_roundtrip_dev_orders(lib, logn, alloc):
+    """DIF forward leaving bit-reversed output, then inverse coset from bit-reversed input: the
+    permutation-free pair of BASELINE config 3.  icoset(fft(x)) == x * g^-i (coefficient-wise)."""
+    n = 1 << logn
+    rng = synth.SplitMix64(5)
+    v = [rng.field(bls.R_MOD) for _ in range(n)]
+    mont = np.frombuffer(helpers.le([bls.fr_to_mont(x) for x in v]), dtype=np.uint8).copy()
+    dptr, upload, download, free = alloc(mont.size)
+    upload(dptr, mont)
+    t = C.c_void_p()
+    lib.check(lib.zk_ntt_create(logn, 0, C.byref(t)))
+    try:
+        lib.check(lib.zk_ntt_run_dev(t, dptr, 1, zk.ZK_NTT_OUT_BITREV))
+        lib.check(lib.zk_ntt_run_dev(t, dptr, 1, zk.ZK_NTT_INVERSE | zk.ZK_NTT_COSET | zk.ZK_NTT_IN_BITREV))
+        lib.check(lib.zk_synchronize())
+        out = download(dptr, mont.size)
+    finally:
+        lib.zk_ntt_free(t)
+        free(dptr)
+    got = [bls.fr_from_mont(x) for x in zk.bytes_to_scalars(out)]
+    ginv = pow(bls.FR_GENERATOR, -1, bls.R_MOD)
+    idx = [0, 1, 2, n // 2, n - 1] if n > 4 else range(n)
+    for i in idx:
+        assert got[i] == v[i] * pow(ginv, i, bls.R_MOD) % bls.R_MOD, i
+    if n <= 4096:
+        assert got == [x * pow(ginv, i, bls.R_MOD) % bls.R_MOD for i, x in enumerate(v)]
+
+
+def msm_golden_vectors(lib, group, n, window_bits, seed=1):
+    """Bases = the reference's golden multiples k*G (k = 0..255, index 0 is the point at
+    infinity), repeated to length n; sum_i s_i * (k_i G) == (sum_i s_i k_i) G."""
+    name = "g1_uncompressed" if group == 1 else "g2_uncompressed"
+    pts = helpers.golden_points(name)
+    rng = synth.SplitMix64(seed)
+    ks = [rng.below(len(pts)) for _ in range(n)]
+    sc = [rng.field(bls.R_MOD) for _ in range(n)]
+    for i, special in enumerate((0, 1, bls.R_MOD - 1, 2, 1)):
+        if i < n:
+            sc[i] = special
+    if n > 8:
+        ks[7], sc[7] = ks[6], sc[6]        # same base, same scalar: forces the doubling branch
+        ks[8] = 0                          # a base at infinity
+    bases = b"".join(pts[k] for k in ks)
+    ctx = zk.MultiexpContext(group, bases, window_bits=window_bits, checked=(n <= 64), lib=lib)
+    try:
+        got = ctx.run(sc)
+        want = sum(a * b for a, b in zip(ks, sc)) % bls.R_MOD
+        assert got == (helpers.g1_of(want) if group == 1 else helpers.g2_of(want))
+        # Montgomery-form scalars give the same answer
+        got_m = ctx.run(np.frombuffer(helpers.le([bls.fr_to_mont(x) for x in sc]), dtype=np.uint8), montgomery=True)
+        assert got_m == got
+        # all-zero scalars -> infinity
+        assert ctx.run([0] * n)[0] == 0x40 or n == 0
+    finally:
+        ctx.close()
+
+
+def msm_edge_cases(lib):
+    for group, size in ((1, 96), (2, 192)):
+        ctx = zk.MultiexpContext(group, b"", lib=lib)
+        assert ctx.run([]) == bytes([0x40]) + bytes(size - 1)
+        ctx.close()
+        one = helpers.golden_points("g1_uncompressed" if group == 1 else "g2_uncompressed")[1]
+        ctx = zk.MultiexpContext(group, one, lib=lib)
+        assert ctx.run([1]) == one
+        assert ctx.run([bls.R_MOD - 1]) == (helpers.g1_of(-1) if group == 1 else helpers.g2_of(-1))
+        with pytest.raises(zk.ZkError) as e:
+            ctx.run(np.frombuffer(int(bls.R_MOD).to_bytes(32, "little"), dtype=np.uint8))
+        assert e.value.variant == "InvalidArgument"
+        ctx.close()
+    with pytest.raises(zk.ZkError) as e:
+        zk.MultiexpContext(1, bytes([0x80]) + bytes(95), lib=lib)
+    assert e.value.variant == "IoError"
+
+
+def prover_small(lib, seed, n_in, n_aux, n_con, checked=True, montgomery=False):
+    r1, asg, P, pk = helpers.small_case(seed, n_in, n_aux, n_con)
+    params = zk.Parameters.read(pk, checked=checked, lib=lib)
+    try:
+        assert params.write() == pk
+        info = params.info
+        assert (info["n_ic"], info["n_l"]) == (n_in, n_aux) and info["n_h"] + 1 == 1 << info["log_domain"]
+        r, s = 0x1234567890abcdef1234567890abcdef, 0xfedcba0987654321fedcba0987654321
+        proof = zk.create_proof(helpers.to_assignment(zk, asg, montgomery), params, r, s)
+        assert proof.write() == helpers.expected_proof_trapdoor(P, asg, r, s)
+        # create_random_proof draws r then s from the rng exactly like the reference
+        seed4 = [0x5dbe6259, 0x8d313d76, 0x3237db17, 0xe5bc0654]
+        proof2 = zk.create_random_proof(helpers.to_assignment(zk, asg), params, zk.XorShiftRng(seed4))
+        rng = bls.XorShiftRng(seed4)
+        r2 = bls.fr_rand(rng)
+        s2 = bls.fr_rand(rng)
+        assert proof2.write() == helpers.expected_proof_trapdoor(P, asg, r2, s2)
+        assert zk.Proof.read(proof2.write()) == proof2
+    finally:
+        params.close()
+
+
+def prover_batch(lib, seed, n_in, n_aux, n_proofs, use_c_oracle=True):
+    """One circuit, n different statements / witnesses / (r, s)."""
+    E = g.Bls12Engine()
+    circ = synth.ChainCircuit(seed, n_in, n_aux)
+    P = g.generate_parameters(E, circ.r1cs, *helpers.TOXIC, scalars_only=True)
+    pk = params_io.write_parameters_from_scalars(P.sc, n_in, threads=4)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    try:
+        asgs, rs = [], []
+        rng = synth.SplitMix64(seed + 1000)
+        for i in range(n_proofs):
+            inputs, aux = circ.witness(seed * 100 + i)
+            asg = g.assign(E, circ.r1cs, inputs, aux)
+            assert g.is_satisfied(E, asg)
+            asgs.append(asg)
+            rs.append((rng.field(bls.R_MOD), rng.field(bls.R_MOD)))
+        proofs = zk.create_proofs([helpers.to_assignment(zk, a) for a in asgs], params, rs)
+        for asg, (r, s), proof in zip(asgs, rs, proofs):
+            assert proof.write() == helpers.expected_proof_trapdoor(P, asg, r, s)
+        if use_c_oracle:
+            cp = cport.Params(pk)
+            a = asgs[-1]
+            want = cp.create_proof(helpers.le(a.a), helpers.le(a.b), helpers.le(a.c), helpers.le(a.inputs),
+                                   helpers.le(a.aux), bytes(a.a_aux_density), bytes(a.b_input_density),
+                                   bytes(a.b_aux_density), bls.fr_le(rs[-1][0]), bls.fr_le(rs[-1][1]), 2)
+            assert proofs[-1].write() == want
+        # the proof of statement 0 verifies under the key (3 pairings, oracle verifier)
+        Pfull = g.generate_parameters(E, circ.r1cs, *helpers.TOXIC) if n_aux <= 16 else None
+        if Pfull is not None:
+            pvk = g.prepare_verifying_key(E, Pfull)
+            pr = params_io.read_proof(proofs[0].write())
+            assert g.verify_proof(E, pvk, pr, asgs[0].inputs[1:])
+    finally:
+        params.close()
+
+
+def prover_errors(lib):
+    r1, asg, P, pk = helpers.small_case(2, 2, 6, 7)
+    for cut in (10, 96 * 2 + 7, len(pk) - 1):
+        with pytest.raises(zk.ZkError) as e:
+            zk.Parameters.read(pk[:cut], checked=False, lib=lib)
+        assert e.value.variant == "IoError"
+    # a point that is not on the curve is only caught in checked mode (bellman: into_affine vs _unchecked)
+    bad = bytearray(pk)
+    off_h0 = 864 + 4 + 96 * 2 + 4      # vk (864) | n_ic | ic[2] | n_h | h[0]
+    bad[off_h0 + 95] ^= 1
+    with pytest.raises(zk.ZkError) as e:
+        zk.Parameters.read(bytes(bad), checked=True, lib=lib)
+    assert e.value.variant == "IoError" and "curve" in str(e.value)
+    zk.Parameters.read(bytes(bad), checked=False, lib=lib).close()
+    # infinity is rejected in both modes
+    inf = bytearray(pk)
+    inf[off_h0:off_h0 + 96] = bytes([0x40]) + bytes(95)
+    with pytest.raises(zk.ZkError) as e:
+        zk.Parameters.read(bytes(inf), checked=False, lib=lib)
+    assert e.value.variant == "IoError"
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    try:
+        pa = helpers.to_assignment(zk, asg)
+        with pytest.raises(zk.ZkError) as e:
+            zk.create_proof(pa, params, bls.R_MOD, 1)
+        assert e.value.variant == "InvalidArgument"
+        big = zk.ProvingAssignment.from_ints(asg.a * 4, asg.b * 4, asg.c * 4, asg.inputs, asg.aux, asg.a_aux_density,
+                                             asg.b_input_density, asg.b_aux_density)
+        with pytest.raises(zk.ZkError) as e:
+            zk.create_proof(big, params, 1, 1)
+        assert e.value.variant == "PolynomialDegreeTooLarge"
+        wrong_in = zk.ProvingAssignment.from_ints(asg.a, asg.b, asg.c, asg.inputs + [5], asg.aux, asg.a_aux_density,
+                                                  asg.b_input_density + [False], asg.b_aux_density)
+        with pytest.raises(zk.ZkError) as e:
+            zk.create_proof(wrong_in, params, 1, 1)
+        assert e.value.variant == "MalformedVerifyingKey"
+        st = pa._struct()
+        st.aux = None
+        out = np.zeros(192, dtype=np.uint8)
+        one = np.frombuffer(bls.fr_le(1), dtype=np.uint8).copy()
+        rc = lib.zk_prove(params._h, C.byref(st), one.ctypes.data, one.ctypes.data, out.ctypes.data)
+        assert rc == 1 and lib.zk_strerror(rc)  # AssignmentMissing
+        # an unsatisfied assignment still yields the reference's (non-verifying) bytes: same algebra
+        unsat = g.Assignment(list(asg.a), list(asg.b), [(x + 1) % bls.R_MOD for x in asg.c], asg.inputs, asg.aux,
+                             asg.a_aux_density, asg.b_input_density, asg.b_aux_density)
+        got = zk.create_proof(helpers.to_assignment(zk, unsat), params, 7, 9).write()
+        want = cport.Params(pk).create_proof(helpers.le(unsat.a), helpers.le(unsat.b), helpers.le(unsat.c),
+                                             helpers.le(unsat.inputs), helpers.le(unsat.aux), bytes(unsat.a_aux_density),
+                                             bytes(unsat.b_input_density), bytes(unsat.b_aux_density), bls.fr_le(7),
+                                             bls.fr_le(9), 1)
+        assert got == want
+    finally:
+        params.close()

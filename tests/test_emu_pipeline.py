@@ -1,0 +1,73 @@
+"""CPU suite: the kernel SOURCES of zero-chain_amd/csrc compiled for x86 (TEST-ONLY emulation,
+csrc/gpu_rt.h) against the oracle.  Exercises the kernels' index math, the sort / accumulate /
+reduce pipeline, the H pipeline and the C-ABI host logic at small sizes.  The product library
+and the GPU itself are covered by the `-m gpu` suite."""
+import numpy as np
+
+import parity_cases as pc
+
+
+def _host_alloc(lib):
+    bufs = {}
+
+    def alloc(nbytes):
+        a = np.zeros(nbytes, dtype=np.uint8)
+        bufs[a.ctypes.data] = a
+
+        def upload(p, src):
+            bufs[p][:] = src
+
+        def download(p, n):
+            return bufs[p][:n].tobytes()
+
+        def free(p):
+            bufs.pop(p, None)
+        return a.ctypes.data, upload, download, free
+    return alloc
+
+
+def test_field_kats(emu_lib):
+    pc.field_kats(emu_lib)
+
+
+def test_ntt_all_four_transforms(emu_lib):
+    pc.ntt_against_oracle(emu_lib, [0, 1, 2, 5, 9, 12])
+
+
+def test_ntt_permutation_free_pair(emu_lib):
+    pc.ntt_roundtrip_dev_orders(emu_lib, 10, _host_alloc(emu_lib))
+
+
+def test_msm_g1_golden(emu_lib):
+    pc.msm_golden_vectors(emu_lib, 1, 300, 5)
+    pc.msm_golden_vectors(emu_lib, 1, 40, 2, seed=2)
+    pc.msm_golden_vectors(emu_lib, 1, 3, 9, seed=3)
+
+
+def test_msm_g2_golden(emu_lib):
+    pc.msm_golden_vectors(emu_lib, 2, 60, 4)
+
+
+def test_msm_edges(emu_lib):
+    pc.msm_edge_cases(emu_lib)
+
+
+def test_prover_small_checked(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
+    pc.prover_small(emu_lib, 1, 3, 10, 12)
+
+
+def test_prover_montgomery_inputs_two_pass_ntt(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "6")
+    pc.prover_small(emu_lib, 7, 4, 300, 330, checked=False, montgomery=True)   # m = 512: two NTT passes
+
+
+def test_prover_batch(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
+    monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "2")
+    pc.prover_batch(emu_lib, 4, 3, 12, 3)
+
+
+def test_prover_errors(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "4")
+    pc.prover_errors(emu_lib)

@@ -1,0 +1,144 @@
+"""GPU suite (`-m gpu`): the product library on a real MI355X, through the C ABI, against the
+oracle.  Small cases are compared byte-for-byte with the Python big-int oracle, large cases with
+the C restatement of bellman's algorithms and through size-independent identities."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import parity_cases as pc
+import helpers
+from oracle import bls12_381 as bls
+from oracle import cport
+from oracle import groth16 as g
+from oracle import params_io, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_alloc():
+    import torch
+    keep = {}
+
+    def alloc(nbytes):
+        t = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+        keep[t.data_ptr()] = t
+
+        def upload(p, src):
+            keep[p].copy_(torch.from_numpy(np.ascontiguousarray(src)))
+
+        def download(p, n):
+            torch.cuda.synchronize()
+            return keep[p][:n].cpu().numpy().tobytes()
+
+        def free(p):
+            keep.pop(p, None)
+        return t.data_ptr(), upload, download, free
+    return alloc
+
+
+def test_field_kats(gpu_lib):
+    pc.field_kats(gpu_lib)
+
+
+def test_ntt_small_sizes_python_oracle(gpu_lib):
+    pc.ntt_against_oracle(gpu_lib, [0, 1, 2, 3, 8, 9, 11, 13])
+
+
+def test_ntt_large_sizes_c_oracle(gpu_lib):
+    pc.ntt_against_oracle(gpu_lib, [15, 16, 17, 20], use_c_oracle=True)
+
+
+def test_ntt_permutation_free_pair_2p20(gpu_lib):
+    pc.ntt_roundtrip_dev_orders(gpu_lib, 12, _torch_alloc())
+    pc.ntt_roundtrip_dev_orders(gpu_lib, 20, _torch_alloc())
+
+
+def test_msm_g1_golden(gpu_lib):
+    pc.msm_golden_vectors(gpu_lib, 1, 300, 5)
+    pc.msm_golden_vectors(gpu_lib, 1, 5000, 0, seed=2)
+    pc.msm_golden_vectors(gpu_lib, 1, 1 << 16, 13, seed=3)
+    pc.msm_golden_vectors(gpu_lib, 1, 33, 16, seed=4)
+
+
+def test_msm_g2_golden(gpu_lib):
+    pc.msm_golden_vectors(gpu_lib, 2, 60, 4)
+    pc.msm_golden_vectors(gpu_lib, 2, 20000, 0, seed=5)
+
+
+def test_msm_edges(gpu_lib):
+    pc.msm_edge_cases(gpu_lib)
+
+
+def test_msm_g1_2p20_identity(gpu_lib):
+    """BASELINE config 2 size.  Bases cycle through the reference's golden multiples, so
+    sum_i s_i (k_i G) must equal (sum_i s_i k_i) G; the heavy base repetition also drives the
+    equal-points (doubling) branch of the bucket accumulation."""
+    pc.msm_golden_vectors(gpu_lib, 1, 1 << 20, 0, seed=6)
+
+
+def test_msm_distinct_bases_vs_bellman_algorithm(gpu_lib):
+    """2^17 distinct random bases and witness-like scalars (12 % zero / one): HIP Pippenger ==
+    the C restatement of bellman's multiexp, byte for byte."""
+    import zero_chain_amd as zk
+    n = 1 << 17
+    rng = synth.SplitMix64(21)
+    ks = [rng.field(bls.R_MOD) for _ in range(n)]
+    bases = cport.fixed_base_mul(1, helpers.le(ks), 8)
+    sc = [rng.below(2) if rng.below(100) < 12 else rng.field(bls.R_MOD) for _ in range(n)]
+    want = cport.Bases(1, bases).multiexp(helpers.le(sc), 8)
+    ctx = zk.MultiexpContext(1, bases, lib=gpu_lib)
+    try:
+        assert ctx.run(sc) == want
+    finally:
+        ctx.close()
+
+
+def test_prover_small(gpu_lib):
+    pc.prover_small(gpu_lib, 1, 3, 10, 12)
+    pc.prover_small(gpu_lib, 7, 4, 300, 330, checked=False, montgomery=True)
+
+
+def test_prover_batch(gpu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "3")
+    pc.prover_batch(gpu_lib, 4, 3, 12, 5)
+    pc.prover_batch(gpu_lib, 9, 5, 700, 7)
+
+
+def test_prover_errors(gpu_lib):
+    pc.prover_errors(gpu_lib)
+
+
+def test_transfer_shaped_proof_bit_exact(gpu_lib):
+    """A circuit with the Transfer circuit's shape (19 974 constraints, 23 inputs, 19 955 aux;
+    core/proofs/src/circuit/confidential_transfer.rs:383-386 -> domain 2^15), synthetic CRS from
+    known toxic waste.  The 192 bytes must equal (1) the proof computed from the discrete logs
+    and (2) the C restatement of bellman's create_proof; checked = true exercises the GPU
+    subgroup check over the whole key."""
+    import zero_chain_amd as zk
+    E = g.Bls12Engine()
+    r1, inputs, aux = synth.random_r1cs(4, 23, 19955, 19974)
+    asg = g.assign(E, r1, inputs, aux)
+    assert g.is_satisfied(E, asg)
+    P = g.generate_parameters(E, r1, *helpers.TOXIC, scalars_only=True)
+    pk = params_io.write_parameters_from_scalars(P.sc, 23, threads=8)
+    params = zk.Parameters.read(pk, checked=True, lib=gpu_lib)
+    try:
+        assert params.info["log_domain"] == 15 and params.info["n_h"] == 32767
+        r, s = 0x0123456789abcdef0123456789abcdef0123456789abcdef, 0x0fedcba9876543210fedcba9876543210fedcba987654321
+        pa = helpers.to_assignment(zk, asg)
+        proof = zk.create_proof(pa, params, r, s).write()
+        assert proof == helpers.expected_proof_trapdoor(P, asg, r, s)
+        want = cport.Params(pk).create_proof(helpers.le(asg.a), helpers.le(asg.b), helpers.le(asg.c),
+                                             helpers.le(asg.inputs), helpers.le(asg.aux), bytes(asg.a_aux_density),
+                                             bytes(asg.b_input_density), bytes(asg.b_aux_density), bls.fr_le(r),
+                                             bls.fr_le(s), 8)
+        assert proof == want
+        # a batch of 6 with distinct (r, s): every proof is still the trapdoor proof
+        rs = [(r + i, s + 7 * i) for i in range(6)]
+        proofs = zk.create_proofs([pa] * 6, params, rs)
+        for (ri, si), pf in zip(rs, proofs):
+            assert pf.write() == helpers.expected_proof_trapdoor(P, asg, ri, si)
+    finally:
+        params.close()

@@ -24,7 +24,8 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 
 __all__ = ["Parameters", "Proof", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
            "multiexp", "MultiexpContext", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
-           "scalars_to_bytes", "bytes_to_scalars", "load_library"]
+           "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
+           "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV"]
 
 FR_MODULUS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
 _FR_R_INV = pow(1 << 256, -1, FR_MODULUS)
@@ -36,8 +37,10 @@ def load_library():
 
 
 def scalars_to_bytes(values):
-    """ints -> n x 32 bytes, plain little-endian (FrRepr::write_le)."""
-    return np.frombuffer(b"".join(int(v % FR_MODULUS).to_bytes(32, "little") for v in values), dtype=np.uint8).copy()
+    """ints in [0, 2^256) -> n x 32 bytes, plain little-endian (FrRepr::write_le).  Values are NOT
+    reduced: a non-canonical scalar reaches the library and is rejected there, as in the reference
+    where FrRepr -> Fr conversion fails for values >= r (fr.rs:276-289)."""
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "little") for v in values), dtype=np.uint8).copy()
 
 
 def bytes_to_scalars(buf):
@@ -294,7 +297,7 @@ class EvaluationDomain:
             m *= 2
             exp += 1
         self.exp = exp
-        self.coeffs = [c % FR_MODULUS for c in coeffs] + [0] * (m - n)
+        self.coeffs = [int(c) for c in coeffs] + [0] * (m - n)
 
     def _run(self, inverse, coset):
         buf = scalars_to_bytes(self.coeffs)

@@ -68,6 +68,7 @@ _PROTOS = {
     "zk_ntt_create": (C.c_int32, [C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_ntt_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "zk_ntt_free": (None, [C.c_void_p]),
+    "zk_debug_field_mul": (C.c_int32, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "zk_profile_begin": (None, []),
     "zk_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
     "zk_profile_end": (None, []),

@@ -1,10 +1,7 @@
-"""Build the native pieces in-tree.
+"""Build the product library in-tree:
 
-  libzkamd.so        gfx950 product library (hipcc --offload-arch=gfx950), the C ABI of
-                     include/zkamd.h.  Cross-compiles without a GPU.
-  tests/emu/libzkamd_emu.so
-                     TEST-ONLY x86 build of the same sources (ZK_EMU, see csrc/gpu_rt.h); loaded
-                     only by the CPU test-suite, never by the product loader.
+  libzkamd.so   gfx950 (hipcc --offload-arch=gfx950), the C ABI of include/zkamd.h.
+                Cross-compiles without a GPU.
 """
 import os
 import subprocess
@@ -15,10 +12,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
-CLANGXX = os.path.join(ROCM, "lib", "llvm", "bin", "clang++")
 
 LIB = os.path.join(HERE, "libzkamd.so")
-EMU_LIB = os.path.join(ROOT, "tests", "emu", "libzkamd_emu.so")
 
 
 def _sources():
@@ -52,20 +47,5 @@ def build_lib(force=False):
     return LIB
 
 
-def build_emu(force=False):
-    deps = _sources() + [os.path.join(ROOT, "tests", "emu", "emu_rt.cpp")]
-    if not force and not _stale(EMU_LIB, deps):
-        return EMU_LIB
-    cxx = CLANGXX if os.path.exists(CLANGXX) else "clang++"
-    _run([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DZK_EMU=1", "-x", "c++",
-          os.path.join(CSRC, "zkamd.cpp"), os.path.join(ROOT, "tests", "emu", "emu_rt.cpp"),
-          "-o", EMU_LIB, "-lpthread"])
-    return EMU_LIB
-
-
 if __name__ == "__main__":
-    force = "--force" in sys.argv
-    if "--emu-only" not in sys.argv:
-        build_lib(force)
-    if "--no-emu" not in sys.argv:
-        build_emu(force)
+    build_lib("--force" in sys.argv)

@@ -144,7 +144,7 @@ ZK_DI Fp<C> dbl(const Fp<C>& a) {
 // Operands and result are passed as N-wide vector values so that the (non-inlined) call keeps
 // them in VGPRs v0..v(2N-1); an aggregate argument would be passed through scratch memory.
 template <class C>
-ZK_MUL_ATTR typename C::vec mul_raw(typename C::vec av, typename C::vec bv) {
+ZK_DI typename C::vec mul_raw_inl(typename C::vec av, typename C::vec bv) {
     constexpr int N = C::N;
     struct { uint32_t l[C::N]; } a, b;
 #pragma unroll
@@ -192,6 +192,12 @@ ZK_MUL_ATTR typename C::vec mul_raw(typename C::vec av, typename C::vec bv) {
 #pragma unroll
     for (int j = 0; j < N; j++) r[j] = bo ? t[j] : s[j];
     return r;
+}
+
+// The out-of-line instance the curve formulas call (see ZK_MUL_ATTR above).
+template <class C>
+ZK_MUL_ATTR typename C::vec mul_raw(typename C::vec av, typename C::vec bv) {
+    return mul_raw_inl<C>(av, bv);
 }
 
 template <class C>

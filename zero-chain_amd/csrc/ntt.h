@@ -198,6 +198,24 @@ k_fr_convert(uint32_t* out, const uint32_t* __restrict__ in, uint32_t from, size
     st_fr(out + i * 8, from ? from_mont(v) : to_mont(v));
 }
 
+// out[i] = a[i] * b[i] as raw Montgomery limbs (a*b*R^-1): lets the tests run the reference's
+// literal field KATs (fr.rs:1239-1340, fq.rs:2562-2672) through the device multiplier.
+template <class C>
+__global__ void __launch_bounds__(64)
+k_field_mul_raw(uint32_t* out, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<C> x, y;
+#pragma unroll
+    for (int j = 0; j < C::N; j++) {
+        x.l[j] = a[(size_t)i * C::N + j];
+        y.l[j] = b[(size_t)i * C::N + j];
+    }
+    Fp<C> z = mul(x, y);
+#pragma unroll
+    for (int j = 0; j < C::N; j++) out[(size_t)i * C::N + j] = z.l[j];
+}
+
 // Per-proof scalar vector for the multiexps: out[p] = [ wit[p][0..nv) | tail[p][0..3) ]
 // (tail = 1, r, s).  Witness scalars are converted out of Montgomery form when `mont` is set.
 __global__ void __launch_bounds__(256)

@@ -1070,6 +1070,31 @@ zk_status zk_ntt_fr(uint8_t* data, uint32_t log_n, int inverse, int coset) {
     return st;
 }
 
+zk_status zk_debug_field_mul(int field, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+    if (!a || !b || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (field != 0 && field != 1) return fail(ZK_ERR_INVALID_ARGUMENT, "field must be 0 (Fr) or 1 (Fq)");
+    zk_status st = use_device(g_device >= 0 ? g_device : 0);
+    if (st != ZK_OK || n == 0) return st;
+    const size_t sz = field ? 48 : 32;
+    DevBuf da, db, dc;
+    ZK_TRY(da.ensure(n * sz));
+    ZK_TRY(db.ensure(n * sz));
+    ZK_TRY(dc.ensure(n * sz));
+    HIP_TRY(hipMemcpy(da.p, a, n * sz, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db.p, b, n * sz, hipMemcpyHostToDevice));
+    dim3 grid((unsigned)((n + 63) / 64));
+    if (field)
+        ZK_LAUNCH(zkdev::k_field_mul_raw<zkdev::FqCfg>, grid, dim3(64), 0, g_stream, dc.as<uint32_t>(), da.as<uint32_t>(),
+                  db.as<uint32_t>(), (uint32_t)n);
+    else
+        ZK_LAUNCH(zkdev::k_field_mul_raw<zkdev::FrCfg>, grid, dim3(64), 0, g_stream, dc.as<uint32_t>(), da.as<uint32_t>(),
+                  db.as<uint32_t>(), (uint32_t)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(out, dc.p, n * sz, hipMemcpyDeviceToHost));
+    return ZK_OK;
+}
+
 void zk_profile_begin(void) {
     zk_profile_end();
     g_prof = true;
