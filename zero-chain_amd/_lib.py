@@ -106,8 +106,17 @@ _lib = None
 
 
 def load():
-    """Open the in-tree gfx950 library (and nothing else)."""
+    """Open the in-tree gfx950 library (and nothing else).
+
+    PyTorch-ROCm ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, SONAME
+    libamdhip64.so.7).  Two HIP runtimes in one process cannot both own the GPU, so torch is
+    imported FIRST: libzkamd.so's DT_NEEDED libamdhip64.so.7 then binds to the runtime torch
+    already loaded, and torch tensors / streams and this library share one device context."""
     global _lib
     if _lib is None:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = ZkLib(LIB_PATH)
     return _lib
