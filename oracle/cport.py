@@ -38,6 +38,9 @@ def lib():
         d.zo_create_proof.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                       C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        d.zo_create_proofs_parallel.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         d.zo_fixed_base_mul.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         _dll = d
     return _dll
@@ -88,6 +91,16 @@ class Params:
         rc = lib().zo_create_proof(self._h, len(a) // 32, _buf(a), _buf(b), _buf(c), len(inputs) // 32, _buf(inputs),
                                    len(aux) // 32, _buf(aux), _buf(bytes(a_aux_d)), _buf(bytes(b_in_d)),
                                    _buf(bytes(b_aux_d)), _buf(r_le), _buf(s_le), threads, out)
+        if rc:
+            raise ValueError("create_proof failed with SynthesisError code %d" % rc)
+        return bytes(out)
+
+    def create_proofs_parallel(self, n, a, b, c, inputs, aux, a_aux_d, b_in_d, b_aux_d, rs, threads):
+        """n single-threaded proofs of one assignment run `threads` at a time; rs = n x 64 bytes."""
+        out = (C.c_uint8 * (192 * n))()
+        rc = lib().zo_create_proofs_parallel(self._h, n, len(a) // 32, _buf(a), _buf(b), _buf(c), len(inputs) // 32,
+                                             _buf(inputs), len(aux) // 32, _buf(aux), _buf(bytes(a_aux_d)),
+                                             _buf(bytes(b_in_d)), _buf(bytes(b_aux_d)), _buf(rs), threads, out)
         if rc:
             raise ValueError("create_proof failed with SynthesisError code %d" % rc)
         return bytes(out)

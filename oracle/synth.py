@@ -69,7 +69,7 @@ class ChainCircuit:
     witness, so a batch of *different* statements of one circuit can be produced (the shape of a
     real prover batch: one R1CS, many witnesses)."""
 
-    def __init__(self, seed, n_in, n_aux, r=bls.R_MOD):
+    def __init__(self, seed, n_in, n_aux, r=bls.R_MOD, extra_rows=0):
         rng = SplitMix64(seed)
         self.r, self.n_in, self.n_aux = r, n_in, n_aux
         cons = []
@@ -80,12 +80,16 @@ class ChainCircuit:
             la = [(v, rng.below(5) + 1) for v in pick(lambda v: v % 3 != 0)]
             lb = [(v, rng.below(5) + 1) for v in pick(lambda v: v % 3 != 1)]
             cons.append((la, lb, [(n_in + j, 1)]))
+        for k in range(extra_rows):   # 1 * aux_j = aux_j : pads the row count without new variables
+            v = n_in + rng.below(n_aux)
+            cons.append(([(0, 1)], [(v, 1)], [(v, 1)]))
+        self.n_chain = n_aux
         self.r1cs = R1CS(n_in, n_aux, cons)
 
     def witness(self, seed):
         rng = SplitMix64(seed)
         inputs = [1] + [rng.field(self.r) if rng.below(4) else rng.below(2) for _ in range(self.n_in - 1)]
         z = list(inputs)
-        for la, lb, _ in self.r1cs.constraints:
+        for la, lb, _ in self.r1cs.constraints[:self.n_chain]:
             z.append(sum(z[v] * c for v, c in la) % self.r * (sum(z[v] * c for v, c in lb) % self.r) % self.r)
         return inputs, z[self.n_in:]

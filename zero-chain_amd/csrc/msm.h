@@ -33,13 +33,62 @@ struct MsmJob {
     uint32_t pair_base;       // first slot of this job in the rank / pair arrays
 };
 
-// Window w of a 256-bit little-endian scalar, c <= 24.
-ZK_DI uint32_t msm_window(const uint32_t* __restrict__ s, uint32_t w, uint32_t c) {
-    uint32_t lo = w * c;
-    uint32_t word = lo >> 5, sh = lo & 31;
-    uint32_t v = s[word] >> sh;
-    if (sh + c > 32 && word + 1 < 8) v |= s[word + 1] << (32 - sh);
-    return v & ((1u << c) - 1);
+constexpr uint32_t MSM_SEG = 64;   // longest run of points one thread accumulates
+
+// (r - 1) / 2 and r as 8 x u32: scalars above the half are replaced by r - s with every digit's
+// sign flipped (s * P == (r - s) * (-P)), which keeps the top window below 2^(c-1) so that the
+// signed recoding never carries out of the last window.
+struct MsmConsts {
+    static constexpr uint32_t R[8] = ZK_FR_P_32;
+};
+
+// Signed-digit decomposition of one scalar.  f(w, magnitude in [1, 2^(c-1)], negative) is called
+// for every non-zero digit.  The scalar's words are consumed in order through a 64-bit shift
+// buffer so that no dynamically indexed register array is needed.
+template <class Fn>
+ZK_DI void msm_digits(const uint32_t* __restrict__ sp, uint32_t c, uint32_t W, Fn&& f) {
+    uint32_t s[8];
+    const uint4* q = reinterpret_cast<const uint4*>(sp);
+    uint4 lo = q[0], hi = q[1];
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w;
+    s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
+    // t = r - s ; neg = (s > (r-1)/2)  <=>  (r - s) < s  <=>  t < s   (s < r assumed)
+    uint32_t t[8], bo = 0, co;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        t[i] = __builtin_subc(MsmConsts::R[i], s[i], bo, &co);
+        bo = co;
+    }
+    uint32_t lt = 0, decided = 0;   // compare t < s from the top word down
+#pragma unroll
+    for (int i = 7; i >= 0; i--) {
+        uint32_t l = (t[i] < s[i]) & ~decided, g = (t[i] > s[i]) & ~decided;
+        lt |= l;
+        decided |= l | g;
+    }
+    uint32_t zero_or = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) zero_or |= s[i];
+    const bool neg = lt && zero_or;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = neg ? t[i] : s[i];
+    const uint32_t nb = 1u << (c - 1), mask = (1u << c) - 1;
+    uint64_t buf = 0;
+    uint32_t nbits = 0, w = 0, carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        buf |= (uint64_t)s[i] << nbits;
+        nbits += 32;
+        while (w < W && (nbits >= c || i == 7)) {
+            uint32_t raw = ((uint32_t)buf & mask) + carry;
+            buf >>= c;
+            nbits = nbits >= c ? nbits - c : 0;
+            carry = raw > nb ? 1u : 0u;
+            uint32_t mag = carry ? (1u << c) - raw : raw;
+            if (mag) f(w, mag, (carry != 0) != neg);
+            w++;
+        }
+    }
 }
 
 // Pass 1: histogram.  Every non-zero signed digit takes a ticket (its rank inside the bucket)
@@ -50,51 +99,65 @@ k_msm_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t W, uint32_t* c
     const MsmJob job = jobs[blockIdx.y];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
+    if (job.map && job.map[i] < 0) return;
     const uint32_t nb = 1u << (c - 1);
     uint32_t* jcnt = cnt + (size_t)blockIdx.y * nb;
     uint32_t* jrank = rank + job.pair_base;
-    bool skip = job.map && job.map[i] < 0;
-    const uint32_t* s = job.scalars + (size_t)i * 8;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t tkt = 0xffffffffu;
-        if (!skip) {
-            uint32_t raw = msm_window(s, w, c) + carry;
-            carry = raw > nb ? 1u : 0u;
-            uint32_t mag = carry ? (1u << c) - raw : raw;
-            if (mag) tkt = atomicAdd(&jcnt[mag - 1], 1u);
-        }
-        jrank[(size_t)w * job.n + i] = tkt;
-    }
+    const uint32_t n = job.n;
+    msm_digits(job.scalars + (size_t)i * 8, c, W, [&](uint32_t w, uint32_t mag, bool) {
+        jrank[(size_t)w * n + i] = atomicAdd(&jcnt[mag - 1], 1u);
+    });
 }
 
-// Pass 2: per-job exclusive scan of the histogram -> first pair slot of every bucket.
-// One workgroup per job; each thread owns a contiguous run of buckets.
+// Pass 2: per-job exclusive scans of the histogram: first pair slot of every bucket, and the
+// bucket's first TASK.  A bucket with k points is cut into ceil(k / MSM_SEG) tasks so that no
+// thread of the accumulation ever walks more than MSM_SEG points, whatever the scalar
+// distribution (boolean witnesses put ~n/2 points into bucket "1"; short top windows
+// concentrate a whole window on a few buckets).  One workgroup per job; each thread owns a
+// contiguous run of buckets and also writes their task descriptors {bucket, segment}.
 __global__ void __launch_bounds__(1024)
-k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ cnt, uint32_t* off) {
+k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ cnt, uint32_t* off,
+           uint32_t* toff, uint32_t* ntasks, uint2* tdesc, const uint32_t* __restrict__ task_base) {
     ZK_SHARED uint32_t part[1024];
+    ZK_SHARED uint32_t tpart[1024];
     const uint32_t nb = 1u << (c - 1);
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint32_t per = (nb + nt - 1) / nt;
     const uint32_t* jcnt = cnt + (size_t)blockIdx.x * nb;
     uint32_t* joff = off + (size_t)blockIdx.x * nb;
+    uint32_t* jtoff = toff + (size_t)blockIdx.x * nb;
     uint32_t b0 = tid * per, b1 = b0 + per < nb ? b0 + per : nb;
-    uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++) sum += jcnt[b];
+    uint32_t sum = 0, tsum = 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        uint32_t k = jcnt[b];
+        sum += k;
+        tsum += (k + MSM_SEG - 1) / MSM_SEG;
+    }
     part[tid] = sum;
+    tpart[tid] = tsum;
     __syncthreads();
-    // Hillis-Steele inclusive scan over the per-thread sums
+    // Hillis-Steele inclusive scans over the per-thread sums
     for (uint32_t d = 1; d < nt; d <<= 1) {
         uint32_t v = tid >= d ? part[tid - d] : 0;
+        uint32_t tv = tid >= d ? tpart[tid - d] : 0;
         __syncthreads();
         part[tid] += v;
+        tpart[tid] += tv;
         __syncthreads();
     }
     uint32_t run = jobs[blockIdx.x].pair_base + (tid ? part[tid - 1] : 0);
+    uint32_t trun = tid ? tpart[tid - 1] : 0;
+    uint2* jdesc = tdesc + task_base[blockIdx.x];
     for (uint32_t b = b0; b < b1; b++) {
+        uint32_t k = jcnt[b];
         joff[b] = run;
-        run += jcnt[b];
+        jtoff[b] = trun;
+        run += k;
+        uint32_t nt_b = (k + MSM_SEG - 1) / MSM_SEG;
+        for (uint32_t sgm = 0; sgm < nt_b; sgm++) jdesc[trun + sgm] = make_uint2(b, sgm);
+        trun += nt_b;
     }
+    if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
 }
 
 // Pass 3: scatter.  pair = (table index << 1) | sign.
@@ -109,41 +172,35 @@ k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t W, const uin
     const uint32_t* jrank = rank + job.pair_base;
     int32_t pos = job.map ? job.map[i] : (int32_t)i;
     if (pos < 0) return;
-    const uint32_t* s = job.scalars + (size_t)i * 8;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < W; w++) {
-        uint32_t raw = msm_window(s, w, c) + carry;
-        carry = raw > nb ? 1u : 0u;
-        uint32_t mag = carry ? (1u << c) - raw : raw;
-        if (mag) {
-            uint32_t tkt = jrank[(size_t)w * job.n + i];
-            uint32_t idx = job.table_base + w * job.n_table + (uint32_t)pos;
-            pairs[joff[mag - 1] + tkt] = (idx << 1) | carry;
-        }
-    }
+    const uint32_t n = job.n, tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
+    msm_digits(job.scalars + (size_t)i * 8, c, W, [&](uint32_t w, uint32_t mag, bool negative) {
+        uint32_t tkt = jrank[(size_t)w * n + i];
+        pairs[joff[mag - 1] + tkt] = ((tbase + w * tstride) << 1) | (negative ? 1u : 0u);
+    });
 }
 
-template <class F>
-ZK_DI Affine<F> ld_affine(const Affine<F>* p) {
-    return *p;
-}
-
-// Pass 4: one thread per bucket (flat over all jobs of the group).
+// Pass 4: one thread per task (= at most MSM_SEG points of one bucket); blockIdx.y = job.
 template <class F>
 __global__ void __launch_bounds__(128)
 k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
                  const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
-                 XYZZ<F>* __restrict__ sums, uint32_t n_buckets) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_buckets) return;
-    uint32_t o = off[b], n = cnt[b];
+                 const uint32_t* __restrict__ ntasks, const uint2* __restrict__ tdesc,
+                 const uint32_t* __restrict__ task_base, XYZZ<F>* __restrict__ tsums, uint32_t nb) {
+    const uint32_t job = blockIdx.y;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntasks[job]) return;
+    const uint32_t tb = task_base[job];
+    uint2 d = tdesc[tb + t];
+    const size_t b = (size_t)job * nb + d.x;
+    uint32_t o = off[b] + d.y * MSM_SEG, n = cnt[b] - d.y * MSM_SEG;
+    if (n > MSM_SEG) n = MSM_SEG;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t k = 0; k < n; k++) {
         uint32_t pr = pairs[o + k];
-        Affine<F> p = ld_affine(table + (pr >> 1));
+        Affine<F> p = table[pr >> 1];
         madd(acc, p, (pr & 1u) != 0);
     }
-    sums[b] = acc;
+    tsums[tb + t] = acc;
 }
 
 // k * a for a small public k (double-and-add, MSB first)
@@ -158,21 +215,28 @@ ZK_DI XYZZ<F> smul_small(const XYZZ<F>& a, uint32_t k) {
 }
 
 // Pass 5: chunked running sum.  Thread t of job j covers buckets [tL, tL+L):
-//   out = sum_k (k+1) * B[tL+k]  +  tL * sum_k B[tL+k]
+//   out = sum_k (k+1) * B[tL+k]  +  tL * sum_k B[tL+k],   B[b] = sum of bucket b's task partials
 template <class F>
 __global__ void __launch_bounds__(64)
-k_msm_reduce(const XYZZ<F>* __restrict__ sums, XYZZ<F>* __restrict__ out, uint32_t nb, uint32_t L) {
+k_msm_reduce(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
+             const uint32_t* __restrict__ task_base, XYZZ<F>* __restrict__ out, uint32_t nb, uint32_t L) {
     const uint32_t T = nb / L;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
-    const XYZZ<F>* B = sums + (size_t)blockIdx.y * nb + (size_t)t * L;
+    const uint32_t job = blockIdx.y;
+    const size_t b0 = (size_t)job * nb + (size_t)t * L;
+    const XYZZ<F>* ts = tsums + task_base[job];
     XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
     for (int k = (int)L - 1; k >= 0; k--) {
-        run = xadd(run, B[k]);
+        uint32_t n = cnt[b0 + k];
+        if (n) {
+            uint32_t o = toff[b0 + k], nt_b = (n + MSM_SEG - 1) / MSM_SEG;
+            for (uint32_t u = 0; u < nt_b; u++) run = xadd(run, ts[o + u]);
+        }
         acc = xadd(acc, run);
     }
     if (t) acc = xadd(acc, smul_small(run, t * L));
-    out[(size_t)blockIdx.y * T + t] = acc;
+    out[(size_t)job * T + t] = acc;
 }
 
 // Pass 6: segmented sum, `fan` inputs -> 1 output; seg_in inputs per job.

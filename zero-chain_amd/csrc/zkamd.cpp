@@ -253,13 +253,28 @@ struct NttPlan {
 // ------------------------------------------------------------------------------------------
 // MSM group: window tables of a set of bases + the bucket pipeline over a list of jobs
 // ------------------------------------------------------------------------------------------
+// Number of c-bit signed windows that cover every scalar after the half-range reduction of
+// msm_digits (s <= (r - 1) / 2 < 2^254): the top window must absorb the incoming carry without
+// producing one.
+uint32_t msm_windows(uint32_t c) {
+    static const uint64_t R[4] = ZK_FR_P_64;
+    uint64_t half[4];
+    for (int i = 0; i < 4; i++) half[i] = (R[i] >> 1) | (i < 3 ? R[i + 1] << 63 : 0);   // (r - 1) / 2, r odd
+    uint32_t W = (254 + c - 1) / c;
+    uint32_t sh = (W - 1) * c;
+    uint64_t top = sh >= 256 ? 0 : half[sh >> 6] >> (sh & 63);
+    if ((sh & 63) && (sh >> 6) + 1 < 4) top |= half[(sh >> 6) + 1] << (64 - (sh & 63));
+    if (top + 1 > ((uint64_t)1 << (c - 1))) W++;
+    return W;
+}
+
 uint32_t pick_window(size_t n) {
     const char* env = getenv("ZKAMD_WINDOW_BITS");
     if (env && atoi(env) >= 2 && atoi(env) <= 22) return (uint32_t)atoi(env);
     uint32_t best = 2;
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 20; c++) {
-        uint32_t W = (256 + c - 1) / c;
+        uint32_t W = msm_windows(c);
         double cost = (double)W * (double)(n ? n : 1) + 6.0 * (double)((size_t)1 << (c - 1));
         if (cost < best_cost) {
             best_cost = cost;
@@ -309,12 +324,13 @@ struct MsmGroup {
     uint32_t c = 0, W = 0, nb = 0;
     size_t n_points = 0;
     DevBuf table;
-    DevBuf jobs_d, cnt, off, rank, pairs, sums, part_a, part_b;
+    DevBuf jobs_d, cnt, off, toff, ntasks, tdesc, tbase, rank, pairs, tsums, part_a, part_b;
+    std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
 
     zk_status build(const std::vector<HAffine>& pts, uint32_t c_, bool checked, const char* what) {
         c = c_;
-        W = (256 + c - 1) / c;
+        W = msm_windows(c);
         nb = 1u << (c - 1);
         n_points = pts.size();
         if ((uint64_t)n_points * W >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "window table too large");
@@ -337,27 +353,40 @@ struct MsmGroup {
         const size_t nj = jobs.size();
         out.resize(nj);
         if (!nj) return ZK_OK;
-        uint64_t total = 0;
-        uint32_t max_n = 0;
-        for (auto& j : jobs) {
+        uint64_t total = 0, total_tasks = 0;
+        uint32_t max_n = 0, max_cap = 0;
+        tbase_h.resize(nj);
+        for (size_t k = 0; k < nj; k++) {
+            MsmJob& j = jobs[k];
             j.pair_base = (uint32_t)total;
             total += (uint64_t)j.n * W;
             max_n = std::max(max_n, j.n);
+            // a bucket with k points becomes ceil(k / MSM_SEG) tasks: at most nb + pairs / SEG of them
+            uint64_t cap = (uint64_t)nb + ((uint64_t)j.n * W) / zkdev::MSM_SEG + 1;
+            tbase_h[k] = (uint32_t)total_tasks;
+            total_tasks += cap;
+            max_cap = std::max<uint32_t>(max_cap, (uint32_t)cap);
         }
-        if (total >= (1ull << 32)) return fail(ZK_ERR_INVALID_ARGUMENT, "too many (digit, point) pairs in one launch");
+        if (total >= (1ull << 32) || total_tasks >= (1ull << 32))
+            return fail(ZK_ERR_INVALID_ARGUMENT, "too many (digit, point) pairs in one launch");
         const size_t n_buckets = nj * (size_t)nb;
         if (n_buckets >= (1ull << 32)) return fail(ZK_ERR_INVALID_ARGUMENT, "too many buckets in one launch");
         ZK_TRY(jobs_d.ensure(nj * sizeof(MsmJob)));
         ZK_TRY(cnt.ensure(n_buckets * 4));
         ZK_TRY(off.ensure(n_buckets * 4));
+        ZK_TRY(toff.ensure(n_buckets * 4));
+        ZK_TRY(ntasks.ensure(nj * 4));
+        ZK_TRY(tbase.ensure(nj * 4));
+        ZK_TRY(tdesc.ensure((size_t)total_tasks * 8));
+        ZK_TRY(tsums.ensure((size_t)total_tasks * sizeof(DPoint)));
         ZK_TRY(rank.ensure((size_t)(total ? total : 1) * 4));
         ZK_TRY(pairs.ensure((size_t)(total ? total : 1) * 4));
-        ZK_TRY(sums.ensure(n_buckets * sizeof(DPoint)));
         const uint32_t L = nb < 64 ? nb : 64;
         const uint32_t T = nb / L;
         ZK_TRY(part_a.ensure(nj * (size_t)T * sizeof(DPoint)));
         ZK_TRY(part_b.ensure(nj * (size_t)((T + 7) / 8) * sizeof(DPoint)));
         HIP_TRY(hipMemcpyAsync(jobs_d.p, jobs.data(), nj * sizeof(MsmJob), hipMemcpyHostToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(tbase.p, tbase_h.data(), nj * 4, hipMemcpyHostToDevice, g_stream));
         HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, g_stream));
         const MsmJob* dj = jobs_d.as<MsmJob>();
         dim3 gridn((max_n + 255) / 256, (unsigned)nj);
@@ -368,7 +397,8 @@ struct MsmGroup {
         {
             ProfScope ps("msm_scan");
             ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < 1024 ? (nb < 64 ? 64 : nb) : 1024), 0, g_stream,
-                           dj, c, cnt.as<uint32_t>(), off.as<uint32_t>());
+                           dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(),
+                           tdesc.as<uint2>(), tbase.as<uint32_t>());
         }
         if (max_n) {
             ProfScope ps("msm_scatter");
@@ -377,14 +407,15 @@ struct MsmGroup {
         }
         {
             ProfScope ps(sizeof(DF) > 48 ? "msm_accumulate_g2" : "msm_accumulate_g1");
-            ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((n_buckets + 127) / 128)), dim3(128), 0, g_stream,
+            ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((max_cap + 127) / 128, (unsigned)nj), dim3(128), 0, g_stream,
                       table.as<DAffine>(), pairs.as<uint32_t>(), off.as<uint32_t>(), cnt.as<uint32_t>(),
-                      sums.as<DPoint>(), (uint32_t)n_buckets);
+                      ntasks.as<uint32_t>(), tdesc.as<uint2>(), tbase.as<uint32_t>(), tsums.as<DPoint>(), nb);
         }
         {
             ProfScope ps(sizeof(DF) > 48 ? "msm_reduce_g2" : "msm_reduce_g1");
             ZK_LAUNCH(zkdev::k_msm_reduce<DF>, dim3((T + 63) / 64, (unsigned)nj), dim3(64), 0, g_stream,
-                      sums.as<DPoint>(), part_a.as<DPoint>(), nb, L);
+                      tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(),
+                      part_a.as<DPoint>(), nb, L);
         }
         DPoint* in = part_a.as<DPoint>();
         DPoint* outp = part_b.as<DPoint>();
