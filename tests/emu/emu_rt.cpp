@@ -33,28 +33,35 @@ void emu_launch(emu_dim3 grid, emu_dim3 block, size_t shmem, bool needs_sync, co
     std::vector<unsigned char> dyn(shmem + 64);
     emu_dyn_shared = dyn.data();
     const unsigned nthreads = block.x * block.y * block.z;
-    for (unsigned bz = 0; bz < grid.z; bz++)
-        for (unsigned by = 0; by < grid.y; by++)
-            for (unsigned bx = 0; bx < grid.x; bx++) {
-                if (!needs_sync) {
+    if (!needs_sync) {
+        for (unsigned bz = 0; bz < grid.z; bz++)
+            for (unsigned by = 0; by < grid.y; by++)
+                for (unsigned bx = 0; bx < grid.x; bx++) {
                     blockIdx = emu_dim3(bx, by, bz);
                     for (unsigned t = 0; t < nthreads; t++) {
                         threadIdx = emu_dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                         body();
                     }
-                } else {
-                    g_parties = nthreads;
-                    g_count = 0;
-                    std::vector<std::thread> ths;
-                    ths.reserve(nthreads);
-                    for (unsigned t = 0; t < nthreads; t++)
-                        ths.emplace_back([&, t] {
-                            blockIdx = emu_dim3(bx, by, bz);
-                            threadIdx = emu_dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
-                            body();
-                        });
-                    for (auto& th : ths) th.join();
                 }
-            }
+    } else {
+        // one OS thread per GPU thread for the whole launch; the blocks are walked in lock step
+        // (a barrier between consecutive blocks keeps static __shared__ storage private to a block)
+        g_parties = nthreads;
+        g_count = 0;
+        std::vector<std::thread> ths;
+        ths.reserve(nthreads);
+        for (unsigned t = 0; t < nthreads; t++)
+            ths.emplace_back([&, t] {
+                threadIdx = emu_dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+                for (unsigned bz = 0; bz < grid.z; bz++)
+                    for (unsigned by = 0; by < grid.y; by++)
+                        for (unsigned bx = 0; bx < grid.x; bx++) {
+                            blockIdx = emu_dim3(bx, by, bz);
+                            body();
+                            emu_barrier_wait();
+                        }
+            });
+        for (auto& th : ths) th.join();
+    }
     emu_dyn_shared = nullptr;
 }

@@ -117,6 +117,37 @@ def msm_golden_vectors(lib, group, n, window_bits, seed=1):
         ctx.close()
 
 
+def msm_recoding_stress(lib, windows=range(2, 23)):
+    """Scalars that stress the width-c NAF recoding (carry chains through all-ones runs, the
+    fold at (r - 1) / 2, a carry landing on the top table slice) for every supported width."""
+    pts = helpers.golden_points("g1_uncompressed")
+    R = bls.R_MOD
+    half = (R - 1) // 2
+    sc = [0, 1, 2, 3, R - 1, R - 2, half, half + 1, half - 1, 1 << 253, (1 << 253) - 1, (1 << 254) - 1,
+          (1 << 254) - 3, int("5" * 63, 16), int("a" * 63, 16) % R, int("3" + "f" * 62, 16), (1 << 252) + 1,
+          (1 << 128) - 1, 1 << 128, (1 << 64) - 1, ((1 << 200) - 1) << 53, 0xffffffff, 0xffffffff00000000,
+          half - (1 << 100), half + (1 << 100), (1 << 253) + (1 << 252) + 5, 0x80000000, (1 << 33) - 1]
+    rng = synth.SplitMix64(77)
+    sc += [rng.field(R) for _ in range(12)]
+    ks = [1 + rng.below(len(pts) - 1) for _ in sc]
+    bases = b"".join(pts[k] for k in ks)
+    want = helpers.g1_of(sum(a * b for a, b in zip(ks, sc)) % R)
+    for c in windows:
+        ctx = zk.MultiexpContext(1, bases, window_bits=c, lib=lib)
+        try:
+            assert ctx.run(sc) == want, "window %d" % c
+            # one scalar at a time: isolates a wrong digit of a single recoding
+            if c in (2, 7, 15, 22):
+                for k, x in zip(ks, sc):
+                    one = zk.MultiexpContext(1, pts[k], window_bits=c, lib=lib)
+                    try:
+                        assert one.run([x]) == helpers.g1_of(k * x % R), (c, hex(x))
+                    finally:
+                        one.close()
+        finally:
+            ctx.close()
+
+
 def msm_edge_cases(lib):
     for group, size in ((1, 96), (2, 192)):
         ctx = zk.MultiexpContext(group, b"", lib=lib)

@@ -71,3 +71,7 @@ def test_prover_batch(emu_lib, monkeypatch):
 def test_prover_errors(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "4")
     pc.prover_errors(emu_lib)
+
+
+def test_msm_recoding_all_widths(emu_lib):
+    pc.msm_recoding_stress(emu_lib, windows=range(2, 13))   # wide windows: GPU suite (thread-per-GPU-thread emulation)

@@ -67,6 +67,10 @@ def test_msm_g2_golden(gpu_lib):
     pc.msm_golden_vectors(gpu_lib, 2, 20000, 0, seed=5)
 
 
+def test_msm_recoding_all_widths(gpu_lib):
+    pc.msm_recoding_stress(gpu_lib)
+
+
 def test_msm_edges(gpu_lib):
     pc.msm_edge_cases(gpu_lib)
 

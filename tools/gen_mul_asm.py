@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Generate zero-chain_amd/csrc/mul_asm.h: hand-scheduled gfx950 assembly for the Montgomery
+product of Fr (8 x u32) and Fq (12 x u32).
+
+Why assembly: the product is >90 % of every hot kernel (MSM bucket accumulation / reduction, NTT
+butterflies), the integer multiplier of CDNA4 issues v_mad_u64_u32 at the full 32-bit-op rate,
+and hipcc's code for the C++ CIOS loop spends one v_mov per limb product on building the
+{t, 0} 64-bit addend pair plus s_nops on the carry hazards (871 VALU instructions for Fq).
+The routine below is finely-integrated product scanning (FIPS): every limb product is
+
+    v_mad_u64_u32 ACC, carry, x, y, ACC      ; 64-bit column accumulator, in place
+    v_addc_co_u32 OVF, -, 0, OVF, carry      ; overflow word, issued two slots later
+
+with three rotating SGPR pairs for the carries, so the gfx940/gfx950 "VALU writes SGPR -> VALU
+reads it" hazard (2 wait states, not interlocked) is covered by useful instructions instead of
+s_nop.  The conditional subtraction of p rides along with the upper columns.
+
+Register contract (= the calling convention of the out-of-line `mul_raw<C>` function):
+    a in v[0:N-1], b in v[N:2N-1], result in v[0:N-1]; clobbers v[2N:3N+3], s[0:N+9], vcc.
+
+Reference for the value computed: core/pairing/src/bls12_381/fr.rs:438-571 (mul_assign +
+mont_reduce) and fq.rs:915-1127: a * b * R^-1 mod p, fully reduced.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+FR_P = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+FQ_P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+
+
+class Emitter:
+    """Program-order emission with the one hazard that is not interlocked on gfx950:
+    a VALU that reads an SGPR (pair) needs >= 2 wait states after the VALU that wrote it."""
+
+    def __init__(self):
+        self.lines = []
+        self.slot = 0
+        self.sgpr_written = {}   # sgpr name -> slot index of the writing VALU
+        self.nops = 0
+        self.valu = 0
+
+    def valu_op(self, text, reads=(), writes=()):
+        need = 0
+        for r in reads:
+            if r in self.sgpr_written:
+                gap = self.slot - self.sgpr_written[r] - 1   # wait states already between them
+                need = max(need, 2 - gap)
+        if need > 0:
+            self.lines.append("s_nop %d" % (need - 1))
+            self.slot += need
+            self.nops += need
+        self.lines.append(text)
+        for w in writes:
+            self.sgpr_written[w] = self.slot
+        self.slot += 1
+        self.valu += 1
+        pad = int(os.environ.get("ZK_ASM_PAD_NOPS", "0"))   # debugging aid: s_nop after every VALU
+        if pad:
+            self.lines.append("s_nop %d" % (pad - 1))
+            self.slot += pad
+
+    def salu_op(self, text):
+        self.lines.append(text)
+        self.slot += 1
+
+
+def gen(N, p, name):
+    P = [(p >> (32 * j)) & 0xffffffff for j in range(N)]
+    inv = (-pow(p, -1, 1 << 32)) & 0xffffffff
+    a = lambda i: "v%d" % i
+    b = lambda i: "v%d" % (N + i)
+    m = lambda i: "v%d" % (2 * N + i)
+    pairs = [(3 * N, 3 * N + 1), (3 * N + 2, 3 * N + 3)]
+    sp = lambda j: "s%d" % j
+    sinv = "s%d" % N
+    cb = N + 2 if (N + 2) % 2 == 0 else N + 3
+    carry = ["s[%d:%d]" % (cb + 2 * t, cb + 2 * t + 1) for t in range(3)]
+    dummy = "s[%d:%d]" % (cb + 6, cb + 7)
+    e = Emitter()
+    for j in range(N):
+        e.salu_op("s_mov_b32 %s, 0x%08x" % (sp(j), P[j]))
+    e.salu_op("s_mov_b32 %s, 0x%08x" % (sinv, inv))
+    cur = 0
+    tcount = 0       # running product counter -> carry pair rotation
+    pending = []     # (carry pair, ovf register, fresh) of mads whose addc has not been issued
+    borrow_started = False
+
+    def flush(keep):
+        while len(pending) > keep:
+            c, ovf, fresh = pending.pop(0)
+            src = "0" if fresh else ovf
+            e.valu_op("v_addc_co_u32_e64 %s, %s, 0, %s, %s" % (ovf, dummy, src, c), reads=[c], writes=[dummy])
+
+    for k in range(2 * N - 1):
+        lo, hi = pairs[cur]
+        nlo, nhi = pairs[1 - cur]
+        acc = "v[%d:%d]" % (lo, hi)
+        ovf = "v%d" % nhi
+        prods = [(a(i), b(k - i)) for i in range(N) if 0 <= k - i < N]
+        prods += [(m(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and i < min(k, N) and (k >= N or i < k)]
+        # (for k < N the m[k] * p[0] product is appended after m[k] is known)
+        first_in_col = [True]
+
+        def mad(x, y, addend):
+            nonlocal tcount
+            c = carry[tcount % 3]
+            tcount += 1
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, c, x, y, addend), writes=[c])
+            pending.append((c, ovf, first_in_col[0]))
+            first_in_col[0] = False
+            flush(2)
+
+        for idx, (x, y) in enumerate(prods):
+            mad(x, y, "0" if (k == 0 and idx == 0) else acc)
+        if k < N:
+            e.valu_op("v_mul_lo_u32 %s, v%d, %s" % (m(k), lo, sinv))
+            mad(m(k), sp(0), acc)
+        # column done: the low word is the output limb (k >= N) or zero (k < N)
+        if k >= N:
+            j = k - N
+            # r_j -> v_j ; s_j = r_j - p_j - borrow -> b_j's register (dead since column N-1+j)
+            e.valu_op("v_mov_b32_e32 %s, v%d" % (a(j), lo))
+            e.valu_op("v_mov_b32_e32 %s, 0x%08x" % (m(0), P[j]))
+            if not borrow_started:
+                e.valu_op("v_subrev_co_u32_e32 %s, vcc, %s, %s" % (b(j), m(0), a(j)), writes=["vcc"])
+                borrow_started = True
+            else:
+                e.valu_op("v_subbrev_co_u32_e32 %s, vcc, %s, %s, vcc" % (b(j), m(0), a(j)), reads=["vcc"], writes=["vcc"])
+        e.valu_op("v_mov_b32_e32 v%d, v%d" % (nlo, hi))
+        flush(0)
+        cur ^= 1
+    # top limb: the carry word of the last column (its overflow word is provably zero)
+    lo, hi = pairs[cur]
+    j = N - 1
+    e.valu_op("v_mov_b32_e32 %s, v%d" % (a(j), lo))
+    e.valu_op("v_mov_b32_e32 %s, 0x%08x" % (m(0), P[j]))
+    e.valu_op("v_subbrev_co_u32_e32 %s, vcc, %s, %s, vcc" % (b(j), m(0), a(j)), reads=["vcc"], writes=["vcc"])
+    for j in range(N):
+        # borrow (r < p): keep r, else take r - p
+        e.valu_op("v_cndmask_b32_e32 %s, %s, %s, vcc" % (a(j), b(j), a(j)), reads=["vcc"] if j == 0 else [])
+    clob_v = ["v%d" % i for i in range(2 * N, 3 * N + 4)]
+    clob_s = ["s%d" % i for i in range(0, cb + 8)]
+    return {"name": name, "N": N, "lines": e.lines, "valu": e.valu, "nops": e.nops,
+            "clobbers": clob_v + clob_s + ["vcc"]}
+
+
+def render(spec):
+    body = "\\n\\t".join(spec["lines"])
+    out = []
+    out.append("// %s: %d VALU instructions, %d hazard wait states (s_nop) per product" % (spec["name"], spec["valu"], spec["nops"]))
+    # split the string literal so that no line of the header is absurdly long
+    parts = spec["lines"]
+    out.append("#define ZK_MUL_ASM_%s \\" % spec["name"])
+    for i, l in enumerate(parts):
+        out.append('    "%s\\n\\t" \\' % l)
+    out[-1] = out[-1][:-2]
+    out.append("#define ZK_MUL_ASM_%s_CLOBBERS %s" % (spec["name"], ", ".join('"%s"' % c for c in spec["clobbers"])))
+    return "\n".join(out)
+
+
+def main():
+    specs = [gen(8, FR_P, "FR"), gen(12, FQ_P, "FQ")]
+    hdr = ["// GENERATED by tools/gen_mul_asm.py - do not edit.",
+           "// Hand-scheduled gfx950 Montgomery products (see the generator for the design notes).",
+           "#pragma once", ""]
+    for s in specs:
+        hdr.append(render(s))
+        hdr.append("")
+    path = os.path.join(ROOT, "zero-chain_amd", "csrc", "mul_asm.h")
+    with open(path, "w") as f:
+        f.write("\n".join(hdr))
+    for s in specs:
+        print("%s: N=%d valu=%d nops=%d lines=%d" % (s["name"], s["N"], s["valu"], s["nops"], len(s["lines"])))
+
+
+if __name__ == "__main__":
+    main()

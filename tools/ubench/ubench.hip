@@ -90,7 +90,7 @@ __global__ void k_add32(uint32_t* out, uint32_t seed, int iters) {
 }
 
 // Montgomery product chains: CHAINS independent dependent-chains per thread
-template <class C, int CHAINS, bool INL>
+template <class C, int CHAINS, int INL>
 __global__ void __launch_bounds__(256) k_montmul(uint32_t* out, const uint32_t* in, int iters) {
     Fp<C> x[CHAINS], y;
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(256) k_montmul(uint32_t* out, const uint32_t* 
             if (INL) {
                 typename C::vec av, bv;
                 for (int j = 0; j < C::N; j++) { av[j] = x[c].l[j]; bv[j] = y.l[j]; }
-                typename C::vec r = mul_raw_inl<C>(av, bv);
+                typename C::vec r = INL == 2 ? mul_raw_fips<C>(av, bv) : mul_raw_inl<C>(av, bv);
                 for (int j = 0; j < C::N; j++) x[c].l[j] = r[j];
             } else {
                 x[c] = mul(x[c], y);
@@ -115,6 +115,28 @@ __global__ void __launch_bounds__(256) k_montmul(uint32_t* out, const uint32_t* 
     for (int c = 0; c < CHAINS; c++)
         for (int j = 0; j < C::N; j++) s ^= x[c].l[j];
     out[tid] = s;
+}
+
+// asm product (mul_raw) vs compiler CIOS (mul_raw_inl) vs C++ FIPS on pseudo-random operands < p
+template <class C>
+__global__ void k_check(uint32_t* bad, uint32_t seed) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + tid * 0xBF58476D1CE4E5B9ull + 1;
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+    typename C::vec a, b;
+    for (int j = 0; j < C::N; j++) { a[j] = next(); b[j] = next(); }
+    // edge patterns on some lanes
+    if ((tid & 15) == 1) for (int j = 0; j < C::N; j++) a[j] = 0xffffffffu;
+    if ((tid & 15) == 2) for (int j = 0; j < C::N; j++) { a[j] = 0xffffffffu; b[j] = 0xffffffffu; }
+    if ((tid & 15) == 3) for (int j = 0; j < C::N; j++) a[j] = 0;
+    a[C::N - 1] %= C::P[C::N - 1];   // < p (top limb strictly below the modulus' top limb)
+    b[C::N - 1] %= C::P[C::N - 1];
+    if ((tid & 15) == 4) { for (int j = 0; j < C::N; j++) { a[j] = C::P[j]; b[j] = C::P[j]; } a[0] -= 1; b[0] -= 1; }   // (p-1)^2
+    typename C::vec r0 = mul_raw<C>(a, b), r1 = mul_raw_inl<C>(a, b), r2 = mul_raw_fips<C>(a, b);
+    uint32_t d = 0, d2 = 0;
+    for (int j = 0; j < C::N; j++) { d |= r0[j] ^ r1[j]; d2 |= r2[j] ^ r1[j]; }
+    if (d) atomicAdd(&bad[0], 1u);
+    if (d2) atomicAdd(&bad[1], 1u);
 }
 
 template <class K, class... Args>
@@ -144,6 +166,13 @@ int main() {
     std::vector<uint32_t> h(1024);
     for (int i = 0; i < 1024; i++) h[i] = 0x12345678u * (i + 1) + 0x9e3779b9u;
     CHECK(hipMemcpy(in, h.data(), 4096, hipMemcpyHostToDevice));
+    {
+        uint32_t* bad; CHECK(hipMalloc(&bad, 16)); CHECK(hipMemset(bad, 0, 16));
+        hipLaunchKernelGGL(k_check<FqCfg>, dim3(4096), dim3(256), 0, 0, bad, 11u);
+        hipLaunchKernelGGL(k_check<FrCfg>, dim3(4096), dim3(256), 0, 0, bad + 2, 12u);
+        uint32_t hb[4]; CHECK(hipMemcpy(hb, bad, 16, hipMemcpyDeviceToHost));
+        printf("mul check (1M products each): Fq asm mismatches %u, Fq c++fips mismatches %u, Fr asm mismatches %u, Fr c++fips mismatches %u\n", hb[0], hb[1], hb[2], hb[3]);
+    }
     const int iters = 4096;
     const double lanes = (double)blocks * threads;
 #define RATE(name, kern, ilp) { double ms = time_kernel(kern, dim3(blocks), dim3(threads), 5, out, 7u, iters); \
@@ -158,13 +187,18 @@ int main() {
 #define MM(name, kern, chains, wgs) { const int it2 = 256; int nb = cus * wgs; \
     double ms = time_kernel(kern, dim3(nb), dim3(256), 3, out, (const uint32_t*)in, it2); \
     double muls = (double)nb * 256 * it2 * chains; printf("%-36s %8.3f ms  %8.2f Gmul/s\n", name, ms, muls / ms * 1e-6); }
-    MM("Fq mul call, 1 chain, 4 WG/CU", (k_montmul<FqCfg, 1, false>), 1, 4)
-    MM("Fq mul call, 1 chain, 8 WG/CU", (k_montmul<FqCfg, 1, false>), 1, 8)
-    MM("Fq mul call, 2 chains, 4 WG/CU", (k_montmul<FqCfg, 2, false>), 2, 4)
-    MM("Fq mul inline, 1 chain, 4 WG/CU", (k_montmul<FqCfg, 1, true>), 1, 4)
-    MM("Fq mul inline, 1 chain, 8 WG/CU", (k_montmul<FqCfg, 1, true>), 1, 8)
-    MM("Fq mul inline, 2 chains, 8 WG/CU", (k_montmul<FqCfg, 2, true>), 2, 8)
-    MM("Fr mul call, 1 chain, 8 WG/CU", (k_montmul<FrCfg, 1, false>), 1, 8)
-    MM("Fr mul inline, 2 chains, 8 WG/CU", (k_montmul<FrCfg, 2, true>), 2, 8)
+    MM("Fq mul call, 1 chain, 4 WG/CU", (k_montmul<FqCfg, 1, 0>), 1, 4)
+    MM("Fq mul call, 1 chain, 8 WG/CU", (k_montmul<FqCfg, 1, 0>), 1, 8)
+    MM("Fq mul call, 2 chains, 4 WG/CU", (k_montmul<FqCfg, 2, 0>), 2, 4)
+    MM("Fq mul inline, 1 chain, 4 WG/CU", (k_montmul<FqCfg, 1, 1>), 1, 4)
+    MM("Fq mul inline, 1 chain, 8 WG/CU", (k_montmul<FqCfg, 1, 1>), 1, 8)
+    MM("Fq mul inline, 2 chains, 8 WG/CU", (k_montmul<FqCfg, 2, 1>), 2, 8)
+    MM("Fq mul FIPS, 1 chain, 4 WG/CU", (k_montmul<FqCfg, 1, 2>), 1, 4)
+    MM("Fq mul FIPS, 1 chain, 8 WG/CU", (k_montmul<FqCfg, 1, 2>), 1, 8)
+    MM("Fq mul FIPS, 2 chains, 4 WG/CU", (k_montmul<FqCfg, 2, 2>), 2, 4)
+    MM("Fr mul FIPS, 1 chain, 8 WG/CU", (k_montmul<FrCfg, 1, 2>), 1, 8)
+    MM("Fr mul FIPS, 2 chains, 8 WG/CU", (k_montmul<FrCfg, 2, 2>), 2, 8)
+    MM("Fr mul call, 1 chain, 8 WG/CU", (k_montmul<FrCfg, 1, 0>), 1, 8)
+    MM("Fr mul inline, 2 chains, 8 WG/CU", (k_montmul<FrCfg, 2, 1>), 2, 8)
     return 0;
 }

@@ -16,6 +16,9 @@
 #include <stdint.h>
 #include "gpu_rt.h"
 #include "consts.h"
+#ifndef ZK_EMU
+#include "mul_asm.h"
+#endif
 
 namespace zkdev {
 
@@ -194,11 +197,109 @@ ZK_DI typename C::vec mul_raw_inl(typename C::vec av, typename C::vec bv) {
     return r;
 }
 
-// The out-of-line instance the curve formulas call (see ZK_MUL_ATTR above).
-template <class C>
-ZK_MUL_ATTR typename C::vec mul_raw(typename C::vec av, typename C::vec bv) {
-    return mul_raw_inl<C>(av, bv);
+// acc (96 bits: 64-bit pair + overflow word) += a * b.  v_mad_u64_u32 accumulates in place and
+// leaves its carry-out in VCC, v_addc_co_u32 folds it into the overflow word: 2 instructions per
+// limb product and no register shuffling (hipcc's own code for `(u64)a * b + t` spends a v_mov
+// per product on building the {t, 0} addend pair).
+ZK_DI void mac96(uint64_t& acc, uint32_t& ovf, uint32_t a, uint32_t b) {
+#ifndef ZK_EMU
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(ovf)
+        : "v"(a), "v"(b)
+        : "vcc");
+#else
+    unsigned __int128 t = (unsigned __int128)((uint64_t)a * b) + acc;
+    acc = (uint64_t)t;
+    ovf += (uint32_t)(t >> 64);
+#endif
 }
+// same with a wave-uniform multiplier (a modulus limb) held in an SGPR
+ZK_DI void mac96_k(uint64_t& acc, uint32_t& ovf, uint32_t a, uint32_t k) {
+#ifndef ZK_EMU
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(acc), "+v"(ovf)
+        : "v"(a), "s"(k)
+        : "vcc");
+#else
+    mac96(acc, ovf, a, k);
+#endif
+}
+
+// Montgomery product, finely integrated product scanning (FIPS): column k of a*b + m*p is summed
+// into one 96-bit accumulator, m[k] is chosen to clear its low word, the accumulator shifts down
+// one word.  2N^2 limb products, each one mac96.
+template <class C>
+ZK_DI typename C::vec mul_raw_fips(typename C::vec av, typename C::vec bv) {
+    constexpr int N = C::N;
+    uint32_t a[N], b[N], m[N], r[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        a[j] = av[j];
+        b[j] = bv[j];
+    }
+    uint64_t acc = 0;
+    uint32_t ovf = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) mac96(acc, ovf, a[i], b[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) mac96_k(acc, ovf, m[i], C::P[k - i]);
+        m[k] = (uint32_t)acc * C::INV;
+        mac96_k(acc, ovf, m[k], C::P[0]);
+        acc = (acc >> 32) | ((uint64_t)ovf << 32);
+        ovf = 0;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) mac96(acc, ovf, a[i], b[k - i]);
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) mac96_k(acc, ovf, m[i], C::P[k - i]);
+        r[k - N] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)ovf << 32);
+        ovf = 0;
+    }
+    r[N - 1] = (uint32_t)acc;   // a*b + m*p < 2pR: the quotient fits N words
+    uint32_t s[N], bo = 0, co;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        s[j] = __builtin_subc(r[j], C::P[j], bo, &co);
+        bo = co;
+    }
+    typename C::vec o;
+#pragma unroll
+    for (int j = 0; j < N; j++) o[j] = bo ? r[j] : s[j];
+    return o;
+}
+
+// The out-of-line instance the curve formulas call (see ZK_MUL_ATTR above).  On the GPU it is the
+// hand-scheduled assembly of mul_asm.h (tools/gen_mul_asm.py): operands arrive in v[0:N-1] and
+// v[N:2N-1] by the calling convention, the result leaves in v[0:N-1].  ZK_MUL_CXX selects the
+// compiler-generated CIOS loop instead (A/B measurements, and the x86 emulation build).
+template <class C>
+ZK_MUL_ATTR typename C::vec mul_raw(typename C::vec av, typename C::vec bv);
+
+#if defined(ZK_EMU) || defined(ZK_MUL_CXX)
+template <>
+ZK_MUL_ATTR u32x8 mul_raw<FrCfg>(u32x8 av, u32x8 bv) { return mul_raw_inl<FrCfg>(av, bv); }
+template <>
+ZK_MUL_ATTR u32x12 mul_raw<FqCfg>(u32x12 av, u32x12 bv) { return mul_raw_inl<FqCfg>(av, bv); }
+#else
+template <>
+ZK_MUL_ATTR u32x8 mul_raw<FrCfg>(u32x8 av, u32x8 bv) {
+    u32x8 r;
+    // b's registers are reused for r - p: read-write operand
+    asm(ZK_MUL_ASM_FR : "={v[0:7]}"(r), "+{v[8:15]}"(bv) : "{v[0:7]}"(av) : ZK_MUL_ASM_FR_CLOBBERS);
+    return r;
+}
+template <>
+ZK_MUL_ATTR u32x12 mul_raw<FqCfg>(u32x12 av, u32x12 bv) {
+    u32x12 r;
+    asm(ZK_MUL_ASM_FQ : "={v[0:11]}"(r), "+{v[12:23]}"(bv) : "{v[0:11]}"(av) : ZK_MUL_ASM_FQ_CLOBBERS);
+    return r;
+}
+#endif
 
 template <class C>
 ZK_DI Fp<C> mul(const Fp<C>& a, const Fp<C>& b) {

@@ -6,15 +6,19 @@
 // sum per window, c doublings per window fold.  The group element computed is the same; the
 // schedule is rebuilt for a GPU with 288 GB of HBM:
 //
-//   * bases are fixed (the CRS), so every window's multiple 2^(c*w) * P_i is precomputed once
-//     into a [W][n] affine table.  All W windows then share ONE set of 2^(c-1) buckets, the
-//     per-window fold (255 serial doublings) disappears and bucket reduction runs once.
-//   * signed digits d in [-2^(c-1)+1, 2^(c-1)] halve the bucket count (negation is free).
+//   * bases are fixed (the CRS), so EVERY doubling 2^k * P_i, k = 0..254, is precomputed once
+//     into a [255][n] affine table (2.7 GB for the Transfer key, 25.7 GB for 2^20 bases).  No
+//     doubling is ever done at proving time, all digits of a scalar share ONE set of buckets,
+//     and bucket reduction runs once per job.
+//   * with a multiple available at every bit position the scalar is recoded in width-c NAF:
+//     odd signed digits |d| < 2^(c-1) at arbitrary positions, on average one non-zero digit
+//     per c + 1 bits (bellman: one per c bits) over only 2^(c-2) buckets (bellman: 2^c - 1).
 //   * (digit, point) pairs are counting-sorted by bucket (histogram with returned ranks ->
-//     per-job exclusive scan -> scatter); one thread then owns one bucket and streams its
-//     points with XYZZ mixed additions (8M+2S, dev_curve.h).
+//     per-job exclusive scan -> scatter).  A bucket is cut into tasks of <= MSM_SEG points and
+//     the tasks of the whole launch are ordered by length, so the 64 lanes of a wave walk
+//     equally long runs of XYZZ mixed additions (8M+2S, dev_curve.h) with no idle lanes.
 //   * buckets are reduced with chunked running sums: chunk t of length L yields
-//     sum_k (k+1) B_{tL+k} + tL * sum_k B_{tL+k}; chunk results are tree-summed.
+//     sum_k (2(tL+k)+1) B_{tL+k}; chunk results are tree-summed.
 //
 // A "job" is one MSM instance (one query of one proof).  Jobs of a batch that live in the
 // same group share every launch; `MsmJob` carries the per-job pointers.
@@ -25,28 +29,52 @@ namespace zkdev {
 
 struct MsmJob {
     const uint32_t* scalars;  // n x 8 u32, plain (non-Montgomery) little-endian, each < r
-    const int32_t* map;       // n entries: position in the window-0 table slice, or -1 (skip);
+    const int32_t* map;       // n entries: position in the slice-0 table, or -1 (skip);
                               // nullptr = identity
     uint32_t n;               // number of scalars
-    uint32_t table_base;      // index of [w = 0][0] of this job's table inside the group table
-    uint32_t n_table;         // table entries per window slice
+    uint32_t table_base;      // index of [k = 0][0] of this job's bases inside the group table
+    uint32_t n_table;         // table entries per slice
     uint32_t pair_base;       // first slot of this job in the rank / pair arrays
 };
 
-constexpr uint32_t MSM_SEG = 64;   // longest run of points one thread accumulates
+// Register budgets.  hipcc sizes a kernel's VGPR allocation from its launch bounds alone (it will
+// happily take 256 registers and one wave per SIMD); the second __launch_bounds__ argument (minimum
+// waves per SIMD) pins the occupancy the dependent carry chains of the Montgomery product need.
+template <class F> struct MsmOcc;
+#ifndef ZK_OCC_G1_ACC
+#define ZK_OCC_G1_ACC 3
+#endif
+#ifndef ZK_OCC_G1_RED
+#define ZK_OCC_G1_RED 3
+#endif
+#ifndef ZK_OCC_G2_ACC
+#define ZK_OCC_G2_ACC 2
+#endif
+#ifndef ZK_OCC_G2_RED
+#define ZK_OCC_G2_RED 2
+#endif
+template <> struct MsmOcc<Fq> { static constexpr int acc = ZK_OCC_G1_ACC, red = ZK_OCC_G1_RED; };
+template <> struct MsmOcc<Fq2> { static constexpr int acc = ZK_OCC_G2_ACC, red = ZK_OCC_G2_RED; };
 
-// (r - 1) / 2 and r as 8 x u32: scalars above the half are replaced by r - s with every digit's
-// sign flipped (s * P == (r - s) * (-P)), which keeps the top window below 2^(c-1) so that the
-// signed recoding never carries out of the last window.
+constexpr uint32_t MSM_SEG = 64;    // longest run of points one thread accumulates
+constexpr uint32_t MSM_NPOS = 255;  // table slices: 2^k * P for k = 0 .. 254
+constexpr uint32_t MSM_MERGE_INLINE = 2;   // buckets with more task partials than this are merged by k_msm_merge_heavy
+
+// upper bound on the non-zero digits of one scalar: digits are >= c positions apart, 0 .. 254
+__host__ ZK_DI uint32_t msm_max_digits(uint32_t c) { return 254 / c + 2; }
+
 struct MsmConsts {
     static constexpr uint32_t R[8] = ZK_FR_P_32;
 };
 
-// Signed-digit decomposition of one scalar.  f(w, magnitude in [1, 2^(c-1)], negative) is called
-// for every non-zero digit.  The scalar's words are consumed in order through a 64-bit shift
-// buffer so that no dynamically indexed register array is needed.
+// Width-c NAF of one scalar.  f(slot, position, odd magnitude in [1, 2^(c-1)), negative) is
+// called for every non-zero digit, slot = 0, 1, 2 ... in order of increasing position.
+// Scalars above (r - 1) / 2 are replaced by r - s with every sign flipped
+// (s * P == (r - s) * (-P)), so the recoded value is < 2^254 and the last digit sits at a
+// position <= 254.  The words are consumed through a 64-bit shift buffer, so no dynamically
+// indexed register array is needed.
 template <class Fn>
-ZK_DI void msm_digits(const uint32_t* __restrict__ sp, uint32_t c, uint32_t W, Fn&& f) {
+ZK_DI void msm_wnaf(const uint32_t* __restrict__ sp, uint32_t c, Fn&& f) {
     uint32_t s[8];
     const uint4* q = reinterpret_cast<const uint4*>(sp);
     uint4 lo = q[0], hi = q[1];
@@ -69,64 +97,91 @@ ZK_DI void msm_digits(const uint32_t* __restrict__ sp, uint32_t c, uint32_t W, F
     uint32_t zero_or = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) zero_or |= s[i];
-    const bool neg = lt && zero_or;
+    if (!zero_or) return;
+    const bool neg = lt != 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = neg ? t[i] : s[i];
-    const uint32_t nb = 1u << (c - 1), mask = (1u << c) - 1;
+    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
     uint64_t buf = 0;
-    uint32_t nbits = 0, w = 0, carry = 0;
+    uint32_t nbits = 0, pos = 0, carry = 0, slot = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        buf |= (uint64_t)s[i] << nbits;
+        buf |= (uint64_t)s[i] << nbits;   // nbits <= 32 here
         nbits += 32;
-        while (w < W && (nbits >= c || i == 7)) {
-            uint32_t raw = ((uint32_t)buf & mask) + carry;
-            buf >>= c;
-            nbits = nbits >= c ? nbits - c : 0;
-            carry = raw > nb ? 1u : 0u;
-            uint32_t mag = carry ? (1u << c) - raw : raw;
-            if (mag) f(w, mag, (carry != 0) != neg);
-            w++;
+        if (i < 7) {
+            // keep >= 32 bits buffered so that a full window (c <= 22) is always available
+            while (nbits > 32) {
+                uint64_t tt = carry ? ~buf : buf;
+                uint32_t z = tt ? (uint32_t)__builtin_ctzll(tt) : 64u;
+                uint32_t room = nbits - 32;
+                if (z >= room) {   // only zero digits up to the refill point
+                    buf >>= room;
+                    pos += room;
+                    nbits = 32;
+                    break;
+                }
+                buf >>= z;
+                uint32_t val = ((uint32_t)buf & mask) + carry;   // odd
+                carry = val > half ? 1u : 0u;
+                uint32_t mag = carry ? (1u << c) - val : val;
+                f(slot++, pos + z, mag, (carry != 0) != neg);
+                buf >>= c;
+                pos += z + c;
+                nbits -= z + c;
+            }
+        } else {
+            // last word: bits above the buffer are genuine zeros of the scalar
+            while (buf != 0 || carry) {
+                uint64_t tt = carry ? ~buf : buf;
+                uint32_t z = (uint32_t)__builtin_ctzll(tt);   // tt != 0: the top two bits of s are clear
+                buf >>= z;
+                uint32_t val = ((uint32_t)buf & mask) + carry;
+                carry = val > half ? 1u : 0u;
+                uint32_t mag = carry ? (1u << c) - val : val;
+                f(slot++, pos + z, mag, (carry != 0) != neg);
+                buf >>= c;
+                pos += z + c;
+            }
         }
     }
 }
 
-// Pass 1: histogram.  Every non-zero signed digit takes a ticket (its rank inside the bucket)
-// from the bucket counter; the ticket is remembered so that the scatter needs no atomics.
-// rank layout per job: [w][i].
+// Pass 1: histogram.  Every non-zero digit takes a ticket (its rank inside the bucket) from the
+// bucket counter; the ticket is remembered so that the scatter needs no atomics.
+// rank layout per job: [slot][i].  Bucket of an odd magnitude m: m >> 1.
 __global__ void __launch_bounds__(256)
-k_msm_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t W, uint32_t* cnt, uint32_t* rank) {
+k_msm_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* rank) {
     const MsmJob job = jobs[blockIdx.y];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
     if (job.map && job.map[i] < 0) return;
-    const uint32_t nb = 1u << (c - 1);
+    const uint32_t nb = 1u << (c - 2);
     uint32_t* jcnt = cnt + (size_t)blockIdx.y * nb;
     uint32_t* jrank = rank + job.pair_base;
     const uint32_t n = job.n;
-    msm_digits(job.scalars + (size_t)i * 8, c, W, [&](uint32_t w, uint32_t mag, bool) {
-        jrank[(size_t)w * n + i] = atomicAdd(&jcnt[mag - 1], 1u);
+    msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t slot, uint32_t, uint32_t mag, bool) {
+        jrank[(size_t)slot * n + i] = atomicAdd(&jcnt[mag >> 1], 1u);
     });
 }
 
 // Pass 2: per-job exclusive scans of the histogram: first pair slot of every bucket, and the
 // bucket's first TASK.  A bucket with k points is cut into ceil(k / MSM_SEG) tasks so that no
 // thread of the accumulation ever walks more than MSM_SEG points, whatever the scalar
-// distribution (boolean witnesses put ~n/2 points into bucket "1"; short top windows
-// concentrate a whole window on a few buckets).  One workgroup per job; each thread owns a
-// contiguous run of buckets and also writes their task descriptors {bucket, segment}.
+// distribution (boolean witnesses put ~n/2 points into bucket "1").  One workgroup per job;
+// each thread owns a contiguous run of buckets.
 __global__ void __launch_bounds__(1024)
 k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ cnt, uint32_t* off,
-           uint32_t* toff, uint32_t* ntasks, uint2* tdesc, const uint32_t* __restrict__ task_base) {
+           uint32_t* toff, uint32_t* ntasks) {
     ZK_SHARED uint32_t part[1024];
     ZK_SHARED uint32_t tpart[1024];
-    const uint32_t nb = 1u << (c - 1);
+    const uint32_t nb = 1u << (c - 2);
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     const uint32_t per = (nb + nt - 1) / nt;
     const uint32_t* jcnt = cnt + (size_t)blockIdx.x * nb;
     uint32_t* joff = off + (size_t)blockIdx.x * nb;
     uint32_t* jtoff = toff + (size_t)blockIdx.x * nb;
     uint32_t b0 = tid * per, b1 = b0 + per < nb ? b0 + per : nb;
+    if (b0 > nb) b0 = nb;
     uint32_t sum = 0, tsum = 0;
     for (uint32_t b = b0; b < b1; b++) {
         uint32_t k = jcnt[b];
@@ -147,113 +202,246 @@ k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restri
     }
     uint32_t run = jobs[blockIdx.x].pair_base + (tid ? part[tid - 1] : 0);
     uint32_t trun = tid ? tpart[tid - 1] : 0;
-    uint2* jdesc = tdesc + task_base[blockIdx.x];
     for (uint32_t b = b0; b < b1; b++) {
         uint32_t k = jcnt[b];
         joff[b] = run;
         jtoff[b] = trun;
         run += k;
-        uint32_t nt_b = (k + MSM_SEG - 1) / MSM_SEG;
-        for (uint32_t sgm = 0; sgm < nt_b; sgm++) jdesc[trun + sgm] = make_uint2(b, sgm);
-        trun += nt_b;
+        trun += (k + MSM_SEG - 1) / MSM_SEG;
     }
     if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
 }
 
-// Pass 3: scatter.  pair = (table index << 1) | sign.
+// Pass 3: scatter.  pair = (table index << 1) | sign, table index = position * n_table + base.
 __global__ void __launch_bounds__(256)
-k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t W, const uint32_t* __restrict__ off,
+k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off,
               const uint32_t* __restrict__ rank, uint32_t* pairs) {
     const MsmJob job = jobs[blockIdx.y];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
-    const uint32_t nb = 1u << (c - 1);
+    const uint32_t nb = 1u << (c - 2);
     const uint32_t* joff = off + (size_t)blockIdx.y * nb;
     const uint32_t* jrank = rank + job.pair_base;
     int32_t pos = job.map ? job.map[i] : (int32_t)i;
     if (pos < 0) return;
     const uint32_t n = job.n, tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
-    msm_digits(job.scalars + (size_t)i * 8, c, W, [&](uint32_t w, uint32_t mag, bool negative) {
-        uint32_t tkt = jrank[(size_t)w * n + i];
-        pairs[joff[mag - 1] + tkt] = ((tbase + w * tstride) << 1) | (negative ? 1u : 0u);
+    msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t slot, uint32_t bit, uint32_t mag, bool negative) {
+        uint32_t tkt = jrank[(size_t)slot * n + i];
+        pairs[joff[mag >> 1] + tkt] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
     });
 }
 
-// Pass 4: one thread per task (= at most MSM_SEG points of one bucket); blockIdx.y = job.
+// Pass 4a: histogram of task lengths (1 .. MSM_SEG) per job.  One thread per bucket.
+__global__ void __launch_bounds__(256)
+k_msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t* lenhist, uint32_t nb) {
+    ZK_SHARED uint32_t h[MSM_SEG];
+    const uint32_t tid = threadIdx.x, job = blockIdx.y;
+    if (tid < MSM_SEG) h[tid] = 0;
+    __syncthreads();
+    uint32_t b = blockIdx.x * blockDim.x + tid;
+    if (b < nb) {
+        uint32_t k = cnt[(size_t)job * nb + b];
+        uint32_t full = k / MSM_SEG, rem = k % MSM_SEG;
+        if (full) atomicAdd(&h[MSM_SEG - 1], full);
+        if (rem) atomicAdd(&h[rem - 1], 1u);
+    }
+    __syncthreads();
+    if (tid < MSM_SEG && h[tid]) atomicAdd(&lenhist[(size_t)job * MSM_SEG + tid], h[tid]);
+}
+
+// Pass 4b: first slot of every (length, job) class in the launch-wide task order: longest tasks
+// first, jobs in order inside a length class.  One workgroup.
+__global__ void __launch_bounds__(1024)
+k_msm_task_base(const uint32_t* __restrict__ lenhist, uint32_t* base, uint32_t* total, uint32_t nj) {
+    ZK_SHARED uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t E = nj * MSM_SEG;
+    const uint32_t per = (E + nt - 1) / nt;
+    uint32_t e0 = tid * per, e1 = e0 + per < E ? e0 + per : E;
+    if (e0 > E) e0 = E;
+    // entry e = (MSM_SEG - 1 - len_index) * nj + job
+    uint32_t sum = 0;
+    for (uint32_t e = e0; e < e1; e++) sum += lenhist[(size_t)(e % nj) * MSM_SEG + (MSM_SEG - 1 - e / nj)];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < nt; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t e = e0; e < e1; e++) {
+        base[e] = run;
+        run += lenhist[(size_t)(e % nj) * MSM_SEG + (MSM_SEG - 1 - e / nj)];
+    }
+    if (tid == nt - 1) total[0] = part[nt - 1];
+}
+
+// Pass 4c: write the task descriptors {first pair, index of the partial sum, length} in that
+// order.  A workgroup reserves a range per length class with one global atomic, its threads
+// take slots inside the range from LDS counters.
+__global__ void __launch_bounds__(256)
+k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff,
+                 const uint32_t* __restrict__ task_base, const uint32_t* __restrict__ base, uint32_t* cursor,
+                 uint4* sorted, uint32_t* n_heavy, uint32_t* heavy, uint32_t nb, uint32_t nj) {
+    ZK_SHARED uint32_t h[MSM_SEG];
+    ZK_SHARED uint32_t start[MSM_SEG];
+    const uint32_t tid = threadIdx.x, job = blockIdx.y;
+    if (tid < MSM_SEG) h[tid] = 0;
+    __syncthreads();
+    uint32_t b = blockIdx.x * blockDim.x + tid;
+    uint32_t k = 0, full = 0, rem = 0;
+    if (b < nb) {
+        k = cnt[(size_t)job * nb + b];
+        full = k / MSM_SEG;
+        rem = k % MSM_SEG;
+        if (full) atomicAdd(&h[MSM_SEG - 1], full);
+        if (rem) atomicAdd(&h[rem - 1], 1u);
+    }
+    __syncthreads();
+    if (tid < MSM_SEG) {
+        uint32_t n = h[tid];
+        start[tid] = base[(size_t)(MSM_SEG - 1 - tid) * nj + job] + (n ? atomicAdd(&cursor[(size_t)job * MSM_SEG + tid], n) : 0u);
+        h[tid] = 0;
+    }
+    __syncthreads();
+    if (full + (rem ? 1u : 0u) > MSM_MERGE_INLINE) heavy[atomicAdd(n_heavy, 1u)] = job * nb + b;
+    if (k) {
+        const uint32_t o = off[(size_t)job * nb + b], ti = task_base[job] + toff[(size_t)job * nb + b];
+        if (full) {
+            uint32_t at = start[MSM_SEG - 1] + atomicAdd(&h[MSM_SEG - 1], full);
+            for (uint32_t sgm = 0; sgm < full; sgm++) sorted[at + sgm] = make_uint4(o + sgm * MSM_SEG, ti + sgm, MSM_SEG, 0);
+        }
+        if (rem) {
+            uint32_t at = start[rem - 1] + atomicAdd(&h[rem - 1], 1u);
+            sorted[at] = make_uint4(o + full * MSM_SEG, ti + full, rem, 0);
+        }
+    }
+}
+
+// Pass 5: one thread per task (= at most MSM_SEG points of one bucket), tasks in length order.
 template <class F>
-__global__ void __launch_bounds__(128)
+__global__ void __launch_bounds__(128, MsmOcc<F>::acc)
 k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
-                 const uint32_t* __restrict__ off, const uint32_t* __restrict__ cnt,
-                 const uint32_t* __restrict__ ntasks, const uint2* __restrict__ tdesc,
-                 const uint32_t* __restrict__ task_base, XYZZ<F>* __restrict__ tsums, uint32_t nb) {
-    const uint32_t job = blockIdx.y;
+                 const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<F>* __restrict__ tsums) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= ntasks[job]) return;
-    const uint32_t tb = task_base[job];
-    uint2 d = tdesc[tb + t];
-    const size_t b = (size_t)job * nb + d.x;
-    uint32_t o = off[b] + d.y * MSM_SEG, n = cnt[b] - d.y * MSM_SEG;
-    if (n > MSM_SEG) n = MSM_SEG;
+    if (t >= total[0]) return;
+    const uint4 d = sorted[t];
+    const uint32_t o = d.x, n = d.z;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t k = 0; k < n; k++) {
         uint32_t pr = pairs[o + k];
         Affine<F> p = table[pr >> 1];
         madd(acc, p, (pr & 1u) != 0);
     }
-    tsums[tb + t] = acc;
+    tsums[d.y] = acc;
 }
 
-// k * a for a small public k (double-and-add, MSB first)
+// Pass 5b: buckets cut into many tasks.  Scalars are not uniform where it matters: the LAST digit
+// of the recoding sits in whatever is left of the 254 bits above the previous digit, so a few small
+// magnitudes collect a large share of all top digits (and boolean witnesses pile up on magnitude 1).
+// Such a bucket yields hundreds of task partials; summing them inside the (one thread per 16
+// buckets) reduction would leave the whole GPU waiting for one thread.  One workgroup per heavy
+// bucket sums its partials with a strided pass and an LDS tree, and leaves the result in the
+// bucket's first partial.
 template <class F>
-ZK_DI XYZZ<F> smul_small(const XYZZ<F>& a, uint32_t k) {
-    XYZZ<F> r = XYZZ<F>::inf();
-    for (int b = 31; b >= 0; b--) {
-        r = xdbl(r);
-        if ((k >> b) & 1u) r = xadd(r, a);
+__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
+                  const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb) {
+    ZK_SHARED XYZZ<F> sm[64];
+    if (blockIdx.x >= n_heavy[0]) return;
+    const uint32_t gb = heavy[blockIdx.x], tid = threadIdx.x;
+    const uint32_t nt = (cnt[gb] + MSM_SEG - 1) / MSM_SEG;
+    XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t u = tid; u < nt; u += 64) acc = xadd(acc, ts[u]);
+    sm[tid] = acc;
+    __syncthreads();
+    for (uint32_t st = 32; st >= 1; st >>= 1) {
+        if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
+        __syncthreads();
     }
-    return r;
+    if (tid == 0) ts[0] = sm[0];
 }
 
-// Pass 5: chunked running sum.  Thread t of job j covers buckets [tL, tL+L):
-//   out = sum_k (k+1) * B[tL+k]  +  tL * sum_k B[tL+k],   B[b] = sum of bucket b's task partials
+// Pass 6: bucket reduction  sum_j (2j + 1) * B_j  (bucket j holds the odd magnitude 2j + 1) as a
+// tree of running sums.  A node covering M buckets carries
+//     W = sum_b (2 (b - first) + 1) * B_b      (weights relative to the node's first bucket)
+//     S = sum_b B_b
+// With R_k = sum_{k' >= k} B_k' the suffix sums inside a node of L buckets:
+//     level 1:    S = R_0,  W = 2 * sum_{k >= 1} R_k + R_0                       (2 additions / bucket)
+//     level l+1:  children c_0 .. c_{f-1} of M buckets each, R'_k suffix sums of S(c_k):
+//                 S = R'_0,  W = 2M * sum_{k >= 1} R'_k + sum_k W(c_k)           (3 additions / child)
+// No scalar multiplication anywhere (2M is a power of two: doublings), and every kernel below
+// keeps exactly ONE point accumulator in registers: an extended-Jacobian addition with a second
+// live accumulator does not fit 168 VGPRs next to the product routine's 40, and scratch spills
+// inside these loops cost more than the arithmetic (measured: 5x on the batched prover, >100x on
+// a single large job whose few waves cannot hide the spill latency).
+//
+// k_msm_suffix_buckets: R over the buckets (task partials merged on the fly), in bucket order.
 template <class F>
-__global__ void __launch_bounds__(64)
-k_msm_reduce(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
-             const uint32_t* __restrict__ task_base, XYZZ<F>* __restrict__ out, uint32_t nb, uint32_t L) {
+__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_suffix_buckets(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restrict__ cnt,
+                     const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base,
+                     XYZZ<F>* __restrict__ R, uint32_t nb, uint32_t L) {
     const uint32_t T = nb / L;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const uint32_t job = blockIdx.y;
     const size_t b0 = (size_t)job * nb + (size_t)t * L;
     const XYZZ<F>* ts = tsums + task_base[job];
-    XYZZ<F> run = XYZZ<F>::inf(), acc = XYZZ<F>::inf();
+    XYZZ<F> run = XYZZ<F>::inf();
     for (int k = (int)L - 1; k >= 0; k--) {
         uint32_t n = cnt[b0 + k];
         if (n) {
             uint32_t o = toff[b0 + k], nt_b = (n + MSM_SEG - 1) / MSM_SEG;
+            if (nt_b > MSM_MERGE_INLINE) nt_b = 1;   // already summed into the first partial (k_msm_merge_heavy)
             for (uint32_t u = 0; u < nt_b; u++) run = xadd(run, ts[o + u]);
         }
-        acc = xadd(acc, run);
+        R[b0 + k] = run;
     }
-    if (t) acc = xadd(acc, smul_small(run, t * L));
-    out[(size_t)job * T + t] = acc;
 }
 
-// Pass 6: segmented sum, `fan` inputs -> 1 output; seg_in inputs per job.
+// k_msm_suffix: out[k] = sum_{k' >= k, same segment} in[k' * stride]; n elements per job, segments
+// of `seg`, one thread per segment.
 template <class F>
-__global__ void __launch_bounds__(64)
-k_msm_sum(const XYZZ<F>* __restrict__ in, XYZZ<F>* __restrict__ out, uint32_t seg_in, uint32_t fan) {
-    const uint32_t seg_out = (seg_in + fan - 1) / fan;
+__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_suffix(const XYZZ<F>* __restrict__ in, XYZZ<F>* __restrict__ out, uint32_t n, uint32_t seg, uint32_t stride) {
+    const uint32_t ns = (n + seg - 1) / seg;
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= seg_out) return;
-    const XYZZ<F>* p = in + (size_t)blockIdx.y * seg_in;
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t k = u * fan; k < seg_in && k < (u + 1) * fan; k++) acc = xadd(acc, p[k]);
-    out[(size_t)blockIdx.y * seg_out + u] = acc;
+    if (u >= ns) return;
+    const XYZZ<F>* p = in + (size_t)blockIdx.y * n * stride;
+    XYZZ<F>* q = out + (size_t)blockIdx.y * n;
+    const uint32_t c0 = u * seg, c1 = c0 + seg < n ? c0 + seg : n;
+    XYZZ<F> run = XYZZ<F>::inf();
+    for (uint32_t k = c1; k-- > c0;) {
+        run = xadd(run, p[(size_t)k * stride]);
+        q[k] = run;
+    }
+}
+
+// k_msm_segsum: per segment s of `seg` elements
+//     acc = (init ? init[s] : 0) + sum_{first <= k < seg} in[s * seg + k]
+//     out[s] = 2^dbl * acc + (plus_first ? in[s * seg] : 0)
+template <class F>
+__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_segsum(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ init, XYZZ<F>* __restrict__ out, uint32_t n,
+             uint32_t seg, uint32_t first, uint32_t dbl, uint32_t plus_first) {
+    const uint32_t ns = (n + seg - 1) / seg;
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= ns) return;
+    const XYZZ<F>* p = in + (size_t)blockIdx.y * n;
+    const uint32_t c0 = u * seg, c1 = c0 + seg < n ? c0 + seg : n;
+    XYZZ<F> acc = init ? init[(size_t)blockIdx.y * ns + u] : XYZZ<F>::inf();
+    for (uint32_t k = c0 + first; k < c1; k++) acc = xadd(acc, p[k]);
+    for (uint32_t i = 0; i < dbl; i++) acc = xdbl(acc);
+    if (plus_first) acc = xadd(acc, p[c0]);
+    out[(size_t)blockIdx.y * ns + u] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Table construction: table[w][i] = 2^(c*w) * P_i  (affine), plus validity checks.
+// Table construction: table[k][i] = 2^k * P_i  (affine), k < MSM_NPOS, plus validity checks.
 // ---------------------------------------------------------------------------------------------
 ZK_DI Fq inv(const Fq& a) {
     const uint32_t e[12] = ZK_FQ_EXP_QM2_32;
@@ -276,16 +464,13 @@ ZK_DI Affine<F> to_affine(const XYZZ<F>& p) {
 
 template <class F>
 __global__ void __launch_bounds__(128)
-k_msm_build_table(Affine<F>* table, uint32_t n, uint32_t c, uint32_t W) {
+k_msm_build_table(Affine<F>* table, uint32_t n, uint32_t npos) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Affine<F> p = table[i];   // slice 0 was uploaded by the host
-    XYZZ<F> q = XYZZ<F>::from_affine(p);
-    for (uint32_t w = 1; w < W; w++) {
-        for (uint32_t k = 0; k < c; k++) q = xdbl(q);
-        Affine<F> a = to_affine(q);
-        table[(size_t)w * n + i] = a;
-        q = XYZZ<F>::from_affine(a);   // keep zz = zzz = 1: cheaper doublings, bounded growth
+    for (uint32_t k = 1; k < npos; k++) {
+        if (!p.is_inf()) p = to_affine(mdbl(p));   // 2-torsion does not exist in G1 / G2: y != 0
+        table[(size_t)k * n + i] = p;
     }
 }
 

@@ -253,29 +253,17 @@ struct NttPlan {
 // ------------------------------------------------------------------------------------------
 // MSM group: window tables of a set of bases + the bucket pipeline over a list of jobs
 // ------------------------------------------------------------------------------------------
-// Number of c-bit signed windows that cover every scalar after the half-range reduction of
-// msm_digits (s <= (r - 1) / 2 < 2^254): the top window must absorb the incoming carry without
-// producing one.
-uint32_t msm_windows(uint32_t c) {
-    static const uint64_t R[4] = ZK_FR_P_64;
-    uint64_t half[4];
-    for (int i = 0; i < 4; i++) half[i] = (R[i] >> 1) | (i < 3 ? R[i + 1] << 63 : 0);   // (r - 1) / 2, r odd
-    uint32_t W = (254 + c - 1) / c;
-    uint32_t sh = (W - 1) * c;
-    uint64_t top = sh >= 256 ? 0 : half[sh >> 6] >> (sh & 63);
-    if ((sh & 63) && (sh >> 6) + 1 < 4) top |= half[(sh >> 6) + 1] << (64 - (sh & 63));
-    if (top + 1 > ((uint64_t)1 << (c - 1))) W++;
-    return W;
-}
+// Width of the NAF recoding for jobs of about n scalars: minimise (in base-field products)
+//   n * 254 / (c + 1) mixed additions of 10   +   2^(c-2) buckets x ~36 for the running sums.
+constexpr uint32_t MSM_RED_FAN = 16;   // buckets per level-1 node and children per upper node (bucket reduction)
 
 uint32_t pick_window(size_t n) {
     const char* env = getenv("ZKAMD_WINDOW_BITS");
     if (env && atoi(env) >= 2 && atoi(env) <= 22) return (uint32_t)atoi(env);
     uint32_t best = 2;
     double best_cost = 1e300;
-    for (uint32_t c = 2; c <= 20; c++) {
-        uint32_t W = msm_windows(c);
-        double cost = (double)W * (double)(n ? n : 1) + 6.0 * (double)((size_t)1 << (c - 1));
+    for (uint32_t c = 2; c <= 22; c++) {
+        double cost = 10.0 * 254.0 / (c + 1) * (double)(n ? n : 1) + 36.0 * (double)((size_t)1 << (c - 2));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
@@ -321,20 +309,20 @@ struct MsmGroup {
     static_assert(sizeof(HAffine) == sizeof(DAffine), "host/device affine layout");
     static_assert(sizeof(HPoint) == sizeof(DPoint), "host/device point layout");
 
-    uint32_t c = 0, W = 0, nb = 0;
+    uint32_t c = 0, maxd = 0, nb = 0;
     size_t n_points = 0;
     DevBuf table;
-    DevBuf jobs_d, cnt, off, toff, ntasks, tdesc, tbase, rank, pairs, tsums, part_a, part_b;
+    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, tbase, rank, pairs, tsums, red_r, red_w, red_t;
     std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
 
     zk_status build(const std::vector<HAffine>& pts, uint32_t c_, bool checked, const char* what) {
         c = c_;
-        W = msm_windows(c);
-        nb = 1u << (c - 1);
+        maxd = zkdev::msm_max_digits(c);
+        nb = 1u << (c - 2);
         n_points = pts.size();
-        if ((uint64_t)n_points * W >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "window table too large");
-        size_t tb = sizeof(DAffine) * n_points * W;
+        if ((uint64_t)n_points * zkdev::MSM_NPOS >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "doubling table too large");
+        size_t tb = sizeof(DAffine) * n_points * zkdev::MSM_NPOS;
         ZK_TRY(table.ensure(tb ? tb : 1));
         bytes = tb;
         if (!n_points) return ZK_OK;
@@ -342,7 +330,7 @@ struct MsmGroup {
         unsigned blocks = (unsigned)((n_points + 127) / 128);
         if (checked) ZK_TRY((check_points_dev<HF, DF>(table.as<DAffine>(), n_points, what)));
         ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3(blocks), dim3(128), 0, g_stream, table.as<DAffine>(),
-                  (uint32_t)n_points, c, W);
+                  (uint32_t)n_points, zkdev::MSM_NPOS);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(g_stream));
         return ZK_OK;
@@ -354,78 +342,120 @@ struct MsmGroup {
         out.resize(nj);
         if (!nj) return ZK_OK;
         uint64_t total = 0, total_tasks = 0;
-        uint32_t max_n = 0, max_cap = 0;
+        uint32_t max_n = 0;
         tbase_h.resize(nj);
         for (size_t k = 0; k < nj; k++) {
             MsmJob& j = jobs[k];
             j.pair_base = (uint32_t)total;
-            total += (uint64_t)j.n * W;
+            total += (uint64_t)j.n * maxd;
             max_n = std::max(max_n, j.n);
             // a bucket with k points becomes ceil(k / MSM_SEG) tasks: at most nb + pairs / SEG of them
-            uint64_t cap = (uint64_t)nb + ((uint64_t)j.n * W) / zkdev::MSM_SEG + 1;
+            uint64_t cap = (uint64_t)nb + ((uint64_t)j.n * maxd) / zkdev::MSM_SEG + 1;
             tbase_h[k] = (uint32_t)total_tasks;
             total_tasks += cap;
-            max_cap = std::max<uint32_t>(max_cap, (uint32_t)cap);
         }
         if (total >= (1ull << 32) || total_tasks >= (1ull << 32))
             return fail(ZK_ERR_INVALID_ARGUMENT, "too many (digit, point) pairs in one launch");
         const size_t n_buckets = nj * (size_t)nb;
         if (n_buckets >= (1ull << 32)) return fail(ZK_ERR_INVALID_ARGUMENT, "too many buckets in one launch");
+        const size_t n_class = nj * (size_t)zkdev::MSM_SEG;
         ZK_TRY(jobs_d.ensure(nj * sizeof(MsmJob)));
         ZK_TRY(cnt.ensure(n_buckets * 4));
         ZK_TRY(off.ensure(n_buckets * 4));
         ZK_TRY(toff.ensure(n_buckets * 4));
         ZK_TRY(ntasks.ensure(nj * 4));
         ZK_TRY(tbase.ensure(nj * 4));
-        ZK_TRY(tdesc.ensure((size_t)total_tasks * 8));
+        ZK_TRY(hist.ensure((2 * n_class + 2) * 4));     // [length histogram | placement cursors | total | #heavy]
+        const size_t heavy_cap = (size_t)(total / (zkdev::MSM_SEG * zkdev::MSM_MERGE_INLINE)) + 1;
+        ZK_TRY(heavy.ensure(heavy_cap * 4));
+        ZK_TRY(tclass.ensure(n_class * 4));
+        ZK_TRY(sorted.ensure((size_t)total_tasks * sizeof(uint4)));
         ZK_TRY(tsums.ensure((size_t)total_tasks * sizeof(DPoint)));
         ZK_TRY(rank.ensure((size_t)(total ? total : 1) * 4));
         ZK_TRY(pairs.ensure((size_t)(total ? total : 1) * 4));
-        const uint32_t L = nb < 64 ? nb : 64;
+        const uint32_t L = nb < MSM_RED_FAN ? nb : MSM_RED_FAN;
         const uint32_t T = nb / L;
-        ZK_TRY(part_a.ensure(nj * (size_t)T * sizeof(DPoint)));
-        ZK_TRY(part_b.ensure(nj * (size_t)((T + 7) / 8) * sizeof(DPoint)));
+        ZK_TRY(red_r.ensure(nj * ((size_t)nb + 2 * (size_t)T) * sizeof(DPoint)));   // suffix sums: level 1 | two upper-level areas
+        ZK_TRY(red_w.ensure(2 * nj * (size_t)T * sizeof(DPoint)));  // W of the nodes (ping-pong halves)
+        ZK_TRY(red_t.ensure(nj * (size_t)T * sizeof(DPoint)));      // 2M * sum R' of the level being built
         HIP_TRY(hipMemcpyAsync(jobs_d.p, jobs.data(), nj * sizeof(MsmJob), hipMemcpyHostToDevice, g_stream));
         HIP_TRY(hipMemcpyAsync(tbase.p, tbase_h.data(), nj * 4, hipMemcpyHostToDevice, g_stream));
         HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, g_stream));
+        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 2) * 4, g_stream));
+        uint32_t* lenhist = hist.as<uint32_t>();
+        uint32_t* cursor = lenhist + n_class;
+        uint32_t* d_total = cursor + n_class;
+        uint32_t* d_nheavy = d_total + 1;
         const MsmJob* dj = jobs_d.as<MsmJob>();
         dim3 gridn((max_n + 255) / 256, (unsigned)nj);
+        dim3 gridb((nb + 255) / 256, (unsigned)nj);
         if (max_n) {
             ProfScope ps("msm_count");
-            ZK_LAUNCH(zkdev::k_msm_count, gridn, dim3(256), 0, g_stream, dj, c, W, cnt.as<uint32_t>(), rank.as<uint32_t>());
+            ZK_LAUNCH(zkdev::k_msm_count, gridn, dim3(256), 0, g_stream, dj, c, cnt.as<uint32_t>(), rank.as<uint32_t>());
         }
         {
             ProfScope ps("msm_scan");
             ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < 1024 ? (nb < 64 ? 64 : nb) : 1024), 0, g_stream,
-                           dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(),
-                           tdesc.as<uint2>(), tbase.as<uint32_t>());
+                           dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>());
         }
         if (max_n) {
             ProfScope ps("msm_scatter");
-            ZK_LAUNCH(zkdev::k_msm_scatter, gridn, dim3(256), 0, g_stream, dj, c, W, off.as<uint32_t>(),
-                      rank.as<uint32_t>(), pairs.as<uint32_t>());
+            ZK_LAUNCH(zkdev::k_msm_scatter, gridn, dim3(256), 0, g_stream, dj, c, off.as<uint32_t>(), rank.as<uint32_t>(),
+                      pairs.as<uint32_t>());
+        }
+        {
+            ProfScope ps("msm_task_sort");
+            ZK_LAUNCH_SYNC(zkdev::k_msm_task_hist, gridb, dim3(256), 0, g_stream, cnt.as<uint32_t>(), lenhist, nb);
+            ZK_LAUNCH_SYNC(zkdev::k_msm_task_base, dim3(1), dim3(1024), 0, g_stream, lenhist, tclass.as<uint32_t>(), d_total,
+                           (uint32_t)nj);
+            ZK_LAUNCH_SYNC(zkdev::k_msm_task_place, gridb, dim3(256), 0, g_stream, cnt.as<uint32_t>(), off.as<uint32_t>(),
+                           toff.as<uint32_t>(), tbase.as<uint32_t>(), tclass.as<uint32_t>(), cursor, sorted.as<uint4>(), d_nheavy,
+                           heavy.as<uint32_t>(), nb, (uint32_t)nj);
         }
         {
             ProfScope ps(sizeof(DF) > 48 ? "msm_accumulate_g2" : "msm_accumulate_g1");
-            ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((max_cap + 127) / 128, (unsigned)nj), dim3(128), 0, g_stream,
-                      table.as<DAffine>(), pairs.as<uint32_t>(), off.as<uint32_t>(), cnt.as<uint32_t>(),
-                      ntasks.as<uint32_t>(), tdesc.as<uint2>(), tbase.as<uint32_t>(), tsums.as<DPoint>(), nb);
+            ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, g_stream,
+                      table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
         }
+        DPoint* R = red_r.as<DPoint>();
+        DPoint* Wa = red_w.as<DPoint>();
+        DPoint* Wb = Wa + nj * (size_t)T;
+        DPoint* in = Wa;
         {
             ProfScope ps(sizeof(DF) > 48 ? "msm_reduce_g2" : "msm_reduce_g1");
-            ZK_LAUNCH(zkdev::k_msm_reduce<DF>, dim3((T + 63) / 64, (unsigned)nj), dim3(64), 0, g_stream,
-                      tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(),
-                      part_a.as<DPoint>(), nb, L);
-        }
-        DPoint* in = part_a.as<DPoint>();
-        DPoint* outp = part_b.as<DPoint>();
-        uint32_t seg = T;
-        while (seg > 1) {
-            uint32_t seg_out = (seg + 7) / 8;
-            ProfScope ps("msm_sum");
-            ZK_LAUNCH(zkdev::k_msm_sum<DF>, dim3((seg_out + 63) / 64, (unsigned)nj), dim3(64), 0, g_stream, in, outp, seg, 8u);
-            std::swap(in, outp);
-            seg = seg_out;
+            auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
+            ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>, dim3((unsigned)heavy_cap), dim3(64), 0, g_stream,
+                           (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy, (const uint32_t*)cnt.as<uint32_t>(),
+                           (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb);
+            // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
+            ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, g_stream, tsums.as<DPoint>(), cnt.as<uint32_t>(),
+                      toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L);
+            ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, g_stream, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
+                      1u, 1u, 1u);
+            uint32_t n = T, m = L, stride = L;   // n nodes per job of m buckets each; S(node k) = R[k * stride]
+            DPoint* Rcur = R;
+            DPoint* Rnext = R + nj * (size_t)nb;       // upper levels ping-pong between two areas behind level 1
+            DPoint* Rspare = Rnext + nj * (size_t)T;
+            while (n > 1) {
+                const uint32_t fan = MSM_RED_FAN, n_out = (n + fan - 1) / fan;
+                uint32_t log2_2m = 1;
+                while ((1u << (log2_2m - 1)) < m) log2_2m++;
+                // R' = suffix sums of S over the children of a parent
+                ZK_LAUNCH(zkdev::k_msm_suffix<DF>, grid(n_out), dim3(64), 0, g_stream, (const DPoint*)Rcur, Rnext, n, fan, stride);
+                // T = 2M * sum_{k>=1} R'_k ;  W(parent) = T + sum_k W(c_k)
+                ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(n_out), dim3(64), 0, g_stream, (const DPoint*)Rnext, (const DPoint*)nullptr,
+                          red_t.as<DPoint>(), n, fan, 1u, log2_2m, 0u);
+                DPoint* outW = in == Wa ? Wb : Wa;
+                ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(n_out), dim3(64), 0, g_stream, (const DPoint*)in,
+                          (const DPoint*)red_t.as<DPoint>(), outW, n, fan, 0u, 0u, 0u);
+                in = outW;
+                // the parents' S are R'[first child of each parent]
+                Rcur = Rnext;
+                std::swap(Rnext, Rspare);
+                stride = fan;
+                m *= fan;
+                n = n_out;
+            }
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out.data(), in, nj * sizeof(DPoint), hipMemcpyDeviceToHost, g_stream));
@@ -1009,7 +1039,7 @@ zk_status zk_params_get_info(const zk_params* p, zk_params_info* info) {
     info->n_b_g2 = p->n_b2;
     info->log_domain = p->log_m;
     info->window_bits = p->g1.c;
-    info->n_windows = p->g1.W;
+    info->n_windows = zkdev::MSM_NPOS;
     info->device = (uint32_t)p->device;
     info->device_bytes = p->g1.bytes + p->g2.bytes + p->ntt.bytes;
     return ZK_OK;
