@@ -58,7 +58,7 @@ template <> struct MsmOcc<Fq2> { static constexpr int acc = ZK_OCC_G2_ACC, red =
 
 constexpr uint32_t MSM_SEG = 64;    // longest run of points one thread accumulates
 constexpr uint32_t MSM_NPOS = 255;  // table slices: 2^k * P for k = 0 .. 254
-constexpr uint32_t MSM_MERGE_INLINE = 2;   // buckets with more task partials than this are merged by k_msm_merge_heavy
+constexpr uint32_t MSM_MERGE_INLINE = 8;   // buckets with more task partials than this are merged by k_msm_merge_heavy
 
 // upper bound on the non-zero digits of one scalar: digits are >= c positions apart, 0 .. 254
 __host__ ZK_DI uint32_t msm_max_digits(uint32_t c) { return 254 / c + 2; }
@@ -229,6 +229,74 @@ k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __res
         uint32_t tkt = jrank[(size_t)slot * n + i];
         pairs[joff[mag >> 1] + tkt] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
     });
+}
+
+// Passes 1-3 fused for jobs whose bucket histogram fits LDS (every per-proof job): one workgroup
+// per job counts the digits in an LDS histogram, scans it in place (writing cnt / off / toff for
+// the later passes) and scatters the pairs with LDS tickets.  No global atomics, no rank array:
+// the three-kernel path above spends its time on ~10^8 returning global atomics per chunk.
+constexpr uint32_t MSM_SORT_THREADS = 1024;
+__global__ void __launch_bounds__(MSM_SORT_THREADS)
+k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* off, uint32_t* toff,
+               uint32_t* ntasks, uint32_t* pairs) {
+    ZK_DYN_SHARED(uint32_t, h);   // [nb] histogram, then running slot cursors
+    ZK_SHARED uint32_t part[MSM_SORT_THREADS];
+    ZK_SHARED uint32_t tpart[MSM_SORT_THREADS];
+    const MsmJob job = jobs[blockIdx.x];
+    const uint32_t nb = 1u << (c - 2), tid = threadIdx.x, nt = MSM_SORT_THREADS;
+    for (uint32_t b = tid; b < nb; b += nt) h[b] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < job.n; i += nt) {
+        if (job.map && job.map[i] < 0) continue;
+        msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[mag >> 1], 1u); });
+    }
+    __syncthreads();
+    // exclusive scans of the counts (pair slots) and of the task counts; thread t owns buckets [t*per, ..)
+    const uint32_t per = (nb + nt - 1) / nt;
+    uint32_t b0 = tid * per, b1 = b0 + per < nb ? b0 + per : nb;
+    if (b0 > nb) b0 = nb;
+    uint32_t sum = 0, tsum = 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        uint32_t k = h[b];
+        sum += k;
+        tsum += (k + MSM_SEG - 1) / MSM_SEG;
+    }
+    part[tid] = sum;
+    tpart[tid] = tsum;
+    __syncthreads();
+    for (uint32_t d = 1; d < nt; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        uint32_t tv = tid >= d ? tpart[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        tpart[tid] += tv;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0, trun = tid ? tpart[tid - 1] : 0;
+    uint32_t* jcnt = cnt + (size_t)blockIdx.x * nb;
+    uint32_t* joff = off + (size_t)blockIdx.x * nb;
+    uint32_t* jtoff = toff + (size_t)blockIdx.x * nb;
+    for (uint32_t b = b0; b < b1; b++) {
+        uint32_t k = h[b];
+        jcnt[b] = k;
+        joff[b] = job.pair_base + run;
+        jtoff[b] = trun;
+        h[b] = run;   // slot cursor of the bucket, relative to the job's first pair
+        run += k;
+        trun += (k + MSM_SEG - 1) / MSM_SEG;
+    }
+    if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
+    __syncthreads();
+    uint32_t* jpairs = pairs + job.pair_base;
+    for (uint32_t i = tid; i < job.n; i += nt) {
+        int32_t pos = job.map ? job.map[i] : (int32_t)i;
+        if (pos < 0) continue;
+        const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
+        msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
+            uint32_t slot = atomicAdd(&h[mag >> 1], 1u);
+            jpairs[slot] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
+        });
+    }
 }
 
 // Pass 4a: histogram of task lengths (1 .. MSM_SEG) per job.  One thread per bucket.

@@ -29,7 +29,9 @@ using zkdev::NttPass;
 namespace {
 
 thread_local std::string g_err;
-hipStream_t g_stream = nullptr;
+hipStream_t g_stream = nullptr;    // main stream: H pipeline, G1 multiexps, stand-alone entries
+hipStream_t g_stream2 = nullptr;   // side stream: the G2 multiexp of a chunk runs beside the G1 work
+hipEvent_t g_ev_fork = nullptr;
 bool g_stream_init = false;
 int g_device = -1;
 
@@ -58,12 +60,16 @@ zk_status use_device(int device) {
         HIP_TRY(hipSetDevice(device));
         if (g_stream_init) {
             (void)hipStreamDestroy(g_stream);
+            (void)hipStreamDestroy(g_stream2);
+            (void)hipEventDestroy(g_ev_fork);
             g_stream_init = false;
         }
         g_device = device;
     }
     if (!g_stream_init) {
         HIP_TRY(hipStreamCreate(&g_stream));
+        HIP_TRY(hipStreamCreate(&g_stream2));
+        HIP_TRY(hipEventCreate(&g_ev_fork));
         g_stream_init = true;
     }
     return ZK_OK;
@@ -108,17 +114,20 @@ std::vector<ProfRec> g_recs;
 
 struct ProfScope {
     bool on;
-    ProfScope(const char* name) : on(g_prof) {
+    hipStream_t st;
+    size_t idx = 0;
+    ProfScope(const char* name, hipStream_t stream = nullptr) : on(g_prof), st(stream ? stream : g_stream) {
         if (!on) return;
         ProfRec r;
         r.name = name;
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
-        (void)hipEventRecord(r.a, g_stream);
+        (void)hipEventRecord(r.a, st);
+        idx = g_recs.size();
         g_recs.push_back(r);
     }
     ~ProfScope() {
-        if (on) (void)hipEventRecord(g_recs.back().b, g_stream);
+        if (on) (void)hipEventRecord(g_recs[idx].b, st);
     }
 };
 
@@ -253,17 +262,23 @@ struct NttPlan {
 // ------------------------------------------------------------------------------------------
 // MSM group: window tables of a set of bases + the bucket pipeline over a list of jobs
 // ------------------------------------------------------------------------------------------
-// Width of the NAF recoding for jobs of about n scalars: minimise (in base-field products)
-//   n * 254 / (c + 1) mixed additions of 10   +   2^(c-2) buckets x ~36 for the running sums.
 constexpr uint32_t MSM_RED_FAN = 16;   // buckets per level-1 node and children per upper node (bucket reduction)
 
-uint32_t pick_window(size_t n) {
-    const char* env = getenv("ZKAMD_WINDOW_BITS");
+// Width of the NAF recoding for jobs of about n scalars: minimise, in units of one mixed addition,
+//   n * 254 / (c + 1)  (bucket accumulation)  +  beta * 2^(c-2)  (bucket reduction),
+// beta = measured cost of reducing one bucket relative to one mixed addition of the same group
+// (G1: 2-3 full additions of 14 products against a mixed addition of 10, plus the tree above;
+// G2: the same in Fq2, where the full addition no longer fits the register file).  `group` 1 / 2.
+uint32_t pick_window(size_t n, int group) {
+    const char* env = getenv(group == 2 ? "ZKAMD_WINDOW_BITS_G2" : "ZKAMD_WINDOW_BITS_G1");
+    if (!env) env = getenv("ZKAMD_WINDOW_BITS");
     if (env && atoi(env) >= 2 && atoi(env) <= 22) return (uint32_t)atoi(env);
+    const char* benv = getenv(group == 2 ? "ZKAMD_BUCKET_COST_G2" : "ZKAMD_BUCKET_COST_G1");
+    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 16.0 : 6.0);
     uint32_t best = 2;
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 22; c++) {
-        double cost = 10.0 * 254.0 / (c + 1) * (double)(n ? n : 1) + 36.0 * (double)((size_t)1 << (c - 2));
+        double cost = 254.0 / (c + 1) * (double)(n ? n : 1) + beta * (double)((size_t)1 << (c - 2));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
@@ -336,8 +351,9 @@ struct MsmGroup {
         return ZK_OK;
     }
 
-    // jobs[i].pair_base is filled in here.  Results (one XYZZ per job) are copied to `out`.
-    zk_status run(std::vector<MsmJob>& jobs, std::vector<HPoint>& out) {
+    // jobs[i].pair_base is filled in here.  Everything, including the copy of the results (one XYZZ
+    // per job) into `out`, is enqueued on `st`; collect() waits for it.
+    zk_status enqueue(std::vector<MsmJob>& jobs, std::vector<HPoint>& out, hipStream_t st) {
         const size_t nj = jobs.size();
         out.resize(nj);
         if (!nj) return ZK_OK;
@@ -371,17 +387,23 @@ struct MsmGroup {
         ZK_TRY(tclass.ensure(n_class * 4));
         ZK_TRY(sorted.ensure((size_t)total_tasks * sizeof(uint4)));
         ZK_TRY(tsums.ensure((size_t)total_tasks * sizeof(DPoint)));
-        ZK_TRY(rank.ensure((size_t)(total ? total : 1) * 4));
         ZK_TRY(pairs.ensure((size_t)(total ? total : 1) * 4));
-        const uint32_t L = nb < MSM_RED_FAN ? nb : MSM_RED_FAN;
+        // nodes of 16 buckets when that still leaves the machine full of threads, narrower nodes (a
+        // shorter serial chain per thread, more levels) when one or a few jobs must fill it alone
+        auto pick_fan = [&](uint64_t items) -> uint32_t {
+            uint32_t f = MSM_RED_FAN;
+            while (f > 4 && items / f < 32768) f >>= 1;
+            return f;
+        };
+        uint32_t L = pick_fan((uint64_t)nj * nb);
+        if (L > nb) L = nb;
         const uint32_t T = nb / L;
         ZK_TRY(red_r.ensure(nj * ((size_t)nb + 2 * (size_t)T) * sizeof(DPoint)));   // suffix sums: level 1 | two upper-level areas
         ZK_TRY(red_w.ensure(2 * nj * (size_t)T * sizeof(DPoint)));  // W of the nodes (ping-pong halves)
         ZK_TRY(red_t.ensure(nj * (size_t)T * sizeof(DPoint)));      // 2M * sum R' of the level being built
-        HIP_TRY(hipMemcpyAsync(jobs_d.p, jobs.data(), nj * sizeof(MsmJob), hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync(tbase.p, tbase_h.data(), nj * 4, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, g_stream));
-        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 2) * 4, g_stream));
+        HIP_TRY(hipMemcpyAsync(jobs_d.p, jobs.data(), nj * sizeof(MsmJob), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(tbase.p, tbase_h.data(), nj * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 2) * 4, st));
         uint32_t* lenhist = hist.as<uint32_t>();
         uint32_t* cursor = lenhist + n_class;
         uint32_t* d_total = cursor + n_class;
@@ -389,32 +411,43 @@ struct MsmGroup {
         const MsmJob* dj = jobs_d.as<MsmJob>();
         dim3 gridn((max_n + 255) / 256, (unsigned)nj);
         dim3 gridb((nb + 255) / 256, (unsigned)nj);
-        if (max_n) {
-            ProfScope ps("msm_count");
-            ZK_LAUNCH(zkdev::k_msm_count, gridn, dim3(256), 0, g_stream, dj, c, cnt.as<uint32_t>(), rank.as<uint32_t>());
+        const bool lds_sort = (size_t)nb * 4 <= 65536 && !getenv("ZKAMD_NO_LDS_SORT");
+        if (lds_sort) {
+            // histogram + scan + scatter of a job inside one workgroup's LDS
+            ProfScope ps("msm_sort_lds", st);
+            ZK_LAUNCH_SYNC(zkdev::k_msm_sort_lds, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c,
+                           cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(),
+                           pairs.as<uint32_t>());
+        } else {
+            HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, st));
+            ZK_TRY(rank.ensure((size_t)(total ? total : 1) * 4));
+            if (max_n) {
+                ProfScope ps("msm_count", st);
+                ZK_LAUNCH(zkdev::k_msm_count, gridn, dim3(256), 0, st, dj, c, cnt.as<uint32_t>(), rank.as<uint32_t>());
+            }
+            {
+                ProfScope ps("msm_scan", st);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < 1024 ? (nb < 64 ? 64 : nb) : 1024), 0, st,
+                               dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>());
+            }
+            if (max_n) {
+                ProfScope ps("msm_scatter", st);
+                ZK_LAUNCH(zkdev::k_msm_scatter, gridn, dim3(256), 0, st, dj, c, off.as<uint32_t>(), rank.as<uint32_t>(),
+                          pairs.as<uint32_t>());
+            }
         }
         {
-            ProfScope ps("msm_scan");
-            ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < 1024 ? (nb < 64 ? 64 : nb) : 1024), 0, g_stream,
-                           dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>());
-        }
-        if (max_n) {
-            ProfScope ps("msm_scatter");
-            ZK_LAUNCH(zkdev::k_msm_scatter, gridn, dim3(256), 0, g_stream, dj, c, off.as<uint32_t>(), rank.as<uint32_t>(),
-                      pairs.as<uint32_t>());
-        }
-        {
-            ProfScope ps("msm_task_sort");
-            ZK_LAUNCH_SYNC(zkdev::k_msm_task_hist, gridb, dim3(256), 0, g_stream, cnt.as<uint32_t>(), lenhist, nb);
-            ZK_LAUNCH_SYNC(zkdev::k_msm_task_base, dim3(1), dim3(1024), 0, g_stream, lenhist, tclass.as<uint32_t>(), d_total,
+            ProfScope ps("msm_task_sort", st);
+            ZK_LAUNCH_SYNC(zkdev::k_msm_task_hist, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), lenhist, nb);
+            ZK_LAUNCH_SYNC(zkdev::k_msm_task_base, dim3(1), dim3(1024), 0, st, lenhist, tclass.as<uint32_t>(), d_total,
                            (uint32_t)nj);
-            ZK_LAUNCH_SYNC(zkdev::k_msm_task_place, gridb, dim3(256), 0, g_stream, cnt.as<uint32_t>(), off.as<uint32_t>(),
+            ZK_LAUNCH_SYNC(zkdev::k_msm_task_place, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), off.as<uint32_t>(),
                            toff.as<uint32_t>(), tbase.as<uint32_t>(), tclass.as<uint32_t>(), cursor, sorted.as<uint4>(), d_nheavy,
                            heavy.as<uint32_t>(), nb, (uint32_t)nj);
         }
         {
-            ProfScope ps(sizeof(DF) > 48 ? "msm_accumulate_g2" : "msm_accumulate_g1");
-            ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, g_stream,
+            ProfScope ps(sizeof(DF) > 48 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
+            ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
                       table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
         }
         DPoint* R = red_r.as<DPoint>();
@@ -422,31 +455,31 @@ struct MsmGroup {
         DPoint* Wb = Wa + nj * (size_t)T;
         DPoint* in = Wa;
         {
-            ProfScope ps(sizeof(DF) > 48 ? "msm_reduce_g2" : "msm_reduce_g1");
+            ProfScope ps(sizeof(DF) > 48 ? "msm_reduce_g2" : "msm_reduce_g1", st);
             auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
-            ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>, dim3((unsigned)heavy_cap), dim3(64), 0, g_stream,
+            ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>, dim3((unsigned)heavy_cap), dim3(64), 0, st,
                            (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy, (const uint32_t*)cnt.as<uint32_t>(),
                            (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb);
             // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
-            ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, g_stream, tsums.as<DPoint>(), cnt.as<uint32_t>(),
+            ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
                       toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L);
-            ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, g_stream, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
+            ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
                       1u, 1u, 1u);
             uint32_t n = T, m = L, stride = L;   // n nodes per job of m buckets each; S(node k) = R[k * stride]
             DPoint* Rcur = R;
             DPoint* Rnext = R + nj * (size_t)nb;       // upper levels ping-pong between two areas behind level 1
             DPoint* Rspare = Rnext + nj * (size_t)T;
             while (n > 1) {
-                const uint32_t fan = MSM_RED_FAN, n_out = (n + fan - 1) / fan;
+                const uint32_t fan = pick_fan((uint64_t)nj * n), n_out = (n + fan - 1) / fan;
                 uint32_t log2_2m = 1;
                 while ((1u << (log2_2m - 1)) < m) log2_2m++;
                 // R' = suffix sums of S over the children of a parent
-                ZK_LAUNCH(zkdev::k_msm_suffix<DF>, grid(n_out), dim3(64), 0, g_stream, (const DPoint*)Rcur, Rnext, n, fan, stride);
+                ZK_LAUNCH(zkdev::k_msm_suffix<DF>, grid(n_out), dim3(64), 0, st, (const DPoint*)Rcur, Rnext, n, fan, stride);
                 // T = 2M * sum_{k>=1} R'_k ;  W(parent) = T + sum_k W(c_k)
-                ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(n_out), dim3(64), 0, g_stream, (const DPoint*)Rnext, (const DPoint*)nullptr,
+                ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(n_out), dim3(64), 0, st, (const DPoint*)Rnext, (const DPoint*)nullptr,
                           red_t.as<DPoint>(), n, fan, 1u, log2_2m, 0u);
                 DPoint* outW = in == Wa ? Wb : Wa;
-                ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(n_out), dim3(64), 0, g_stream, (const DPoint*)in,
+                ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(n_out), dim3(64), 0, st, (const DPoint*)in,
                           (const DPoint*)red_t.as<DPoint>(), outW, n, fan, 0u, 0u, 0u);
                 in = outW;
                 // the parents' S are R'[first child of each parent]
@@ -458,9 +491,16 @@ struct MsmGroup {
             }
         }
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out.data(), in, nj * sizeof(DPoint), hipMemcpyDeviceToHost, g_stream));
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipMemcpyAsync(out.data(), in, nj * sizeof(DPoint), hipMemcpyDeviceToHost, st));
         return ZK_OK;
+    }
+    zk_status collect(hipStream_t st) {
+        HIP_TRY(hipStreamSynchronize(st));
+        return ZK_OK;
+    }
+    zk_status run(std::vector<MsmJob>& jobs, std::vector<HPoint>& out) {
+        ZK_TRY(enqueue(jobs, out, g_stream));
+        return collect(g_stream);
     }
 };
 
@@ -608,9 +648,11 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
         ZK_TRY((check_points_host<zkhost::Fq, zkdev::Fq>(ic, "vk.ic")));
         ZK_TRY((check_points_host<zkhost::Fq2, zkdev::Fq2>(std::vector<HG2A>{gamma_g2}, "vk.gamma_g2")));
     }
-    uint32_t c = pick_window(std::max<size_t>(P->n_h, P->n_l));
-    ZK_TRY(P->g1.build(pts1, c, checked != 0, "parameters (G1)"));
-    ZK_TRY(P->g2.build(pts2, c, checked != 0, "parameters (G2)"));
+    // one width per group: the G1 jobs of a proof (H, L, A, B1) average a quarter of the G1 terms
+    const uint32_t c1 = pick_window(((size_t)P->n_h + P->n_l + P->n_a + P->n_b1) / 4, 1);
+    const uint32_t c2 = pick_window(P->n_b2, 2);
+    ZK_TRY(P->g1.build(pts1, c1, checked != 0, "parameters (G1)"));
+    ZK_TRY(P->g2.build(pts2, c2, checked != 0, "parameters (G2)"));
     ZK_TRY(P->ntt.init(P->log_m));
     guard.p = nullptr;
     *out = P;
@@ -701,6 +743,20 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     HIP_TRY(hipMemcpyAsync(P->tail.p, tail.data(), np * 96, hipMemcpyHostToDevice, g_stream));
     ZK_LAUNCH(zkdev::k_build_scalars, dim3((nv + 3 + 255) / 256, (unsigned)np), dim3(256), 0, g_stream, wit,
               (const uint32_t*)bt->d_wit + first * (size_t)nv * 8, P->tail.as<uint32_t>(), nv, mont ? 1u : 0u);
+    // ---- multiexps (create_proof step 4).  The G2 job only needs the witness scalars: it is
+    // enqueued first, on the side stream, and runs beside the H pipeline and the G1 multiexps (its
+    // reduction tree is latency-bound with one job per proof; the G1 work fills the machine).
+    P->jobs1.clear();
+    P->jobs2.clear();
+    const uint32_t npts1 = (uint32_t)P->g1.n_points, npts2 = (uint32_t)P->g2.n_points;
+    for (size_t p = 0; p < np; p++) {
+        const uint32_t* w = wit + p * wstride * 8;
+        MsmJob j2 = {w, P->map_b2.as<int32_t>(), nv + 3, 0, npts2, 0};
+        P->jobs2.push_back(j2);
+    }
+    HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
+    HIP_TRY(hipStreamWaitEvent(g_stream2, g_ev_fork, 0));
+    ZK_TRY(P->g2.enqueue(P->jobs2, P->res2, g_stream2));
     // ---- H pipeline (create_proof step 3)
     ZK_TRY(P->abc.ensure(3 * np * m * 32));
     uint32_t* A = P->abc.as<uint32_t>();
@@ -723,25 +779,20 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     }
     // icoset fft: ifft (natural -> bit-reversed), * g^-i / m, Montgomery factor dropped
     ZK_TRY(P->ntt.chain(A, (uint32_t)np, (uint32_t)m, true, true, nullptr, P->ntt.s2.as<uint32_t>()));
-    // ---- multiexps (create_proof step 4)
-    P->jobs1.clear();
-    P->jobs2.clear();
-    const uint32_t npts1 = (uint32_t)P->g1.n_points, npts2 = (uint32_t)P->g2.n_points;
     for (size_t p = 0; p < np; p++) {
         const uint32_t* w = wit + p * wstride * 8;
         MsmJob jh = {A + p * m * 8, P->map_h.as<int32_t>(), (uint32_t)m, P->off_h, npts1, 0};
         MsmJob jl = {w + (size_t)n_in * 8, nullptr, n_aux, P->off_l, npts1, 0};
         MsmJob ja = {w, P->map_a.as<int32_t>(), nv + 3, P->off_a, npts1, 0};
         MsmJob jb = {w, P->map_b1.as<int32_t>(), nv + 3, P->off_b1, npts1, 0};
-        MsmJob j2 = {w, P->map_b2.as<int32_t>(), nv + 3, 0, npts2, 0};
         P->jobs1.push_back(jh);
         P->jobs1.push_back(jl);
         P->jobs1.push_back(ja);
         P->jobs1.push_back(jb);
-        P->jobs2.push_back(j2);
     }
-    ZK_TRY(P->g1.run(P->jobs1, P->res1));
-    ZK_TRY(P->g2.run(P->jobs2, P->res2));
+    ZK_TRY(P->g1.enqueue(P->jobs1, P->res1, g_stream));
+    ZK_TRY(P->g1.collect(g_stream));
+    ZK_TRY(P->g2.collect(g_stream2));
     // ---- final fold + encoding (host, one thread per slice of the chunk)
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
@@ -864,7 +915,7 @@ zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits,
     M->group = group;
     M->device = device;
     M->n = n;
-    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(n);
+    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(n, group);
     if (c < 2 || c > 22) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 22]");
     // points at infinity are legal multiexp bases: they are mapped out (map = -1)
     std::vector<int32_t> map(n);
