@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=128, help="proofs per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step (BASELINE config 4: 1024)")
     ap.add_argument("--no-micro", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -180,7 +180,7 @@ def main():
     a_terms = N_IN + int(dens[0].sum()) + 2
     b_terms = int(dens[1].sum()) + int(dens[2].sum()) + 1
     g1_terms = info["n_h"] + info["n_l"] + a_terms + b_terms
-    chunk = int(os.environ.get("ZKAMD_BATCH_CHUNK", "128"))
+    chunk = int(os.environ.get("ZKAMD_BATCH_CHUNK", "1024"))
     roof = None
     if "msm_accumulate_g1" in kernels:
         k = kernels["msm_accumulate_g1"]

@@ -47,6 +47,9 @@ def run(lines, N, a, b):
             t = val(ops[3]) - val(ops[2]); setv(ops[0], t & M32); s["vcc"] = 1 if t < 0 else 0
         elif op == "v_subbrev_co_u32_e32":
             t = val(ops[3]) - val(ops[2]) - val(ops[4]); setv(ops[0], t & M32); s["vcc"] = 1 if t < 0 else 0
+        elif op == "v_and_b32_e32": setv(ops[0], val(ops[1]) & val(ops[2]))
+        elif op == "v_alignbit_b32": setv(ops[0], (((val(ops[1]) << 32) | val(ops[2])) >> val(ops[3])) & M32)
+        elif op == "v_lshrrev_b32_e32": setv(ops[0], val(ops[2]) >> val(ops[1]))
         elif op == "v_cndmask_b32_e32":
             setv(ops[0], val(ops[2]) if val(ops[3]) else val(ops[1]))
         else: raise SystemExit("unknown op " + ln)
@@ -64,5 +67,80 @@ def main():
             assert got == a * b * Rinv % p, (name, hex(a), hex(b), hex(got))
         print(name, "ok:", len(cases), "products;", spec["valu"], "VALU,", spec["nops"], "wait states")
 
+def run28(lines, a_limbs, b_limbs):
+    """radix-2^28 routine: operands / result as lists of 14 limbs in v[0:13] / v[16:29]."""
+    import types
+    v = {}; s = {}
+    # reuse run()'s interpreter through a tiny shim: build pseudo 32-bit packing of the registers
+    return _run_regs(lines, {**{i: a_limbs[i] for i in range(14)}, **{16 + i: b_limbs[i] for i in range(14)}}, 14)
+
+
+def _run_regs(lines, init, nout):
+    class R(dict):
+        pass
+    # same interpreter as run(), on an explicit register file
+    N = 0
+    v = dict(init); s = {}
+    def val(tok):
+        tok = tok.strip()
+        if tok.startswith("v["):
+            lo = int(tok[2:tok.index(":")]); return v[lo] | (v[lo + 1] << 32)
+        if tok.startswith("s["):
+            lo = int(tok[2:tok.index(":")]); return s.get(lo, 0)
+        if tok == "vcc": return s["vcc"]
+        if tok.startswith("v"): return v[int(tok[1:])]
+        if tok.startswith("s"): return s[int(tok[1:])]
+        return int(tok, 0)
+    def setv(tok, x):
+        tok = tok.strip()
+        if tok.startswith("v["):
+            lo = int(tok[2:tok.index(":")]); v[lo] = x & M32; v[lo + 1] = (x >> 32) & M32
+        elif tok.startswith("s["):
+            s[int(tok[2:tok.index(":")])] = x
+        elif tok == "vcc": s["vcc"] = x
+        elif tok.startswith("v"): v[int(tok[1:])] = x & M32
+        else: s[int(tok[1:])] = x & M32
+    for ln in lines:
+        op, rest = ln.split(None, 1)
+        ops = [o.strip() for o in re.split(r",\s*(?![^\[]*\])", rest)]
+        if op == "s_mov_b32": setv(ops[0], val(ops[1]))
+        elif op == "s_nop": pass
+        elif op == "v_mad_u64_u32":
+            t = val(ops[2]) * val(ops[3]) + val(ops[4])
+            assert t < 2**64, "column accumulator overflow"
+            setv(ops[0], t); setv(ops[1], 0)
+        elif op == "v_mul_lo_u32": setv(ops[0], (val(ops[1]) * val(ops[2])) & M32)
+        elif op == "v_mov_b32_e32": setv(ops[0], val(ops[1]))
+        elif op == "v_and_b32_e32": setv(ops[0], val(ops[1]) & val(ops[2]))
+        elif op == "v_alignbit_b32": setv(ops[0], (((val(ops[1]) << 32) | val(ops[2])) >> val(ops[3])) & M32)
+        elif op == "v_lshrrev_b32_e32": setv(ops[0], val(ops[2]) >> val(ops[1]))
+        else: raise SystemExit("unknown op " + ln)
+    return [v[i] for i in range(nout)]
+
+
+def main28():
+    rnd = random.Random(2)
+    p = g.FQ_P
+    spec = g.gen28(p, "FQ28")
+    Rinv = pow(1 << 392, -1, p)
+    lim = lambda x: [(x >> (28 * i)) & ((1 << 28) - 1) if i < 13 else x >> (28 * 13) for i in range(14)]
+    val = lambda l: sum(x << (28 * i) for i, x in enumerate(l))
+    cases = [(0, 0), (1, 1), (p - 1, p - 1), (2 * p - 1, 2 * p - 1), (40 * p, 40 * p), (45 * p + 12345, 50 * p - 1)]
+    cases += [(rnd.randrange(8 * p), rnd.randrange(8 * p)) for _ in range(300)]
+    for a, b in cases:
+        la, lb = lim(a), lim(b)
+        if rnd.random() < 0.5:   # weakly normalised operands: limbs up to 2^28 + 8 with the same value
+            for i in range(13):
+                if la[i] + 8 < (1 << 28) + 8 and la[i + 1] > 0 and la[i] < 8:
+                    la[i] += 1 << 28; la[i + 1] -= 1
+        out = run28(spec["lines"], la, lb)
+        got = val(out)
+        assert all(x < (1 << 28) for x in out[:13]), "limbs not normalised"
+        assert got % p == val(la) * val(lb) * Rinv % p, (hex(a), hex(b))
+        assert got < 2 * p, "output bound"
+    print("FQ28 ok:", len(cases), "products;", spec["valu"], "VALU,", spec["nops"], "wait states")
+
+
 if __name__ == "__main__":
     main()
+    main28()

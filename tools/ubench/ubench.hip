@@ -139,6 +139,37 @@ __global__ void k_check(uint32_t* bad, uint32_t seed) {
     if (d2) atomicAdd(&bad[1], 1u);
 }
 
+// radix-2^28 product: assembly vs C++ on weakly normalised operands of value < 45 p
+__global__ void k_check28(uint32_t* bad, uint32_t seed) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t st = seed * 0x9E3779B97F4A7C15ull + tid * 0xBF58476D1CE4E5B9ull + 1;
+    auto next = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (uint32_t)(st >> 16); };
+    u32x16 a, b;
+    for (int j = 0; j < 13; j++) { a[j] = next() & FQ28_MASK; b[j] = next() & FQ28_MASK; if ((tid & 3) == 1) { a[j] += next() & 7; b[j] += 8; } }
+    a[13] = next() % (44u * Fq28Consts::P[13]); b[13] = next() % (49u * Fq28Consts::P[13]);
+    a[14] = a[15] = b[14] = b[15] = 0;
+    if ((tid & 15) == 2) for (int j = 0; j < 14; j++) a[j] = 0;
+    u32x16 r0 = mul28_raw(a, b), r1 = mul28_cxx(a, b);
+    uint32_t d = 0;
+    for (int j = 0; j < 14; j++) d |= r0[j] ^ r1[j];
+    if (d) atomicAdd(&bad[0], 1u);
+}
+template <int CHAINS>
+__global__ void __launch_bounds__(256) k_montmul28(uint32_t* out, const uint32_t* in, int iters) {
+    u32x16 x[CHAINS], y;
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int j = 0; j < 14; j++) y[j] = (in[j] ^ (j == 0 ? tid : 0)) & FQ28_MASK;
+    y[13] &= 0xffff; y[14] = y[15] = 0;
+    for (int c = 0; c < CHAINS; c++) { for (int j = 0; j < 14; j++) x[c][j] = (in[14 + j] + c) & FQ28_MASK; x[c][13] &= 0xffff; x[c][14] = x[c][15] = 0; }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; c++) x[c] = mul28_raw(x[c], y);
+    }
+    uint32_t s = 0;
+    for (int c = 0; c < CHAINS; c++) for (int j = 0; j < 14; j++) s ^= x[c][j];
+    out[tid] = s;
+}
+
 template <class K, class... Args>
 static double time_kernel(K kernel, dim3 grid, dim3 block, int reps, Args... args) {
     hipEvent_t a, b;
@@ -171,6 +202,10 @@ int main() {
         hipLaunchKernelGGL(k_check<FqCfg>, dim3(4096), dim3(256), 0, 0, bad, 11u);
         hipLaunchKernelGGL(k_check<FrCfg>, dim3(4096), dim3(256), 0, 0, bad + 2, 12u);
         uint32_t hb[4]; CHECK(hipMemcpy(hb, bad, 16, hipMemcpyDeviceToHost));
+        uint32_t* bad28; CHECK(hipMalloc(&bad28, 16)); CHECK(hipMemset(bad28, 0, 16));
+        hipLaunchKernelGGL(k_check28, dim3(4096), dim3(256), 0, 0, bad28, 13u);
+        uint32_t hb28[4]; CHECK(hipMemcpy(hb28, bad28, 16, hipMemcpyDeviceToHost));
+        printf("radix-2^28 Fq product, asm vs c++ over 1M operands: mismatches %u\n", hb28[0]);
         printf("mul check (1M products each): Fq asm mismatches %u, Fq c++fips mismatches %u, Fr asm mismatches %u, Fr c++fips mismatches %u\n", hb[0], hb[1], hb[2], hb[3]);
     }
     const int iters = 4096;
@@ -193,6 +228,11 @@ int main() {
     MM("Fq mul inline, 1 chain, 4 WG/CU", (k_montmul<FqCfg, 1, 1>), 1, 4)
     MM("Fq mul inline, 1 chain, 8 WG/CU", (k_montmul<FqCfg, 1, 1>), 1, 8)
     MM("Fq mul inline, 2 chains, 8 WG/CU", (k_montmul<FqCfg, 2, 1>), 2, 8)
+    MM("Fq28 mul asm, 1 chain, 2 WG/CU", (k_montmul28<1>), 1, 2)
+    MM("Fq28 mul asm, 1 chain, 4 WG/CU", (k_montmul28<1>), 1, 4)
+    MM("Fq28 mul asm, 1 chain, 8 WG/CU", (k_montmul28<1>), 1, 8)
+    MM("Fq28 mul asm, 2 chains, 4 WG/CU", (k_montmul28<2>), 2, 4)
+    MM("Fq mul asm call, 1 chain, 2 WG/CU", (k_montmul<FqCfg, 1, 0>), 1, 2)
     MM("Fq mul FIPS, 1 chain, 4 WG/CU", (k_montmul<FqCfg, 1, 2>), 1, 4)
     MM("Fq mul FIPS, 1 chain, 8 WG/CU", (k_montmul<FqCfg, 1, 2>), 1, 8)
     MM("Fq mul FIPS, 2 chains, 4 WG/CU", (k_montmul<FqCfg, 2, 2>), 2, 4)

@@ -6,113 +6,132 @@
 // :839-867), so the device is free to use the representation that is cheapest on CDNA4:
 // extended Jacobian "XYZZ" (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2), EFD madd-2008-s (8M+2S),
 // add-2008-s (12M+2S), dbl-2008-s-1 (6M+4S).  Fewer field additions than madd-2007-bl and one
-// multiplication less, which matters when every Fq product is ~300 quarter-rate multiplier ops.
+// multiplication less, which matters when every Fq product is ~500 multiplier-rate instructions.
 //
 // Infinity: accumulator points use ZZ == 0; affine inputs use (0, 0), which is not on either
 // curve (b != 0).
+//
+// Magnitudes.  G1 runs on the lazily reduced Fq28 (dev_field.h): a product is < MO p (MO = 2), a
+// subtraction a - b adds (B + 1) p for a subtrahend b < B p.  With the formulas as written below
+//     X of a stored point < BX p = (4 MO + 2) p,   Y < BY p = (2 MO + 1) p,   ZZ, ZZZ < MO p,
+// affine table entries < MO p, and the largest operands of a product are (MO + BX + 1) p and
+// (MO + BY + 1) p: 13 p x 13 p = 169 p^2 against the 2^11.3 p^2 the product routine allows.  The
+// bounds are template arguments of sub_b / neg_b; the saturated fields (G2 this round) ignore them.
+//
+// Special cases (equal points, opposite points) are detected AFTER the generic formula from
+// ZZ3 == 0 - a product, hence exactly normalised and testable in 42 instructions - because the
+// natural test P == 0 would need a full reduction of a lazily reduced difference per addition.
 #pragma once
 #include "dev_field.h"
 
 namespace zkdev {
 
 template <class F>
-struct Affine {
+struct alignas(16) Affine {
     F x, y;
-    ZK_DI bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    ZK_DI bool is_inf() const { return x.is_zero_norm() && y.is_zero_norm(); }
 };
 
 template <class F>
-struct XYZZ {
+struct alignas(16) XYZZ {
+    static constexpr int MO = F::MO, BX = 4 * MO + 2, BY = 2 * MO + 1;
     F x, y, zz, zzz;
     ZK_DI static XYZZ inf() { return XYZZ{F::zero(), F::zero(), F::zero(), F::zero()}; }
-    ZK_DI bool is_inf() const { return zz.is_zero(); }
+    ZK_DI bool is_inf() const { return zz.is_zero_norm(); }
     ZK_DI static XYZZ from_affine(const Affine<F>& p) {
         if (p.is_inf()) return inf();
         return XYZZ{p.x, p.y, F::one(), F::one()};
     }
 };
 
-// 2 * (affine p) -> XYZZ     (EFD mdbl-2008-s-1)
+// 2 * (affine p) -> XYZZ     (EFD mdbl-2008-s-1); p not infinity
 template <class F>
 ZK_DI XYZZ<F> mdbl(const Affine<F>& p) {
-    F u = dbl(p.y);
+    constexpr int MO = F::MO;
+    F u = dbl(p.y);                                             // < 2 MO
     F v = sqr(u);
     F w = mul(u, v);
     F s = mul(p.x, v);
     F xx = sqr(p.x);
-    F m = add(dbl(xx), xx);
-    F x3 = sub(sqr(m), dbl(s));
-    F y3 = sub(mul(m, sub(s, x3)), mul(w, p.y));
+    F m = add(dbl(xx), xx);                                     // < 3 MO
+    F x3 = sub_b<2 * MO>(sqr(m), dbl(s));                       // < 3 MO + 1
+    F y3 = sub_b<MO>(mul(m, sub_b<3 * MO + 1>(s, x3)), mul(w, p.y));   // < 2 MO + 1
     return XYZZ<F>{x3, y3, v, w};
 }
 
 // 2 * a   (EFD dbl-2008-s-1)
 template <class F>
 ZK_DI XYZZ<F> xdbl(const XYZZ<F>& a) {
+    constexpr int MO = F::MO;
     if (a.is_inf()) return a;
-    F u = dbl(a.y);
+    F u = dbl(a.y);                                             // < 2 BY
     F v = sqr(u);
     F w = mul(u, v);
     F s = mul(a.x, v);
     F xx = sqr(a.x);
     F m = add(dbl(xx), xx);
-    F x3 = sub(sqr(m), dbl(s));
-    F y3 = sub(mul(m, sub(s, x3)), mul(w, a.y));
+    F x3 = sub_b<2 * MO>(sqr(m), dbl(s));
+    F y3 = sub_b<MO>(mul(m, sub_b<3 * MO + 1>(s, x3)), mul(w, a.y));
     return XYZZ<F>{x3, y3, mul(v, a.zz), mul(w, a.zzz)};
 }
 
-// acc + (sign ? -p : p), p affine and not infinity   (EFD madd-2008-s), all special cases handled
+// acc + (negate ? -p : p), p affine and not infinity   (EFD madd-2008-s), all special cases handled
 template <class F>
 ZK_DI void madd(XYZZ<F>& acc, const Affine<F>& p, bool negate) {
-    F py = negate ? neg(p.y) : p.y;
+    constexpr int MO = F::MO, BX = XYZZ<F>::BX, BY = XYZZ<F>::BY;
+    F py = negate ? neg_b<MO>(p.y) : p.y;                       // < MO + 1
     if (acc.is_inf()) {
         acc = XYZZ<F>{p.x, py, F::one(), F::one()};
         return;
     }
     F u2 = mul(p.x, acc.zz);
     F s2 = mul(py, acc.zzz);
-    F pp_ = sub(u2, acc.x);
-    F r = sub(s2, acc.y);
-    if (pp_.is_zero()) {
-        if (r.is_zero()) {
+    F pp_ = sub_b<BX>(u2, acc.x);                               // < MO + BX + 1
+    F r = sub_b<BY>(s2, acc.y);                                 // < MO + BY + 1
+    F pp = sqr(pp_);
+    F ppp = mul(pp_, pp);
+    F q = mul(acc.x, pp);
+    F zz3 = mul(acc.zz, pp);
+    if (zz3.is_zero_norm()) {
+        // p.x == acc.x: the same point (double it) or its negative (infinity)
+        if (is_zero_full(r)) {
             acc = mdbl(Affine<F>{p.x, py});
         } else {
             acc = XYZZ<F>::inf();
         }
         return;
     }
-    F pp = sqr(pp_);
-    F ppp = mul(pp_, pp);
-    F q = mul(acc.x, pp);
-    F x3 = sub(sub(sqr(r), ppp), dbl(q));
-    F y3 = sub(mul(r, sub(q, x3)), mul(acc.y, ppp));
+    F x3 = sub_b<2 * MO>(sub_b<MO>(sqr(r), ppp), dbl(q));       // < 4 MO + 2 = BX
+    F y3 = sub_b<MO>(mul(r, sub_b<BX>(q, x3)), mul(acc.y, ppp));   // < 2 MO + 1 = BY
     acc.x = x3;
     acc.y = y3;
-    acc.zz = mul(acc.zz, pp);
+    acc.zz = zz3;
     acc.zzz = mul(acc.zzz, ppp);
 }
 
 // a + b   (EFD add-2008-s), all special cases handled
 template <class F>
 ZK_DI XYZZ<F> xadd(const XYZZ<F>& a, const XYZZ<F>& b) {
+    constexpr int MO = F::MO, BX = XYZZ<F>::BX;
     if (a.is_inf()) return b;
     if (b.is_inf()) return a;
     F u1 = mul(a.x, b.zz);
     F u2 = mul(b.x, a.zz);
     F s1 = mul(a.y, b.zzz);
     F s2 = mul(b.y, a.zzz);
-    F p = sub(u2, u1);
-    F r = sub(s2, s1);
-    if (p.is_zero()) {
-        if (r.is_zero()) return xdbl(a);
-        return XYZZ<F>::inf();
-    }
+    F p = sub_b<MO>(u2, u1);                                    // < 2 MO + 1
+    F r = sub_b<MO>(s2, s1);
     F pp = sqr(p);
     F ppp = mul(p, pp);
     F q = mul(u1, pp);
-    F x3 = sub(sub(sqr(r), ppp), dbl(q));
-    F y3 = sub(mul(r, sub(q, x3)), mul(s1, ppp));
-    return XYZZ<F>{x3, y3, mul(mul(a.zz, b.zz), pp), mul(mul(a.zzz, b.zzz), ppp)};
+    F zz3 = mul(mul(a.zz, b.zz), pp);
+    if (zz3.is_zero_norm()) {
+        if (is_zero_full(r)) return xdbl(a);
+        return XYZZ<F>::inf();
+    }
+    F x3 = sub_b<2 * MO>(sub_b<MO>(sqr(r), ppp), dbl(q));
+    F y3 = sub_b<MO>(mul(r, sub_b<BX>(q, x3)), mul(s1, ppp));
+    return XYZZ<F>{x3, y3, zz3, mul(mul(a.zzz, b.zzz), ppp)};
 }
 
 }  // namespace zkdev

@@ -14,6 +14,10 @@
 // v_addc_co_u32 in a carry chain: 2N^2 + N multiplier ops and ~2N^2 adds per product.
 #pragma once
 #include <stdint.h>
+#ifdef ZK_EMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 #include "gpu_rt.h"
 #include "consts.h"
 #ifndef ZK_EMU
@@ -57,7 +61,9 @@ struct FqCfg {
 template <class C>
 struct Fp {
     static constexpr int N = C::N;
+    static constexpr int MO = 1;   // fully reduced
     uint32_t l[N];
+    ZK_DI bool is_zero_norm() const { return is_zero(); }
 
     ZK_DI static Fp zero() {
         Fp r;
@@ -351,34 +357,295 @@ ZK_DI Fp<C> pow_limbs(const Fp<C>& a, const uint32_t (&e)[EN]) {
 }
 
 typedef Fp<FrCfg> Fr;
-typedef Fp<FqCfg> Fq;
+typedef Fp<FqCfg> Fq32;   // Fq in saturated 32-bit limbs: host interchange format, debug entries
+
+// ---------------------------------------------------------------------------------------------
+// Fq for the MSM kernels: radix 2^28, 14 limbs, Montgomery radix 2^392, lazily reduced.
+//
+// The saturated 32-bit product above is bound by its carries: 288 v_mad_u64_u32 + 288 v_addc at
+// 4 cycles each, whatever the schedule (three implementations measure the same 59 G products/s).
+// With 28-bit limbs a whole column of the product (28 limb products < 2^56.01) fits one 64-bit
+// accumulator, so there is no carry instruction anywhere: 392 v_mad_u64_u32 + 96 others per
+// product (mul_asm.h FQ28), additions are 14 independent v_add + a 3-instruction-per-limb weak
+// normalisation, and there is no carry chain for the gfx950 SGPR hazard to stall.
+//
+// Invariants of a stored value x:  limbs x_i <= 2^28 + 8 for i < 13 ("weakly normalised"; the top
+// limb takes whatever is left), integer value < 64 p.  Products need |a| |b| < 2^11.3 p^2 (then
+// a*b*2^-392 + m p / 2^392 < 2p); the curve formulas below carry the bound of every intermediate
+// in their template arguments, and the x86 emulation build checks them at run time.
+// mul outputs are EXACTLY normalised (limbs < 2^28) and < 2p but not reduced below p.
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+struct Fq28Consts {
+    static constexpr uint32_t P[14] = ZK_FQ28_P;
+    static constexpr uint32_t ONE[14] = ZK_FQ28_ONE;
+    static constexpr uint32_t KIN[14] = ZK_FQ28_KIN;
+    static constexpr uint32_t KOUT[14] = ZK_FQ28_KOUT;
+    static constexpr uint32_t B[14] = ZK_FQ28_B;
+    static constexpr uint32_t INV = ZK_FQ28_INV;
+};
+template <int M> struct Fq28Spread;
+#define ZK_SPREAD_DEF(M) template <> struct Fq28Spread<M> { static constexpr uint32_t V[14] = ZK_FQ28_SPREAD_##M; };
+ZK_SPREAD_DEF(2) ZK_SPREAD_DEF(3) ZK_SPREAD_DEF(4) ZK_SPREAD_DEF(5) ZK_SPREAD_DEF(6) ZK_SPREAD_DEF(7) ZK_SPREAD_DEF(8)
+ZK_SPREAD_DEF(9) ZK_SPREAD_DEF(10) ZK_SPREAD_DEF(11) ZK_SPREAD_DEF(12) ZK_SPREAD_DEF(13) ZK_SPREAD_DEF(14)
+ZK_SPREAD_DEF(15) ZK_SPREAD_DEF(16) ZK_SPREAD_DEF(17) ZK_SPREAD_DEF(18) ZK_SPREAD_DEF(19) ZK_SPREAD_DEF(20)
+ZK_SPREAD_DEF(21) ZK_SPREAD_DEF(22) ZK_SPREAD_DEF(23) ZK_SPREAD_DEF(24) ZK_SPREAD_DEF(25) ZK_SPREAD_DEF(26)
+ZK_SPREAD_DEF(27) ZK_SPREAD_DEF(28) ZK_SPREAD_DEF(29) ZK_SPREAD_DEF(30) ZK_SPREAD_DEF(31) ZK_SPREAD_DEF(32)
+ZK_SPREAD_DEF(33) ZK_SPREAD_DEF(34) ZK_SPREAD_DEF(35) ZK_SPREAD_DEF(36) ZK_SPREAD_DEF(37) ZK_SPREAD_DEF(38)
+ZK_SPREAD_DEF(39) ZK_SPREAD_DEF(40) ZK_SPREAD_DEF(41) ZK_SPREAD_DEF(42) ZK_SPREAD_DEF(43) ZK_SPREAD_DEF(44)
+ZK_SPREAD_DEF(45) ZK_SPREAD_DEF(46) ZK_SPREAD_DEF(47) ZK_SPREAD_DEF(48) ZK_SPREAD_DEF(49) ZK_SPREAD_DEF(50)
+ZK_SPREAD_DEF(51) ZK_SPREAD_DEF(52) ZK_SPREAD_DEF(53) ZK_SPREAD_DEF(54) ZK_SPREAD_DEF(55) ZK_SPREAD_DEF(56)
+ZK_SPREAD_DEF(57) ZK_SPREAD_DEF(58) ZK_SPREAD_DEF(59) ZK_SPREAD_DEF(60) ZK_SPREAD_DEF(61) ZK_SPREAD_DEF(62)
+ZK_SPREAD_DEF(63) ZK_SPREAD_DEF(64)
+#undef ZK_SPREAD_DEF
+
+constexpr uint32_t FQ28_MASK = (1u << 28) - 1;
+
+// plain C++ product (the emulation build, and the checker of the assembly in tools/ubench)
+ZK_DI u32x16 mul28_cxx(u32x16 av, u32x16 bv) {
+    uint32_t a[14], b[14], m[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        a[j] = av[j];
+        b[j] = bv[j];
+    }
+    u32x16 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+            if (k - i >= 0 && k - i < 14) acc += (uint64_t)a[i] * b[k - i];
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+            if (k - i >= 0 && k - i < 14 && (k >= 14 || i < k)) acc += (uint64_t)m[i] * Fq28Consts::P[k - i];
+        if (k < 14) {
+            m[k] = ((uint32_t)acc * Fq28Consts::INV) & FQ28_MASK;
+            acc += (uint64_t)m[k] * Fq28Consts::P[0];
+        } else {
+            r[k - 14] = (uint32_t)acc & FQ28_MASK;
+        }
+        acc >>= 28;
+    }
+    r[13] = (uint32_t)acc;
+    r[14] = 0;
+    r[15] = 0;
+    return r;
+}
+
+#if defined(ZK_EMU) || defined(ZK_MUL_CXX)
+ZK_MUL_ATTR u32x16 mul28_raw(u32x16 av, u32x16 bv) { return mul28_cxx(av, bv); }
+#else
+ZK_MUL_ATTR u32x16 mul28_raw(u32x16 av, u32x16 bv) {
+    u32x16 r;
+    asm(ZK_MUL_ASM_FQ28 : "={v[0:15]}"(r), "+{v[16:31]}"(bv) : "{v[0:15]}"(av) : ZK_MUL_ASM_FQ28_CLOBBERS);
+    return r;
+}
+#endif
+
+
+
+#ifdef ZK_EMU
+// run-time check of the magnitude bookkeeping (x86 emulation build only): value / p
+static inline long double fq28_ratio(const uint32_t* l) {
+    long double v = 0, p = 0;
+    for (int i = 13; i >= 0; i--) {
+        v = v * 268435456.0L + (long double)l[i];
+        p = p * 268435456.0L + (long double)Fq28Consts::P[i];
+    }
+    return v / p;
+}
+#define ZK_FQ28_CHECK(cond) do { if (!(cond)) { fprintf(stderr, "Fq28 bound violated: %s (%s:%d)\n", #cond, __FILE__, __LINE__); abort(); } } while (0)
+#else
+#define ZK_FQ28_CHECK(cond) do { } while (0)
+#endif
+
+struct Fq28 {
+    static constexpr int MO = 2;   // a product is < MO * p
+    uint32_t l[14];
+
+    ZK_DI static Fq28 zero() {
+        Fq28 r;
+#pragma unroll
+        for (int i = 0; i < 14; i++) r.l[i] = 0;
+        return r;
+    }
+    ZK_DI static Fq28 from_const(const uint32_t (&v)[14]) {
+        Fq28 r;
+#pragma unroll
+        for (int i = 0; i < 14; i++) r.l[i] = v[i];
+        return r;
+    }
+    ZK_DI static Fq28 one() { return from_const(Fq28Consts::ONE); }
+    // zero test of an EXACTLY normalised value < 2p (a product, or a constant): 0 or p
+    ZK_DI bool is_zero_norm() const {
+        uint32_t o = 0, q = 0;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            o |= l[i];
+            q |= l[i] ^ Fq28Consts::P[i];
+        }
+        return o == 0 || q == 0;
+    }
+};
+
+// limbs <= 2^28 + 8 again after an addition / subtraction (inputs: any 32-bit limbs)
+ZK_DI void fq28_wnorm(uint32_t (&t)[14]) {
+    uint32_t c[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) c[i] = t[i] >> 28;
+#pragma unroll
+    for (int i = 1; i < 13; i++) t[i] = (t[i] & FQ28_MASK) + c[i - 1];
+    t[0] &= FQ28_MASK;
+    t[13] += c[12];
+}
+
+ZK_DI Fq28 add(const Fq28& a, const Fq28& b) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + b.l[i];
+    fq28_wnorm(r.l);
+    ZK_FQ28_CHECK(fq28_ratio(r.l) < 64.0L);
+    return r;
+}
+ZK_DI Fq28 dbl(const Fq28& a) { return add(a, a); }
+
+// a - b + (B + 1) p  for b < B p  (limb-wise against the spread form of (B + 1) p: never negative)
+template <int B>
+ZK_DI Fq28 sub_b(const Fq28& a, const Fq28& b) {
+    static_assert(B + 1 >= 2 && B + 1 <= 64, "no spread constant for this bound");
+    ZK_FQ28_CHECK(fq28_ratio(b.l) < (long double)B);
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + Fq28Spread<B + 1>::V[i] - b.l[i];
+    fq28_wnorm(r.l);
+    ZK_FQ28_CHECK(fq28_ratio(r.l) < 64.0L);
+    return r;
+}
+template <int B>
+ZK_DI Fq28 neg_b(const Fq28& a) {
+    return sub_b<B>(Fq28::zero(), a);
+}
+
+ZK_DI Fq28 mul(const Fq28& a, const Fq28& b) {
+    ZK_FQ28_CHECK(fq28_ratio(a.l) * fq28_ratio(b.l) < 2500.0L);
+    u32x16 av, bv;
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        av[j] = a.l[j];
+        bv[j] = b.l[j];
+    }
+    av[14] = av[15] = bv[14] = bv[15] = 0;
+    u32x16 rv = mul28_raw(av, bv);
+    Fq28 r;
+#pragma unroll
+    for (int j = 0; j < 14; j++) r.l[j] = rv[j];
+    return r;
+}
+ZK_DI Fq28 sqr(const Fq28& a) { return mul(a, a); }
+
+// the unique representative in [0, p), exactly normalised (rare paths: export, equality)
+ZK_DI Fq28 canon(const Fq28& a) {
+    Fq28 t = mul(a, Fq28::one());   // < 2p, exact limbs
+    int32_t d[14], bo = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        int32_t v = (int32_t)t.l[i] - (int32_t)Fq28Consts::P[i] - bo;
+        bo = v < 0 ? 1 : 0;
+        d[i] = i < 13 ? (v & (int32_t)FQ28_MASK) : v;
+    }
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = bo ? t.l[i] : (uint32_t)d[i];
+    return r;
+}
+ZK_DI bool is_zero_full(const Fq28& a) { return mul(a, Fq28::one()).is_zero_norm(); }
+
+// host interchange: 12 x u32 canonical Montgomery (radix 2^384) limbs  <->  Fq28
+ZK_DI Fq28 fq28_import(const uint32_t* h) {
+    Fq28 t;
+    uint32_t w[13];
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = h[i];
+    w[12] = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const int bit = 28 * i, q = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)w[q] | ((uint64_t)w[q + 1] << 32);
+        t.l[i] = (uint32_t)(two >> sh) & FQ28_MASK;
+    }
+    return mul(t, Fq28::from_const(Fq28Consts::KIN));
+}
+ZK_DI void fq28_export(const Fq28& a, uint32_t* h) {
+    Fq28 t = mul(a, Fq28::from_const(Fq28Consts::KOUT));
+    // canonical: subtract p once if needed (t < 2p, exact limbs)
+    int32_t d[14], bo = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        int32_t v = (int32_t)t.l[i] - (int32_t)Fq28Consts::P[i] - bo;
+        bo = v < 0 ? 1 : 0;
+        d[i] = i < 13 ? (v & (int32_t)FQ28_MASK) : v;
+    }
+    uint32_t c[14];
+#pragma unroll
+    for (int i = 0; i < 14; i++) c[i] = bo ? t.l[i] : (uint32_t)d[i];
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const int lo = 28 * i - 32 * q;   // position of limb i inside word q
+            if (lo > -28 && lo < 32) v |= lo >= 0 ? (c[i] << lo) : (c[i] >> (-lo));
+        }
+        h[q] = v;
+    }
+}
+
+// The same interface on the saturated representation (G2 still runs on it): bounds are ignored,
+// every value is fully reduced.
+template <int B, class C>
+ZK_DI Fp<C> sub_b(const Fp<C>& a, const Fp<C>& b) { return sub(a, b); }
+template <int B, class C>
+ZK_DI Fp<C> neg_b(const Fp<C>& a) { return neg(a); }
+template <class C>
+ZK_DI bool is_zero_full(const Fp<C>& a) { return a.is_zero(); }
 
 // ---------------------------------------------------------------------------------------------
 // Fq2 = Fq[u]/(u^2 + 1)  (fq2.rs:90-182)
 // ---------------------------------------------------------------------------------------------
+typedef Fq28 Fq;   // G1 base field as the MSM kernels see it
 struct Fq2 {
+    typedef Fq32 Fq;   // G2 stays on the saturated representation this round
+    static constexpr int MO = 1;
     Fq c0, c1;
-    ZK_DI static Fq2 zero() { return Fq2{Fq::zero(), Fq::zero()}; }
-    ZK_DI static Fq2 one() { return Fq2{Fq::one(), Fq::zero()}; }
+    ZK_DI bool is_zero_norm() const { return is_zero(); }
+    ZK_DI static Fq2 zero() { return Fq2{Fq32::zero(), Fq32::zero()}; }
+    ZK_DI static Fq2 one() { return Fq2{Fq32::one(), Fq32::zero()}; }
     ZK_DI bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
     ZK_DI bool operator==(const Fq2& b) const { return c0 == b.c0 && c1 == b.c1; }
     ZK_DI bool operator!=(const Fq2& b) const { return !(*this == b); }
 };
+template <int B>
+ZK_DI Fq2 sub_b(const Fq2& a, const Fq2& b) { return Fq2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
+template <int B>
+ZK_DI Fq2 neg_b(const Fq2& a) { return Fq2{neg(a.c0), neg(a.c1)}; }
+ZK_DI bool is_zero_full(const Fq2& a) { return a.is_zero(); }
 ZK_DI Fq2 add(const Fq2& a, const Fq2& b) { return Fq2{add(a.c0, b.c0), add(a.c1, b.c1)}; }
 ZK_DI Fq2 sub(const Fq2& a, const Fq2& b) { return Fq2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
 ZK_DI Fq2 neg(const Fq2& a) { return Fq2{neg(a.c0), neg(a.c1)}; }
 ZK_DI Fq2 dbl(const Fq2& a) { return Fq2{dbl(a.c0), dbl(a.c1)}; }
 ZK_DI Fq2 mul(const Fq2& a, const Fq2& b) {
     // Karatsuba, fq2.rs:133-158: 3 base-field products
-    Fq aa = mul(a.c0, b.c0);
-    Fq bb = mul(a.c1, b.c1);
-    Fq o = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    Fq32 aa = mul(a.c0, b.c0);
+    Fq32 bb = mul(a.c1, b.c1);
+    Fq32 o = mul(add(a.c0, a.c1), add(b.c0, b.c1));
     return Fq2{sub(aa, bb), sub(sub(o, aa), bb)};
 }
 ZK_DI Fq2 sqr(const Fq2& a) {
     // complex squaring, fq2.rs:109-131: 2 base-field products
-    Fq ab = mul(a.c0, a.c1);
-    Fq s = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
+    Fq32 ab = mul(a.c0, a.c1);
+    Fq32 s = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
     return Fq2{s, dbl(ab)};
 }
 

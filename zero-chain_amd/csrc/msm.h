@@ -511,14 +511,28 @@ k_msm_segsum(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ init, X
 // ---------------------------------------------------------------------------------------------
 // Table construction: table[k][i] = 2^k * P_i  (affine), k < MSM_NPOS, plus validity checks.
 // ---------------------------------------------------------------------------------------------
-ZK_DI Fq inv(const Fq& a) {
+// a^(q - 2) by square-and-multiply, MSB first (off the hot path: table construction only)
+template <class F>
+ZK_DI F fq_pow_qm2(const F& a) {
     const uint32_t e[12] = ZK_FQ_EXP_QM2_32;
-    return pow_limbs<FqCfg, 12>(a, e);
+    F r = a;
+    bool started = false;
+    for (int i = 11; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            if (started) r = sqr(r);
+            if ((e[i] >> b) & 1u) {
+                if (started) r = mul(r, a);
+                started = true;
+            }
+        }
+    return r;
 }
+ZK_DI Fq28 inv(const Fq28& a) { return fq_pow_qm2(a); }
+ZK_DI Fq32 inv(const Fq32& a) { return fq_pow_qm2(a); }
 ZK_DI Fq2 inv(const Fq2& a) {
     // fq2.rs:160-176
-    Fq n = add(sqr(a.c0), sqr(a.c1));
-    Fq t = inv(n);
+    Fq32 n = add(sqr(a.c0), sqr(a.c1));
+    Fq32 t = inv(n);
     return Fq2{mul(a.c0, t), neg(mul(a.c1, t))};
 }
 
@@ -542,16 +556,64 @@ k_msm_build_table(Affine<F>* table, uint32_t n, uint32_t npos) {
     }
 }
 
-ZK_DI Fq curve_b(const Fq*) {
-    Fq b;
+ZK_DI Fq28 curve_b(const Fq28*) { return Fq28::from_const(Fq28Consts::B); }
+ZK_DI Fq32 curve_b32() {
+    Fq32 b;
     const uint32_t v[12] = ZK_FQ_B_MONT_32;
 #pragma unroll
     for (int i = 0; i < 12; i++) b.l[i] = v[i];
     return b;
 }
 ZK_DI Fq2 curve_b(const Fq2*) {
-    Fq b = curve_b((const Fq*)nullptr);
+    Fq32 b = curve_b32();
     return Fq2{b, b};   // 4(u + 1), ec.rs:1567-1572
+}
+
+// Host interchange.  The host side (host_math.h) and the C ABI speak the reference's layout:
+// 6 x u64 Montgomery limbs per Fq (fq.rs:700-701), c0 then c1 for Fq2.  G1 is converted to /
+// from the device's Fq28 by these kernels; for G2 they are plain copies.
+ZK_DI void fld_import(Fq28& d, const uint32_t* h) { d = fq28_import(h); }
+ZK_DI void fld_export(const Fq28& d, uint32_t* h) { fq28_export(d, h); }
+ZK_DI void fld_import(Fq2& d, const uint32_t* h) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        d.c0.l[i] = h[i];
+        d.c1.l[i] = h[12 + i];
+    }
+}
+ZK_DI void fld_export(const Fq2& d, uint32_t* h) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        h[i] = d.c0.l[i];
+        h[12 + i] = d.c1.l[i];
+    }
+}
+template <class F> struct HostWords;
+template <> struct HostWords<Fq28> { static constexpr int N = 12; };
+template <> struct HostWords<Fq2> { static constexpr int N = 24; };
+
+template <class F>
+__global__ void __launch_bounds__(128)
+k_import_affine(const uint32_t* __restrict__ src, Affine<F>* dst, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int W = HostWords<F>::N;
+    Affine<F> p;
+    fld_import(p.x, src + (size_t)i * 2 * W);
+    fld_import(p.y, src + (size_t)i * 2 * W + W);
+    dst[i] = p;
+}
+template <class F>
+__global__ void __launch_bounds__(64)
+k_export_xyzz(const XYZZ<F>* __restrict__ src, uint32_t* dst, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int W = HostWords<F>::N;
+    XYZZ<F> p = src[i];
+    fld_export(p.x, dst + (size_t)i * 4 * W);
+    fld_export(p.y, dst + (size_t)i * 4 * W + W);
+    fld_export(p.zz, dst + (size_t)i * 4 * W + 2 * W);
+    fld_export(p.zzz, dst + (size_t)i * 4 * W + 3 * W);
 }
 
 // flags[i] bit0: not on curve, bit1: not in the r-torsion subgroup.  Infinity ((0,0)) passes.
@@ -565,8 +627,8 @@ k_check_points(const Affine<F>* __restrict__ pts, uint32_t n, uint32_t do_subgro
     uint32_t f = 0;
     if (!p.is_inf()) {
         F lhs = sqr(p.y);
-        F rhs = add(mul(sqr(p.x), p.x), curve_b((const F*)nullptr));
-        if (lhs != rhs) f |= 1u;
+        F rhs = add(mul(sqr(p.x), p.x), curve_b((const F*)nullptr));   // < 2 MO
+        if (!is_zero_full(sub_b<2 * F::MO>(lhs, rhs))) f |= 1u;
         if (do_subgroup && !f) {
             const uint32_t r[8] = ZK_FR_P_32;
             XYZZ<F> acc = XYZZ<F>::inf();

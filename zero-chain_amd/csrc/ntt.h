@@ -128,17 +128,20 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
     }
 }
 
-// h = (a*b - c) * zinv, element-wise over `count` elements (a, b, c Montgomery; result in a).
+// h = (a*b - c) * zinv, element-wise over `count` = batch * m elements (a, b, c Montgomery), written
+// to out[proof * out_stride + e]: the last inverse transform then runs in place inside the
+// per-proof scalar vector of the merged C multiexp.
 // bellman: a.mul_assign(b); a.sub_assign(c); a.divide_by_z_on_coset()  
 __global__ void __launch_bounds__(256)
-k_h_pointwise(uint32_t* a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
-              const uint32_t* __restrict__ zinv, size_t count) {
+k_h_pointwise(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
+              const uint32_t* __restrict__ zinv, uint32_t* out, uint32_t m, uint32_t out_stride, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     Fr z = ld_fr(zinv);
     Fr x = mul(ld_fr(a + i * 8), ld_fr(b + i * 8));
     x = sub(x, ld_fr(c + i * 8));
-    st_fr(a + i * 8, mul(x, z));
+    size_t proof = i / m, e = i % m;
+    st_fr(out + (proof * out_stride + e) * 8, mul(x, z));
 }
 
 // out[i] = in[i] * tab[i]  (optional table) ; used by the stand-alone zk_ntt_fr entry
@@ -216,22 +219,38 @@ k_field_mul_raw(uint32_t* out, const uint32_t* __restrict__ a, const uint32_t* _
     for (int j = 0; j < C::N; j++) out[(size_t)i * C::N + j] = z.l[j];
 }
 
-// Per-proof scalar vector for the multiexps: out[p] = [ wit[p][0..nv) | tail[p][0..3) ]
-// (tail = 1, r, s).  Witness scalars are converted out of Montgomery form when `mont` is set.
+// Per-proof scalar vectors for the multiexps (plain form):
+//   wit_out[p] = [ wit[p][0..nv) | 1 | r | s ]                          (A and B2 multiexps)
+//   cvec[p]    = [ h (m, written later) | aux (n_aux) | r * z (nv) | r ]  (merged C multiexp:
+//                C' = H + L + r * (B1 + beta_1), one bucket set instead of three)
+// tail[p] = (1, r, s).  Witness scalars are converted out of Montgomery form when `mont` is set.
 __global__ void __launch_bounds__(256)
-k_build_scalars(uint32_t* out, const uint32_t* __restrict__ wit, const uint32_t* __restrict__ tail, uint32_t nv,
-                uint32_t mont) {
+k_build_scalars(uint32_t* wit_out, uint32_t* cvec, const uint32_t* __restrict__ wit, const uint32_t* __restrict__ tail,
+                uint32_t nv, uint32_t n_in, uint32_t m, uint32_t cstride, uint32_t mont) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv + 3) return;
-    size_t p = blockIdx.y;
+    const size_t p = blockIdx.y;
+    uint32_t* cv = cvec + p * (size_t)cstride * 8;
+    const uint32_t n_aux = nv - n_in;
+    Fr r = ld_fr(tail + (p * 3 + 1) * 8);   // plain
     Fr v;
     if (i < nv) {
-        v = ld_fr(wit + (p * nv + i) * 8);
-        if (mont) v = from_mont(v);
+        Fr raw = ld_fr(wit + (p * nv + i) * 8);
+        Fr rz;
+        if (mont) {
+            v = from_mont(raw);
+            rz = mul(raw, r);                     // (z R)(r) / R = z r
+        } else {
+            v = raw;
+            rz = mul(mul(raw, r), Fr::r2());      // (z r / R)(R^2) / R = z r
+        }
+        if (i >= n_in) st_fr(cv + (size_t)(m + (i - n_in)) * 8, v);
+        st_fr(cv + (size_t)(m + n_aux + i) * 8, rz);
     } else {
         v = ld_fr(tail + (p * 3 + (i - nv)) * 8);
+        if (i == nv) st_fr(cv + (size_t)(m + n_aux + nv) * 8, r);   // r * 1 for beta_1
     }
-    st_fr(out + (p * (nv + 3) + i) * 8, v);
+    st_fr(wit_out + (p * (nv + 3) + i) * 8, v);
 }
 
 }  // namespace zkdev

@@ -309,10 +309,16 @@ zk_status check_points_dev(const zkdev::Affine<DF>* d_pts, size_t n, const char*
 template <class HF, class DF>
 zk_status check_points_host(const std::vector<zkhost::Affine<HF>>& pts, const char* what) {
     if (pts.empty()) return ZK_OK;
-    DevBuf d;
+    DevBuf stage, d;
+    ZK_TRY(stage.ensure(pts.size() * sizeof(zkhost::Affine<HF>)));
     ZK_TRY(d.ensure(pts.size() * sizeof(zkdev::Affine<DF>)));
-    HIP_TRY(hipMemcpy(d.p, pts.data(), pts.size() * sizeof(zkdev::Affine<DF>), hipMemcpyHostToDevice));
-    return check_points_dev<HF, DF>(d.as<zkdev::Affine<DF>>(), pts.size(), what);
+    HIP_TRY(hipMemcpy(stage.p, pts.data(), pts.size() * sizeof(zkhost::Affine<HF>), hipMemcpyHostToDevice));
+    ZK_LAUNCH(zkdev::k_import_affine<DF>, dim3((unsigned)((pts.size() + 127) / 128)), dim3(128), 0, g_stream,
+              (const uint32_t*)stage.as<uint32_t>(), d.as<zkdev::Affine<DF>>(), (uint32_t)pts.size());
+    HIP_TRY(hipGetLastError());
+    zk_status st = check_points_dev<HF, DF>(d.as<zkdev::Affine<DF>>(), pts.size(), what);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return st;
 }
 
 template <class HF, class DF>
@@ -321,13 +327,15 @@ struct MsmGroup {
     typedef zkhost::Point<HF> HPoint;
     typedef zkdev::Affine<DF> DAffine;
     typedef zkdev::XYZZ<DF> DPoint;
-    static_assert(sizeof(HAffine) == sizeof(DAffine), "host/device affine layout");
-    static_assert(sizeof(HPoint) == sizeof(DPoint), "host/device point layout");
+    // host layout = the reference's (6 x u64 Montgomery limbs per Fq); the device keeps G1 in
+    // radix-2^28 limbs: k_import_affine / k_export_xyzz convert at the two ends of a run
+    static_assert(sizeof(HAffine) == 2 * 4 * zkdev::HostWords<DF>::N, "host affine layout");
+    static_assert(sizeof(HPoint) == 4 * 4 * zkdev::HostWords<DF>::N, "host point layout");
 
     uint32_t c = 0, maxd = 0, nb = 0;
     size_t n_points = 0;
     DevBuf table;
-    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, tbase, rank, pairs, tsums, red_r, red_w, red_t;
+    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, tbase, rank, pairs, tsums, red_r, red_w, red_t, result;
     std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
 
@@ -341,8 +349,16 @@ struct MsmGroup {
         ZK_TRY(table.ensure(tb ? tb : 1));
         bytes = tb;
         if (!n_points) return ZK_OK;
-        HIP_TRY(hipMemcpy(table.p, pts.data(), sizeof(DAffine) * n_points, hipMemcpyHostToDevice));
         unsigned blocks = (unsigned)((n_points + 127) / 128);
+        {
+            DevBuf stage;
+            ZK_TRY(stage.ensure(sizeof(HAffine) * n_points));
+            HIP_TRY(hipMemcpy(stage.p, pts.data(), sizeof(HAffine) * n_points, hipMemcpyHostToDevice));
+            ZK_LAUNCH(zkdev::k_import_affine<DF>, dim3(blocks), dim3(128), 0, g_stream, (const uint32_t*)stage.as<uint32_t>(),
+                      table.as<DAffine>(), (uint32_t)n_points);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(g_stream));
+        }
         if (checked) ZK_TRY((check_points_dev<HF, DF>(table.as<DAffine>(), n_points, what)));
         ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3(blocks), dim3(128), 0, g_stream, table.as<DAffine>(),
                   (uint32_t)n_points, zkdev::MSM_NPOS);
@@ -446,7 +462,7 @@ struct MsmGroup {
                            heavy.as<uint32_t>(), nb, (uint32_t)nj);
         }
         {
-            ProfScope ps(sizeof(DF) > 48 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
+            ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
             ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
                       table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
         }
@@ -455,7 +471,7 @@ struct MsmGroup {
         DPoint* Wb = Wa + nj * (size_t)T;
         DPoint* in = Wa;
         {
-            ProfScope ps(sizeof(DF) > 48 ? "msm_reduce_g2" : "msm_reduce_g1", st);
+            ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_reduce_g2" : "msm_reduce_g1", st);
             auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
             ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>, dim3((unsigned)heavy_cap), dim3(64), 0, st,
                            (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy, (const uint32_t*)cnt.as<uint32_t>(),
@@ -490,8 +506,11 @@ struct MsmGroup {
                 n = n_out;
             }
         }
+        ZK_TRY(result.ensure(nj * sizeof(HPoint)));
+        ZK_LAUNCH(zkdev::k_export_xyzz<DF>, dim3((unsigned)((nj + 63) / 64)), dim3(64), 0, st, (const DPoint*)in,
+                  result.as<uint32_t>(), (uint32_t)nj);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(out.data(), in, nj * sizeof(DPoint), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out.data(), result.p, nj * sizeof(HPoint), hipMemcpyDeviceToHost, st));
         return ZK_OK;
     }
     zk_status collect(hipStream_t st) {
@@ -574,10 +593,10 @@ struct zk_params {
     NttPlan ntt;
     // cached per-circuit index maps (keyed by the density bytes)
     std::vector<uint8_t> dens_key;
-    DevBuf map_h, map_a, map_b1, map_b2;
+    DevBuf map_a, map_b2, map_c;
     uint32_t map_nv = 0;
     // workspaces
-    DevBuf abc, wit, tail, stage_a, stage_b, stage_c, stage_w;
+    DevBuf abc, wit, cvec, tail, stage_a, stage_b, stage_c, stage_w;
     std::vector<MsmJob> jobs1, jobs2;
     std::vector<HG1> res1;
     std::vector<HG2> res2;
@@ -649,7 +668,8 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
         ZK_TRY((check_points_host<zkhost::Fq2, zkdev::Fq2>(std::vector<HG2A>{gamma_g2}, "vk.gamma_g2")));
     }
     // one width per group: the G1 jobs of a proof (H, L, A, B1) average a quarter of the G1 terms
-    const uint32_t c1 = pick_window(((size_t)P->n_h + P->n_l + P->n_a + P->n_b1) / 4, 1);
+    // two G1 jobs per proof: A, and the merged C' = H + L + r * B1
+    const uint32_t c1 = pick_window(((size_t)P->n_h + P->n_l + P->n_a + P->n_b1) / 2, 1);
     const uint32_t c2 = pick_window(P->n_b2, 2);
     ZK_TRY(P->g1.build(pts1, c1, checked != 0, "parameters (G1)"));
     ZK_TRY(P->g2.build(pts2, c2, checked != 0, "parameters (G2)"));
@@ -696,25 +716,30 @@ zk_status ensure_maps(zk_params* P, uint32_t n_in, uint32_t n_aux, const uint8_t
         uint32_t e = P->log_m ? (__builtin_bitreverse32((uint32_t)pos) >> (32 - P->log_m)) : 0;
         mh[pos] = e < P->n_h ? (int32_t)e : -1;
     }
+    // merged C job: [h (m) | aux (n_aux) | r z (nv) | r], absolute positions in the G1 group table
+    std::vector<int32_t> mc;
+    mc.reserve(P->m + n_aux + nv + 1);
+    for (size_t pos = 0; pos < P->m; pos++) mc.push_back(mh[pos] < 0 ? -1 : (int32_t)(P->off_h + mh[pos]));
+    for (uint32_t j = 0; j < n_aux; j++) mc.push_back((int32_t)(P->off_l + j));
+    for (uint32_t i = 0; i < nv; i++) mc.push_back(mb1[i] < 0 ? -1 : (int32_t)(P->off_b1 + mb1[i]));
+    mc.push_back((int32_t)(P->off_b1 + P->n_b1));   // r * beta_g1
     ZK_TRY(P->map_a.ensure(ma.size() * 4));
-    ZK_TRY(P->map_b1.ensure(mb1.size() * 4));
     ZK_TRY(P->map_b2.ensure(mb2.size() * 4));
-    ZK_TRY(P->map_h.ensure(mh.size() * 4));
+    ZK_TRY(P->map_c.ensure(mc.size() * 4));
     HIP_TRY(hipMemcpy(P->map_a.p, ma.data(), ma.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(P->map_b1.p, mb1.data(), mb1.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(P->map_b2.p, mb2.data(), mb2.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(P->map_h.p, mh.data(), mh.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(P->map_c.p, mc.data(), mc.size() * 4, hipMemcpyHostToDevice));
     P->dens_key.swap(key);
     P->map_nv = nv;
     return ZK_OK;
 }
 
 // create_proof step 6, rearranged:  with A = alpha + sum_A + r*delta (already
-// complete, the alpha and r*delta terms rode along in the A multiexp) and B1 = beta_1 + sum_B1,
-//   C = s*A + r*B1 + h + l   ==  rs*delta + s*alpha + r*beta_1 + s*sum_A + r*sum_B1 + h + l.
-void fold_proof(const HG1& h, const HG1& l, const HG1& a, const HG1& b1, const HG2& b2, const uint64_t r[4],
-                const uint64_t s[4], uint8_t* out) {
-    HG1 c = zkhost::padd(zkhost::padd(zkhost::pmul(a, s), zkhost::pmul(b1, r)), zkhost::padd(h, l));
+// complete, the alpha and r*delta terms rode along in the A multiexp) and
+// C' = h + l + r*(beta_1 + sum_B1) from the merged multiexp,
+//   C = s*A + C'   ==  rs*delta + s*alpha + r*beta_1 + s*sum_A + r*sum_B1 + h + l.
+void fold_proof(const HG1& cprime, const HG1& a, const HG2& b2, const uint64_t s[4], uint8_t* out) {
+    HG1 c = zkhost::padd(zkhost::pmul(a, s), cprime);
     zkhost::g1_to_compressed(zkhost::to_affine(a), out);
     zkhost::g2_to_compressed(zkhost::to_affine(b2), out + 48);
     zkhost::g1_to_compressed(zkhost::to_affine(c), out + 144);
@@ -741,8 +766,12 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     }
     ZK_TRY(P->tail.ensure(np * 96));
     HIP_TRY(hipMemcpyAsync(P->tail.p, tail.data(), np * 96, hipMemcpyHostToDevice, g_stream));
-    ZK_LAUNCH(zkdev::k_build_scalars, dim3((nv + 3 + 255) / 256, (unsigned)np), dim3(256), 0, g_stream, wit,
-              (const uint32_t*)bt->d_wit + first * (size_t)nv * 8, P->tail.as<uint32_t>(), nv, mont ? 1u : 0u);
+    const uint32_t cstride = (uint32_t)(m + n_aux + nv + 1);
+    ZK_TRY(P->cvec.ensure(np * (size_t)cstride * 32));
+    uint32_t* cvec = P->cvec.as<uint32_t>();
+    ZK_LAUNCH(zkdev::k_build_scalars, dim3((nv + 3 + 255) / 256, (unsigned)np), dim3(256), 0, g_stream, wit, cvec,
+              (const uint32_t*)bt->d_wit + first * (size_t)nv * 8, P->tail.as<uint32_t>(), nv, n_in, (uint32_t)m, cstride,
+              mont ? 1u : 0u);
     // ---- multiexps (create_proof step 4).  The G2 job only needs the witness scalars: it is
     // enqueued first, on the side stream, and runs beside the H pipeline and the G1 multiexps (its
     // reduction tree is latency-bound with one job per proof; the G1 work fills the machine).
@@ -754,9 +783,10 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
         MsmJob j2 = {w, P->map_b2.as<int32_t>(), nv + 3, 0, npts2, 0};
         P->jobs2.push_back(j2);
     }
+    hipStream_t side = getenv("ZKAMD_NO_OVERLAP") ? g_stream : g_stream2;
     HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
-    HIP_TRY(hipStreamWaitEvent(g_stream2, g_ev_fork, 0));
-    ZK_TRY(P->g2.enqueue(P->jobs2, P->res2, g_stream2));
+    HIP_TRY(hipStreamWaitEvent(side, g_ev_fork, 0));
+    ZK_TRY(P->g2.enqueue(P->jobs2, P->res2, side));
     // ---- H pipeline (create_proof step 3)
     ZK_TRY(P->abc.ensure(3 * np * m * 32));
     uint32_t* A = P->abc.as<uint32_t>();
@@ -774,25 +804,22 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     {
         ProfScope ps("h_pointwise");
         size_t count = np * m;
-        ZK_LAUNCH(zkdev::k_h_pointwise, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, g_stream, A, B, C,
-                  P->ntt.consts.as<uint32_t>() + 8, count);
+        ZK_LAUNCH(zkdev::k_h_pointwise, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, g_stream, (const uint32_t*)A,
+                  (const uint32_t*)B, (const uint32_t*)C, P->ntt.consts.as<uint32_t>() + 8, cvec, (uint32_t)m, cstride, count);
     }
-    // icoset fft: ifft (natural -> bit-reversed), * g^-i / m, Montgomery factor dropped
-    ZK_TRY(P->ntt.chain(A, (uint32_t)np, (uint32_t)m, true, true, nullptr, P->ntt.s2.as<uint32_t>()));
+    // icoset fft: ifft (natural -> bit-reversed), * g^-i / m, Montgomery factor dropped; in place
+    // inside the merged scalar vectors
+    ZK_TRY(P->ntt.chain(cvec, (uint32_t)np, cstride, true, true, nullptr, P->ntt.s2.as<uint32_t>()));
     for (size_t p = 0; p < np; p++) {
         const uint32_t* w = wit + p * wstride * 8;
-        MsmJob jh = {A + p * m * 8, P->map_h.as<int32_t>(), (uint32_t)m, P->off_h, npts1, 0};
-        MsmJob jl = {w + (size_t)n_in * 8, nullptr, n_aux, P->off_l, npts1, 0};
         MsmJob ja = {w, P->map_a.as<int32_t>(), nv + 3, P->off_a, npts1, 0};
-        MsmJob jb = {w, P->map_b1.as<int32_t>(), nv + 3, P->off_b1, npts1, 0};
-        P->jobs1.push_back(jh);
-        P->jobs1.push_back(jl);
+        MsmJob jc = {cvec + p * (size_t)cstride * 8, P->map_c.as<int32_t>(), cstride, 0, npts1, 0};
         P->jobs1.push_back(ja);
-        P->jobs1.push_back(jb);
+        P->jobs1.push_back(jc);
     }
     ZK_TRY(P->g1.enqueue(P->jobs1, P->res1, g_stream));
     ZK_TRY(P->g1.collect(g_stream));
-    ZK_TRY(P->g2.collect(g_stream2));
+    ZK_TRY(P->g2.collect(side));
     // ---- final fold + encoding (host, one thread per slice of the chunk)
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
@@ -800,8 +827,7 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     if (nthreads > np) nthreads = (unsigned)np;
     auto work = [&](size_t lo, size_t hi) {
         for (size_t p = lo; p < hi; p++)
-            fold_proof(P->res1[4 * p], P->res1[4 * p + 1], P->res1[4 * p + 2], P->res1[4 * p + 3], P->res2[p],
-                       &rsv[p * 8], &rsv[p * 8 + 4], proofs_out + (first + p) * 192);
+            fold_proof(P->res1[2 * p + 1], P->res1[2 * p], P->res2[p], &rsv[p * 8 + 4], proofs_out + (first + p) * 192);
     };
     if (nthreads <= 1) {
         work(0, np);
@@ -824,7 +850,9 @@ zk_status prove_batch_dev(zk_params* P, size_t n, const zk_batch_dev* bt, const 
     if (!bt->d_a || !bt->d_b || !bt->d_c || !bt->d_wit || !bt->a_aux_density || !bt->b_input_density || !bt->b_aux_density)
         return fail(ZK_ERR_ASSIGNMENT_MISSING, "assignment pointer is null");
     ZK_TRY(ensure_maps(P, bt->n_inputs, bt->n_aux, bt->a_aux_density, bt->b_input_density, bt->b_aux_density));
-    size_t chunk = 128;
+    // proofs per launch set: large chunks amortise the latency-bound tails (reduction trees, sorts);
+    // the workspaces of a 1024-proof chunk of the Transfer circuit take ~35 GB of the 288 GB
+    size_t chunk = 1024;
     const char* env = getenv("ZKAMD_BATCH_CHUNK");
     if (env && atoi(env) > 0) chunk = (size_t)atoi(env);
     for (size_t first = 0; first < n; first += chunk) {
