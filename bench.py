@@ -91,12 +91,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ZK_BENCH_ONE_GPU=1 (smoke test of the N > 1 code path on a 1-GPU box): every rank uses cuda:0 and
+    # the 192-byte gather goes over gloo, since RCCL refuses two ranks on one device
+    one_gpu = os.environ.get("ZK_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    gather_dev = torch.device("cpu") if one_gpu else dev
 
     import zero_chain_amd as zk
     from zero_chain_amd import _lib as zl
@@ -108,7 +117,7 @@ def main():
     n_wit = 8
     t0 = time.time()
     P, pk, asgs = build_workload(n_wit)
-    params = zk.Parameters.read(pk, checked=False, device=local_rank, lib=lib)
+    params = zk.Parameters.read(pk, checked=False, device=dev_index, lib=lib)
     setup_s = time.time() - t0
     n_rows = len(asgs[0].a)
     B = args.batch
@@ -129,17 +138,17 @@ def main():
     rs_ints = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(B)]
     rs = zk.scalars_to_bytes([x for pair in rs_ints for x in pair])
     out = np.zeros(192 * B, dtype=np.uint8)
-    gathered = [torch.empty(192 * B, dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 and rank == 0 else None
+    last_gather = [None]
 
     def step():
         lib.check(lib.zk_prove_batch_dev(params._h, B, C.byref(bt), rs.ctypes.data, out.ctypes.data))
         if world > 1:
-            import torch.distributed as dist
-            dist.gather(torch.from_numpy(out).to(dev), gathered, dst=0)   # RCCL: 192 B x B per rank
+            # every rank proved its contiguous block of the B * world proofs; one gather of 192 B per
+            # proof to rank 0 (RCCL under "nccl"): the only collective of the data path
+            last_gather[0] = zk.gather_proofs(out, B * world, dist=dist, device=gather_dev, dst=0)
 
     def fence():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
         lib.check(lib.zk_synchronize())
@@ -161,10 +170,11 @@ def main():
             kernels[name] = {"launches": cnt, "total_ms": round(ms.value, 3)}
     lib.zk_profile_end()
     if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if rank == 0:   # rank 0's own block sits at the front of the gathered batch
+            assert last_gather[0][:192 * B] == out.tobytes() and len(last_gather[0]) == 192 * B * world
 
     # ---- parity gate: every proof of the last step equals the oracle's (discrete-log) proof
     checked = 0
@@ -229,7 +239,7 @@ def main():
                                "domain 2^15), full create_proof from a finished assignment: 7 NTT + 5 multiexp "
                                "(H, L, A, B1 in G1; B2 in G2) + fold + 192-byte encoding",
                    "proofs_per_gpu_per_step": B, "distinct_witnesses": n_wit, "window_bits": info["window_bits"],
-                   "batch_chunk": chunk, "parallelism": "dp%d (independent proofs, RCCL gather of 192 B/proof)" % world,
+                   "batch_chunk": chunk, "parallelism": "dp%d (independent proofs, %s gather of 192 B/proof)" % (world, "gloo" if one_gpu else "RCCL"),
                    "proofs_checked_vs_oracle": checked, "setup_s": round(setup_s, 2)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "micro": micro,
     }

@@ -146,7 +146,7 @@ def gen(N, p, name):
             "clobbers": clob_v + clob_s + ["vcc"]}
 
 
-def gen28(p, name):
+def gen28(p, name, dual=False):
     """Fq in radix 2^28, 14 limbs, Montgomery radix 2^392, product scanning with ONE 64-bit column
     accumulator and no carry instructions at all: 28 products of < 2^56.01 fit 64 bits.  Inputs:
     limbs <= 2^28 + 8 (weakly normalised), values with |a||b| < 2^11.3 p^2.  Output: limbs < 2^28
@@ -163,6 +163,7 @@ def gen28(p, name):
     m = lambda i: "v%d" % mreg[i]
     lo, hi = 54, 55
     acc = "v[%d:%d]" % (lo, hi)
+    acc2 = "v[64:65]"     # second accumulator (dual variant): the m * p products
     sp = lambda j: "s%d" % j
     sinv = "s%d" % N
     dummy = "s[16:17]"
@@ -173,10 +174,25 @@ def gen28(p, name):
     first = True
     for k in range(2 * N - 1):
         prods = [(a(i), b(k - i)) for i in range(N) if 0 <= k - i < N]
-        prods += [(m(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
-        for x, y in prods:
-            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, dummy, x, y, "0" if first else acc))
-            first = False
+        mprods = [(m(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
+        if not dual:
+            for x, y in prods + mprods:
+                e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, dummy, x, y, "0" if first else acc))
+                first = False
+        else:
+            # two independent dependency chains, interleaved; merged with one 64-bit add per column
+            first2 = True
+            for t in range(max(len(prods), len(mprods))):
+                if t < len(prods):
+                    x, y = prods[t]
+                    e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, dummy, x, y, "0" if first else acc))
+                    first = False
+                if t < len(mprods):
+                    x, y = mprods[t]
+                    e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc2, dummy, x, y, "0" if first2 else acc2))
+                    first2 = False
+            if mprods:
+                e.valu_op("v_lshl_add_u64 %s, %s, 0, %s" % (acc, acc2, acc))
         if k < N:
             e.valu_op("v_mul_lo_u32 %s, v%d, %s" % (m(k), lo, sinv))
             e.valu_op("v_and_b32_e32 %s, 0x%08x, %s" % (m(k), MASK, m(k)))
@@ -186,7 +202,58 @@ def gen28(p, name):
         e.valu_op("v_alignbit_b32 v%d, v%d, v%d, %d" % (lo, hi, lo, B))
         e.valu_op("v_lshrrev_b32_e32 v%d, %d, v%d" % (hi, B, hi))
     e.valu_op("v_mov_b32_e32 %s, v%d" % (a(N - 1), lo))
-    clob_v = ["v%d" % i for i in list(range(32, 40)) + list(range(48, 56))]
+    clob_v = ["v%d" % i for i in list(range(32, 40)) + list(range(48, 56)) + ([64, 65] if dual else [])]
+    clob_s = ["s%d" % i for i in range(0, 18)]
+    return {"name": name, "N": N, "lines": e.lines, "valu": e.valu, "nops": e.nops,
+            "clobbers": clob_v + clob_s + ["vcc"]}
+
+
+def gen28_sqr(p, name):
+    """Square in the radix-2^28 representation: the 91 cross products a_i a_j (i < j) are taken once
+    against pre-doubled limbs (2 a_j <= 2^29 + 16 still leaves the column sums below 2^64), so the
+    a*a half costs 14 + 105 instructions instead of 196.  a in v[0:13]; result in v[0:13].
+    clobbers v[16:29] (doubled limbs), v[32:39], v[48:55], s[0:17], vcc."""
+    N, B = 14, 28
+    MASK = (1 << B) - 1
+    P = [(p >> (B * j)) & MASK for j in range(N)]
+    inv = (-pow(p, -1, 1 << B)) & MASK
+    a = lambda i: "v%d" % i
+    d = lambda i: "v%d" % (16 + i)
+    mreg = list(range(32, 40)) + list(range(48, 54))
+    m = lambda i: "v%d" % mreg[i]
+    lo, hi = 54, 55
+    acc = "v[%d:%d]" % (lo, hi)
+    sp = lambda j: "s%d" % j
+    sinv = "s%d" % N
+    dummy = "s[16:17]"
+    e = Emitter()
+    for j in range(N):
+        e.salu_op("s_mov_b32 %s, 0x%08x" % (sp(j), P[j]))
+    e.salu_op("s_mov_b32 %s, 0x%08x" % (sinv, inv))
+    for j in range(1, N):
+        e.valu_op("v_lshlrev_b32_e32 %s, 1, %s" % (d(j), a(j)))
+    first = True
+    for k in range(2 * N - 1):
+        prods = []
+        for i in range(N):
+            j = k - i
+            if 0 <= j < N and i <= j:
+                prods.append((a(i), a(j)) if i == j else (a(i), d(j)))
+        prods += [(m(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
+        for x, y in prods:
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, dummy, x, y, "0" if first else acc))
+            first = False
+        if k < N:
+            e.valu_op("v_mul_lo_u32 %s, v%d, %s" % (m(k), lo, sinv))
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, %s" % (m(k), MASK, m(k)))
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, dummy, m(k), sp(0), acc))
+        else:
+            # a[k - N] is dead from column k on (it only meets a[j], j >= k - N + 1 ... in earlier columns)
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, v%d" % (a(k - N), MASK, lo))
+        e.valu_op("v_alignbit_b32 v%d, v%d, v%d, %d" % (lo, hi, lo, B))
+        e.valu_op("v_lshrrev_b32_e32 v%d, %d, v%d" % (hi, B, hi))
+    e.valu_op("v_mov_b32_e32 %s, v%d" % (a(N - 1), lo))
+    clob_v = ["v%d" % i for i in list(range(16, 30)) + list(range(32, 40)) + list(range(48, 56))]
     clob_s = ["s%d" % i for i in range(0, 18)]
     return {"name": name, "N": N, "lines": e.lines, "valu": e.valu, "nops": e.nops,
             "clobbers": clob_v + clob_s + ["vcc"]}
@@ -207,7 +274,7 @@ def render(spec):
 
 
 def main():
-    specs = [gen(8, FR_P, "FR"), gen(12, FQ_P, "FQ"), gen28(FQ_P, "FQ28")]
+    specs = [gen(8, FR_P, "FR"), gen(12, FQ_P, "FQ"), gen28(FQ_P, "FQ28"), gen28(FQ_P, "FQ28D", dual=True), gen28_sqr(FQ_P, "FQ28SQR")]
     hdr = ["// GENERATED by tools/gen_mul_asm.py - do not edit.",
            "// Hand-scheduled gfx950 Montgomery products (see the generator for the design notes).",
            "#pragma once", ""]

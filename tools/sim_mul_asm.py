@@ -114,14 +114,40 @@ def _run_regs(lines, init, nout):
         elif op == "v_and_b32_e32": setv(ops[0], val(ops[1]) & val(ops[2]))
         elif op == "v_alignbit_b32": setv(ops[0], (((val(ops[1]) << 32) | val(ops[2])) >> val(ops[3])) & M32)
         elif op == "v_lshrrev_b32_e32": setv(ops[0], val(ops[2]) >> val(ops[1]))
+        elif op == "v_lshlrev_b32_e32": setv(ops[0], (val(ops[2]) << val(ops[1])) & M32)
+        elif op == "v_lshl_add_u64":
+            t = (val(ops[1]) << val(ops[2])) + val(ops[3])
+            assert t < 2**64, "64-bit add overflow"
+            setv(ops[0], t)
         else: raise SystemExit("unknown op " + ln)
     return [v[i] for i in range(nout)]
 
 
-def main28():
+def main28_sqr():
+    rnd = random.Random(3)
+    p = g.FQ_P
+    spec = g.gen28_sqr(p, "FQ28SQR")
+    Rinv = pow(1 << 392, -1, p)
+    lim = lambda x: [(x >> (28 * i)) & ((1 << 28) - 1) if i < 13 else x >> (28 * 13) for i in range(14)]
+    val = lambda l: sum(x << (28 * i) for i, x in enumerate(l))
+    cases = [0, 1, p - 1, 2 * p - 1, 49 * p + 5] + [rnd.randrange(40 * p) for _ in range(300)]
+    for a in cases:
+        la = lim(a)
+        if rnd.random() < 0.5:
+            for i in range(13):
+                if la[i] < 8 and la[i + 1] > 0:
+                    la[i] += 1 << 28; la[i + 1] -= 1
+        out = _run_regs(spec["lines"], {i: la[i] for i in range(14)}, 14)
+        got = val(out)
+        assert all(x < (1 << 28) for x in out[:13])
+        assert got % p == val(la) * val(la) * Rinv % p and got < 2 * p, hex(a)
+    print(spec["name"], "ok:", len(cases), "squares;", spec["valu"], "VALU,", spec["nops"], "wait states")
+
+
+def main28(dual=False):
     rnd = random.Random(2)
     p = g.FQ_P
-    spec = g.gen28(p, "FQ28")
+    spec = g.gen28(p, "FQ28D" if dual else "FQ28", dual=dual)
     Rinv = pow(1 << 392, -1, p)
     lim = lambda x: [(x >> (28 * i)) & ((1 << 28) - 1) if i < 13 else x >> (28 * 13) for i in range(14)]
     val = lambda l: sum(x << (28 * i) for i, x in enumerate(l))
@@ -138,9 +164,11 @@ def main28():
         assert all(x < (1 << 28) for x in out[:13]), "limbs not normalised"
         assert got % p == val(la) * val(lb) * Rinv % p, (hex(a), hex(b))
         assert got < 2 * p, "output bound"
-    print("FQ28 ok:", len(cases), "products;", spec["valu"], "VALU,", spec["nops"], "wait states")
+    print(spec["name"], "ok:", len(cases), "products;", spec["valu"], "VALU,", spec["nops"], "wait states")
 
 
 if __name__ == "__main__":
     main()
     main28()
+    main28(dual=True)
+    main28_sqr()

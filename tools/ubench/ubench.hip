@@ -153,6 +153,10 @@ __global__ void k_check28(uint32_t* bad, uint32_t seed) {
     uint32_t d = 0;
     for (int j = 0; j < 14; j++) d |= r0[j] ^ r1[j];
     if (d) atomicAdd(&bad[0], 1u);
+    u32x16 s0 = sqr28_raw(a), s1 = mul28_cxx(a, a);
+    d = 0;
+    for (int j = 0; j < 14; j++) d |= s0[j] ^ s1[j];
+    if (d) atomicAdd(&bad[1], 1u);
 }
 template <int CHAINS>
 __global__ void __launch_bounds__(256) k_montmul28(uint32_t* out, const uint32_t* in, int iters) {
@@ -205,7 +209,7 @@ int main() {
         uint32_t* bad28; CHECK(hipMalloc(&bad28, 16)); CHECK(hipMemset(bad28, 0, 16));
         hipLaunchKernelGGL(k_check28, dim3(4096), dim3(256), 0, 0, bad28, 13u);
         uint32_t hb28[4]; CHECK(hipMemcpy(hb28, bad28, 16, hipMemcpyDeviceToHost));
-        printf("radix-2^28 Fq product, asm vs c++ over 1M operands: mismatches %u\n", hb28[0]);
+        printf("radix-2^28 Fq product, asm vs c++ over 1M operands: mismatches %u (mul) %u (sqr)\n", hb28[0], hb28[1]);
         printf("mul check (1M products each): Fq asm mismatches %u, Fq c++fips mismatches %u, Fr asm mismatches %u, Fr c++fips mismatches %u\n", hb[0], hb[1], hb[2], hb[3]);
     }
     const int iters = 4096;

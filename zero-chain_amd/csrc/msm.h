@@ -42,7 +42,7 @@ struct MsmJob {
 // waves per SIMD) pins the occupancy the dependent carry chains of the Montgomery product need.
 template <class F> struct MsmOcc;
 #ifndef ZK_OCC_G1_ACC
-#define ZK_OCC_G1_ACC 3
+#define ZK_OCC_G1_ACC 2
 #endif
 #ifndef ZK_OCC_G1_RED
 #define ZK_OCC_G1_RED 3
