@@ -75,3 +75,12 @@ def test_prover_errors(emu_lib, monkeypatch):
 
 def test_msm_recoding_all_widths(emu_lib):
     pc.msm_recoding_stress(emu_lib, windows=range(2, 13))   # wide windows: GPU suite (thread-per-GPU-thread emulation)
+
+
+def test_msm_global_sort_path(emu_lib, monkeypatch):
+    """The three-kernel global-atomic sort (used when the bucket histogram does not fit LDS), with
+    the hot-bucket pre-aggregation of single-job launches."""
+    monkeypatch.setenv("ZKAMD_NO_LDS_SORT", "1")
+    pc.msm_golden_vectors(emu_lib, 1, 300, 5)
+    pc.msm_golden_vectors(emu_lib, 1, 700, 9, seed=8)
+    pc.msm_golden_vectors(emu_lib, 2, 60, 4)

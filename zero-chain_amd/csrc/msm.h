@@ -58,7 +58,8 @@ template <> struct MsmOcc<Fq2> { static constexpr int acc = ZK_OCC_G2_ACC, red =
 
 constexpr uint32_t MSM_SEG = 64;    // longest run of points one thread accumulates
 constexpr uint32_t MSM_NPOS = 255;  // table slices: 2^k * P for k = 0 .. 254
-constexpr uint32_t MSM_MERGE_INLINE = 8;   // buckets with more task partials than this are merged by k_msm_merge_heavy
+// buckets with more task partials than `merge_inline` (8 when many jobs fill the machine, 2 for a
+// single job whose reduction threads must stay short) are merged by k_msm_merge_heavy
 
 // upper bound on the non-zero digits of one scalar: digits are >= c positions apart, 0 .. 254
 __host__ ZK_DI uint32_t msm_max_digits(uint32_t c) { return 254 / c + 2; }
@@ -149,19 +150,40 @@ ZK_DI void msm_wnaf(const uint32_t* __restrict__ sp, uint32_t c, Fn&& f) {
 // Pass 1: histogram.  Every non-zero digit takes a ticket (its rank inside the bucket) from the
 // bucket counter; the ticket is remembered so that the scatter needs no atomics.
 // rank layout per job: [slot][i].  Bucket of an odd magnitude m: m >> 1.
+// The lowest MSM_HOT buckets are hot (small last digits, boolean witnesses: tens of thousands of
+// tickets on one address serialise in L2): when `blockbase` is given a workgroup counts them in an
+// LDS histogram, takes ONE global ticket range per bucket, and the scatter adds the range base to
+// the workgroup-local rank (flagged with bit 31).
+constexpr uint32_t MSM_HOT = 1024;
 __global__ void __launch_bounds__(256)
-k_msm_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* rank) {
+k_msm_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* rank, uint32_t* blockbase) {
+    ZK_SHARED uint32_t h[MSM_HOT];
     const MsmJob job = jobs[blockIdx.y];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= job.n) return;
-    if (job.map && job.map[i] < 0) return;
+    const uint32_t tid = threadIdx.x;
+    uint32_t i = blockIdx.x * blockDim.x + tid;
     const uint32_t nb = 1u << (c - 2);
     uint32_t* jcnt = cnt + (size_t)blockIdx.y * nb;
     uint32_t* jrank = rank + job.pair_base;
     const uint32_t n = job.n;
-    msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t slot, uint32_t, uint32_t mag, bool) {
-        jrank[(size_t)slot * n + i] = atomicAdd(&jcnt[mag >> 1], 1u);
-    });
+    const bool active = i < n && !(job.map && job.map[i] < 0);
+    if (blockbase) {
+        for (uint32_t t = tid; t < MSM_HOT; t += blockDim.x) h[t] = 0;
+        __syncthreads();
+    }
+    if (active) {
+        msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t slot, uint32_t, uint32_t mag, bool) {
+            const uint32_t b = mag >> 1;
+            if (blockbase && b < MSM_HOT)
+                jrank[(size_t)slot * n + i] = atomicAdd(&h[b], 1u) | 0x80000000u;
+            else
+                jrank[(size_t)slot * n + i] = atomicAdd(&jcnt[b], 1u);
+        });
+    }
+    if (blockbase) {
+        __syncthreads();
+        uint32_t* bb = blockbase + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * MSM_HOT;
+        for (uint32_t t = tid; t < MSM_HOT && t < nb; t += blockDim.x) bb[t] = h[t] ? atomicAdd(&jcnt[t], h[t]) : 0u;
+    }
 }
 
 // Pass 2: per-job exclusive scans of the histogram: first pair slot of every bucket, and the
@@ -215,7 +237,7 @@ k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restri
 // Pass 3: scatter.  pair = (table index << 1) | sign, table index = position * n_table + base.
 __global__ void __launch_bounds__(256)
 k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off,
-              const uint32_t* __restrict__ rank, uint32_t* pairs) {
+              const uint32_t* __restrict__ rank, uint32_t* pairs, const uint32_t* __restrict__ blockbase) {
     const MsmJob job = jobs[blockIdx.y];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= job.n) return;
@@ -227,6 +249,8 @@ k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __res
     const uint32_t n = job.n, tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
     msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t slot, uint32_t bit, uint32_t mag, bool negative) {
         uint32_t tkt = jrank[(size_t)slot * n + i];
+        if (tkt & 0x80000000u)   // workgroup-local rank of a hot bucket
+            tkt = (tkt & 0x7fffffffu) + blockbase[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * MSM_HOT + (mag >> 1)];
         pairs[joff[mag >> 1] + tkt] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
     });
 }
@@ -352,7 +376,7 @@ k_msm_task_base(const uint32_t* __restrict__ lenhist, uint32_t* base, uint32_t* 
 __global__ void __launch_bounds__(256)
 k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff,
                  const uint32_t* __restrict__ task_base, const uint32_t* __restrict__ base, uint32_t* cursor,
-                 uint4* sorted, uint32_t* n_heavy, uint32_t* heavy, uint32_t nb, uint32_t nj) {
+                 uint4* sorted, uint32_t* n_heavy, uint32_t* heavy, uint32_t nb, uint32_t nj, uint32_t merge_inline) {
     ZK_SHARED uint32_t h[MSM_SEG];
     ZK_SHARED uint32_t start[MSM_SEG];
     const uint32_t tid = threadIdx.x, job = blockIdx.y;
@@ -374,7 +398,7 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
         h[tid] = 0;
     }
     __syncthreads();
-    if (full + (rem ? 1u : 0u) > MSM_MERGE_INLINE) heavy[atomicAdd(n_heavy, 1u)] = job * nb + b;
+    if (full + (rem ? 1u : 0u) > merge_inline) heavy[atomicAdd(n_heavy, 1u)] = job * nb + b;
     if (k) {
         const uint32_t o = off[(size_t)job * nb + b], ti = task_base[job] + toff[(size_t)job * nb + b];
         if (full) {
@@ -452,7 +476,7 @@ template <class F>
 __global__ void __launch_bounds__(64, MsmOcc<F>::red)
 k_msm_suffix_buckets(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restrict__ cnt,
                      const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base,
-                     XYZZ<F>* __restrict__ R, uint32_t nb, uint32_t L) {
+                     XYZZ<F>* __restrict__ R, uint32_t nb, uint32_t L, uint32_t merge_inline) {
     const uint32_t T = nb / L;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -464,7 +488,7 @@ k_msm_suffix_buckets(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restri
         uint32_t n = cnt[b0 + k];
         if (n) {
             uint32_t o = toff[b0 + k], nt_b = (n + MSM_SEG - 1) / MSM_SEG;
-            if (nt_b > MSM_MERGE_INLINE) nt_b = 1;   // already summed into the first partial (k_msm_merge_heavy)
+            if (nt_b > merge_inline) nt_b = 1;   // already summed into the first partial (k_msm_merge_heavy)
             for (uint32_t u = 0; u < nt_b; u++) run = xadd(run, ts[o + u]);
         }
         R[b0 + k] = run;

@@ -335,7 +335,7 @@ struct MsmGroup {
     uint32_t c = 0, maxd = 0, nb = 0;
     size_t n_points = 0;
     DevBuf table;
-    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, tbase, rank, pairs, tsums, red_r, red_w, red_t, result;
+    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, blockbase, tbase, rank, pairs, tsums, red_r, red_w, red_t, result;
     std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
 
@@ -398,7 +398,8 @@ struct MsmGroup {
         ZK_TRY(ntasks.ensure(nj * 4));
         ZK_TRY(tbase.ensure(nj * 4));
         ZK_TRY(hist.ensure((2 * n_class + 2) * 4));     // [length histogram | placement cursors | total | #heavy]
-        const size_t heavy_cap = (size_t)(total / (zkdev::MSM_SEG * zkdev::MSM_MERGE_INLINE)) + 1;
+        const uint32_t merge_inline = nj >= 64 ? 8u : 2u;
+        const size_t heavy_cap = (size_t)(total / (zkdev::MSM_SEG * merge_inline)) + 1;
         ZK_TRY(heavy.ensure(heavy_cap * 4));
         ZK_TRY(tclass.ensure(n_class * 4));
         ZK_TRY(sorted.ensure((size_t)total_tasks * sizeof(uint4)));
@@ -437,9 +438,15 @@ struct MsmGroup {
         } else {
             HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, st));
             ZK_TRY(rank.ensure((size_t)(total ? total : 1) * 4));
+            // hot-bucket pre-aggregation for the few-big-jobs case (its side array is per workgroup)
+            uint32_t* bbase = nullptr;
+            if (nj <= 8) {
+                ZK_TRY(blockbase.ensure((size_t)gridn.x * nj * zkdev::MSM_HOT * 4));
+                bbase = blockbase.as<uint32_t>();
+            }
             if (max_n) {
                 ProfScope ps("msm_count", st);
-                ZK_LAUNCH(zkdev::k_msm_count, gridn, dim3(256), 0, st, dj, c, cnt.as<uint32_t>(), rank.as<uint32_t>());
+                ZK_LAUNCH_SYNC(zkdev::k_msm_count, gridn, dim3(256), 0, st, dj, c, cnt.as<uint32_t>(), rank.as<uint32_t>(), bbase);
             }
             {
                 ProfScope ps("msm_scan", st);
@@ -449,7 +456,7 @@ struct MsmGroup {
             if (max_n) {
                 ProfScope ps("msm_scatter", st);
                 ZK_LAUNCH(zkdev::k_msm_scatter, gridn, dim3(256), 0, st, dj, c, off.as<uint32_t>(), rank.as<uint32_t>(),
-                          pairs.as<uint32_t>());
+                          pairs.as<uint32_t>(), (const uint32_t*)bbase);
             }
         }
         {
@@ -459,7 +466,7 @@ struct MsmGroup {
                            (uint32_t)nj);
             ZK_LAUNCH_SYNC(zkdev::k_msm_task_place, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), off.as<uint32_t>(),
                            toff.as<uint32_t>(), tbase.as<uint32_t>(), tclass.as<uint32_t>(), cursor, sorted.as<uint4>(), d_nheavy,
-                           heavy.as<uint32_t>(), nb, (uint32_t)nj);
+                           heavy.as<uint32_t>(), nb, (uint32_t)nj, merge_inline);
         }
         {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
@@ -478,7 +485,7 @@ struct MsmGroup {
                            (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb);
             // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
             ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
-                      toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L);
+                      toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, merge_inline);
             ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
                       1u, 1u, 1u);
             uint32_t n = T, m = L, stride = L;   // n nodes per job of m buckets each; S(node k) = R[k * stride]
