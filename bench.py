@@ -4,11 +4,12 @@
   python bench.py --gpus N --steps K --warmup W [--batch B]
   (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one batch of B independent proofs per GPU through the whole hot path
-(zk_prove_batch_dev: 7 NTTs of size 2^15, the multiexps H / L / A / B1 over G1 and B2 over G2, the
-final fold and the 192-byte encoding).  The assignments (row evaluations a, b, c and the witness)
-are resident in HBM when the timed region starts; proofs are independent, so ranks shard the
-batch with no data-path collective and rank 0 gathers the 192-byte proofs at the end of a step.
+One "step" = one batch of B = 1024 independent proofs per GPU (BASELINE config 4) through the whole
+hot path (zk_prove_batch_dev: 7 NTTs of size 2^15 per proof, bellman's eight multiexps as three
+jobs - A and C' = H + L + r*B1 over G1, B2 over G2 -, the final fold and the 192-byte encoding).
+The assignments (row evaluations a, b, c and the witness) are resident in HBM when the timed
+region starts; proofs are independent, so ranks shard the batch with no data-path collective and
+rank 0 gathers the 192-byte proofs at the end of a step.
 
 Workload: a circuit with exactly the Transfer circuit's shape - 19 974 constraints, 23 public
 inputs, 19 955 aux variables -> 19 997 rows -> domain 2^15
@@ -198,11 +199,23 @@ def main():
         proofs_per_launch = B * args.steps / k["launches"]
         alg_bytes = 128.0 * g1_terms * proofs_per_launch     # 96 B base + 32 B scalar per term
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_msm_accumulate<Fq> (G1 bucket accumulation)",
+        # HBM bytes of one launch of the same kernel from the committed rocprofv3 PMC passes
+        # (profiles/r01_traffic.json, tools/gpu_session.sh DO_PMC=1): only if taken at this launch size
+        traffic, traffic_src = None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj.get("batch") == proofs_per_launch:
+                kk = tj["kernels"]["void zkdev::k_msm_accumulate<zkdev::Fq28>"]
+                traffic = int(kk["fetch_bytes"] + kk["write_bytes"])
+                traffic_src = "profiles/r01_traffic.json (FETCH_SIZE + WRITE_SIZE, separate passes; raw FETCH_SIZE " \
+                              "calibrated against the known gather bytes of this kernel, see DESIGN.md 4.1)"
+        except Exception:
+            pass
+        roof = {"bound": "hbm", "kernel": "k_msm_accumulate<Fq28> (G1 bucket accumulation)",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                "note": "integer-ALU bound kernel (381-bit modular arithmetic); see DESIGN.md"}
+                "note": "integer-VALU bound kernel (381-bit modular arithmetic, no dense contraction); see DESIGN.md 4.1"}
 
     cpu = None
     if not args.no_cpu:
@@ -233,7 +246,7 @@ def main():
     line = {
         "metric": "Groth16 proofs/sec (Transfer circuit)", "value": round(total_proofs / elapsed, 3), "unit": "proofs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (Fq 381-bit, Fr 255-bit modular)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (Fq 381-bit: 14 x 28-bit for G1, 12 x 32-bit for G2; Fr 255-bit: 8 x 32-bit; modular)",
         "data": "synthetic",
         "config": {"workload": "batch of Transfer-shaped Groth16 proofs (19974 constraints, 23 inputs, 19955 aux, "
                                "domain 2^15), full create_proof from a finished assignment: 7 NTT + 5 multiexp "
