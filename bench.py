@@ -11,11 +11,12 @@ The assignments (row evaluations a, b, c and the witness) are resident in HBM wh
 region starts; proofs are independent, so ranks shard the batch with no data-path collective and
 rank 0 gathers the 192-byte proofs at the end of a step.
 
-Workload: a circuit with exactly the Transfer circuit's shape - 19 974 constraints, 23 public
-inputs, 19 955 aux variables -> 19 997 rows -> domain 2^15
-(/root/reference/core/proofs/src/circuit/confidential_transfer.rs:383-386), under a synthetic CRS
-(fixed toxic waste; the reference's proving keys are missing blobs).  Witnesses are synthetic
-(8 distinct satisfying assignments cycled through the batch, every proof with its own r, s).
+Workload: the reference's confidential-transfer circuit itself - 19 974 constraints, 23 public
+inputs, 19 955 aux variables -> 19 997 rows -> domain 2^15, constraint-system hash d23c92fb...1784
+(core/proofs/src/circuit/confidential_transfer.rs:383-386; restated in oracle/transfer_circuit.py
+and checked against that fingerprint) - under a synthetic CRS (fixed toxic waste; the reference's
+proving keys are missing blobs).  Witnesses: 8 different transfer statements (keys, amounts,
+balances from a seeded stream) cycled through the batch, every proof with its own r, s.
 Every proof of the last step is checked against the oracle before the line is printed.
 
 The JSON line carries, besides the contract fields:
@@ -48,20 +49,25 @@ HBM_PEAK_GBPS = 8000.0                   # /opt/skills/guides/MI355X_MICROARCH.m
 
 
 def build_workload(n_witness):
-    from oracle import bls12_381 as bls
+    """The reference's confidential-transfer circuit (restated in oracle/transfer_circuit.py and
+    checked there against the reference's fingerprint: 19 974 constraints, 23 inputs, cs.hash
+    d23c92fb...1784), a synthetic CRS (fixed toxic waste), n_witness different statements."""
     from oracle import groth16 as g
-    from oracle import params_io, synth
+    from oracle import params_io
+    from oracle import transfer_circuit as tc
     import helpers
     E = g.Bls12Engine()
-    circ = synth.ChainCircuit(2026, N_IN, N_AUX, extra_rows=N_CON - N_AUX)
-    P = g.generate_parameters(E, circ.r1cs, *helpers.TOXIC, scalars_only=True)
-    pk = params_io.write_parameters_from_scalars(P.sc, N_IN, threads=min(64, usable_cores()))
-    asgs = []
+    r1cs, asgs = None, []
     for i in range(n_witness):
-        inputs, aux = circ.witness(7000 + i)
-        asg = g.assign(E, circ.r1cs, inputs, aux)
+        cs = tc.synthesize(tc.make_witness(7000 + i, amount=10 + i, fee=1 + (i & 1), balance=1000 + 17 * i))
+        if r1cs is None:
+            assert cs.hash() == tc.REFERENCE_HASH and len(cs.constraints) == N_CON and len(cs.inputs) == N_IN
+            r1cs = cs.to_r1cs()
+        asg = g.assign(E, r1cs, cs.inputs, cs.aux)
         assert g.is_satisfied(E, asg)
         asgs.append(asg)
+    P = g.generate_parameters(E, r1cs, *helpers.TOXIC, scalars_only=True)
+    pk = params_io.write_parameters_from_scalars(P.sc, N_IN, threads=min(64, usable_cores()))
     return P, pk, asgs
 
 
@@ -239,7 +245,7 @@ def main():
                         bytes(dens[0]), bytes(dens[1]), bytes(dens[2]), bls.fr_le(1), bls.fr_le(2), min(cores, 32))
         lat = time.perf_counter() - t1
         cpu = {"value": round(n_cpu / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
-               "sample": "%d Transfer-shaped proofs, one single-threaded create_proof per core, %.1f s wall" % (n_cpu, dt),
+               "sample": "%d confidential-transfer proofs, one single-threaded create_proof per core, %.1f s wall" % (n_cpu, dt),
                "single_proof_latency_s": round(lat, 3), "single_proof_threads": min(cores, 32)}
 
     micro = None
@@ -264,8 +270,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (Fq 381-bit: 14 x 28-bit for G1, 12 x 32-bit for G2; Fr 255-bit: 8 x 32-bit; modular)",
         "data": "synthetic",
-        "config": {"workload": "batch of Transfer-shaped Groth16 proofs (19974 constraints, 23 inputs, 19955 aux, "
-                               "domain 2^15), full create_proof from a finished assignment: 7 NTT + 5 multiexp "
+        "config": {"workload": "batch of Groth16 proofs of the confidential-transfer circuit (19974 constraints, 23 inputs, "
+                               "19955 aux, cs.hash d23c92fb..1784, domain 2^15), full create_proof from a finished assignment: 7 NTT + 5 multiexp "
                                "(H, L, A, B1 in G1; B2 in G2) + fold + 192-byte encoding",
                    "proofs_per_gpu_per_step": B, "distinct_witnesses": n_wit, "window_bits": info["window_bits"],
                    "batch_chunk": chunk, "parallelism": "dp%d (independent proofs, %s gather of 192 B/proof)" % (world, "gloo" if one_gpu else "RCCL"),

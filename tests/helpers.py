@@ -66,3 +66,26 @@ def g1_of(k):
 
 def g2_of(k):
     return bls.g2_uncompressed(bls.G2.to_affine(bls.G2.mul(bls.G2_GEN, k % bls.R_MOD)))
+
+
+@functools.lru_cache(maxsize=None)
+def transfer_case(n_witnesses=1, seed=1):
+    """The reference's confidential-transfer circuit (oracle/transfer_circuit.py, fingerprint-checked
+    against core/proofs/src/circuit/confidential_transfer.rs:383-386), a synthetic CRS from known
+    toxic waste (the reference's proving keys are missing blobs) and `n_witnesses` satisfying
+    assignments of different statements.  Returns (r1cs, [assignment], Params(scalars), pk bytes)."""
+    from oracle import transfer_circuit as tc
+    E = g.Bls12Engine()
+    r1cs, asgs = None, []
+    for i in range(n_witnesses):
+        cs = tc.synthesize(tc.make_witness(seed + i, amount=10 + i, fee=1, balance=100 + 3 * i))
+        assert cs.which_is_unsatisfied() is None
+        if r1cs is None:
+            assert cs.hash() == tc.REFERENCE_HASH
+            r1cs = cs.to_r1cs()
+        asg = g.assign(E, r1cs, cs.inputs, cs.aux)
+        assert g.is_satisfied(E, asg)
+        asgs.append(asg)
+    P = g.generate_parameters(E, r1cs, *TOXIC, scalars_only=True)
+    pk = params_io.write_parameters_from_scalars(P.sc, r1cs.n_in, threads=8)
+    return r1cs, asgs, P, pk

@@ -114,22 +114,19 @@ def test_prover_errors(gpu_lib):
     pc.prover_errors(gpu_lib)
 
 
-def test_transfer_shaped_proof_bit_exact(gpu_lib):
-    """A circuit with the Transfer circuit's shape (19 974 constraints, 23 inputs, 19 955 aux;
-    core/proofs/src/circuit/confidential_transfer.rs:383-386 -> domain 2^15), synthetic CRS from
-    known toxic waste.  The 192 bytes must equal (1) the proof computed from the discrete logs
-    and (2) the C restatement of bellman's create_proof; checked = true exercises the GPU
-    subgroup check over the whole key."""
+def test_transfer_circuit_proof_bit_exact(gpu_lib):
+    """The reference's confidential-transfer circuit itself (19 974 constraints, 23 inputs, cs.hash
+    d23c92fb...1784: core/proofs/src/circuit/confidential_transfer.rs:383-386, restated in
+    oracle/transfer_circuit.py), synthetic CRS from known toxic waste.  The 192 bytes must equal
+    (1) the proof computed from the discrete logs and (2) the C restatement of bellman's
+    create_proof; checked = true exercises the GPU subgroup check over the whole key."""
     import zero_chain_amd as zk
-    E = g.Bls12Engine()
-    r1, inputs, aux = synth.random_r1cs(4, 23, 19955, 19974)
-    asg = g.assign(E, r1, inputs, aux)
-    assert g.is_satisfied(E, asg)
-    P = g.generate_parameters(E, r1, *helpers.TOXIC, scalars_only=True)
-    pk = params_io.write_parameters_from_scalars(P.sc, 23, threads=8)
+    r1, asgs, P, pk = helpers.transfer_case(3)
+    asg = asgs[0]
     params = zk.Parameters.read(pk, checked=True, lib=gpu_lib)
     try:
-        assert params.info["log_domain"] == 15 and params.info["n_h"] == 32767
+        assert params.info["log_domain"] == 15 and params.info["n_h"] == 32767 and params.info["n_ic"] == 23
+        assert params.info["n_l"] == 19955
         r, s = 0x0123456789abcdef0123456789abcdef0123456789abcdef, 0x0fedcba9876543210fedcba9876543210fedcba987654321
         pa = helpers.to_assignment(zk, asg)
         proof = zk.create_proof(pa, params, r, s).write()
@@ -139,10 +136,11 @@ def test_transfer_shaped_proof_bit_exact(gpu_lib):
                                              bytes(asg.b_input_density), bytes(asg.b_aux_density), bls.fr_le(r),
                                              bls.fr_le(s), 8)
         assert proof == want
-        # a batch of 6 with distinct (r, s): every proof is still the trapdoor proof
+        # a batch of different statements with distinct (r, s): every proof is the trapdoor proof
         rs = [(r + i, s + 7 * i) for i in range(6)]
-        proofs = zk.create_proofs([pa] * 6, params, rs)
-        for (ri, si), pf in zip(rs, proofs):
-            assert pf.write() == helpers.expected_proof_trapdoor(P, asg, ri, si)
+        batch = [asgs[i % len(asgs)] for i in range(6)]
+        proofs = zk.create_proofs([helpers.to_assignment(zk, a) for a in batch], params, rs)
+        for a, (ri, si), pf in zip(batch, rs, proofs):
+            assert pf.write() == helpers.expected_proof_trapdoor(P, a, ri, si)
     finally:
         params.close()
