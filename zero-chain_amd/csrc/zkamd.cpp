@@ -274,7 +274,7 @@ uint32_t pick_window(size_t n, int group) {
     if (!env) env = getenv("ZKAMD_WINDOW_BITS");
     if (env && atoi(env) >= 2 && atoi(env) <= 22) return (uint32_t)atoi(env);
     const char* benv = getenv(group == 2 ? "ZKAMD_BUCKET_COST_G2" : "ZKAMD_BUCKET_COST_G1");
-    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 16.0 : 6.0);
+    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 12.0 : 6.0);
     uint32_t best = 2;
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 22; c++) {
