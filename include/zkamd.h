@@ -134,6 +134,30 @@ zk_status zk_prove_batch_dev(zk_params* p, size_t n, const zk_batch_dev* batch, 
                              uint8_t* proofs_out);
 
 /* ------------------------------------------------------------------------------------------
+ * Proving from the variable assignment alone (row f-1 of the hot-path scope).
+ * bellman's ProvingAssignment evaluates every constraint row on the host while the circuit is
+ * synthesized (a_j = <A_j, z>, b_j, c_j).  The R1CS of a circuit is fixed,
+ * so it can live on the GPU: zk_r1cs_load takes the three matrices in CSR form once, and
+ * zk_prove_batch_witness takes only z = (inputs | aux) per proof - a quarter of the bytes - and
+ * computes a, b, c with a sparse matrix-vector product on the device.  The density trackers and
+ * the per-input rows `Input(i) * 0 = 0` are derived from the matrices exactly as bellman's prover
+ * derives them.  Coefficients: 32 bytes little-endian plain integers < r.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zk_r1cs zk_r1cs;
+typedef struct {
+    const uint32_t* row_ptr; /* n_constraints + 1 */
+    const uint32_t* col;     /* variable index: input i -> i, aux j -> n_inputs + j */
+    const uint8_t* coeff;    /* nnz x 32 */
+} zk_csr;
+zk_status zk_r1cs_load(uint32_t n_inputs, uint32_t n_aux, uint32_t n_constraints, const zk_csr* a, const zk_csr* b,
+                       const zk_csr* c, int device, zk_r1cs** out);
+void zk_r1cs_free(zk_r1cs* r);
+/* witness: n x (n_inputs + n_aux) x 32 bytes on the HOST (plain, or Montgomery limbs with
+ * ZK_FR_MONTGOMERY in flags); rs: n x 64; proofs_out: n x 192. */
+zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const uint8_t* witness, uint32_t flags,
+                                 const uint8_t* rs, uint8_t* proofs_out);
+
+/* ------------------------------------------------------------------------------------------
  * Stand-alone kernels (micro-benchmark / test entries)
  * ------------------------------------------------------------------------------------------ */
 /* multiexp over G1 / G2: sum_i scalars[i] * bases[i].   replaces bellman multiexp (FullDensity).

@@ -224,6 +224,39 @@ def prover_batch(lib, seed, n_in, n_aux, n_proofs, use_c_oracle=True):
         params.close()
 
 
+def prover_from_witness(lib, seed, n_in, n_aux, n_proofs, montgomery=False):
+    """zk_r1cs_load + zk_prove_batch_witness: the row evaluations are computed on the device from
+    the constraint matrices; the proofs must be the ones made from a host-evaluated assignment."""
+    E = g.Bls12Engine()
+    circ = synth.ChainCircuit(seed, n_in, n_aux, extra_rows=3)
+    P = g.generate_parameters(E, circ.r1cs, *helpers.TOXIC, scalars_only=True)
+    pk = params_io.write_parameters_from_scalars(P.sc, n_in, threads=4)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    mats = zk.ConstraintMatrices(n_in, n_aux, circ.r1cs.constraints, lib=lib)
+    try:
+        asgs, rs, zs = [], [], []
+        rng = synth.SplitMix64(seed + 5)
+        for i in range(n_proofs):
+            inputs, aux = circ.witness(seed * 10 + i)
+            asgs.append(g.assign(E, circ.r1cs, inputs, aux))
+            zs.append([bls.fr_to_mont(v) for v in inputs + aux] if montgomery else inputs + aux)
+            rs.append((rng.field(bls.R_MOD), rng.field(bls.R_MOD)))
+        got = zk.create_proofs_from_witness(mats, params, zs, rs, montgomery=montgomery)
+        want = zk.create_proofs([helpers.to_assignment(zk, a) for a in asgs], params, rs)
+        for a, (r, s), x, y in zip(asgs, rs, got, want):
+            assert x == y and x.write() == helpers.expected_proof_trapdoor(P, a, r, s)
+        # argument checks
+        with pytest.raises(zk.ZkError) as e:
+            zk.ConstraintMatrices(n_in, n_aux, [([(n_in + n_aux, 1)], [], [])], lib=lib)
+        assert e.value.variant == "InvalidArgument"
+        with pytest.raises(zk.ZkError) as e:
+            zk.ConstraintMatrices(n_in, n_aux, [([(0, bls.R_MOD)], [], [])], lib=lib)
+        assert e.value.variant == "InvalidArgument"
+    finally:
+        mats.close()
+        params.close()
+
+
 def prover_errors(lib):
     r1, asg, P, pk = helpers.small_case(2, 2, 6, 7)
     for cut in (10, 96 * 2 + 7, len(pk) - 1):

@@ -84,3 +84,8 @@ def test_msm_global_sort_path(emu_lib, monkeypatch):
     pc.msm_golden_vectors(emu_lib, 1, 300, 5)
     pc.msm_golden_vectors(emu_lib, 1, 700, 9, seed=8)
     pc.msm_golden_vectors(emu_lib, 2, 60, 4)
+
+
+def test_prover_from_witness(emu_lib):
+    pc.prover_from_witness(emu_lib, 3, 3, 14, 3)
+    pc.prover_from_witness(emu_lib, 4, 2, 9, 2, montgomery=True)

@@ -110,6 +110,29 @@ def test_prover_batch(gpu_lib, monkeypatch):
     pc.prover_batch(gpu_lib, 9, 5, 700, 7)
 
 
+def test_prover_from_witness(gpu_lib):
+    pc.prover_from_witness(gpu_lib, 3, 3, 14, 3)
+    pc.prover_from_witness(gpu_lib, 6, 5, 900, 9, montgomery=True)
+
+
+def test_transfer_circuit_from_witness(gpu_lib):
+    """The reference's circuit, proved from the variable assignment alone: the 19 997 row evaluations
+    of A z, B z, C z are computed on the GPU from the CSR matrices of the fingerprint-checked R1CS."""
+    import zero_chain_amd as zk
+    r1, asgs, P, pk = helpers.transfer_case(3)
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices(r1.n_in, r1.n_aux, r1.constraints, lib=gpu_lib)
+    try:
+        rs = [(11 + i, 1000003 * (i + 1)) for i in range(5)]
+        batch = [asgs[i % len(asgs)] for i in range(5)]
+        proofs = zk.create_proofs_from_witness(mats, params, [a.inputs + a.aux for a in batch], rs)
+        for a, (r, s), pf in zip(batch, rs, proofs):
+            assert pf.write() == helpers.expected_proof_trapdoor(P, a, r, s)
+    finally:
+        mats.close()
+        params.close()
+
+
 def test_prover_errors(gpu_lib):
     pc.prover_errors(gpu_lib)
 

@@ -24,7 +24,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
                    ZK_NTT_OUT_BITREV)
 
 __all__ = ["Parameters", "Proof", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
-           "multiexp", "MultiexpContext", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
+           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
 
@@ -235,6 +235,64 @@ def create_proofs(assignments, params, rs):
     rsb = scalars_to_bytes([x for pair in rs for x in pair])
     out = np.zeros(PROOF_SIZE * n, dtype=np.uint8)
     lib.check(lib.zk_prove_batch(params._h, n, arr, _ptr(rsb), _ptr(out)))
+    ob = out.tobytes()
+    return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
+
+
+class ConstraintMatrices:
+    """The fixed R1CS of a circuit on the GPU (zk_r1cs): proofs are then made from the variable
+    assignment alone (`create_proofs_from_witness`), the row evaluations a = A z, b = B z, c = C z
+    being computed on the device.  `constraints`: list of (A, B, C), each a list of
+    (variable index, coefficient) with inputs first (ONE = 0), aux variable j at n_inputs + j."""
+
+    def __init__(self, n_inputs, n_aux, constraints, device=0, lib=None):
+        self._lib = lib or _lib.load()
+        self.n_inputs, self.n_aux = n_inputs, n_aux
+        keep, structs = [], []
+        for m in range(3):
+            row_ptr, col, coeff = [0], [], []
+            for con in constraints:
+                for v, c in con[m]:
+                    col.append(v)
+                    coeff.append(int(c))
+                row_ptr.append(len(col))
+            rp = np.asarray(row_ptr, dtype=np.uint32)
+            cl = np.asarray(col if col else [0], dtype=np.uint32)
+            cf = scalars_to_bytes(coeff) if coeff else np.zeros(32, dtype=np.uint8)
+            keep += [rp, cl, cf]
+            st = _lib.Csr()
+            st.row_ptr, st.col, st.coeff = rp.ctypes.data, cl.ctypes.data, cf.ctypes.data
+            structs.append(st)
+        h = C.c_void_p()
+        self._lib.check(self._lib.zk_r1cs_load(n_inputs, n_aux, len(constraints), C.byref(structs[0]), C.byref(structs[1]),
+                                               C.byref(structs[2]), device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.zk_r1cs_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def create_proofs_from_witness(matrices, params, witnesses, rs, montgomery=False):
+    """witnesses: list of (inputs + aux) integer lists, or an (n, n_vars * 32)-byte array."""
+    lib = params._lib
+    n = len(rs)
+    nv = matrices.n_inputs + matrices.n_aux
+    if isinstance(witnesses, np.ndarray):
+        w = _u8(witnesses, n * nv * 32)
+    else:
+        w = scalars_to_bytes([x for z in witnesses for x in z])
+    rsb = scalars_to_bytes([x for pair in rs for x in pair])
+    out = np.zeros(PROOF_SIZE * n, dtype=np.uint8)
+    lib.check(lib.zk_prove_batch_witness(params._h, matrices._h, n, _ptr(w), ZK_FR_MONTGOMERY if montgomery else 0,
+                                         _ptr(rsb), _ptr(out)))
     ob = out.tobytes()
     return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
 

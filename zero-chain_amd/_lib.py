@@ -42,6 +42,10 @@ class Assignment(C.Structure):
                 ("a_aux_density", C.c_void_p), ("b_input_density", C.c_void_p), ("b_aux_density", C.c_void_p)]
 
 
+class Csr(C.Structure):
+    _fields_ = [("row_ptr", C.c_void_p), ("col", C.c_void_p), ("coeff", C.c_void_p)]
+
+
 class BatchDev(C.Structure):
     _fields_ = [("n_rows", C.c_uint32), ("n_inputs", C.c_uint32), ("n_aux", C.c_uint32), ("flags", C.c_uint32),
                 ("d_a", C.c_void_p), ("d_b", C.c_void_p), ("d_c", C.c_void_p), ("d_wit", C.c_void_p),
@@ -58,6 +62,10 @@ _PROTOS = {
     "zk_prove": (C.c_int32, [C.c_void_p, C.POINTER(Assignment), C.c_void_p, C.c_void_p, C.c_void_p]),
     "zk_prove_batch": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(Assignment), C.c_void_p, C.c_void_p]),
     "zk_prove_batch_dev": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(BatchDev), C.c_void_p, C.c_void_p]),
+    "zk_r1cs_load": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), C.c_int,
+                                 C.POINTER(C.c_void_p)]),
+    "zk_r1cs_free": (None, [C.c_void_p]),
+    "zk_prove_batch_witness": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "zk_msm_create": (C.c_int32, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_msm_run": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zk_msm_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),

@@ -219,6 +219,33 @@ k_field_mul_raw(uint32_t* out, const uint32_t* __restrict__ a, const uint32_t* _
     for (int j = 0; j < C::N; j++) out[(size_t)i * C::N + j] = z.l[j];
 }
 
+// Row evaluations of a fixed R1CS: out[mat][p][row] = sum_k coeff[k] * z[p][col[k]] (Montgomery in,
+// Montgomery out), one thread per (row, matrix, proof).  Rows >= n_con are bellman's per-input rows
+// Input(i) * 0 = 0: a = z_i, b = c = 0.  blockIdx.y = matrix (0..2), blockIdx.z = proof.
+struct R1csMat {
+    const uint32_t* row_ptr;
+    const uint32_t* col;
+    const uint32_t* coeff;   // Montgomery
+};
+__global__ void __launch_bounds__(256)
+k_r1cs_eval(R1csMat ma, R1csMat mb, R1csMat mc, const uint32_t* __restrict__ z, uint32_t* out, uint32_t n_con,
+            uint32_t n_in, uint32_t nv, uint32_t n_rows, size_t out_mat_stride) {
+    uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const uint32_t mat = blockIdx.y;
+    const size_t p = blockIdx.z;
+    const R1csMat m = mat == 0 ? ma : (mat == 1 ? mb : mc);
+    const uint32_t* zp = z + p * (size_t)nv * 8;
+    Fr acc = Fr::zero();
+    if (row < n_con) {
+        for (uint32_t k = m.row_ptr[row]; k < m.row_ptr[row + 1]; k++)
+            acc = add(acc, mul(ld_fr(m.coeff + (size_t)k * 8), ld_fr(zp + (size_t)m.col[k] * 8)));
+    } else if (mat == 0) {
+        acc = ld_fr(zp + (size_t)(row - n_con) * 8);
+    }
+    st_fr(out + (size_t)mat * out_mat_stride * 8 + (p * n_rows + row) * 8, acc);
+}
+
 // Per-proof scalar vectors for the multiexps (plain form):
 //   wit_out[p] = [ wit[p][0..nv) | 1 | r | s ]                          (A and B2 multiexps)
 //   cvec[p]    = [ h (m, written later) | aux (n_aux) | r * z (nv) | r ]  (merged C multiexp:

@@ -920,6 +920,127 @@ zk_status prove_batch_host(zk_params* P, size_t n, const zk_assignment* asgs, co
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
+// zk_r1cs: the fixed constraint matrices of a circuit, resident on the GPU
+// ------------------------------------------------------------------------------------------
+struct zk_r1cs {
+    int device = 0;
+    uint32_t n_in = 0, n_aux = 0, n_con = 0;
+    DevBuf row_ptr[3], col[3], coeff[3];
+    std::vector<uint8_t> a_aux_density, b_input_density, b_aux_density;
+    DevBuf z, abc;   // per-chunk workspaces: Montgomery assignment, row evaluations
+};
+
+namespace {
+
+zk_status r1cs_load(uint32_t n_in, uint32_t n_aux, uint32_t n_con, const zk_csr* const mats[3], int device, zk_r1cs** out) {
+    ZK_TRY(use_device(device));
+    if (n_in == 0) return fail(ZK_ERR_INVALID_ARGUMENT, "n_inputs must include ONE");
+    zk_r1cs* R = new (std::nothrow) zk_r1cs();
+    if (!R) return fail(ZK_ERR_OUT_OF_MEMORY, "host allocation failed");
+    struct Guard {
+        zk_r1cs* p;
+        ~Guard() { delete p; }
+    } guard{R};
+    R->device = device;
+    R->n_in = n_in;
+    R->n_aux = n_aux;
+    R->n_con = n_con;
+    const uint32_t nv = n_in + n_aux;
+    R->a_aux_density.assign(n_aux, 0);
+    R->b_input_density.assign(n_in, 0);
+    R->b_aux_density.assign(n_aux, 0);
+    for (int m = 0; m < 3; m++) {
+        const zk_csr* M = mats[m];
+        if (!M || !M->row_ptr || (n_con && M->row_ptr[n_con] && (!M->col || !M->coeff)))
+            return fail(ZK_ERR_INVALID_ARGUMENT, "null matrix pointer");
+        if (M->row_ptr[0] != 0) return fail(ZK_ERR_INVALID_ARGUMENT, "row_ptr[0] must be 0");
+        for (uint32_t r = 0; r < n_con; r++)
+            if (M->row_ptr[r + 1] < M->row_ptr[r]) return fail(ZK_ERR_INVALID_ARGUMENT, "row_ptr is not monotone");
+        const uint32_t nnz = M->row_ptr[n_con];
+        for (uint32_t k = 0; k < nnz; k++) {
+            const uint32_t v = M->col[k];
+            if (v >= nv) return fail(ZK_ERR_INVALID_ARGUMENT, "variable index out of range in matrix " + std::to_string(m));
+            uint64_t c[4];
+            load_scalar_le(M->coeff + (size_t)k * 32, c);
+            if (!scalar_lt_r(c)) return fail(ZK_ERR_INVALID_ARGUMENT, "coefficient is not < r");
+            // bellman's density trackers: a variable counts as soon as it APPEARS in a row of A / B
+            if (m == 0 && v >= n_in) R->a_aux_density[v - n_in] = 1;
+            if (m == 1) {
+                if (v >= n_in)
+                    R->b_aux_density[v - n_in] = 1;
+                else
+                    R->b_input_density[v] = 1;
+            }
+        }
+        ZK_TRY(R->row_ptr[m].ensure(((size_t)n_con + 1) * 4));
+        ZK_TRY(R->col[m].ensure((size_t)(nnz ? nnz : 1) * 4));
+        ZK_TRY(R->coeff[m].ensure((size_t)(nnz ? nnz : 1) * 32));
+        HIP_TRY(hipMemcpy(R->row_ptr[m].p, M->row_ptr, ((size_t)n_con + 1) * 4, hipMemcpyHostToDevice));
+        if (nnz) {
+            HIP_TRY(hipMemcpy(R->col[m].p, M->col, (size_t)nnz * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(R->coeff[m].p, M->coeff, (size_t)nnz * 32, hipMemcpyHostToDevice));
+            ZK_LAUNCH(zkdev::k_fr_convert, dim3((nnz + 255) / 256), dim3(256), 0, g_stream, R->coeff[m].as<uint32_t>(),
+                      (const uint32_t*)R->coeff[m].as<uint32_t>(), 0u, (size_t)nnz);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    guard.p = nullptr;
+    *out = R;
+    return ZK_OK;
+}
+
+zk_status prove_batch_witness(zk_params* P, zk_r1cs* R, size_t n, const uint8_t* witness, uint32_t flags, const uint8_t* rs,
+                              uint8_t* proofs_out) {
+    if (!P || !R || !witness || !rs || !proofs_out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return ZK_OK;
+    if (R->device != P->device) return fail(ZK_ERR_INVALID_ARGUMENT, "parameters and circuit live on different devices");
+    ZK_TRY(use_device(P->device));
+    const uint32_t nv = R->n_in + R->n_aux, n_rows = R->n_con + R->n_in;
+    if (n_rows > P->m) return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
+    size_t chunk = 1024;
+    const char* env = getenv("ZKAMD_BATCH_CHUNK");
+    if (env && atoi(env) > 0) chunk = (size_t)atoi(env);
+    for (size_t first = 0; first < n; first += chunk) {
+        const size_t np = std::min(chunk, n - first);
+        ZK_TRY(R->z.ensure(np * (size_t)nv * 32));
+        ZK_TRY(R->abc.ensure(3 * np * (size_t)n_rows * 32));
+        HIP_TRY(hipMemcpyAsync(R->z.p, witness + first * (size_t)nv * 32, np * (size_t)nv * 32, hipMemcpyHostToDevice, g_stream));
+        if (!(flags & ZK_FR_MONTGOMERY)) {
+            const size_t cnt = np * (size_t)nv;
+            ZK_LAUNCH(zkdev::k_fr_convert, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g_stream, R->z.as<uint32_t>(),
+                      (const uint32_t*)R->z.as<uint32_t>(), 0u, cnt);
+        }
+        zkdev::R1csMat mm[3];
+        for (int m = 0; m < 3; m++)
+            mm[m] = zkdev::R1csMat{R->row_ptr[m].as<uint32_t>(), R->col[m].as<uint32_t>(), R->coeff[m].as<uint32_t>()};
+        {
+            ProfScope ps("r1cs_eval");
+            ZK_LAUNCH(zkdev::k_r1cs_eval, dim3((n_rows + 255) / 256, 3, (unsigned)np), dim3(256), 0, g_stream, mm[0], mm[1], mm[2],
+                      (const uint32_t*)R->z.as<uint32_t>(), R->abc.as<uint32_t>(), R->n_con, R->n_in, nv, n_rows,
+                      np * (size_t)n_rows);
+        }
+        HIP_TRY(hipGetLastError());
+        zk_batch_dev bt;
+        bt.n_rows = n_rows;
+        bt.n_inputs = R->n_in;
+        bt.n_aux = R->n_aux;
+        bt.flags = ZK_FR_MONTGOMERY;
+        bt.d_a = R->abc.as<uint32_t>();
+        bt.d_b = R->abc.as<uint32_t>() + np * (size_t)n_rows * 8;
+        bt.d_c = R->abc.as<uint32_t>() + 2 * np * (size_t)n_rows * 8;
+        bt.d_wit = R->z.p;
+        bt.a_aux_density = R->a_aux_density.data();
+        bt.b_input_density = R->b_input_density.data();
+        bt.b_aux_density = R->b_aux_density.data();
+        ZK_TRY(prove_batch_dev(P, np, &bt, rs + first * 64, proofs_out + first * 192));
+    }
+    return ZK_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
 // stand-alone MSM / NTT handles
 // ------------------------------------------------------------------------------------------
 struct zk_msm {
@@ -1144,6 +1265,19 @@ zk_status zk_prove_batch(zk_params* p, size_t n, const zk_assignment* asgs, cons
 }
 zk_status zk_prove_batch_dev(zk_params* p, size_t n, const zk_batch_dev* batch, const uint8_t* rs, uint8_t* proofs_out) {
     return prove_batch_dev(p, n, batch, rs, proofs_out);
+}
+
+zk_status zk_r1cs_load(uint32_t n_inputs, uint32_t n_aux, uint32_t n_constraints, const zk_csr* a, const zk_csr* b,
+                       const zk_csr* c, int device, zk_r1cs** out) {
+    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const zk_csr* mats[3] = {a, b, c};
+    return r1cs_load(n_inputs, n_aux, n_constraints, mats, device, out);
+}
+void zk_r1cs_free(zk_r1cs* r) { delete r; }
+zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const uint8_t* witness, uint32_t flags,
+                                 const uint8_t* rs, uint8_t* proofs_out) {
+    return prove_batch_witness(p, circuit, n, witness, flags, rs, proofs_out);
 }
 
 zk_status zk_msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
