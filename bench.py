@@ -46,7 +46,8 @@ N_IN, N_AUX, N_CON = 23, 19955, 19974   # confidential_transfer.rs:383-386 (+ de
 KERNEL_NAMES = ("msm_accumulate_g1", "msm_accumulate_g2", "msm_sort_lds", "msm_count", "msm_scan", "msm_scatter", "msm_task_sort",
                 "msm_reduce_g1", "msm_reduce_g2", "msm_sum", "ntt_pass_dif", "ntt_pass_dit", "h_pointwise")
 HBM_PEAK_GBPS = 8000.0
-WORKLOAD_R1CS = [None]                   # /opt/skills/guides/MI355X_MICROARCH.md
+WORKLOAD_R1CS = [None]
+WORKLOAD_STATEMENTS = []                   # /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def build_workload(n_witness):
@@ -60,7 +61,9 @@ def build_workload(n_witness):
     E = g.Bls12Engine()
     r1cs, asgs = None, []
     for i in range(n_witness):
-        cs = tc.synthesize(tc.make_witness(7000 + i, amount=10 + i, fee=1 + (i & 1), balance=1000 + 17 * i))
+        wit = tc.make_witness(7000 + i, amount=10 + i, fee=1 + (i & 1), balance=1000 + 17 * i)
+        WORKLOAD_STATEMENTS.append(wit)
+        cs = tc.synthesize(wit)
         if r1cs is None:
             assert cs.hash() == tc.REFERENCE_HASH and len(cs.constraints) == N_CON and len(cs.inputs) == N_IN
             r1cs = cs.to_r1cs()
@@ -92,9 +95,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step (BASELINE config 4: 1024)")
     ap.add_argument("--no-micro", action="store_true")
-    ap.add_argument("--host-path", action="store_true",
-                    help="also time zk_prove_batch on HOST assignment buffers (PCIe-inclusive rate; reported as "
-                         "\"pcie_inclusive\", never as value)")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the host-side legs (zk_prove_batch / zk_prove_batch_witness / zk_transfer_prove_batch "
+                         "from host memory; reported as \"pcie_inclusive\", never as value)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -254,7 +257,7 @@ def main():
     if not args.no_micro and world == 1:
         micro = run_micro(lib, zk, dev)
     pcie = None
-    if args.host_path and world == 1:
+    if not args.no_host_path and world == 1:
         # the same batch handed over as host buffers (zk_prove_batch): H2D copies inside the timed region
         hb = min(B, 1024)
         pas = [helpers.to_assignment(zk, asgs[i % n_wit]) for i in range(n_wit)]
@@ -279,6 +282,22 @@ def main():
         assert got[0].write() == out[:192].tobytes() and got[hb - 1].write() == out[192 * (hb - 1):192 * hb].tobytes()
         pcie["from_witness"] = {"value": round(hb / dt, 3), "unit": "proofs/s",
                                 "note": "zk_prove_batch_witness: host witness vectors only, row evaluations on the GPU"}
+        # the whole reference call, statement -> proof (zk_transfer_prove_batch): native witness calculator
+        # on the host cores + row evaluations on the GPU + create_proof
+        from oracle import transfer_circuit as tc
+        sts = zk.transfer_statements([tc.statement_dict(WORKLOAD_STATEMENTS[i % n_wit]) for i in range(hb)])
+        zk.transfer_prove_batch(mats, params, sts, rs_ints[:hb])
+        t0 = time.perf_counter()
+        got = zk.transfer_prove_batch(mats, params, sts, rs_ints[:hb])
+        dt = time.perf_counter() - t0
+        assert got[0].write() == out[:192].tobytes() and got[hb - 1].write() == out[192 * (hb - 1):192 * hb].tobytes()
+        t0 = time.perf_counter()
+        zk.transfer_witness(sts, montgomery=True, lib=lib)
+        dtw = time.perf_counter() - t0
+        pcie["from_statements"] = {"value": round(hb / dt, 3), "unit": "proofs/s", "host_cores": usable_cores(),
+                                   "witness_only_per_s": round(hb / dtw, 1),
+                                   "note": "zk_transfer_prove_batch: witness generation (host C++, all cores, not "
+                                           "overlapped with the GPU) + row evaluations + create_proof"}
         mats.close()
 
     line = {

@@ -158,6 +158,29 @@ zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const
                                  const uint8_t* rs, uint8_t* proofs_out);
 
 /* ------------------------------------------------------------------------------------------
+ * Native witness calculator of the reference's confidential-transfer circuit (row a3 / f-1).
+ * replaces, value-wise: ConfidentialTransfer::synthesize under bellman's ProvingAssignment
+ *   core/proofs/src/circuit/confidential_transfer.rs:61-305 (+ range_check.rs, utils.rs and the
+ *   sapling-crypto gadgets).  The statement is the ten private values of the circuit
+ *   (confidential_transfer.rs:29-41): u32 amounts, Fs scalars as 32 bytes little-endian, Jubjub
+ *   points in the reference's 32-byte encoding (core/jubjub/src/curve/edwards.rs:92-117, 190-206).
+ * zk_transfer_witness writes z = (23 inputs | 19 955 aux) per statement, in the reference's
+ * variable order (host, multithreaded); zk_transfer_prove_batch = witness + row evaluations on
+ * the GPU + create_proof, for the R1CS loaded with zk_r1cs_load.
+ * ------------------------------------------------------------------------------------------ */
+#define ZK_TRANSFER_N_INPUTS 23u
+#define ZK_TRANSFER_N_AUX 19955u
+typedef struct {
+    uint32_t amount, remaining_balance, fee, reserved;
+    uint8_t randomness[32], alpha[32], dec_key_sender[32];
+    uint8_t proof_generation_key[32], enc_key_recipient[32], enc_balance_left[32], enc_balance_right[32], g_epoch[32];
+} zk_transfer_statement;
+/* witness_out: n x (23 + 19955) x 32 bytes; plain little-endian, or Montgomery limbs with ZK_FR_MONTGOMERY */
+zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out);
+zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
+                                  const uint8_t* rs, uint8_t* proofs_out);
+
+/* ------------------------------------------------------------------------------------------
  * Stand-alone kernels (micro-benchmark / test entries)
  * ------------------------------------------------------------------------------------------ */
 /* multiexp over G1 / G2: sum_i scalars[i] * bases[i].   replaces bellman multiexp (FullDensity).

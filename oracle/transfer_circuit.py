@@ -397,6 +397,16 @@ def make_witness(seed, amount=10, fee=1, balance=100):
     return TransferWitness(amount, remaining, fs(), fs(), pgk, dec_key, enc_key_recipient, (enc_left, enc_right), fee, g_epoch)
 
 
+def statement_dict(w):
+    """The witness as the C ABI's zk_transfer_statement fields (points in the 32-byte encoding)."""
+    return {"amount": w.amount, "remaining_balance": w.remaining_balance, "fee": w.fee, "randomness": w.randomness,
+            "alpha": w.alpha, "dec_key_sender": w.dec_key_sender,
+            "proof_generation_key": jj.write_point(w.proof_generation_key),
+            "enc_key_recipient": jj.write_point(w.enc_key_recipient),
+            "enc_balance_left": jj.write_point(w.encrypted_balance[0]),
+            "enc_balance_right": jj.write_point(w.encrypted_balance[1]), "g_epoch": jj.write_point(w.g_epoch)}
+
+
 def synthesize(w):
     cs = ConstraintSystem()
     amount_bits = u32_into_bit_vec_le(cs, w.amount)

@@ -133,6 +133,29 @@ def test_transfer_circuit_from_witness(gpu_lib):
         params.close()
 
 
+def test_transfer_prove_from_statements(gpu_lib):
+    """zk_transfer_prove_batch: native witness calculator (host) -> A z, B z, C z (GPU) -> create_proof,
+    from the ten private values of each statement; proofs equal the trapdoor proofs of the oracle's
+    assignment of the same statement."""
+    import zero_chain_amd as zk
+    from oracle import transfer_circuit as tc
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    E = g.Bls12Engine()
+    ws = [tc.make_witness(40 + i, amount=5 + i, fee=i & 1, balance=77 + i) for i in range(4)]
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices(r1.n_in, r1.n_aux, r1.constraints, lib=gpu_lib)
+    try:
+        rs = [(3 + i, 5 + 11 * i) for i in range(len(ws))]
+        proofs = zk.transfer_prove_batch(mats, params, zk.transfer_statements([tc.statement_dict(w) for w in ws]), rs)
+        for w, (r, s), pf in zip(ws, rs, proofs):
+            cs = tc.synthesize(w)
+            asg = g.assign(E, r1, cs.inputs, cs.aux)
+            assert pf.write() == helpers.expected_proof_trapdoor(P, asg, r, s)
+    finally:
+        mats.close()
+        params.close()
+
+
 def test_prover_errors(gpu_lib):
     pc.prover_errors(gpu_lib)
 

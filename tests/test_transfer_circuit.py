@@ -71,3 +71,52 @@ def test_range_gadget_rejects_u32_max():
     assert tc.synthesize(w).which_is_unsatisfied() is None
     w = tc.make_witness(3, amount=0xFFFFFFFF, fee=0, balance=0xFFFFFFFF)
     assert tc.synthesize(w).which_is_unsatisfied() is not None
+
+
+# ---- the product's native witness calculator (zk_transfer_witness: host code of libzkamd.so, no GPU
+# needed) against the fingerprint-checked oracle circuit
+def _product_lib():
+    import zero_chain_amd
+    return zero_chain_amd.load_library()
+
+
+def test_native_witness_matches_oracle_vector():
+    import zero_chain_amd as zk
+    lib = _product_lib()
+    ws = [tc.make_witness(s, amount=10 + s, fee=s % 3, balance=1000 + 13 * s) for s in (1, 2, 5)]
+    ws.append(tc.make_witness(8, amount=0, fee=0, balance=0))
+    ws.append(tc.make_witness(9, amount=0xFFFFFFFE, fee=0, balance=0xFFFFFFFE))
+    sts = zk.transfer_statements([tc.statement_dict(w) for w in ws])
+    nv = zk.TRANSFER_N_INPUTS + zk.TRANSFER_N_AUX if hasattr(zk, "TRANSFER_N_INPUTS") else 23 + 19955
+    plain = zk.transfer_witness(sts, lib=lib)
+    mont = zk.transfer_witness(sts, montgomery=True, lib=lib)
+    from oracle import bls12_381 as bls
+    for i, w in enumerate(ws):
+        cs = tc.synthesize(w)
+        want = cs.inputs + cs.aux
+        got = zk.bytes_to_scalars(plain[i * nv * 32:(i + 1) * nv * 32])
+        assert got == want, "statement %d differs at variable %d" % (i, next(j for j in range(nv) if got[j] != want[j]))
+        gm = zk.bytes_to_scalars(mont[i * nv * 32:(i + 1) * nv * 32])
+        assert gm[:40] == [bls.fr_to_mont(v) for v in want[:40]] and gm[-1] == bls.fr_to_mont(want[-1])
+
+
+def test_native_witness_rejects_bad_statements():
+    import zero_chain_amd as zk
+    lib = _product_lib()
+    d = tc.statement_dict(tc.make_witness(1))
+    bad = dict(d, g_epoch=bytes([0xff] * 32))                    # y >= r: not in the field
+    with pytest.raises(zk.ZkError) as e:
+        zk.transfer_witness(zk.transfer_statements([bad]), lib=lib)
+    assert e.value.variant == "InvalidArgument" and "g_epoch" in str(e.value)
+    bad = dict(d, randomness=jj.FS_MOD)                          # not a canonical Fs scalar
+    with pytest.raises(zk.ZkError) as e:
+        zk.transfer_witness(zk.transfer_statements([bad]), lib=lib)
+    assert e.value.variant == "InvalidArgument" and "randomness" in str(e.value)
+    # a y with no x on the curve
+    y = 2
+    while jj.get_for_y(y, False) is not None:
+        y += 1
+    bad = dict(d, enc_key_recipient=y.to_bytes(32, "little"))
+    with pytest.raises(zk.ZkError) as e:
+        zk.transfer_witness(zk.transfer_statements([bad]), lib=lib)
+    assert e.value.variant == "InvalidArgument"

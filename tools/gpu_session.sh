@@ -14,7 +14,7 @@ fi
 timeout 900 python bench.py "$@" > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cat $OUT/bench.json
 if [ "${SKIP_PROF:-0}" != "1" ]; then
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python bench.py --no-cpu --no-micro "$@" > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python bench.py --no-cpu --no-micro --no-host-path "$@" > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
   find $OUT/prof -name '*stats*' | head; 
   for f in $(find $OUT/prof -name '*kernel_stats.csv'); do head -30 $f; done
   # keep only the stats csv (traces are large)
@@ -24,7 +24,7 @@ if [ "${DO_PMC:-0}" = "1" ]; then
   # HBM traffic and VALU counters, one pass each (FETCH_SIZE and WRITE_SIZE cannot share a pass)
   for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
     name=$(echo $ctr | cut -d' ' -f1)
-    timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$name -o pmc -- python bench.py --no-cpu --no-micro --steps 1 --warmup 0 --batch ${PMC_BATCH:-256} "$@" > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err; echo "pmc $name rc=$?"
+    timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_$name -o pmc -- python bench.py --no-cpu --no-micro --no-host-path --steps 1 --warmup 0 --batch ${PMC_BATCH:-256} "$@" > $OUT/pmc_$name.json 2> $OUT/pmc_$name.err; echo "pmc $name rc=$?"
     python tools/pmc_summary.py $OUT/pmc_$name > $OUT/pmc_$name.summary.txt 2>&1; cat $OUT/pmc_$name.summary.txt | head -40
     find $OUT/pmc_$name -type f -size +2M -delete
   done

@@ -2,7 +2,7 @@
 # bash tools/sweep.sh "<ENVVAR>" "<v1 v2 ...>" [bench args]   -> one summary line per value
 VAR=$1; VALS=$2; shift 2
 for v in $VALS; do
-  env $VAR=$v timeout 600 python bench.py --no-cpu --no-micro "$@" > /tmp/sw.json 2>/tmp/sw.err
+  env $VAR=$v timeout 600 python bench.py --no-cpu --no-micro --no-host-path "$@" > /tmp/sw.json 2>/tmp/sw.err
   python - "$VAR=$v" <<'PY'
 import json,sys
 try:

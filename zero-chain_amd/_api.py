@@ -24,7 +24,8 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
                    ZK_NTT_OUT_BITREV)
 
 __all__ = ["Parameters", "Proof", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
-           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
+           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness",
+           "transfer_prove_batch", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
 
@@ -293,6 +294,43 @@ def create_proofs_from_witness(matrices, params, witnesses, rs, montgomery=False
     out = np.zeros(PROOF_SIZE * n, dtype=np.uint8)
     lib.check(lib.zk_prove_batch_witness(params._h, matrices._h, n, _ptr(w), ZK_FR_MONTGOMERY if montgomery else 0,
                                          _ptr(rsb), _ptr(out)))
+    ob = out.tobytes()
+    return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
+
+
+TRANSFER_N_INPUTS, TRANSFER_N_AUX = 23, 19955
+
+
+def transfer_statements(items):
+    """items: dicts with amount, remaining_balance, fee (ints), randomness, alpha, dec_key_sender (Fs ints)
+    and proof_generation_key, enc_key_recipient, enc_balance_left, enc_balance_right, g_epoch (32-byte
+    Jubjub encodings) -> ctypes array of zk_transfer_statement."""
+    arr = (_lib.TransferStatement * len(items))()
+    for st, it in zip(arr, items):
+        st.amount, st.remaining_balance, st.fee = it["amount"], it["remaining_balance"], it["fee"]
+        for name in ("randomness", "alpha", "dec_key_sender"):
+            getattr(st, name)[:] = int(it[name]).to_bytes(32, "little")
+        for name in ("proof_generation_key", "enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch"):
+            getattr(st, name)[:] = bytes(it[name])
+    return arr
+
+
+def transfer_witness(statements, montgomery=False, lib=None):
+    """zk_transfer_witness: the (23 + 19955) x 32-byte variable assignment of every statement."""
+    lib = lib or _lib.load()
+    n = len(statements)
+    out = np.zeros(n * (TRANSFER_N_INPUTS + TRANSFER_N_AUX) * 32, dtype=np.uint8)
+    lib.check(lib.zk_transfer_witness(statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
+    return out
+
+
+def transfer_prove_batch(matrices, params, statements, rs):
+    """zk_transfer_prove_batch: statements -> witnesses (host) -> row evaluations + create_proof (GPU)."""
+    lib = params._lib
+    n = len(statements)
+    rsb = scalars_to_bytes([x for pair in rs for x in pair])
+    out = np.zeros(PROOF_SIZE * n, dtype=np.uint8)
+    lib.check(lib.zk_transfer_prove_batch(params._h, matrices._h, n, statements, _ptr(rsb), _ptr(out)))
     ob = out.tobytes()
     return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
 

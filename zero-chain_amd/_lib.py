@@ -46,6 +46,12 @@ class Csr(C.Structure):
     _fields_ = [("row_ptr", C.c_void_p), ("col", C.c_void_p), ("coeff", C.c_void_p)]
 
 
+class TransferStatement(C.Structure):
+    _fields_ = [("amount", C.c_uint32), ("remaining_balance", C.c_uint32), ("fee", C.c_uint32), ("reserved", C.c_uint32)] + \
+               [(n, C.c_uint8 * 32) for n in ("randomness", "alpha", "dec_key_sender", "proof_generation_key",
+                                              "enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch")]
+
+
 class BatchDev(C.Structure):
     _fields_ = [("n_rows", C.c_uint32), ("n_inputs", C.c_uint32), ("n_aux", C.c_uint32), ("flags", C.c_uint32),
                 ("d_a", C.c_void_p), ("d_b", C.c_void_p), ("d_c", C.c_void_p), ("d_wit", C.c_void_p),
@@ -66,6 +72,9 @@ _PROTOS = {
                                  C.POINTER(C.c_void_p)]),
     "zk_r1cs_free": (None, [C.c_void_p]),
     "zk_prove_batch_witness": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "zk_transfer_witness": (C.c_int32, [C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
+    "zk_transfer_prove_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TransferStatement), C.c_void_p,
+                                            C.c_void_p]),
     "zk_msm_create": (C.c_int32, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_msm_run": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zk_msm_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),

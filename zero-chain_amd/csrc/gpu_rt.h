@@ -58,6 +58,8 @@ static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
+static inline hipError_t hipHostMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }

@@ -22,6 +22,7 @@
 #include "host_math.h"
 #include "ntt.h"
 #include "msm.h"
+#include "transfer_witness.h"
 
 using zkdev::MsmJob;
 using zkdev::NttPass;
@@ -928,6 +929,24 @@ struct zk_r1cs {
     DevBuf row_ptr[3], col[3], coeff[3];
     std::vector<uint8_t> a_aux_density, b_input_density, b_aux_density;
     DevBuf z, abc;   // per-chunk workspaces: Montgomery assignment, row evaluations
+    // pinned host buffer of zk_transfer_prove_batch (witness vectors of one chunk); never zero-filled
+    void* host_z = nullptr;
+    size_t host_z_cap = 0;
+    ~zk_r1cs() {
+        if (host_z) (void)hipHostFree(host_z);
+    }
+    zk_status host_ensure(size_t bytes) {
+        if (bytes <= host_z_cap) return ZK_OK;
+        if (host_z) (void)hipHostFree(host_z);
+        host_z = nullptr;
+        host_z_cap = 0;
+        if (hipHostMalloc(&host_z, bytes) != hipSuccess) {
+            host_z = nullptr;
+            return fail(ZK_ERR_OUT_OF_MEMORY, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+        }
+        host_z_cap = bytes;
+        return ZK_OK;
+    }
 };
 
 namespace {
@@ -1035,6 +1054,92 @@ zk_status prove_batch_witness(zk_params* P, zk_r1cs* R, size_t n, const uint8_t*
         bt.b_aux_density = R->b_aux_density.data();
         ZK_TRY(prove_batch_dev(P, np, &bt, rs + first * 64, proofs_out + first * 192));
     }
+    return ZK_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// transfer-circuit witness calculator (transfer_witness.h) behind the C ABI
+// ------------------------------------------------------------------------------------------
+namespace {
+
+zk_status transfer_decode(const zk_transfer_statement& in, size_t index, zkwit::Statement* out) {
+    static const uint64_t FS[4] = ZK_JUBJUB_FS_MODULUS_64;
+    auto scalar = [&](const uint8_t* b, uint64_t (&v)[4], const char* what) -> zk_status {
+        load_scalar_le(b, v);
+        for (int i = 3; i >= 0; i--) {
+            if (v[i] < FS[i]) return ZK_OK;
+            if (v[i] > FS[i]) break;
+        }
+        return fail(ZK_ERR_INVALID_ARGUMENT, "statement " + std::to_string(index) + ": " + what + " is not a canonical Fs scalar");
+    };
+    auto point = [&](const uint8_t* b, zkwit::JPoint* p, const char* what) -> zk_status {
+        if (!zkwit::decode_point(b, p))
+            return fail(ZK_ERR_INVALID_ARGUMENT, "statement " + std::to_string(index) + ": " + what + " is not a Jubjub point");
+        return ZK_OK;
+    };
+    out->amount = in.amount;
+    out->remaining_balance = in.remaining_balance;
+    out->fee = in.fee;
+    ZK_TRY(scalar(in.randomness, out->randomness, "randomness"));
+    ZK_TRY(scalar(in.alpha, out->alpha, "alpha"));
+    ZK_TRY(scalar(in.dec_key_sender, out->dec_key, "dec_key_sender"));
+    ZK_TRY(point(in.proof_generation_key, &out->pgk, "proof_generation_key"));
+    ZK_TRY(point(in.enc_key_recipient, &out->enc_key_recipient, "enc_key_recipient"));
+    ZK_TRY(point(in.enc_balance_left, &out->enc_balance_left, "enc_balance_left"));
+    ZK_TRY(point(in.enc_balance_right, &out->enc_balance_right, "enc_balance_right"));
+    ZK_TRY(point(in.g_epoch, &out->g_epoch, "g_epoch"));
+    return ZK_OK;
+}
+
+zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* out) {
+    if ((!st || !out) && n) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return ZK_OK;
+    (void)zkwit::tables();   // build the window tables before the threads start
+    const size_t nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX;
+    unsigned nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > 64) nthreads = 64;
+    if (nthreads > n) nthreads = (unsigned)n;
+    std::vector<zk_status> sts(nthreads, ZK_OK);
+    std::vector<std::string> msgs(nthreads);
+    const bool mont = (flags & ZK_FR_MONTGOMERY) != 0;
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
+            zkwit::Statement s;
+            zk_status rc = transfer_decode(st[i], i, &s);
+            if (rc != ZK_OK) {
+                sts[t] = rc;
+                msgs[t] = g_err;
+                return;
+            }
+            zkwit::Wit w;
+            zkwit::synthesize(s, w);
+            if (w.inputs.size() != ZK_TRANSFER_N_INPUTS || w.aux.size() != ZK_TRANSFER_N_AUX) {
+                sts[t] = ZK_ERR_INVALID_ARGUMENT;
+                msgs[t] = "internal: witness size mismatch";
+                return;
+            }
+            uint64_t* dst = reinterpret_cast<uint64_t*>(out + i * nv * 32);
+            size_t k = 0;
+            for (const auto* vec : {&w.inputs, &w.aux})
+                for (const zkhost::Fr& v : *vec) {
+                    zkhost::Fr x = mont ? v : v.from_mont();
+                    memcpy(dst + 4 * k, x.l, 32);
+                    k++;
+                }
+        }
+    };
+    if (nthreads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> ths;
+        for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, t);
+        for (auto& th : ths) th.join();
+    }
+    for (unsigned t = 0; t < nthreads; t++)
+        if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
     return ZK_OK;
 }
 
@@ -1278,6 +1383,33 @@ void zk_r1cs_free(zk_r1cs* r) { delete r; }
 zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const uint8_t* witness, uint32_t flags,
                                  const uint8_t* rs, uint8_t* proofs_out) {
     return prove_batch_witness(p, circuit, n, witness, flags, rs, proofs_out);
+}
+
+zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
+    return transfer_witness(st, n, flags, witness_out);
+}
+zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
+                                  const uint8_t* rs, uint8_t* proofs_out) {
+    if (!p || !circuit || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the transfer circuit's");
+    const size_t nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX;
+    size_t chunk = 1024;
+    const char* env = getenv("ZKAMD_BATCH_CHUNK");
+    if (env && atoi(env) > 0) chunk = (size_t)atoi(env);
+    zk_status rc = use_device(p->device);
+    if (rc != ZK_OK) return rc;
+    for (size_t first = 0; first < n; first += chunk) {
+        const size_t np = std::min(chunk, n - first);
+        rc = circuit->host_ensure(np * nv * 32);
+        if (rc != ZK_OK) return rc;
+        uint8_t* z = (uint8_t*)circuit->host_z;
+        rc = transfer_witness(st + first, np, ZK_FR_MONTGOMERY, z);
+        if (rc != ZK_OK) return rc;
+        rc = prove_batch_witness(p, circuit, np, z, ZK_FR_MONTGOMERY, rs + first * 64, proofs_out + first * 192);
+        if (rc != ZK_OK) return rc;
+    }
+    return ZK_OK;
 }
 
 zk_status zk_msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
