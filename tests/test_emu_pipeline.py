@@ -74,7 +74,7 @@ def test_prover_errors(emu_lib, monkeypatch):
 
 
 def test_msm_recoding_all_widths(emu_lib):
-    pc.msm_recoding_stress(emu_lib, windows=range(2, 13))   # wide windows: GPU suite (thread-per-GPU-thread emulation)
+    pc.msm_recoding_stress(emu_lib, windows=(2, 3, 5, 8, 12))   # every width 2..22: GPU suite (the emulation is thread-per-GPU-thread)
 
 
 def test_msm_global_sort_path(emu_lib, monkeypatch):
@@ -89,3 +89,9 @@ def test_msm_global_sort_path(emu_lib, monkeypatch):
 def test_prover_from_witness(emu_lib):
     pc.prover_from_witness(emu_lib, 3, 3, 14, 3)
     pc.prover_from_witness(emu_lib, 4, 2, 9, 2, montgomery=True)
+
+
+def test_msm_long_tasks(emu_lib, monkeypatch):
+    """Accumulation tasks of up to 256 points (the setting of large batches)."""
+    monkeypatch.setenv("ZKAMD_MSM_SEG", "256")
+    pc.msm_golden_vectors(emu_lib, 1, 1500, 6, seed=12)

@@ -14,7 +14,7 @@
 //     odd signed digits |d| < 2^(c-1) at arbitrary positions, on average one non-zero digit
 //     per c + 1 bits (bellman: one per c bits) over only 2^(c-2) buckets (bellman: 2^c - 1).
 //   * (digit, point) pairs are counting-sorted by bucket (histogram with returned ranks ->
-//     per-job exclusive scan -> scatter).  A bucket is cut into tasks of <= MSM_SEG points and
+//     per-job exclusive scan -> scatter).  A bucket is cut into tasks of <= seg points and
 //     the tasks of the whole launch are ordered by length, so the 64 lanes of a wave walk
 //     equally long runs of XYZZ mixed additions (8M+2S, dev_curve.h) with no idle lanes.
 //   * buckets are reduced with chunked running sums: chunk t of length L yields
@@ -56,7 +56,10 @@ template <class F> struct MsmOcc;
 template <> struct MsmOcc<Fq> { static constexpr int acc = ZK_OCC_G1_ACC, red = ZK_OCC_G1_RED; };
 template <> struct MsmOcc<Fq2> { static constexpr int acc = ZK_OCC_G2_ACC, red = ZK_OCC_G2_RED; };
 
-constexpr uint32_t MSM_SEG = 64;    // longest run of points one thread accumulates
+// Longest run of points one accumulation thread walks (`seg`, a launch parameter): 256 when
+// thousands of jobs fill the machine (fewer task partials to merge in the reduction), 64 for a
+// single job (more, shorter tasks to spread over the CUs).  MSM_SEG_MAX sizes the class arrays.
+constexpr uint32_t MSM_SEG_MAX = 256;
 constexpr uint32_t MSM_NPOS = 255;  // table slices: 2^k * P for k = 0 .. 254
 // buckets with more task partials than `merge_inline` (8 when many jobs fill the machine, 2 for a
 // single job whose reduction threads must stay short) are merged by k_msm_merge_heavy
@@ -187,13 +190,13 @@ k_msm_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t
 }
 
 // Pass 2: per-job exclusive scans of the histogram: first pair slot of every bucket, and the
-// bucket's first TASK.  A bucket with k points is cut into ceil(k / MSM_SEG) tasks so that no
-// thread of the accumulation ever walks more than MSM_SEG points, whatever the scalar
+// bucket's first TASK.  A bucket with k points is cut into ceil(k / seg) tasks so that no
+// thread of the accumulation ever walks more than seg points, whatever the scalar
 // distribution (boolean witnesses put ~n/2 points into bucket "1").  One workgroup per job;
 // each thread owns a contiguous run of buckets.
 __global__ void __launch_bounds__(1024)
 k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ cnt, uint32_t* off,
-           uint32_t* toff, uint32_t* ntasks) {
+           uint32_t* toff, uint32_t* ntasks, uint32_t seg) {
     ZK_SHARED uint32_t part[1024];
     ZK_SHARED uint32_t tpart[1024];
     const uint32_t nb = 1u << (c - 2);
@@ -208,7 +211,7 @@ k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restri
     for (uint32_t b = b0; b < b1; b++) {
         uint32_t k = jcnt[b];
         sum += k;
-        tsum += (k + MSM_SEG - 1) / MSM_SEG;
+        tsum += (k + seg - 1) / seg;
     }
     part[tid] = sum;
     tpart[tid] = tsum;
@@ -229,7 +232,7 @@ k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restri
         joff[b] = run;
         jtoff[b] = trun;
         run += k;
-        trun += (k + MSM_SEG - 1) / MSM_SEG;
+        trun += (k + seg - 1) / seg;
     }
     if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
 }
@@ -262,7 +265,7 @@ k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __res
 constexpr uint32_t MSM_SORT_THREADS = 1024;
 __global__ void __launch_bounds__(MSM_SORT_THREADS)
 k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* off, uint32_t* toff,
-               uint32_t* ntasks, uint32_t* pairs) {
+               uint32_t* ntasks, uint32_t* pairs, uint32_t seg) {
     ZK_DYN_SHARED(uint32_t, h);   // [nb] histogram, then running slot cursors
     ZK_SHARED uint32_t part[MSM_SORT_THREADS];
     ZK_SHARED uint32_t tpart[MSM_SORT_THREADS];
@@ -283,7 +286,7 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
     for (uint32_t b = b0; b < b1; b++) {
         uint32_t k = h[b];
         sum += k;
-        tsum += (k + MSM_SEG - 1) / MSM_SEG;
+        tsum += (k + seg - 1) / seg;
     }
     part[tid] = sum;
     tpart[tid] = tsum;
@@ -307,7 +310,7 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
         jtoff[b] = trun;
         h[b] = run;   // slot cursor of the bucket, relative to the job's first pair
         run += k;
-        trun += (k + MSM_SEG - 1) / MSM_SEG;
+        trun += (k + seg - 1) / seg;
     }
     if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
     __syncthreads();
@@ -323,37 +326,37 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
     }
 }
 
-// Pass 4a: histogram of task lengths (1 .. MSM_SEG) per job.  One thread per bucket.
+// Pass 4a: histogram of task lengths (1 .. seg) per job.  One thread per bucket.
 __global__ void __launch_bounds__(256)
-k_msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t* lenhist, uint32_t nb) {
-    ZK_SHARED uint32_t h[MSM_SEG];
+k_msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t* lenhist, uint32_t nb, uint32_t seg) {
+    ZK_SHARED uint32_t h[MSM_SEG_MAX];
     const uint32_t tid = threadIdx.x, job = blockIdx.y;
-    if (tid < MSM_SEG) h[tid] = 0;
+    if (tid < seg) h[tid] = 0;
     __syncthreads();
     uint32_t b = blockIdx.x * blockDim.x + tid;
     if (b < nb) {
         uint32_t k = cnt[(size_t)job * nb + b];
-        uint32_t full = k / MSM_SEG, rem = k % MSM_SEG;
-        if (full) atomicAdd(&h[MSM_SEG - 1], full);
+        uint32_t full = k / seg, rem = k % seg;
+        if (full) atomicAdd(&h[seg - 1], full);
         if (rem) atomicAdd(&h[rem - 1], 1u);
     }
     __syncthreads();
-    if (tid < MSM_SEG && h[tid]) atomicAdd(&lenhist[(size_t)job * MSM_SEG + tid], h[tid]);
+    if (tid < seg && h[tid]) atomicAdd(&lenhist[(size_t)job * seg + tid], h[tid]);
 }
 
 // Pass 4b: first slot of every (length, job) class in the launch-wide task order: longest tasks
 // first, jobs in order inside a length class.  One workgroup.
 __global__ void __launch_bounds__(1024)
-k_msm_task_base(const uint32_t* __restrict__ lenhist, uint32_t* base, uint32_t* total, uint32_t nj) {
+k_msm_task_base(const uint32_t* __restrict__ lenhist, uint32_t* base, uint32_t* total, uint32_t nj, uint32_t seg) {
     ZK_SHARED uint32_t part[1024];
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t E = nj * MSM_SEG;
+    const uint32_t E = nj * seg;
     const uint32_t per = (E + nt - 1) / nt;
     uint32_t e0 = tid * per, e1 = e0 + per < E ? e0 + per : E;
     if (e0 > E) e0 = E;
-    // entry e = (MSM_SEG - 1 - len_index) * nj + job
+    // entry e = (seg - 1 - len_index) * nj + job
     uint32_t sum = 0;
-    for (uint32_t e = e0; e < e1; e++) sum += lenhist[(size_t)(e % nj) * MSM_SEG + (MSM_SEG - 1 - e / nj)];
+    for (uint32_t e = e0; e < e1; e++) sum += lenhist[(size_t)(e % nj) * seg + (seg - 1 - e / nj)];
     part[tid] = sum;
     __syncthreads();
     for (uint32_t d = 1; d < nt; d <<= 1) {
@@ -365,7 +368,7 @@ k_msm_task_base(const uint32_t* __restrict__ lenhist, uint32_t* base, uint32_t* 
     uint32_t run = tid ? part[tid - 1] : 0;
     for (uint32_t e = e0; e < e1; e++) {
         base[e] = run;
-        run += lenhist[(size_t)(e % nj) * MSM_SEG + (MSM_SEG - 1 - e / nj)];
+        run += lenhist[(size_t)(e % nj) * seg + (seg - 1 - e / nj)];
     }
     if (tid == nt - 1) total[0] = part[nt - 1];
 }
@@ -376,25 +379,26 @@ k_msm_task_base(const uint32_t* __restrict__ lenhist, uint32_t* base, uint32_t* 
 __global__ void __launch_bounds__(256)
 k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff,
                  const uint32_t* __restrict__ task_base, const uint32_t* __restrict__ base, uint32_t* cursor,
-                 uint4* sorted, uint32_t* n_heavy, uint32_t* heavy, uint32_t nb, uint32_t nj, uint32_t merge_inline) {
-    ZK_SHARED uint32_t h[MSM_SEG];
-    ZK_SHARED uint32_t start[MSM_SEG];
+                 uint4* sorted, uint32_t* n_heavy, uint32_t* heavy, uint32_t nb, uint32_t nj, uint32_t merge_inline,
+                 uint32_t seg) {
+    ZK_SHARED uint32_t h[MSM_SEG_MAX];
+    ZK_SHARED uint32_t start[MSM_SEG_MAX];
     const uint32_t tid = threadIdx.x, job = blockIdx.y;
-    if (tid < MSM_SEG) h[tid] = 0;
+    if (tid < seg) h[tid] = 0;
     __syncthreads();
     uint32_t b = blockIdx.x * blockDim.x + tid;
     uint32_t k = 0, full = 0, rem = 0;
     if (b < nb) {
         k = cnt[(size_t)job * nb + b];
-        full = k / MSM_SEG;
-        rem = k % MSM_SEG;
-        if (full) atomicAdd(&h[MSM_SEG - 1], full);
+        full = k / seg;
+        rem = k % seg;
+        if (full) atomicAdd(&h[seg - 1], full);
         if (rem) atomicAdd(&h[rem - 1], 1u);
     }
     __syncthreads();
-    if (tid < MSM_SEG) {
+    if (tid < seg) {
         uint32_t n = h[tid];
-        start[tid] = base[(size_t)(MSM_SEG - 1 - tid) * nj + job] + (n ? atomicAdd(&cursor[(size_t)job * MSM_SEG + tid], n) : 0u);
+        start[tid] = base[(size_t)(seg - 1 - tid) * nj + job] + (n ? atomicAdd(&cursor[(size_t)job * seg + tid], n) : 0u);
         h[tid] = 0;
     }
     __syncthreads();
@@ -402,17 +406,17 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
     if (k) {
         const uint32_t o = off[(size_t)job * nb + b], ti = task_base[job] + toff[(size_t)job * nb + b];
         if (full) {
-            uint32_t at = start[MSM_SEG - 1] + atomicAdd(&h[MSM_SEG - 1], full);
-            for (uint32_t sgm = 0; sgm < full; sgm++) sorted[at + sgm] = make_uint4(o + sgm * MSM_SEG, ti + sgm, MSM_SEG, 0);
+            uint32_t at = start[seg - 1] + atomicAdd(&h[seg - 1], full);
+            for (uint32_t sgm = 0; sgm < full; sgm++) sorted[at + sgm] = make_uint4(o + sgm * seg, ti + sgm, seg, 0);
         }
         if (rem) {
             uint32_t at = start[rem - 1] + atomicAdd(&h[rem - 1], 1u);
-            sorted[at] = make_uint4(o + full * MSM_SEG, ti + full, rem, 0);
+            sorted[at] = make_uint4(o + full * seg, ti + full, rem, 0);
         }
     }
 }
 
-// Pass 5: one thread per task (= at most MSM_SEG points of one bucket), tasks in length order.
+// Pass 5: one thread per task (= at most seg points of one bucket), tasks in length order.
 template <class F>
 __global__ void __launch_bounds__(128, MsmOcc<F>::acc)
 k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
@@ -440,11 +444,12 @@ k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict
 template <class F>
 __global__ void __launch_bounds__(64, MsmOcc<F>::red)
 k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
-                  const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb) {
+                  const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb,
+                  uint32_t seg) {
     ZK_SHARED XYZZ<F> sm[64];
     if (blockIdx.x >= n_heavy[0]) return;
     const uint32_t gb = heavy[blockIdx.x], tid = threadIdx.x;
-    const uint32_t nt = (cnt[gb] + MSM_SEG - 1) / MSM_SEG;
+    const uint32_t nt = (cnt[gb] + seg - 1) / seg;
     XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t u = tid; u < nt; u += 64) acc = xadd(acc, ts[u]);
@@ -476,7 +481,7 @@ template <class F>
 __global__ void __launch_bounds__(64, MsmOcc<F>::red)
 k_msm_suffix_buckets(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restrict__ cnt,
                      const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base,
-                     XYZZ<F>* __restrict__ R, uint32_t nb, uint32_t L, uint32_t merge_inline) {
+                     XYZZ<F>* __restrict__ R, uint32_t nb, uint32_t L, uint32_t merge_inline, uint32_t seg) {
     const uint32_t T = nb / L;
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -487,7 +492,7 @@ k_msm_suffix_buckets(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restri
     for (int k = (int)L - 1; k >= 0; k--) {
         uint32_t n = cnt[b0 + k];
         if (n) {
-            uint32_t o = toff[b0 + k], nt_b = (n + MSM_SEG - 1) / MSM_SEG;
+            uint32_t o = toff[b0 + k], nt_b = (n + seg - 1) / seg;
             if (nt_b > merge_inline) nt_b = 1;   // already summed into the first partial (k_msm_merge_heavy)
             for (uint32_t u = 0; u < nt_b; u++) run = xadd(run, ts[o + u]);
         }

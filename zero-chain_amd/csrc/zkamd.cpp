@@ -374,6 +374,10 @@ struct MsmGroup {
         const size_t nj = jobs.size();
         out.resize(nj);
         if (!nj) return ZK_OK;
+        const char* seg_env = getenv("ZKAMD_MSM_SEG");
+        const uint32_t seg = seg_env && atoi(seg_env) > 0 && atoi(seg_env) <= (int)zkdev::MSM_SEG_MAX
+                                 ? (uint32_t)atoi(seg_env)
+                                 : (nj >= 64 ? 256u : 64u);   // points per accumulation task (msm.h)
         uint64_t total = 0, total_tasks = 0;
         uint32_t max_n = 0;
         tbase_h.resize(nj);
@@ -383,7 +387,7 @@ struct MsmGroup {
             total += (uint64_t)j.n * maxd;
             max_n = std::max(max_n, j.n);
             // a bucket with k points becomes ceil(k / MSM_SEG) tasks: at most nb + pairs / SEG of them
-            uint64_t cap = (uint64_t)nb + ((uint64_t)j.n * maxd) / zkdev::MSM_SEG + 1;
+            uint64_t cap = (uint64_t)nb + ((uint64_t)j.n * maxd) / seg + 1;
             tbase_h[k] = (uint32_t)total_tasks;
             total_tasks += cap;
         }
@@ -391,7 +395,7 @@ struct MsmGroup {
             return fail(ZK_ERR_INVALID_ARGUMENT, "too many (digit, point) pairs in one launch");
         const size_t n_buckets = nj * (size_t)nb;
         if (n_buckets >= (1ull << 32)) return fail(ZK_ERR_INVALID_ARGUMENT, "too many buckets in one launch");
-        const size_t n_class = nj * (size_t)zkdev::MSM_SEG;
+        const size_t n_class = nj * (size_t)seg;
         ZK_TRY(jobs_d.ensure(nj * sizeof(MsmJob)));
         ZK_TRY(cnt.ensure(n_buckets * 4));
         ZK_TRY(off.ensure(n_buckets * 4));
@@ -400,7 +404,7 @@ struct MsmGroup {
         ZK_TRY(tbase.ensure(nj * 4));
         ZK_TRY(hist.ensure((2 * n_class + 2) * 4));     // [length histogram | placement cursors | total | #heavy]
         const uint32_t merge_inline = nj >= 64 ? 8u : 2u;
-        const size_t heavy_cap = (size_t)(total / (zkdev::MSM_SEG * merge_inline)) + 1;
+        const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
         ZK_TRY(heavy.ensure(heavy_cap * 4));
         ZK_TRY(tclass.ensure(n_class * 4));
         ZK_TRY(sorted.ensure((size_t)total_tasks * sizeof(uint4)));
@@ -435,7 +439,7 @@ struct MsmGroup {
             ProfScope ps("msm_sort_lds", st);
             ZK_LAUNCH_SYNC(zkdev::k_msm_sort_lds, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c,
                            cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(),
-                           pairs.as<uint32_t>());
+                           pairs.as<uint32_t>(), seg);
         } else {
             HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, st));
             ZK_TRY(rank.ensure((size_t)(total ? total : 1) * 4));
@@ -452,7 +456,7 @@ struct MsmGroup {
             {
                 ProfScope ps("msm_scan", st);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < 1024 ? (nb < 64 ? 64 : nb) : 1024), 0, st,
-                               dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>());
+                               dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(), seg);
             }
             if (max_n) {
                 ProfScope ps("msm_scatter", st);
@@ -462,12 +466,12 @@ struct MsmGroup {
         }
         {
             ProfScope ps("msm_task_sort", st);
-            ZK_LAUNCH_SYNC(zkdev::k_msm_task_hist, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), lenhist, nb);
+            ZK_LAUNCH_SYNC(zkdev::k_msm_task_hist, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), lenhist, nb, seg);
             ZK_LAUNCH_SYNC(zkdev::k_msm_task_base, dim3(1), dim3(1024), 0, st, lenhist, tclass.as<uint32_t>(), d_total,
-                           (uint32_t)nj);
+                           (uint32_t)nj, seg);
             ZK_LAUNCH_SYNC(zkdev::k_msm_task_place, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), off.as<uint32_t>(),
                            toff.as<uint32_t>(), tbase.as<uint32_t>(), tclass.as<uint32_t>(), cursor, sorted.as<uint4>(), d_nheavy,
-                           heavy.as<uint32_t>(), nb, (uint32_t)nj, merge_inline);
+                           heavy.as<uint32_t>(), nb, (uint32_t)nj, merge_inline, seg);
         }
         {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
@@ -483,10 +487,10 @@ struct MsmGroup {
             auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
             ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>, dim3((unsigned)heavy_cap), dim3(64), 0, st,
                            (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy, (const uint32_t*)cnt.as<uint32_t>(),
-                           (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb);
+                           (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg);
             // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
             ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
-                      toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, merge_inline);
+                      toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, merge_inline, seg);
             ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
                       1u, 1u, 1u);
             uint32_t n = T, m = L, stride = L;   // n nodes per job of m buckets each; S(node k) = R[k * stride]
