@@ -262,7 +262,11 @@ k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __res
 // per job counts the digits in an LDS histogram, scans it in place (writing cnt / off / toff for
 // the later passes) and scatters the pairs with LDS tickets.  No global atomics, no rank array:
 // the three-kernel path above spends its time on ~10^8 returning global atomics per chunk.
+#ifdef ZK_EMU
+constexpr uint32_t MSM_SORT_THREADS = 64;     // the test-only emulation runs one OS thread per GPU thread
+#else
 constexpr uint32_t MSM_SORT_THREADS = 1024;
+#endif
 __global__ void __launch_bounds__(MSM_SORT_THREADS)
 k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* off, uint32_t* toff,
                uint32_t* ntasks, uint32_t* pairs, uint32_t seg) {

@@ -455,7 +455,7 @@ struct MsmGroup {
             }
             {
                 ProfScope ps("msm_scan", st);
-                ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < 1024 ? (nb < 64 ? 64 : nb) : 1024), 0, st,
+                ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < zkdev::MSM_SORT_THREADS ? (nb < 64 ? 64 : nb) : zkdev::MSM_SORT_THREADS), 0, st,
                                dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(), seg);
             }
             if (max_n) {
@@ -467,7 +467,7 @@ struct MsmGroup {
         {
             ProfScope ps("msm_task_sort", st);
             ZK_LAUNCH_SYNC(zkdev::k_msm_task_hist, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), lenhist, nb, seg);
-            ZK_LAUNCH_SYNC(zkdev::k_msm_task_base, dim3(1), dim3(1024), 0, st, lenhist, tclass.as<uint32_t>(), d_total,
+            ZK_LAUNCH_SYNC(zkdev::k_msm_task_base, dim3(1), dim3(zkdev::MSM_SORT_THREADS), 0, st, lenhist, tclass.as<uint32_t>(), d_total,
                            (uint32_t)nj, seg);
             ZK_LAUNCH_SYNC(zkdev::k_msm_task_place, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), off.as<uint32_t>(),
                            toff.as<uint32_t>(), tbase.as<uint32_t>(), tclass.as<uint32_t>(), cursor, sorted.as<uint4>(), d_nheavy,
