@@ -44,18 +44,26 @@ struct alignas(16) XYZZ {
     }
 };
 
+// (sqr_b<K>: square of a value whose components are < K p; wr(): weak reduction to < 3 p.  Both
+//  are no-ops except on Fq2x, whose Karatsuba / complex-squaring operands are range-limited.)
+
+// bound of a value after wr(): F::WB where wr() reduces, unchanged where it is the identity
+template <class F>
+constexpr int wrb(int b) { return b < F::WB ? b : F::WB; }
+
 // 2 * (affine p) -> XYZZ     (EFD mdbl-2008-s-1); p not infinity
 template <class F>
 ZK_DI XYZZ<F> mdbl(const Affine<F>& p) {
     constexpr int MO = F::MO;
     F u = dbl(p.y);                                             // < 2 MO
-    F v = sqr(u);
+    F v = sqr_b<2 * MO>(u);
     F w = mul(u, v);
     F s = mul(p.x, v);
-    F xx = sqr(p.x);
+    F xx = sqr_b<MO>(p.x);
     F m = add(dbl(xx), xx);                                     // < 3 MO
-    F x3 = sub_b<2 * MO>(sqr(m), dbl(s));                       // < 3 MO + 1
-    F y3 = sub_b<MO>(mul(m, sub_b<3 * MO + 1>(s, x3)), mul(w, p.y));   // < 2 MO + 1
+    F x3 = sub_b<2 * MO>(sqr_b<3 * MO>(m), dbl(s));             // < 3 MO + 1
+    F t = wr(sub_b<3 * MO + 1>(s, x3));
+    F y3 = sub_b<MO>(mul(m, t), mul(w, p.y));                   // < 2 MO + 1
     return XYZZ<F>{x3, y3, v, w};
 }
 
@@ -64,14 +72,16 @@ template <class F>
 ZK_DI XYZZ<F> xdbl(const XYZZ<F>& a) {
     constexpr int MO = F::MO;
     if (a.is_inf()) return a;
-    F u = dbl(a.y);                                             // < 2 BY
-    F v = sqr(u);
+    F ax = wr(a.x), ay = wr(a.y);                               // < BX, BY (or < 3 after a weak reduction)
+    F u = dbl(ay);
+    F v = sqr_b<2 * wrb<F>(XYZZ<F>::BY)>(u);
     F w = mul(u, v);
-    F s = mul(a.x, v);
-    F xx = sqr(a.x);
+    F s = mul(ax, v);
+    F xx = sqr_b<wrb<F>(XYZZ<F>::BX)>(ax);
     F m = add(dbl(xx), xx);
-    F x3 = sub_b<2 * MO>(sqr(m), dbl(s));
-    F y3 = sub_b<MO>(mul(m, sub_b<3 * MO + 1>(s, x3)), mul(w, a.y));
+    F x3 = sub_b<2 * MO>(sqr_b<3 * MO>(m), dbl(s));
+    F t = wr(sub_b<3 * MO + 1>(s, x3));
+    F y3 = sub_b<MO>(mul(m, t), mul(w, ay));
     return XYZZ<F>{x3, y3, mul(v, a.zz), mul(w, a.zzz)};
 }
 
@@ -86,9 +96,9 @@ ZK_DI void madd(XYZZ<F>& acc, const Affine<F>& p, bool negate) {
     }
     F u2 = mul(p.x, acc.zz);
     F s2 = mul(py, acc.zzz);
-    F pp_ = sub_b<BX>(u2, acc.x);                               // < MO + BX + 1
+    F pp_ = wr(sub_b<BX>(u2, acc.x));                           // < MO + BX + 1
     F r = sub_b<BY>(s2, acc.y);                                 // < MO + BY + 1
-    F pp = sqr(pp_);
+    F pp = sqr_b<wrb<F>(MO + BX + 1)>(pp_);
     F ppp = mul(pp_, pp);
     F q = mul(acc.x, pp);
     F zz3 = mul(acc.zz, pp);
@@ -101,8 +111,9 @@ ZK_DI void madd(XYZZ<F>& acc, const Affine<F>& p, bool negate) {
         }
         return;
     }
-    F x3 = sub_b<2 * MO>(sub_b<MO>(sqr(r), ppp), dbl(q));       // < 4 MO + 2 = BX
-    F y3 = sub_b<MO>(mul(r, sub_b<BX>(q, x3)), mul(acc.y, ppp));   // < 2 MO + 1 = BY
+    F x3 = sub_b<2 * MO>(sub_b<MO>(sqr_b<MO + BY + 1>(r), ppp), dbl(q));   // < 4 MO + 2 = BX
+    F t = wr(sub_b<BX>(q, x3));
+    F y3 = sub_b<MO>(mul(r, t), mul(acc.y, ppp));               // < 2 MO + 1 = BY
     acc.x = x3;
     acc.y = y3;
     acc.zz = zz3;
@@ -121,7 +132,7 @@ ZK_DI XYZZ<F> xadd(const XYZZ<F>& a, const XYZZ<F>& b) {
     F s2 = mul(b.y, a.zzz);
     F p = sub_b<MO>(u2, u1);                                    // < 2 MO + 1
     F r = sub_b<MO>(s2, s1);
-    F pp = sqr(p);
+    F pp = sqr_b<2 * MO + 1>(p);
     F ppp = mul(p, pp);
     F q = mul(u1, pp);
     F zz3 = mul(mul(a.zz, b.zz), pp);
@@ -129,8 +140,9 @@ ZK_DI XYZZ<F> xadd(const XYZZ<F>& a, const XYZZ<F>& b) {
         if (is_zero_full(r)) return xdbl(a);
         return XYZZ<F>::inf();
     }
-    F x3 = sub_b<2 * MO>(sub_b<MO>(sqr(r), ppp), dbl(q));
-    F y3 = sub_b<MO>(mul(r, sub_b<BX>(q, x3)), mul(s1, ppp));
+    F x3 = sub_b<2 * MO>(sub_b<MO>(sqr_b<2 * MO + 1>(r), ppp), dbl(q));
+    F t = wr(sub_b<BX>(q, x3));
+    F y3 = sub_b<MO>(mul(r, t), mul(s1, ppp));
     return XYZZ<F>{x3, y3, zz3, mul(mul(a.zzz, b.zzz), ppp)};
 }
 

@@ -62,6 +62,7 @@ template <class C>
 struct Fp {
     static constexpr int N = C::N;
     static constexpr int MO = 1;   // fully reduced
+    static constexpr int WB = 64;  // wr() is the identity
     uint32_t l[N];
     ZK_DI bool is_zero_norm() const { return is_zero(); }
 
@@ -467,6 +468,7 @@ static inline long double fq28_ratio(const uint32_t* l) {
 
 struct Fq28 {
     static constexpr int MO = 2;   // a product is < MO * p
+    static constexpr int WB = 64;  // wr() is the identity for G1
     uint32_t l[14];
 
     ZK_DI static Fq28 zero() {
@@ -627,6 +629,93 @@ ZK_DI void fq28_export(const Fq28& a, uint32_t* h) {
     }
 }
 
+// Weak reduction: any stored value (< 64 p) -> the same residue, EXACTLY normalised, < 3 p.
+// q = floor(top limb / (p_top + 1)) never exceeds floor(x / p) and misses it by at most 2
+// (x < 64 p, p_top ~ 2^16.7); x - q p is then formed with a signed borrow chain (no SGPR carries).
+ZK_DI Fq28 fq28_wred(const Fq28& x) {
+    constexpr uint32_t PT = Fq28Consts::P[13] + 1;
+    // the float quotient is rounded towards zero and scaled down by 2^-18 so that it never overshoots
+    uint32_t q = (uint32_t)((float)x.l[13] * ((1.0f / (float)PT) * (1.0f - 1.0f / 262144.0f)));
+    uint32_t qp[14];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        acc += (uint64_t)q * Fq28Consts::P[i];
+        qp[i] = i < 13 ? ((uint32_t)acc & FQ28_MASK) : (uint32_t)acc;
+        acc >>= 28;
+    }
+    Fq28 r;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        int32_t d = (int32_t)x.l[i] - (int32_t)qp[i] + c;
+        if (i < 13) {
+            c = d >> 28;   // arithmetic: -1, 0 or +1 (weakly normalised input limbs exceed 2^28 by at most 8)
+            r.l[i] = (uint32_t)d & FQ28_MASK;
+        } else {
+            r.l[i] = (uint32_t)d;
+        }
+    }
+    ZK_FQ28_CHECK((int32_t)r.l[13] >= 0 && fq28_ratio(r.l) < 3.0L);
+    return r;
+}
+// zero test of any stored value: after the weak reduction the candidates are 0, p and 2p
+ZK_DI bool fq28_is_zero_lazy(const Fq28& x) {
+    Fq28 t = fq28_wred(x);
+    uint32_t o0 = 0, o1 = 0, o2 = 0;
+    constexpr uint32_t P2[14] = ZK_FQ28_2P;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        o0 |= t.l[i];
+        o1 |= t.l[i] ^ Fq28Consts::P[i];
+        o2 |= t.l[i] ^ P2[i];
+    }
+    return o0 == 0 || o1 == 0 || o2 == 0;
+}
+// identity hook: a G1 intermediate never needs a weak reduction (see the bounds in dev_curve.h)
+ZK_DI Fq28 wr(const Fq28& a) { return a; }
+
+// ---------------------------------------------------------------------------------------------
+// Fq2 = Fq[u]/(u^2 + 1) over the radix-2^28 representation (G2 under -DZK_G2_RADIX28; measured
+// slower than the saturated Fq2 for register-pressure reasons, see zkamd.cpp).  fq2.rs:90-182.
+// Karatsuba leaves lazily reduced differences: a product's components are < 5 p and < 7 p
+// (MO = 7) provided the operands' component bounds A, B satisfy (2A)(2B) < 2^11.3, i.e. A B <= 625;
+// a square needs A <= 24.  Where the curve formulas exceed that, they call wr() (weak reduction of
+// both components, ~200 instructions) - twice per mixed addition.
+// ---------------------------------------------------------------------------------------------
+struct Fq2x {
+    static constexpr int MO = 7;
+    static constexpr int WB = 3;   // components after wr()
+    Fq28 c0, c1;
+    ZK_DI static Fq2x zero() { return Fq2x{Fq28::zero(), Fq28::zero()}; }
+    ZK_DI static Fq2x one() { return Fq2x{Fq28::one(), Fq28::zero()}; }
+    // (components are lazily reduced: the test normalises first; c1 is only looked at when c0 is zero)
+    ZK_DI bool is_zero_norm() const { return fq28_is_zero_lazy(c0) && fq28_is_zero_lazy(c1); }
+};
+ZK_DI Fq2x add(const Fq2x& a, const Fq2x& b) { return Fq2x{add(a.c0, b.c0), add(a.c1, b.c1)}; }
+ZK_DI Fq2x dbl(const Fq2x& a) { return add(a, a); }
+template <int B>
+ZK_DI Fq2x sub_b(const Fq2x& a, const Fq2x& b) { return Fq2x{sub_b<B>(a.c0, b.c0), sub_b<B>(a.c1, b.c1)}; }
+template <int B>
+ZK_DI Fq2x neg_b(const Fq2x& a) { return Fq2x{neg_b<B>(a.c0), neg_b<B>(a.c1)}; }
+ZK_DI Fq2x wr(const Fq2x& a) { return Fq2x{fq28_wred(a.c0), fq28_wred(a.c1)}; }
+ZK_DI bool is_zero_full(const Fq2x& a) { return a.is_zero_norm(); }
+ZK_DI Fq2x mul(const Fq2x& a, const Fq2x& b) {
+    Fq28 aa = mul(a.c0, b.c0);                                  // < 2
+    Fq28 bb = mul(a.c1, b.c1);
+    Fq28 o = mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    return Fq2x{sub_b<2>(aa, bb), sub_b<4>(o, add(aa, bb))};    // < 5, < 7
+}
+template <int A>   // A = bound of the operand's components (needed for the difference a0 - a1)
+ZK_DI Fq2x sqr_b(const Fq2x& a) {
+    static_assert(A <= 24, "operand of an Fq2 square out of range: weak-reduce it first");
+    Fq28 ab = mul(a.c0, a.c1);
+    Fq28 s = mul(add(a.c0, a.c1), sub_b<A>(a.c0, a.c1));
+    return Fq2x{s, dbl(ab)};                                    // < 2, < 4
+}
+// square of a product / table entry / imported value (components < 8 p)
+ZK_DI Fq2x sqr(const Fq2x& a) { return sqr_b<8>(a); }
+
 // The same interface on the saturated representation (G2 still runs on it): bounds are ignored,
 // every value is fully reduced.
 template <int B, class C>
@@ -635,14 +724,21 @@ template <int B, class C>
 ZK_DI Fp<C> neg_b(const Fp<C>& a) { return neg(a); }
 template <class C>
 ZK_DI bool is_zero_full(const Fp<C>& a) { return a.is_zero(); }
+template <class C>
+ZK_DI Fp<C> wr(const Fp<C>& a) { return a; }
+template <int A, class C>
+ZK_DI Fp<C> sqr_b(const Fp<C>& a) { return sqr(a); }
+template <int A>
+ZK_DI Fq28 sqr_b(const Fq28& a) { return sqr(a); }
 
 // ---------------------------------------------------------------------------------------------
 // Fq2 = Fq[u]/(u^2 + 1)  (fq2.rs:90-182)
 // ---------------------------------------------------------------------------------------------
 typedef Fq28 Fq;   // G1 base field as the MSM kernels see it
 struct Fq2 {
-    typedef Fq32 Fq;   // G2 stays on the saturated representation this round
+    typedef Fq32 Fq;   // the saturated representation (kept for A/B measurements and the debug entries)
     static constexpr int MO = 1;
+    static constexpr int WB = 64;
     Fq c0, c1;
     ZK_DI bool is_zero_norm() const { return is_zero(); }
     ZK_DI static Fq2 zero() { return Fq2{Fq32::zero(), Fq32::zero()}; }
@@ -656,6 +752,7 @@ ZK_DI Fq2 sub_b(const Fq2& a, const Fq2& b) { return Fq2{sub(a.c0, b.c0), sub(a.
 template <int B>
 ZK_DI Fq2 neg_b(const Fq2& a) { return Fq2{neg(a.c0), neg(a.c1)}; }
 ZK_DI bool is_zero_full(const Fq2& a) { return a.is_zero(); }
+ZK_DI Fq2 wr(const Fq2& a) { return a; }
 ZK_DI Fq2 add(const Fq2& a, const Fq2& b) { return Fq2{add(a.c0, b.c0), add(a.c1, b.c1)}; }
 ZK_DI Fq2 sub(const Fq2& a, const Fq2& b) { return Fq2{sub(a.c0, b.c0), sub(a.c1, b.c1)}; }
 ZK_DI Fq2 neg(const Fq2& a) { return Fq2{neg(a.c0), neg(a.c1)}; }
@@ -667,6 +764,9 @@ ZK_DI Fq2 mul(const Fq2& a, const Fq2& b) {
     Fq32 o = mul(add(a.c0, a.c1), add(b.c0, b.c1));
     return Fq2{sub(aa, bb), sub(sub(o, aa), bb)};
 }
+ZK_DI Fq2 sqr(const Fq2& a);
+template <int A>
+ZK_DI Fq2 sqr_b(const Fq2& a) { return sqr(a); }
 ZK_DI Fq2 sqr(const Fq2& a) {
     // complex squaring, fq2.rs:109-131: 2 base-field products
     Fq32 ab = mul(a.c0, a.c1);

@@ -55,6 +55,7 @@ template <class F> struct MsmOcc;
 #endif
 template <> struct MsmOcc<Fq> { static constexpr int acc = ZK_OCC_G1_ACC, red = ZK_OCC_G1_RED; };
 template <> struct MsmOcc<Fq2> { static constexpr int acc = ZK_OCC_G2_ACC, red = ZK_OCC_G2_RED; };
+template <> struct MsmOcc<Fq2x> { static constexpr int acc = ZK_OCC_G2_ACC, red = ZK_OCC_G2_RED; };
 
 // Longest run of points one accumulation thread walks (`seg`, a launch parameter): 256 when
 // thousands of jobs fill the machine (fewer task partials to merge in the reduction), 64 for a
@@ -562,6 +563,13 @@ ZK_DI F fq_pow_qm2(const F& a) {
 }
 ZK_DI Fq28 inv(const Fq28& a) { return fq_pow_qm2(a); }
 ZK_DI Fq32 inv(const Fq32& a) { return fq_pow_qm2(a); }
+ZK_DI Fq2x inv(const Fq2x& a) {
+    // fq2.rs:160-176
+    Fq28 n = add(sqr(wr(a).c0), sqr(wr(a).c1));
+    Fq28 t = inv(n);
+    Fq2x w = wr(a);
+    return Fq2x{mul(w.c0, t), neg_b<2>(mul(w.c1, t))};
+}
 ZK_DI Fq2 inv(const Fq2& a) {
     // fq2.rs:160-176
     Fq32 n = add(sqr(a.c0), sqr(a.c1));
@@ -597,6 +605,10 @@ ZK_DI Fq32 curve_b32() {
     for (int i = 0; i < 12; i++) b.l[i] = v[i];
     return b;
 }
+ZK_DI Fq2x curve_b(const Fq2x*) {
+    Fq28 b = Fq28::from_const(Fq28Consts::B);
+    return Fq2x{b, b};   // 4(u + 1), ec.rs:1567-1572
+}
 ZK_DI Fq2 curve_b(const Fq2*) {
     Fq32 b = curve_b32();
     return Fq2{b, b};   // 4(u + 1), ec.rs:1567-1572
@@ -621,9 +633,18 @@ ZK_DI void fld_export(const Fq2& d, uint32_t* h) {
         h[12 + i] = d.c1.l[i];
     }
 }
+ZK_DI void fld_import(Fq2x& d, const uint32_t* h) {
+    d.c0 = fq28_import(h);
+    d.c1 = fq28_import(h + 12);
+}
+ZK_DI void fld_export(const Fq2x& d, uint32_t* h) {
+    fq28_export(d.c0, h);
+    fq28_export(d.c1, h + 12);
+}
 template <class F> struct HostWords;
 template <> struct HostWords<Fq28> { static constexpr int N = 12; };
 template <> struct HostWords<Fq2> { static constexpr int N = 24; };
+template <> struct HostWords<Fq2x> { static constexpr int N = 24; };
 
 template <class F>
 __global__ void __launch_bounds__(128)

@@ -536,7 +536,16 @@ struct MsmGroup {
 };
 
 typedef MsmGroup<zkhost::Fq, zkdev::Fq> MsmG1;
-typedef MsmGroup<zkhost::Fq2, zkdev::Fq2> MsmG2;
+// G2 stays on 12 x 32-bit limbs.  Fq2 over the radix-2^28 representation (dev_field.h Fq2x, with weak
+// reductions; parity-green under -DZK_G2_RADIX28) measured SLOWER: 113-118 ms per 1024-proof launch
+// against 99 ms - an XYZZ accumulator is 112 registers, so the kernel either spills (2 waves / SIMD) or
+// runs one wave / SIMD, where the product's dependent multiply-add chain is exposed.
+#ifdef ZK_G2_RADIX28
+typedef zkdev::Fq2x DevFq2;
+#else
+typedef zkdev::Fq2 DevFq2;
+#endif
+typedef MsmGroup<zkhost::Fq2, DevFq2> MsmG2;
 typedef zkhost::Affine<zkhost::Fq> HG1A;
 typedef zkhost::Affine<zkhost::Fq2> HG2A;
 typedef zkhost::Point<zkhost::Fq> HG1;
@@ -677,7 +686,7 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     if (checked) {
         // vk points that never enter a table are checked on the host side of the same kernel
         ZK_TRY((check_points_host<zkhost::Fq, zkdev::Fq>(ic, "vk.ic")));
-        ZK_TRY((check_points_host<zkhost::Fq2, zkdev::Fq2>(std::vector<HG2A>{gamma_g2}, "vk.gamma_g2")));
+        ZK_TRY((check_points_host<zkhost::Fq2, DevFq2>(std::vector<HG2A>{gamma_g2}, "vk.gamma_g2")));
     }
     // one width per group: the G1 jobs of a proof (H, L, A, B1) average a quarter of the G1 terms
     // two G1 jobs per proof: A, and the merged C' = H + L + r * B1
