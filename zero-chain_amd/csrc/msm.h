@@ -446,26 +446,32 @@ k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict
 // buckets) reduction would leave the whole GPU waiting for one thread.  One workgroup per heavy
 // bucket sums its partials with a strided pass and an LDS tree, and leaves the result in the
 // bucket's first partial.
+constexpr uint32_t MSM_MERGE_THREADS = 256;
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+__global__ void __launch_bounds__(MSM_MERGE_THREADS)
 k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
                   const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb,
                   uint32_t seg) {
-    ZK_SHARED XYZZ<F> sm[64];
-    if (blockIdx.x >= n_heavy[0]) return;
-    const uint32_t gb = heavy[blockIdx.x], tid = threadIdx.x;
-    const uint32_t nt = (cnt[gb] + seg - 1) / seg;
-    XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t u = tid; u < nt; u += 64) acc = xadd(acc, ts[u]);
-    sm[tid] = acc;
-    __syncthreads();
-    for (uint32_t st = 32; st >= 1; st >>= 1) {
-        if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
+    ZK_SHARED XYZZ<F> sm[MSM_MERGE_THREADS];
+    const uint32_t tid = threadIdx.x;
+    // a fixed grid walks the list (launching one workgroup per POSSIBLE heavy bucket costs more than the work)
+    for (uint32_t hb = blockIdx.x; hb < n_heavy[0]; hb += gridDim.x) {
+        const uint32_t gb = heavy[hb];
+        const uint32_t nt = (cnt[gb] + seg - 1) / seg;
+        XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t u = tid; u < nt; u += MSM_MERGE_THREADS) acc = xadd(acc, ts[u]);
+        sm[tid] = acc;
+        __syncthreads();
+        for (uint32_t st = MSM_MERGE_THREADS / 2; st >= 1; st >>= 1) {
+            if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
+            __syncthreads();
+        }
+        if (tid == 0) ts[0] = sm[0];
         __syncthreads();
     }
-    if (tid == 0) ts[0] = sm[0];
 }
+
 
 // Pass 6: bucket reduction  sum_j (2j + 1) * B_j  (bucket j holds the odd magnitude 2j + 1) as a
 // tree of running sums.  A node covering M buckets carries

@@ -485,7 +485,7 @@ struct MsmGroup {
         {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_reduce_g2" : "msm_reduce_g1", st);
             auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
-            ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>, dim3((unsigned)heavy_cap), dim3(64), 0, st,
+            ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>, dim3((unsigned)std::min<size_t>(heavy_cap, 4096)), dim3(zkdev::MSM_MERGE_THREADS), 0, st,
                            (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy, (const uint32_t*)cnt.as<uint32_t>(),
                            (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg);
             // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
