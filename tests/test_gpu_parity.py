@@ -133,12 +133,13 @@ def test_transfer_circuit_from_witness(gpu_lib):
         params.close()
 
 
-def test_transfer_prove_from_statements(gpu_lib):
+def test_transfer_prove_from_statements(gpu_lib, monkeypatch):
     """zk_transfer_prove_batch: native witness calculator (host) -> A z, B z, C z (GPU) -> create_proof,
     from the ten private values of each statement; proofs equal the trapdoor proofs of the oracle's
     assignment of the same statement."""
     import zero_chain_amd as zk
     from oracle import transfer_circuit as tc
+    monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "3")   # two chunks: the witness producer thread runs beside the GPU
     r1, asgs, P, pk = helpers.transfer_case(1)
     E = g.Bls12Engine()
     ws = [tc.make_witness(40 + i, amount=5 + i, fee=i & 1, balance=77 + i) for i in range(4)]

@@ -1412,15 +1412,31 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
     if (env && atoi(env) > 0) chunk = (size_t)atoi(env);
     zk_status rc = use_device(p->device);
     if (rc != ZK_OK) return rc;
+    // two pinned buffers: the witnesses of chunk k + 1 are computed on the host cores while the GPU
+    // proves chunk k
+    const size_t cap = std::min(chunk, n) * nv * 32;
+    rc = circuit->host_ensure(2 * cap);
+    if (rc != ZK_OK) return rc;
+    uint8_t* buf[2] = {(uint8_t*)circuit->host_z, (uint8_t*)circuit->host_z + cap};
+    rc = transfer_witness(st, std::min(chunk, n), ZK_FR_MONTGOMERY, buf[0]);
+    if (rc != ZK_OK) return rc;
+    int cur = 0;
     for (size_t first = 0; first < n; first += chunk) {
         const size_t np = std::min(chunk, n - first);
-        rc = circuit->host_ensure(np * nv * 32);
+        const size_t next = first + chunk;
+        zk_status next_rc = ZK_OK;
+        std::string next_err;
+        std::thread producer;
+        if (next < n)
+            producer = std::thread([&, next] {
+                next_rc = transfer_witness(st + next, std::min(chunk, n - next), ZK_FR_MONTGOMERY, buf[cur ^ 1]);
+                if (next_rc != ZK_OK) next_err = g_err;   // g_err is thread-local
+            });
+        rc = prove_batch_witness(p, circuit, np, buf[cur], ZK_FR_MONTGOMERY, rs + first * 64, proofs_out + first * 192);
+        if (producer.joinable()) producer.join();
         if (rc != ZK_OK) return rc;
-        uint8_t* z = (uint8_t*)circuit->host_z;
-        rc = transfer_witness(st + first, np, ZK_FR_MONTGOMERY, z);
-        if (rc != ZK_OK) return rc;
-        rc = prove_batch_witness(p, circuit, np, z, ZK_FR_MONTGOMERY, rs + first * 64, proofs_out + first * 192);
-        if (rc != ZK_OK) return rc;
+        if (next_rc != ZK_OK) return fail(next_rc, next_err);
+        cur ^= 1;
     }
     return ZK_OK;
 }
