@@ -69,15 +69,16 @@ zk_status zk_device_count(int* count);
  * gamma_g2 | delta_g1 | delta_g2 | u32be n_ic | ic[] ; then u32be len | points for h, l, a,
  * b_g1 (G1) and b_g2 (G2).  checked != 0 additionally verifies on-curve and subgroup membership
  * of every point (on the GPU); both modes reject the point at infinity, as bellman does.
- * The bases are uploaded once, expanded into per-window tables and stay resident in HBM.
+ * The bases are uploaded once, expanded into the table of all their doublings 2^k * P (k = 0..254;
+ * ~4.2 GB for the transfer key) and stay resident in HBM.
  * ------------------------------------------------------------------------------------------ */
 typedef struct zk_params zk_params;
 
 typedef struct {
     uint32_t n_ic, n_h, n_l, n_a, n_b_g1, n_b_g2;
     uint32_t log_domain;  /* m = 2^log_domain = n_h + 1 */
-    uint32_t window_bits; /* Pippenger window c used for this key */
-    uint32_t n_windows;
+    uint32_t window_bits; /* width c of the NAF recoding used for the G1 jobs of this key */
+    uint32_t n_windows;   /* table slices per base (255: every doubling 2^k * P) */
     uint32_t device;
     uint64_t device_bytes; /* HBM held by the handle (tables + twiddles) */
 } zk_params_info;

@@ -137,7 +137,7 @@ class Proof:
 
 class Parameters:
     """groth16::Parameters<Bls12>, resident on one GPU.  `read` parses bellman's Parameters::write
-    format, uploads the query bases once and expands the per-window tables."""
+    format, uploads the query bases once and expands the table of all their doublings."""
 
     def __init__(self, lib, handle, pk_bytes):
         self._lib = lib
