@@ -65,7 +65,10 @@ def test_prover_montgomery_inputs_two_pass_ntt(emu_lib, monkeypatch):
 def test_prover_batch(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
     monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "2")
-    pc.prover_batch(emu_lib, 4, 3, 12, 3)
+    pc.prover_batch(emu_lib, 4, 3, 12, 3)       # two device chunks: block 2 is staged beside block 1
+    monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "8")
+    monkeypatch.setenv("ZKAMD_HOST_CHUNK", "1")
+    pc.prover_batch(emu_lib, 5, 3, 12, 3)       # one device chunk staged in three blocks
 
 
 def test_prover_errors(emu_lib, monkeypatch):
@@ -95,3 +98,12 @@ def test_msm_long_tasks(emu_lib, monkeypatch):
     """Accumulation tasks of up to 256 points (the setting of large batches)."""
     monkeypatch.setenv("ZKAMD_MSM_SEG", "256")
     pc.msm_golden_vectors(emu_lib, 1, 1500, 6, seed=12)
+
+
+def test_msm_sliced(emu_lib, monkeypatch):
+    """A stand-alone multiexp cut into independent jobs over runs of the bases (the default from 2^14
+    bases up), ragged last slice, a base at infinity (mapped positions), both groups."""
+    monkeypatch.setenv("ZKAMD_MSM_SLICE", "128")
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "6")
+    pc.msm_golden_vectors(emu_lib, 1, 300, 0, seed=14)
+    pc.msm_golden_vectors(emu_lib, 2, 150, 0, seed=15)

@@ -62,6 +62,13 @@ def test_msm_g1_golden(gpu_lib):
     pc.msm_golden_vectors(gpu_lib, 1, 33, 16, seed=4)
 
 
+def test_msm_sliced(gpu_lib, monkeypatch):
+    """A stand-alone multiexp run as independent jobs over runs of the bases (ZKAMD_MSM_SLICE)."""
+    monkeypatch.setenv("ZKAMD_MSM_SLICE", "1024")
+    pc.msm_golden_vectors(gpu_lib, 1, 1 << 16, 0, seed=9)
+    pc.msm_golden_vectors(gpu_lib, 2, 5000, 0, seed=10)
+
+
 def test_msm_g2_golden(gpu_lib):
     pc.msm_golden_vectors(gpu_lib, 2, 60, 4)
     pc.msm_golden_vectors(gpu_lib, 2, 20000, 0, seed=5)
@@ -108,6 +115,9 @@ def test_prover_batch(gpu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "3")
     pc.prover_batch(gpu_lib, 4, 3, 12, 5)
     pc.prover_batch(gpu_lib, 9, 5, 700, 7)
+    monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "1024")
+    monkeypatch.setenv("ZKAMD_HOST_CHUNK", "2")   # one device chunk staged in blocks by the copy thread
+    pc.prover_batch(gpu_lib, 11, 5, 700, 7)
 
 
 def test_prover_from_witness(gpu_lib):

@@ -26,15 +26,23 @@ res = ctx.run_dev(d_sc.data_ptr())
 to_int = lambda row: sum(int(row[j]) << (64 * j) for j in range(4))
 tot = sum(to_int(a) * b for a, b in zip(ks, ints)) % bls.R_MOD
 assert res == helpers.g1_of(tot), "identity failed"
-lib.zk_profile_begin()
-t0 = time.perf_counter()
-for _ in range(reps):
-    ctx.run_dev(d_sc.data_ptr())
-dt = (time.perf_counter() - t0) / reps
-ms = C.c_double(0); kern = {}
-for name in bench.KERNEL_NAMES:
-    if lib.zk_profile_get(name.encode(), C.byref(ms)):
-        kern[name] = round(ms.value / reps, 3)
-lib.zk_profile_end()
-print(json.dumps({"log_n": logn, "window_bits": wb, "ms": round(dt * 1e3, 3), "mscalar_per_s": round(n / dt / 1e6, 2),
-                  "table_build_s": round(table_s, 2), "kernel_ms": kern}))
+def timed(tag):
+    assert ctx.run_dev(d_sc.data_ptr()) == res
+    lib.zk_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.run_dev(d_sc.data_ptr())
+    dt = (time.perf_counter() - t0) / reps
+    ms = C.c_double(0); kern = {}
+    for name in bench.KERNEL_NAMES:
+        if lib.zk_profile_get(name.encode(), C.byref(ms)):
+            kern[name] = round(ms.value / reps, 3)
+    lib.zk_profile_end()
+    print(json.dumps({"variant": tag, "log_n": logn, "window_bits": wb, "ms": round(dt * 1e3, 3),
+                      "mscalar_per_s": round(n / dt / 1e6, 2), "table_build_s": round(table_s, 2), "kernel_ms": kern}))
+
+
+timed("default")
+if os.environ.get("MICRO_COMPARE_TREE"):
+    os.environ["ZKAMD_NO_BITSUM"] = "1"      # the full tree for the upper levels of the bucket reduction
+    timed("tree_only")

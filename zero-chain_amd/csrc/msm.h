@@ -62,8 +62,9 @@ template <> struct MsmOcc<Fq2x> { static constexpr int acc = ZK_OCC_G2_ACC, red 
 // single job (more, shorter tasks to spread over the CUs).  MSM_SEG_MAX sizes the class arrays.
 constexpr uint32_t MSM_SEG_MAX = 256;
 constexpr uint32_t MSM_NPOS = 255;  // table slices: 2^k * P for k = 0 .. 254
-// buckets with more task partials than `merge_inline` (8 when many jobs fill the machine, 2 for a
-// single job whose reduction threads must stay short) are merged by k_msm_merge_heavy
+// buckets with more than `merge_inline` (8) task partials are merged by k_msm_merge_heavy, one
+// workgroup each; the others by the level-1 thread of the reduction (many jobs) or by one thread
+// per bucket ahead of it (k_msm_merge_light: few jobs, where level 1 is a latency chain)
 
 // upper bound on the non-zero digits of one scalar: digits are >= c positions apart, 0 .. 254
 __host__ ZK_DI uint32_t msm_max_digits(uint32_t c) { return 254 / c + 2; }
@@ -331,6 +332,19 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
     }
 }
 
+// A bucket of k points becomes nt = ceil(k / seg) tasks of EQUAL length (n_long of len + 1 points,
+// then n_short of len): the tasks of a launch run in rounds over the thread slots of the GPU, and a
+// round lasts as long as its longest task - cutting 102 points into 64 + 38 instead of 51 + 51 left
+// a third of the lanes idle on a single large job (VALU 64 % busy, 3.1 ms).
+struct TaskCut {
+    uint32_t n_long, n_short, len;
+};
+ZK_DI TaskCut task_cut(uint32_t k, uint32_t seg) {
+    if (!k) return TaskCut{0, 0, 1};
+    const uint32_t nt = (k + seg - 1) / seg;
+    return TaskCut{k % nt, nt - k % nt, k / nt};
+}
+
 // Pass 4a: histogram of task lengths (1 .. seg) per job.  One thread per bucket.
 __global__ void __launch_bounds__(256)
 k_msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t* lenhist, uint32_t nb, uint32_t seg) {
@@ -340,10 +354,9 @@ k_msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t* lenhist, uint32_t nb
     __syncthreads();
     uint32_t b = blockIdx.x * blockDim.x + tid;
     if (b < nb) {
-        uint32_t k = cnt[(size_t)job * nb + b];
-        uint32_t full = k / seg, rem = k % seg;
-        if (full) atomicAdd(&h[seg - 1], full);
-        if (rem) atomicAdd(&h[rem - 1], 1u);
+        const TaskCut tc = task_cut(cnt[(size_t)job * nb + b], seg);
+        if (tc.n_long) atomicAdd(&h[tc.len], tc.n_long);
+        if (tc.n_short) atomicAdd(&h[tc.len - 1], tc.n_short);
     }
     __syncthreads();
     if (tid < seg && h[tid]) atomicAdd(&lenhist[(size_t)job * seg + tid], h[tid]);
@@ -392,13 +405,11 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
     if (tid < seg) h[tid] = 0;
     __syncthreads();
     uint32_t b = blockIdx.x * blockDim.x + tid;
-    uint32_t k = 0, full = 0, rem = 0;
+    TaskCut tc = {0, 0, 1};
     if (b < nb) {
-        k = cnt[(size_t)job * nb + b];
-        full = k / seg;
-        rem = k % seg;
-        if (full) atomicAdd(&h[seg - 1], full);
-        if (rem) atomicAdd(&h[rem - 1], 1u);
+        tc = task_cut(cnt[(size_t)job * nb + b], seg);
+        if (tc.n_long) atomicAdd(&h[tc.len], tc.n_long);
+        if (tc.n_short) atomicAdd(&h[tc.len - 1], tc.n_short);
     }
     __syncthreads();
     if (tid < seg) {
@@ -407,21 +418,24 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
         h[tid] = 0;
     }
     __syncthreads();
-    if (full + (rem ? 1u : 0u) > merge_inline) heavy[atomicAdd(n_heavy, 1u)] = job * nb + b;
-    if (k) {
+    if (tc.n_long + tc.n_short > merge_inline) heavy[atomicAdd(n_heavy, 1u)] = job * nb + b;
+    if (tc.n_long + tc.n_short) {
         const uint32_t o = off[(size_t)job * nb + b], ti = task_base[job] + toff[(size_t)job * nb + b];
-        if (full) {
-            uint32_t at = start[seg - 1] + atomicAdd(&h[seg - 1], full);
-            for (uint32_t sgm = 0; sgm < full; sgm++) sorted[at + sgm] = make_uint4(o + sgm * seg, ti + sgm, seg, 0);
+        if (tc.n_long) {
+            uint32_t at = start[tc.len] + atomicAdd(&h[tc.len], tc.n_long);
+            for (uint32_t i = 0; i < tc.n_long; i++) sorted[at + i] = make_uint4(o + i * (tc.len + 1), ti + i, tc.len + 1, 0);
         }
-        if (rem) {
-            uint32_t at = start[rem - 1] + atomicAdd(&h[rem - 1], 1u);
-            sorted[at] = make_uint4(o + full * seg, ti + full, rem, 0);
-        }
+        const uint32_t o2 = o + tc.n_long * (tc.len + 1), at = start[tc.len - 1] + atomicAdd(&h[tc.len - 1], tc.n_short);
+        for (uint32_t i = 0; i < tc.n_short; i++) sorted[at + i] = make_uint4(o2 + i * tc.len, ti + tc.n_long + i, tc.len, 0);
     }
 }
 
 // Pass 5: one thread per task (= at most seg points of one bucket), tasks in length order.
+// Two things measured NOT to matter here, neither in the batched prover (4 GB of tables) nor on one
+// 2^20-point job (30 GB): fetching the next point while the current one is added (28 more live
+// registers), and sorting every task's pairs by table index so that all lanes sweep the doubling
+// slices in step.  The single job's lower rate (4.3 G additions/s against 7.0) is 88 % occupancy at
+// the two ends of a 3 ms launch, a 12 % lower issue rate per resident wave and a lower clock.
 template <class F>
 __global__ void __launch_bounds__(128, MsmOcc<F>::acc)
 k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
@@ -472,6 +486,25 @@ k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict
     }
 }
 
+
+// Pass 5c (few jobs only): one thread per bucket sums the 2 .. merge_inline partials of a bucket into
+// its first partial, so that the level-1 threads of the reduction below, each a serial chain over
+// L buckets, add one point per bucket.  With one large job the recoding's top digit alone gives
+// ~2^(c-6) buckets twice the average load, i.e. a run of neighbouring buckets with 4 partials each.
+template <class F>
+__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_merge_light(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base,
+                  XYZZ<F>* tsums, uint32_t nb, uint32_t merge_inline, uint32_t seg) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const size_t gb = (size_t)blockIdx.y * nb + b;
+    const uint32_t nt_b = (cnt[gb] + seg - 1) / seg;
+    if (nt_b < 2 || nt_b > merge_inline) return;
+    XYZZ<F>* ts = tsums + task_base[blockIdx.y] + toff[gb];
+    XYZZ<F> acc = ts[0];
+    for (uint32_t u = 1; u < nt_b; u++) acc = xadd(acc, ts[u]);
+    ts[0] = acc;
+}
 
 // Pass 6: bucket reduction  sum_j (2j + 1) * B_j  (bucket j holds the odd magnitude 2j + 1) as a
 // tree of running sums.  A node covering M buckets carries
@@ -546,6 +579,91 @@ k_msm_segsum(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ init, X
     for (uint32_t i = 0; i < dbl; i++) acc = xdbl(acc);
     if (plus_first) acc = xadd(acc, p[c0]);
     out[(size_t)blockIdx.y * ns + u] = acc;
+}
+
+// Few-jobs tail of the bucket reduction.  One or a few large jobs cannot fill the GPU with the
+// upper levels of the tree (each level is a chain of ~15 dependent point additions executed by a
+// handful of waves, ~13 us per addition), so after level 1 the T nodes are folded in one step:
+//     total = sum_t W_t + 2L * sum_t t * S_t,     sum_t t * S_t = sum_j 2^j * Y_j,
+//     Y_j = sum of S_t over the nodes t whose index has bit j set
+// - log2(T) + 1 independent plain sums (parallel trees in LDS, depth 8 + 8) and one Horner chain.
+// It costs (log2 T + 1) / 2 additions per node instead of 3, so it is used only when the tree's
+// latency, not its work, is what the launch waits for.
+//
+// k_msm_bitsum: grid (blocks of 256 nodes, log2(T) + 1 planes, jobs); plane nbits sums W.  One wave
+// per block: every lane sums 4 nodes from HBM, then a 6-step tree in LDS (14 KB, so that all the
+// blocks of a launch are resident at once - the launch takes one chain of 10 additions).
+constexpr uint32_t MSM_BITSUM_NODES = 256;
+template <class F>
+__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_bitsum(const XYZZ<F>* __restrict__ S, uint32_t s_stride, const XYZZ<F>* __restrict__ W, XYZZ<F>* __restrict__ part,
+             uint32_t T, uint32_t nbits) {
+    ZK_SHARED XYZZ<F> sm[64];
+    const uint32_t tid = threadIdx.x, plane = blockIdx.y, job = blockIdx.z;
+    XYZZ<F>* dst = part + ((size_t)job * (nbits + 1) + plane) * gridDim.x + blockIdx.x;
+    // bits 8 and up are constant over the 256 nodes of a block
+    if (plane < nbits && plane >= 8 && !((blockIdx.x >> (plane - 8)) & 1u)) {
+        if (tid == 0) *dst = XYZZ<F>::inf();
+        return;
+    }
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t e = 0; e < MSM_BITSUM_NODES / 64; e++) {
+        const uint32_t t = blockIdx.x * MSM_BITSUM_NODES + e * 64 + tid;
+        if (t >= T) break;
+        if (plane == nbits) acc = xadd(acc, W[(size_t)job * T + t]);
+        else if ((t >> plane) & 1u) acc = xadd(acc, S[((size_t)job * T + t) * s_stride]);
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    for (uint32_t st = 32; st >= 1; st >>= 1) {
+        if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
+        __syncthreads();
+    }
+    if (tid == 0) *dst = sm[0];
+}
+
+// k_msm_bitsum_fold: grid (planes, jobs); Y[job][plane] = sum of the plane's block partials.
+template <class F>
+__global__ void __launch_bounds__(MSM_MERGE_THREADS)
+k_msm_bitsum_fold(const XYZZ<F>* __restrict__ part, XYZZ<F>* __restrict__ Y, uint32_t nblk) {
+    ZK_SHARED XYZZ<F> sm[MSM_MERGE_THREADS];
+    const uint32_t tid = threadIdx.x;
+    const size_t row = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t u = tid; u < nblk; u += MSM_MERGE_THREADS) acc = xadd(acc, part[row * nblk + u]);
+    sm[tid] = acc;
+    __syncthreads();
+    for (uint32_t st = MSM_MERGE_THREADS / 2; st >= 1; st >>= 1) {
+        if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
+        __syncthreads();
+    }
+    if (tid == 0) Y[row] = sm[0];
+}
+
+// k_msm_bitsum_combine: one wave per job; out = 2^dbl * sum_j 2^j Y_j + Y_nbits.  The weighted sum is
+// folded pairwise (step s adds 2^(2^s) times the upper neighbour), which keeps the unavoidable
+// nbits doublings but only log2(nbits) additions on the critical path.
+template <class F>
+__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_bitsum_combine(const XYZZ<F>* __restrict__ Y, XYZZ<F>* __restrict__ out, uint32_t nbits, uint32_t dbl) {
+    ZK_SHARED XYZZ<F> sm[64];
+    const uint32_t tid = threadIdx.x, job = blockIdx.x;
+    const XYZZ<F>* y = Y + (size_t)job * (nbits + 1);
+    sm[tid] = tid < nbits ? y[tid] : XYZZ<F>::inf();
+    __syncthreads();
+    for (uint32_t stride = 1; stride < nbits; stride <<= 1) {
+        if (tid % (2 * stride) == 0 && tid + stride < nbits) {
+            XYZZ<F> hi = sm[tid + stride];
+            for (uint32_t d = 0; d < stride; d++) hi = xdbl(hi);
+            sm[tid] = xadd(sm[tid], hi);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        XYZZ<F> acc = sm[0];
+        for (uint32_t i = 0; i < dbl; i++) acc = xdbl(acc);
+        out[job] = xadd(acc, y[nbits]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

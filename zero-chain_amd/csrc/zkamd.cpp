@@ -32,6 +32,7 @@ namespace {
 thread_local std::string g_err;
 hipStream_t g_stream = nullptr;    // main stream: H pipeline, G1 multiexps, stand-alone entries
 hipStream_t g_stream2 = nullptr;   // side stream: the G2 multiexp of a chunk runs beside the G1 work
+hipStream_t g_copy_stream = nullptr;   // staging copies of the next block of a host batch
 hipEvent_t g_ev_fork = nullptr;
 bool g_stream_init = false;
 int g_device = -1;
@@ -62,6 +63,7 @@ zk_status use_device(int device) {
         if (g_stream_init) {
             (void)hipStreamDestroy(g_stream);
             (void)hipStreamDestroy(g_stream2);
+            (void)hipStreamDestroy(g_copy_stream);
             (void)hipEventDestroy(g_ev_fork);
             g_stream_init = false;
         }
@@ -70,6 +72,7 @@ zk_status use_device(int device) {
     if (!g_stream_init) {
         HIP_TRY(hipStreamCreate(&g_stream));
         HIP_TRY(hipStreamCreate(&g_stream2));
+        HIP_TRY(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&g_ev_fork));
         g_stream_init = true;
     }
@@ -263,6 +266,7 @@ struct NttPlan {
 // ------------------------------------------------------------------------------------------
 // MSM group: window tables of a set of bases + the bucket pipeline over a list of jobs
 // ------------------------------------------------------------------------------------------
+constexpr size_t MSM_FEW_JOBS = 8;      // at most this many jobs per launch: latency-optimised reduction tail
 constexpr uint32_t MSM_RED_FAN = 16;   // buckets per level-1 node and children per upper node (bucket reduction)
 
 // Width of the NAF recoding for jobs of about n scalars: minimise, in units of one mixed addition,
@@ -375,12 +379,17 @@ struct MsmGroup {
         out.resize(nj);
         if (!nj) return ZK_OK;
         const char* seg_env = getenv("ZKAMD_MSM_SEG");
-        const uint32_t seg = seg_env && atoi(seg_env) > 0 && atoi(seg_env) <= (int)zkdev::MSM_SEG_MAX
+        const uint32_t seg_forced = seg_env && atoi(seg_env) > 0 && atoi(seg_env) <= (int)zkdev::MSM_SEG_MAX
                                  ? (uint32_t)atoi(seg_env)
-                                 : (nj >= 64 ? 256u : 64u);   // points per accumulation task (msm.h)
+                                 : 0u;
         uint64_t total = 0, total_tasks = 0;
         uint32_t max_n = 0;
         tbase_h.resize(nj);
+        for (size_t k = 0; k < nj; k++) total += (uint64_t)jobs[k].n * maxd;
+        // points per accumulation task (msm.h): a task is a serial chain of ~10 us per point, so the
+        // long form is for launches that keep the GPU busy for tens of milliseconds anyway
+        const uint32_t seg = seg_forced ? seg_forced : (nj >= 64 && total >= 100000000ull ? 256u : 64u);
+        total = 0;
         for (size_t k = 0; k < nj; k++) {
             MsmJob& j = jobs[k];
             j.pair_base = (uint32_t)total;
@@ -403,7 +412,8 @@ struct MsmGroup {
         ZK_TRY(ntasks.ensure(nj * 4));
         ZK_TRY(tbase.ensure(nj * 4));
         ZK_TRY(hist.ensure((2 * n_class + 2) * 4));     // [length histogram | placement cursors | total | #heavy]
-        const uint32_t merge_inline = nj >= 64 ? 8u : 2u;
+        const bool few = nj <= MSM_FEW_JOBS;   // latency-optimised bucket reduction (msm.h, passes 5c and 6)
+        const uint32_t merge_inline = nj >= 64 || few ? 8u : 2u;
         const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
         ZK_TRY(heavy.ensure(heavy_cap * 4));
         ZK_TRY(tclass.ensure(n_class * 4));
@@ -489,14 +499,34 @@ struct MsmGroup {
                            (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy, (const uint32_t*)cnt.as<uint32_t>(),
                            (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg);
             // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
+            if (few)
+                ZK_LAUNCH(zkdev::k_msm_merge_light<DF>, grid(nb), dim3(64), 0, st, (const uint32_t*)cnt.as<uint32_t>(),
+                          (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb,
+                          merge_inline, seg);
             ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
-                      toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, merge_inline, seg);
+                      toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, few ? 0u : merge_inline, seg);
             ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
                       1u, 1u, 1u);
             uint32_t n = T, m = L, stride = L;   // n nodes per job of m buckets each; S(node k) = R[k * stride]
             DPoint* Rcur = R;
             DPoint* Rnext = R + nj * (size_t)nb;       // upper levels ping-pong between two areas behind level 1
             DPoint* Rspare = Rnext + nj * (size_t)T;
+            if (few && T >= 2 && !getenv("ZKAMD_NO_BITSUM")) {
+                // few large jobs: fold the T nodes of level 1 at once (msm.h, k_msm_bitsum)
+                uint32_t nbits = 0, log2_2l = 1;
+                while ((1u << nbits) < T) nbits++;
+                while ((1u << (log2_2l - 1)) < L) log2_2l++;
+                const uint32_t nblk = (T + zkdev::MSM_BITSUM_NODES - 1) / zkdev::MSM_BITSUM_NODES;
+                DPoint* part = red_t.as<DPoint>();   // (nbits + 1) * nblk <= T partials per job
+                ZK_LAUNCH_SYNC(zkdev::k_msm_bitsum<DF>, dim3(nblk, nbits + 1, (unsigned)nj), dim3(64), 0, st,
+                          (const DPoint*)R, L, (const DPoint*)Wa, part, T, nbits);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_bitsum_fold<DF>, dim3(nbits + 1, (unsigned)nj), dim3(zkdev::MSM_MERGE_THREADS), 0, st,
+                          (const DPoint*)part, Wb, nblk);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_bitsum_combine<DF>, dim3((unsigned)nj), dim3(64), 0, st, (const DPoint*)Wb, Rnext, nbits,
+                               log2_2l);
+                in = Rnext;
+                n = 1;
+            }
             while (n > 1) {
                 const uint32_t fan = pick_fan((uint64_t)nj * n), n_out = (n + fan - 1) / fan;
                 uint32_t log2_2m = 1;
@@ -902,33 +932,72 @@ zk_status prove_batch_host(zk_params* P, size_t n, const zk_assignment* asgs, co
         if (i && !same_circuit(z, x)) return fail(ZK_ERR_INVALID_ARGUMENT, "batch mixes different circuits");
     }
     const size_t rb = (size_t)z.n_rows * 32, nvb = (size_t)(z.n_inputs + z.n_aux) * 32;
-    ZK_TRY(P->stage_a.ensure(n * rb));
-    ZK_TRY(P->stage_b.ensure(n * rb));
-    ZK_TRY(P->stage_c.ensure(n * rb));
-    ZK_TRY(P->stage_w.ensure(n * nvb));
-    for (size_t i = 0; i < n; i++) {
-        const zk_assignment& x = asgs[i];
-        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_a.p + i * rb, x.a, rb, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_b.p + i * rb, x.b, rb, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_c.p + i * rb, x.c, rb, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_w.p + i * nvb, x.inputs, (size_t)z.n_inputs * 32, hipMemcpyHostToDevice, g_stream));
-        HIP_TRY(hipMemcpyAsync((uint8_t*)P->stage_w.p + i * nvb + (size_t)z.n_inputs * 32, x.aux, (size_t)z.n_aux * 32,
-                               hipMemcpyHostToDevice, g_stream));
+    // The assignments (2.6 MB per Transfer proof) cross PCIe in blocks: block k + 1 is staged by a
+    // helper thread on its own stream while the GPU proves block k out of the other half of the
+    // staging buffers.  A batch that fits one device chunk is cut in two halves so that only the first
+    // half's copy is exposed (measured on 1024 Transfer proofs: whole 2101, halves 2240, quarters 2119
+    // proofs/s - smaller launch sets lose more in the kernels than the hidden copy gains).
+    size_t chunk = 1024;
+    if (const char* env = getenv("ZKAMD_BATCH_CHUNK"))
+        if (atoi(env) > 0) chunk = (size_t)atoi(env);
+    size_t hc = n > chunk ? chunk : (n >= 512 ? (n + 1) / 2 : n);
+    if (const char* env = getenv("ZKAMD_HOST_CHUNK"))
+        if (atoi(env) > 0) hc = std::min(chunk, (size_t)atoi(env));
+    hc = std::min(hc, n);
+    const size_t slots = n > hc ? 2 : 1;
+    ZK_TRY(P->stage_a.ensure(slots * hc * rb));
+    ZK_TRY(P->stage_b.ensure(slots * hc * rb));
+    ZK_TRY(P->stage_c.ensure(slots * hc * rb));
+    ZK_TRY(P->stage_w.ensure(slots * hc * nvb));
+    auto stage = [&](size_t slot, size_t first, size_t np) -> zk_status {
+        HIP_TRY(hipSetDevice(P->device));   // the current device is per host thread
+        uint8_t* da = (uint8_t*)P->stage_a.p + slot * hc * rb;
+        uint8_t* db = (uint8_t*)P->stage_b.p + slot * hc * rb;
+        uint8_t* dc = (uint8_t*)P->stage_c.p + slot * hc * rb;
+        uint8_t* dw = (uint8_t*)P->stage_w.p + slot * hc * nvb;
+        for (size_t i = 0; i < np; i++) {
+            const zk_assignment& x = asgs[first + i];
+            HIP_TRY(hipMemcpyAsync(da + i * rb, x.a, rb, hipMemcpyHostToDevice, g_copy_stream));
+            HIP_TRY(hipMemcpyAsync(db + i * rb, x.b, rb, hipMemcpyHostToDevice, g_copy_stream));
+            HIP_TRY(hipMemcpyAsync(dc + i * rb, x.c, rb, hipMemcpyHostToDevice, g_copy_stream));
+            HIP_TRY(hipMemcpyAsync(dw + i * nvb, x.inputs, (size_t)z.n_inputs * 32, hipMemcpyHostToDevice, g_copy_stream));
+            HIP_TRY(hipMemcpyAsync(dw + i * nvb + (size_t)z.n_inputs * 32, x.aux, (size_t)z.n_aux * 32, hipMemcpyHostToDevice,
+                                   g_copy_stream));
+        }
+        HIP_TRY(hipStreamSynchronize(g_copy_stream));
+        return ZK_OK;
+    };
+    ZK_TRY(stage(0, 0, hc));
+    size_t cur = 0;
+    for (size_t first = 0; first < n; first += hc) {
+        const size_t np = std::min(hc, n - first), next = first + hc;
+        zk_status next_rc = ZK_OK;
+        std::string next_err;
+        std::thread copier;
+        if (next < n)
+            copier = std::thread([&, next] {
+                next_rc = stage(cur ^ 1, next, std::min(hc, n - next));
+                if (next_rc != ZK_OK) next_err = g_err;   // g_err is thread-local
+            });
+        zk_batch_dev bt;
+        bt.n_rows = z.n_rows;
+        bt.n_inputs = z.n_inputs;
+        bt.n_aux = z.n_aux;
+        bt.flags = z.flags;
+        bt.d_a = (uint8_t*)P->stage_a.p + cur * hc * rb;
+        bt.d_b = (uint8_t*)P->stage_b.p + cur * hc * rb;
+        bt.d_c = (uint8_t*)P->stage_c.p + cur * hc * rb;
+        bt.d_wit = (uint8_t*)P->stage_w.p + cur * hc * nvb;
+        bt.a_aux_density = z.a_aux_density;
+        bt.b_input_density = z.b_input_density;
+        bt.b_aux_density = z.b_aux_density;
+        zk_status rc = prove_batch_dev(P, np, &bt, rs + first * 64, proofs_out + first * 192);
+        if (copier.joinable()) copier.join();
+        if (rc != ZK_OK) return rc;
+        if (next_rc != ZK_OK) return fail(next_rc, next_err);
+        cur ^= 1;
     }
-    HIP_TRY(hipStreamSynchronize(g_stream));
-    zk_batch_dev bt;
-    bt.n_rows = z.n_rows;
-    bt.n_inputs = z.n_inputs;
-    bt.n_aux = z.n_aux;
-    bt.flags = z.flags;
-    bt.d_a = P->stage_a.p;
-    bt.d_b = P->stage_b.p;
-    bt.d_c = P->stage_c.p;
-    bt.d_wit = P->stage_w.p;
-    bt.a_aux_density = z.a_aux_density;
-    bt.b_input_density = z.b_input_density;
-    bt.b_aux_density = z.b_aux_density;
-    return prove_batch_dev(P, n, &bt, rs, proofs_out);
+    return ZK_OK;
 }
 
 }  // namespace
@@ -1164,6 +1233,7 @@ zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t f
 struct zk_msm {
     int group = 1, device = 0;
     size_t n = 0;
+    size_t slice = 0;   // > 0: the multiexp runs as ceil(n / slice) independent jobs (msm_slice below)
     MsmG1 g1;
     MsmG2 g2;
     DevBuf map, scal, conv;
@@ -1175,6 +1245,20 @@ struct zk_ntt {
 };
 
 namespace {
+
+// ZKAMD_MSM_SLICE = k runs a stand-alone multiexp as ceil(n / k) independent jobs over consecutive
+// runs of the bases, i.e. as a batch (LDS sort per job, reduction tree over all jobs, slice results
+// added on the host).  Off by default: the narrower windows a slice can afford cost more additions
+// than the cheaper sort saves - measured on 2^20 G1 points 7.1 ms (k = 4096, c = 13) against 6.0 ms
+// as one job with c = 19.  Kept as a tested option (a bucket histogram per slice fits LDS, so it is
+// the form to use if the scalars arrive in pieces).
+size_t msm_slice(size_t n) {
+    if (const char* env = getenv("ZKAMD_MSM_SLICE")) {
+        const long v = atol(env);
+        return v > 0 && (size_t)v < n ? (size_t)v : 0;
+    }
+    return 0;
+}
 
 zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
     if (group != 1 && group != 2) return fail(ZK_ERR_INVALID_ARGUMENT, "group must be 1 (G1) or 2 (G2)");
@@ -1189,7 +1273,8 @@ zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits,
     M->group = group;
     M->device = device;
     M->n = n;
-    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(n, group);
+    M->slice = window_bits > 0 ? 0 : msm_slice(n);
+    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(M->slice ? M->slice : n, group);
     if (c < 2 || c > 22) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 22]");
     // points at infinity are legal multiexp bases: they are mapped out (map = -1)
     std::vector<int32_t> map(n);
@@ -1233,19 +1318,28 @@ zk_status msm_run_dev(zk_msm* M, const void* d_scalars, uint32_t flags, uint8_t*
                   1u, M->n);
         sc = M->conv.as<uint32_t>();
     }
+    // a sliced multiexp is a batch of independent jobs over consecutive runs of the bases (their
+    // table entries start at `first`; with a map the map already holds absolute positions)
     std::vector<MsmJob> jobs;
-    if (M->n) {
-        MsmJob j = {sc, M->has_map ? M->map.as<int32_t>() : nullptr, (uint32_t)M->n, 0, (uint32_t)M->n, 0};
+    const size_t sl = M->slice ? M->slice : M->n;
+    for (size_t first = 0; first < M->n; first += sl) {
+        const uint32_t cnt = (uint32_t)std::min(sl, M->n - first);
+        MsmJob j = {sc + first * 8, M->has_map ? M->map.as<int32_t>() + first : nullptr, cnt,
+                    M->has_map ? 0u : (uint32_t)first, (uint32_t)M->n, 0};
         jobs.push_back(j);
     }
     if (M->group == 1) {
         std::vector<HG1> res;
         ZK_TRY(M->g1.run(jobs, res));
-        zkhost::g1_to_uncompressed(zkhost::to_affine(res.empty() ? HG1::inf() : res[0]), out);
+        HG1 sum = HG1::inf();
+        for (const HG1& r : res) sum = zkhost::padd(sum, r);
+        zkhost::g1_to_uncompressed(zkhost::to_affine(sum), out);
     } else {
         std::vector<HG2> res;
         ZK_TRY(M->g2.run(jobs, res));
-        zkhost::g2_to_uncompressed(zkhost::to_affine(res.empty() ? HG2::inf() : res[0]), out);
+        HG2 sum = HG2::inf();
+        for (const HG2& r : res) sum = zkhost::padd(sum, r);
+        zkhost::g2_to_uncompressed(zkhost::to_affine(sum), out);
     }
     return ZK_OK;
 }
