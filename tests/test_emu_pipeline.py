@@ -77,16 +77,19 @@ def test_prover_errors(emu_lib, monkeypatch):
 
 
 def test_msm_recoding_all_widths(emu_lib):
-    pc.msm_recoding_stress(emu_lib, windows=(2, 3, 5, 8, 12))   # every width 2..22: GPU suite (the emulation is thread-per-GPU-thread)
+    pc.msm_recoding_stress(emu_lib, windows=(2, 3, 5, 8, 12, 14))   # every width 2..22: GPU suite (the emulation is thread-per-GPU-thread)
 
 
-def test_msm_global_sort_path(emu_lib, monkeypatch):
-    """The three-kernel global-atomic sort (used when the bucket histogram does not fit LDS), with
-    the hot-bucket pre-aggregation of single-job launches."""
+def test_msm_two_level_sort_path(emu_lib, monkeypatch):
+    """The two-level counting sort used when the bucket histogram of a job does not fit LDS: one
+    coarse bin (degenerate), several bins, a ragged scalar count, both groups, a prover run."""
     monkeypatch.setenv("ZKAMD_NO_LDS_SORT", "1")
-    pc.msm_golden_vectors(emu_lib, 1, 300, 5)
-    pc.msm_golden_vectors(emu_lib, 1, 700, 9, seed=8)
-    pc.msm_golden_vectors(emu_lib, 2, 60, 4)
+    pc.msm_golden_vectors(emu_lib, 1, 300, 5)                 # 8 buckets, one bin
+    monkeypatch.setenv("ZKAMD_SORT_FINE_LOG", "3")
+    pc.msm_golden_vectors(emu_lib, 1, 1300, 9, seed=8)        # 128 buckets in 16 bins, two workgroups of scalars
+    pc.msm_golden_vectors(emu_lib, 2, 60, 6)                  # 16 buckets in 2 bins
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "7")
+    pc.prover_small(emu_lib, 5, 3, 10, 12)
 
 
 def test_prover_from_witness(emu_lib):

@@ -152,73 +152,141 @@ ZK_DI void msm_wnaf(const uint32_t* __restrict__ sp, uint32_t c, Fn&& f) {
     }
 }
 
-// Pass 1: histogram.  Every non-zero digit takes a ticket (its rank inside the bucket) from the
-// bucket counter; the ticket is remembered so that the scatter needs no atomics.
-// rank layout per job: [slot][i].  Bucket of an odd magnitude m: m >> 1.
-// The lowest MSM_HOT buckets are hot (small last digits, boolean witnesses: tens of thousands of
-// tickets on one address serialise in L2): when `blockbase` is given a workgroup counts them in an
-// LDS histogram, takes ONE global ticket range per bucket, and the scatter adds the range base to
-// the workgroup-local rank (flagged with bit 31).
-constexpr uint32_t MSM_HOT = 1024;
+// Passes 1-3 for jobs whose bucket histogram does NOT fit LDS (one or a few large multiexps,
+// c >= 17): a two-level counting sort that keeps every per-digit atomic in LDS.
+//   coarse bin = bucket >> fine_log  (n_coarse <= 1024 bins of `fine` = 2^fine_log buckets)
+//   1. k_msm_coarse_count    a workgroup histograms the digits of its 1024 scalars over the coarse
+//                            bins in LDS and reserves a range per bin with ONE global atomic
+//   2. k_msm_coarse_scan     exclusive scan of the bin totals (one workgroup per job)
+//   3. k_msm_coarse_scatter  the same workgroups recode again and write (bucket inside the bin,
+//                            pair) records into their ranges: the digits are now grouped by bin
+//   4. k_msm_fine_sort       one workgroup per bin: LDS histogram of its `fine` buckets, scan,
+//                            scatter of the pairs; writes cnt / off / bin-local toff
+//   5. k_msm_task_offsets    scan of the bins' task counts, added to toff
+// (The first version took one returning global atomic per digit - 13.4 M of them for 2^20 scalars,
+// 0.63 ms at ~21 G atomics/s - and remembered the tickets for an atomic-free scatter: 1.2 ms for
+// the three passes against the accumulation's 3.1 ms.)
+constexpr uint32_t MSM_COARSE_MAX = 1024;      // coarse bins per job
+constexpr uint32_t MSM_FINE_MAX = 2048;        // buckets per coarse bin
+constexpr uint32_t MSM_COARSE_SCALARS = 1024;  // scalars per workgroup of passes 1 and 3 (4 per thread)
+
 __global__ void __launch_bounds__(256)
-k_msm_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* rank, uint32_t* blockbase) {
-    ZK_SHARED uint32_t h[MSM_HOT];
+k_msm_coarse_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse, uint32_t* coarse_cnt,
+                   uint32_t* blockbase) {
+    ZK_SHARED uint32_t h[MSM_COARSE_MAX];
     const MsmJob job = jobs[blockIdx.y];
     const uint32_t tid = threadIdx.x;
-    uint32_t i = blockIdx.x * blockDim.x + tid;
-    const uint32_t nb = 1u << (c - 2);
-    uint32_t* jcnt = cnt + (size_t)blockIdx.y * nb;
-    uint32_t* jrank = rank + job.pair_base;
-    const uint32_t n = job.n;
-    const bool active = i < n && !(job.map && job.map[i] < 0);
-    if (blockbase) {
-        for (uint32_t t = tid; t < MSM_HOT; t += blockDim.x) h[t] = 0;
+    for (uint32_t t = tid; t < n_coarse; t += blockDim.x) h[t] = 0;
+    __syncthreads();
+    for (uint32_t e = 0; e < MSM_COARSE_SCALARS / 256; e++) {
+        const uint32_t i = blockIdx.x * MSM_COARSE_SCALARS + e * 256 + tid;
+        if (i >= job.n || (job.map && job.map[i] < 0)) continue;
+        msm_wnaf(job.scalars + (size_t)i * 8, c,
+                 [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[(mag >> 1) >> fine_log], 1u); });
+    }
+    __syncthreads();
+    uint32_t* bb = blockbase + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n_coarse;
+    uint32_t* jc = coarse_cnt + (size_t)blockIdx.y * n_coarse;
+    for (uint32_t t = tid; t < n_coarse; t += blockDim.x) bb[t] = h[t] ? atomicAdd(&jc[t], h[t]) : 0u;
+}
+
+// exclusive scan of n values per job (n <= a few thousand), one workgroup per job; total[job] = sum
+__global__ void __launch_bounds__(1024)
+k_msm_coarse_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ total, uint32_t n) {
+    ZK_SHARED uint32_t part[1024];
+    const uint32_t tid = threadIdx.x, nt = blockDim.x;
+    const uint32_t per = (n + nt - 1) / nt;
+    const uint32_t* src = in + (size_t)blockIdx.x * n;
+    uint32_t* dst = out + (size_t)blockIdx.x * n;
+    uint32_t e0 = tid * per, e1 = e0 + per < n ? e0 + per : n;
+    if (e0 > n) e0 = n;
+    uint32_t sum = 0;
+    for (uint32_t e = e0; e < e1; e++) sum += src[e];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < nt; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
         __syncthreads();
     }
-    if (active) {
-        msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t slot, uint32_t, uint32_t mag, bool) {
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t k = src[e];
+        dst[e] = run;
+        run += k;
+    }
+    if (total && tid == nt - 1) total[blockIdx.x] = part[nt - 1];
+}
+
+// record = (bucket inside its coarse bin, pair);  pair = (table index << 1) | sign,
+// table index = position * n_table + base
+__global__ void __launch_bounds__(256)
+k_msm_coarse_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse,
+                     const uint32_t* __restrict__ coarse_off, const uint32_t* __restrict__ blockbase, uint2* __restrict__ rec) {
+    ZK_SHARED uint32_t h[MSM_COARSE_MAX];
+    const MsmJob job = jobs[blockIdx.y];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t* bb = blockbase + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n_coarse;
+    const uint32_t* jo = coarse_off + (size_t)blockIdx.y * n_coarse;
+    for (uint32_t t = tid; t < n_coarse; t += blockDim.x) h[t] = jo[t] + bb[t];
+    __syncthreads();
+    uint2* jrec = rec + job.pair_base;
+    const uint32_t fmask = (1u << fine_log) - 1;
+    for (uint32_t e = 0; e < MSM_COARSE_SCALARS / 256; e++) {
+        const uint32_t i = blockIdx.x * MSM_COARSE_SCALARS + e * 256 + tid;
+        if (i >= job.n) continue;
+        const int32_t pos = job.map ? job.map[i] : (int32_t)i;
+        if (pos < 0) continue;
+        const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
+        msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
             const uint32_t b = mag >> 1;
-            if (blockbase && b < MSM_HOT)
-                jrank[(size_t)slot * n + i] = atomicAdd(&h[b], 1u) | 0x80000000u;
-            else
-                jrank[(size_t)slot * n + i] = atomicAdd(&jcnt[b], 1u);
+            const uint32_t slot = atomicAdd(&h[b >> fine_log], 1u);
+            jrec[slot] = make_uint2(b & fmask, ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u));
         });
-    }
-    if (blockbase) {
-        __syncthreads();
-        uint32_t* bb = blockbase + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * MSM_HOT;
-        for (uint32_t t = tid; t < MSM_HOT && t < nb; t += blockDim.x) bb[t] = h[t] ? atomicAdd(&jcnt[t], h[t]) : 0u;
     }
 }
 
-// Pass 2: per-job exclusive scans of the histogram: first pair slot of every bucket, and the
-// bucket's first TASK.  A bucket with k points is cut into ceil(k / seg) tasks so that no
-// thread of the accumulation ever walks more than seg points, whatever the scalar
-// distribution (boolean witnesses put ~n/2 points into bucket "1").  One workgroup per job;
-// each thread owns a contiguous run of buckets.
+// grid (coarse bins, jobs).  A bucket with k points is cut into ceil(k / seg) tasks (see below);
+// toff is left relative to the bin's first task, bin_tasks[bin] = tasks of the bin.
 __global__ void __launch_bounds__(1024)
-k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ cnt, uint32_t* off,
-           uint32_t* toff, uint32_t* ntasks, uint32_t seg) {
+k_msm_fine_sort(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, const uint32_t* __restrict__ coarse_cnt,
+                const uint32_t* __restrict__ coarse_off, uint32_t fine, uint32_t nb, uint32_t* cnt, uint32_t* off, uint32_t* toff,
+                uint32_t* bin_tasks, uint32_t* pairs, uint32_t seg) {
+    ZK_SHARED uint32_t h[MSM_FINE_MAX];
     ZK_SHARED uint32_t part[1024];
     ZK_SHARED uint32_t tpart[1024];
-    const uint32_t nb = 1u << (c - 2);
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t per = (nb + nt - 1) / nt;
-    const uint32_t* jcnt = cnt + (size_t)blockIdx.x * nb;
-    uint32_t* joff = off + (size_t)blockIdx.x * nb;
-    uint32_t* jtoff = toff + (size_t)blockIdx.x * nb;
-    uint32_t b0 = tid * per, b1 = b0 + per < nb ? b0 + per : nb;
-    if (b0 > nb) b0 = nb;
+    const uint32_t tid = threadIdx.x, nt = blockDim.x, bin = blockIdx.x, n_coarse = gridDim.x;
+    const MsmJob job = jobs[blockIdx.y];
+    const uint32_t n_rec = coarse_cnt[(size_t)blockIdx.y * n_coarse + bin];
+    const uint32_t first = job.pair_base + coarse_off[(size_t)blockIdx.y * n_coarse + bin];
+    for (uint32_t t = tid; t < fine; t += nt) h[t] = 0;
+    __syncthreads();
+    {
+        // four records in flight per thread
+        uint32_t e = tid;
+        for (; e + 3 * nt < n_rec; e += 4 * nt) {
+            const uint32_t k0 = rec[first + e].x, k1 = rec[first + e + nt].x, k2 = rec[first + e + 2 * nt].x,
+                           k3 = rec[first + e + 3 * nt].x;
+            atomicAdd(&h[k0], 1u);
+            atomicAdd(&h[k1], 1u);
+            atomicAdd(&h[k2], 1u);
+            atomicAdd(&h[k3], 1u);
+        }
+        for (; e < n_rec; e += nt) atomicAdd(&h[rec[first + e].x], 1u);
+    }
+    __syncthreads();
+    const uint32_t per = (fine + nt - 1) / nt;
+    uint32_t f0 = tid * per, f1 = f0 + per < fine ? f0 + per : fine;
+    if (f0 > fine) f0 = fine;
     uint32_t sum = 0, tsum = 0;
-    for (uint32_t b = b0; b < b1; b++) {
-        uint32_t k = jcnt[b];
-        sum += k;
-        tsum += (k + seg - 1) / seg;
+    for (uint32_t f = f0; f < f1; f++) {
+        sum += h[f];
+        tsum += (h[f] + seg - 1) / seg;
     }
     part[tid] = sum;
     tpart[tid] = tsum;
     __syncthreads();
-    // Hillis-Steele inclusive scans over the per-thread sums
     for (uint32_t d = 1; d < nt; d <<= 1) {
         uint32_t v = tid >= d ? part[tid - d] : 0;
         uint32_t tv = tid >= d ? tpart[tid - d] : 0;
@@ -227,37 +295,40 @@ k_msm_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restri
         tpart[tid] += tv;
         __syncthreads();
     }
-    uint32_t run = jobs[blockIdx.x].pair_base + (tid ? part[tid - 1] : 0);
-    uint32_t trun = tid ? tpart[tid - 1] : 0;
-    for (uint32_t b = b0; b < b1; b++) {
-        uint32_t k = jcnt[b];
-        joff[b] = run;
-        jtoff[b] = trun;
+    uint32_t run = tid ? part[tid - 1] : 0, trun = tid ? tpart[tid - 1] : 0;
+    const size_t b0 = (size_t)blockIdx.y * nb + (size_t)bin * fine;
+    for (uint32_t f = f0; f < f1; f++) {
+        const uint32_t k = h[f];
+        cnt[b0 + f] = k;
+        off[b0 + f] = first + run;
+        toff[b0 + f] = trun;
+        h[f] = run;   // slot cursor of the bucket, relative to the bin's first pair
         run += k;
         trun += (k + seg - 1) / seg;
     }
-    if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
+    if (tid == nt - 1) bin_tasks[(size_t)blockIdx.y * n_coarse + bin] = tpart[nt - 1];
+    __syncthreads();
+    uint32_t e = tid;
+    for (; e + 3 * nt < n_rec; e += 4 * nt) {
+        const uint2 r0 = rec[first + e], r1 = rec[first + e + nt], r2 = rec[first + e + 2 * nt], r3 = rec[first + e + 3 * nt];
+        const uint32_t s0 = atomicAdd(&h[r0.x], 1u), s1 = atomicAdd(&h[r1.x], 1u), s2 = atomicAdd(&h[r2.x], 1u),
+                       s3 = atomicAdd(&h[r3.x], 1u);
+        pairs[first + s0] = r0.y;
+        pairs[first + s1] = r1.y;
+        pairs[first + s2] = r2.y;
+        pairs[first + s3] = r3.y;
+    }
+    for (; e < n_rec; e += nt) {
+        const uint2 r = rec[first + e];
+        pairs[first + atomicAdd(&h[r.x], 1u)] = r.y;
+    }
 }
 
-// Pass 3: scatter.  pair = (table index << 1) | sign, table index = position * n_table + base.
+// toff[b] += first task of b's bin; grid (blocks over the buckets, jobs)
 __global__ void __launch_bounds__(256)
-k_msm_scatter(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ off,
-              const uint32_t* __restrict__ rank, uint32_t* pairs, const uint32_t* __restrict__ blockbase) {
-    const MsmJob job = jobs[blockIdx.y];
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= job.n) return;
-    const uint32_t nb = 1u << (c - 2);
-    const uint32_t* joff = off + (size_t)blockIdx.y * nb;
-    const uint32_t* jrank = rank + job.pair_base;
-    int32_t pos = job.map ? job.map[i] : (int32_t)i;
-    if (pos < 0) return;
-    const uint32_t n = job.n, tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
-    msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t slot, uint32_t bit, uint32_t mag, bool negative) {
-        uint32_t tkt = jrank[(size_t)slot * n + i];
-        if (tkt & 0x80000000u)   // workgroup-local rank of a hot bucket
-            tkt = (tkt & 0x7fffffffu) + blockbase[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * MSM_HOT + (mag >> 1)];
-        pairs[joff[mag >> 1] + tkt] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
-    });
+k_msm_task_offsets(uint32_t* toff, const uint32_t* __restrict__ bin_tbase, uint32_t nb, uint32_t fine_log, uint32_t n_coarse) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) toff[(size_t)blockIdx.y * nb + b] += bin_tbase[(size_t)blockIdx.y * n_coarse + (b >> fine_log)];
 }
 
 // Passes 1-3 fused for jobs whose bucket histogram fits LDS (every per-proof job): one workgroup
@@ -465,11 +536,25 @@ template <class F>
 __global__ void __launch_bounds__(MSM_MERGE_THREADS)
 k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
                   const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb,
-                  uint32_t seg) {
+                  uint32_t seg, uint32_t heavy_blocks, uint32_t light_buckets, uint32_t merge_inline) {
     ZK_SHARED XYZZ<F> sm[MSM_MERGE_THREADS];
     const uint32_t tid = threadIdx.x;
+    if (blockIdx.x >= heavy_blocks) {
+        // pass 5c inside the same launch (few jobs): the workgroups behind the first heavy_blocks take
+        // one bucket per thread and sum its 2 .. merge_inline partials, beside - not after - the
+        // heavy buckets' trees
+        const uint32_t gb = (blockIdx.x - heavy_blocks) * MSM_MERGE_THREADS + tid;
+        if (gb >= light_buckets) return;
+        const uint32_t nt_b = (cnt[gb] + seg - 1) / seg;
+        if (nt_b < 2 || nt_b > merge_inline) return;
+        XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
+        XYZZ<F> acc = ts[0];
+        for (uint32_t u = 1; u < nt_b; u++) acc = xadd(acc, ts[u]);
+        ts[0] = acc;
+        return;
+    }
     // a fixed grid walks the list (launching one workgroup per POSSIBLE heavy bucket costs more than the work)
-    for (uint32_t hb = blockIdx.x; hb < n_heavy[0]; hb += gridDim.x) {
+    for (uint32_t hb = blockIdx.x; hb < n_heavy[0]; hb += heavy_blocks) {
         const uint32_t gb = heavy[hb];
         const uint32_t nt = (cnt[gb] + seg - 1) / seg;
         XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
@@ -487,24 +572,11 @@ k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict
 }
 
 
-// Pass 5c (few jobs only): one thread per bucket sums the 2 .. merge_inline partials of a bucket into
-// its first partial, so that the level-1 threads of the reduction below, each a serial chain over
-// L buckets, add one point per bucket.  With one large job the recoding's top digit alone gives
-// ~2^(c-6) buckets twice the average load, i.e. a run of neighbouring buckets with 4 partials each.
-template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::red)
-k_msm_merge_light(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base,
-                  XYZZ<F>* tsums, uint32_t nb, uint32_t merge_inline, uint32_t seg) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    const size_t gb = (size_t)blockIdx.y * nb + b;
-    const uint32_t nt_b = (cnt[gb] + seg - 1) / seg;
-    if (nt_b < 2 || nt_b > merge_inline) return;
-    XYZZ<F>* ts = tsums + task_base[blockIdx.y] + toff[gb];
-    XYZZ<F> acc = ts[0];
-    for (uint32_t u = 1; u < nt_b; u++) acc = xadd(acc, ts[u]);
-    ts[0] = acc;
-}
+// Pass 5c (few jobs only, the trailing workgroups of k_msm_merge_heavy): one thread per bucket sums the
+// 2 .. merge_inline partials of a bucket into its first partial, so that the level-1 threads of the
+// reduction below, each a serial chain over L buckets, add one point per bucket.  With one large job
+// the recoding's top digit alone gives ~2^(c-6) buckets twice the average load, i.e. a run of
+// neighbouring buckets with 4 partials each.
 
 // Pass 6: bucket reduction  sum_j (2j + 1) * B_j  (bucket j holds the odd magnitude 2j + 1) as a
 // tree of running sums.  A node covering M buckets carries
@@ -590,28 +662,26 @@ k_msm_segsum(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ init, X
 // It costs (log2 T + 1) / 2 additions per node instead of 3, so it is used only when the tree's
 // latency, not its work, is what the launch waits for.
 //
-// k_msm_bitsum: grid (blocks of 256 nodes, log2(T) + 1 planes, jobs); plane nbits sums W.  One wave
-// per block: every lane sums 4 nodes from HBM, then a 6-step tree in LDS (14 KB, so that all the
-// blocks of a launch are resident at once - the launch takes one chain of 10 additions).
-constexpr uint32_t MSM_BITSUM_NODES = 256;
+// k_msm_bitsum: grid (blocks of 512 nodes, planes, jobs).  Planes 0 .. nlow-1 (nlow = min(nbits, 9))
+// sum the S of the nodes whose index has that bit set; the bits above 8 are constant over a block, so
+// ONE further plane of plain block sums U serves all of them (k_msm_bitsum_fold masks by the block
+// index); the last plane sums W.  One wave per block: every lane adds 8 nodes from HBM, then a 6-step
+// tree in LDS (14 KB, so all blocks of a launch are resident at once: one chain of 14 additions).
+constexpr uint32_t MSM_BITSUM_LOG = 9, MSM_BITSUM_NODES = 1u << MSM_BITSUM_LOG;
 template <class F>
 __global__ void __launch_bounds__(64, MsmOcc<F>::red)
 k_msm_bitsum(const XYZZ<F>* __restrict__ S, uint32_t s_stride, const XYZZ<F>* __restrict__ W, XYZZ<F>* __restrict__ part,
              uint32_t T, uint32_t nbits) {
     ZK_SHARED XYZZ<F> sm[64];
     const uint32_t tid = threadIdx.x, plane = blockIdx.y, job = blockIdx.z;
-    XYZZ<F>* dst = part + ((size_t)job * (nbits + 1) + plane) * gridDim.x + blockIdx.x;
-    // bits 8 and up are constant over the 256 nodes of a block
-    if (plane < nbits && plane >= 8 && !((blockIdx.x >> (plane - 8)) & 1u)) {
-        if (tid == 0) *dst = XYZZ<F>::inf();
-        return;
-    }
+    const uint32_t nlow = nbits < MSM_BITSUM_LOG ? nbits : MSM_BITSUM_LOG;
+    const bool is_w = plane == gridDim.y - 1, is_bit = plane < nlow;
     XYZZ<F> acc = XYZZ<F>::inf();
     for (uint32_t e = 0; e < MSM_BITSUM_NODES / 64; e++) {
         const uint32_t t = blockIdx.x * MSM_BITSUM_NODES + e * 64 + tid;
         if (t >= T) break;
-        if (plane == nbits) acc = xadd(acc, W[(size_t)job * T + t]);
-        else if ((t >> plane) & 1u) acc = xadd(acc, S[((size_t)job * T + t) * s_stride]);
+        if (is_w) acc = xadd(acc, W[(size_t)job * T + t]);
+        else if (!is_bit || ((t >> plane) & 1u)) acc = xadd(acc, S[((size_t)job * T + t) * s_stride]);
     }
     sm[tid] = acc;
     __syncthreads();
@@ -619,25 +689,29 @@ k_msm_bitsum(const XYZZ<F>* __restrict__ S, uint32_t s_stride, const XYZZ<F>* __
         if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
         __syncthreads();
     }
-    if (tid == 0) *dst = sm[0];
+    if (tid == 0) part[((size_t)job * gridDim.y + plane) * gridDim.x + blockIdx.x] = sm[0];
 }
 
-// k_msm_bitsum_fold: grid (planes, jobs); Y[job][plane] = sum of the plane's block partials.
+// k_msm_bitsum_fold: grid (nbits + 1, jobs), one wave; Y[job][j] = plane sum over the blocks
+// (j < nbits: the nodes with bit j set; j = nbits: W).
 template <class F>
-__global__ void __launch_bounds__(MSM_MERGE_THREADS)
-k_msm_bitsum_fold(const XYZZ<F>* __restrict__ part, XYZZ<F>* __restrict__ Y, uint32_t nblk) {
-    ZK_SHARED XYZZ<F> sm[MSM_MERGE_THREADS];
-    const uint32_t tid = threadIdx.x;
-    const size_t row = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_bitsum_fold(const XYZZ<F>* __restrict__ part, XYZZ<F>* __restrict__ Y, uint32_t nblk, uint32_t nbits, uint32_t n_planes) {
+    ZK_SHARED XYZZ<F> sm[64];
+    const uint32_t tid = threadIdx.x, j = blockIdx.x, job = blockIdx.y;
+    const uint32_t nlow = nbits < MSM_BITSUM_LOG ? nbits : MSM_BITSUM_LOG;
+    const uint32_t plane = j == nbits ? n_planes - 1 : (j < nlow ? j : nlow);   // W | bit plane | U
+    const XYZZ<F>* row = part + ((size_t)job * n_planes + plane) * nblk;
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t u = tid; u < nblk; u += MSM_MERGE_THREADS) acc = xadd(acc, part[row * nblk + u]);
+    for (uint32_t u = tid; u < nblk; u += 64)
+        if (j == nbits || j < nlow || ((u >> (j - MSM_BITSUM_LOG)) & 1u)) acc = xadd(acc, row[u]);
     sm[tid] = acc;
     __syncthreads();
-    for (uint32_t st = MSM_MERGE_THREADS / 2; st >= 1; st >>= 1) {
+    for (uint32_t st = 32; st >= 1; st >>= 1) {
         if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
         __syncthreads();
     }
-    if (tid == 0) Y[row] = sm[0];
+    if (tid == 0) Y[(size_t)job * (nbits + 1) + j] = sm[0];
 }
 
 // k_msm_bitsum_combine: one wave per job; out = 2^dbl * sum_j 2^j Y_j + Y_nbits.  The weighted sum is

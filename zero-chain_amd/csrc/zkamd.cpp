@@ -340,7 +340,7 @@ struct MsmGroup {
     uint32_t c = 0, maxd = 0, nb = 0;
     size_t n_points = 0;
     DevBuf table;
-    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, blockbase, tbase, rank, pairs, tsums, red_r, red_w, red_t, result;
+    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, blockbase, coarse, tbase, rank, pairs, tsums, red_r, red_w, red_t, result;
     std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
 
@@ -451,27 +451,41 @@ struct MsmGroup {
                            cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(),
                            pairs.as<uint32_t>(), seg);
         } else {
-            HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, st));
-            ZK_TRY(rank.ensure((size_t)(total ? total : 1) * 4));
-            // hot-bucket pre-aggregation for the few-big-jobs case (its side array is per workgroup)
-            uint32_t* bbase = nullptr;
-            if (nj <= 8) {
-                ZK_TRY(blockbase.ensure((size_t)gridn.x * nj * zkdev::MSM_HOT * 4));
-                bbase = blockbase.as<uint32_t>();
-            }
-            if (max_n) {
-                ProfScope ps("msm_count", st);
-                ZK_LAUNCH_SYNC(zkdev::k_msm_count, gridn, dim3(256), 0, st, dj, c, cnt.as<uint32_t>(), rank.as<uint32_t>(), bbase);
+            // two-level counting sort, every per-digit atomic in LDS (msm.h)
+            uint32_t fine_log = 7;
+            if (const char* env = getenv("ZKAMD_SORT_FINE_LOG")) fine_log = (uint32_t)atoi(env);
+            while (fine_log < c - 2 && (nb >> fine_log) > zkdev::MSM_COARSE_MAX) fine_log++;
+            if (fine_log > c - 2) fine_log = c - 2;
+            const uint32_t fine = 1u << fine_log, n_coarse = nb >> fine_log;
+            if (fine > zkdev::MSM_FINE_MAX) return fail(ZK_ERR_INVALID_ARGUMENT, "ZKAMD_SORT_FINE_LOG out of range");
+            dim3 gridc((max_n + zkdev::MSM_COARSE_SCALARS - 1) / zkdev::MSM_COARSE_SCALARS, (unsigned)nj);
+            if (gridc.x == 0) gridc.x = 1;
+            ZK_TRY(rank.ensure((size_t)(total ? total : 1) * sizeof(uint2)));          // (bucket in bin, pair) records
+            ZK_TRY(blockbase.ensure((size_t)gridc.x * nj * n_coarse * 4));
+            ZK_TRY(coarse.ensure(4 * nj * (size_t)n_coarse * 4));                       // bin counts | offsets | tasks | first task
+            uint32_t* coarse_cnt = coarse.as<uint32_t>();
+            uint32_t* coarse_off = coarse_cnt + nj * (size_t)n_coarse;
+            uint32_t* bin_tasks = coarse_off + nj * (size_t)n_coarse;
+            uint32_t* bin_tbase = bin_tasks + nj * (size_t)n_coarse;
+            HIP_TRY(hipMemsetAsync(coarse_cnt, 0, nj * (size_t)n_coarse * 4, st));
+            {
+                ProfScope ps("msm_sort_coarse", st);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_count, gridc, dim3(256), 0, st, dj, c, fine_log, n_coarse, coarse_cnt,
+                               blockbase.as<uint32_t>());
+                ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st,
+                               (const uint32_t*)coarse_cnt, coarse_off, (uint32_t*)nullptr, n_coarse);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scatter, gridc, dim3(256), 0, st, dj, c, fine_log, n_coarse,
+                               (const uint32_t*)coarse_off, (const uint32_t*)blockbase.as<uint32_t>(), rank.as<uint2>());
             }
             {
-                ProfScope ps("msm_scan", st);
-                ZK_LAUNCH_SYNC(zkdev::k_msm_scan, dim3((unsigned)nj), dim3(nb < zkdev::MSM_SORT_THREADS ? (nb < 64 ? 64 : nb) : zkdev::MSM_SORT_THREADS), 0, st,
-                               dj, c, cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(), seg);
-            }
-            if (max_n) {
-                ProfScope ps("msm_scatter", st);
-                ZK_LAUNCH(zkdev::k_msm_scatter, gridn, dim3(256), 0, st, dj, c, off.as<uint32_t>(), rank.as<uint32_t>(),
-                          pairs.as<uint32_t>(), (const uint32_t*)bbase);
+                ProfScope ps("msm_sort_fine", st);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort, dim3(n_coarse, (unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st, dj,
+                               (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
+                               cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st,
+                               (const uint32_t*)bin_tasks, bin_tbase, ntasks.as<uint32_t>(), n_coarse);
+                ZK_LAUNCH(zkdev::k_msm_task_offsets, gridb, dim3(256), 0, st, toff.as<uint32_t>(), (const uint32_t*)bin_tbase, nb,
+                          fine_log, n_coarse);
             }
         }
         {
@@ -495,14 +509,15 @@ struct MsmGroup {
         {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_reduce_g2" : "msm_reduce_g1", st);
             auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
-            ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>, dim3((unsigned)std::min<size_t>(heavy_cap, 4096)), dim3(zkdev::MSM_MERGE_THREADS), 0, st,
-                           (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy, (const uint32_t*)cnt.as<uint32_t>(),
-                           (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg);
+            const uint32_t heavy_blocks = (uint32_t)std::min<size_t>(heavy_cap, few ? 512 : 4096);
+            const uint32_t light_buckets = few ? (uint32_t)n_buckets : 0u;
+            ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>,
+                           dim3(heavy_blocks + (light_buckets + zkdev::MSM_MERGE_THREADS - 1) / zkdev::MSM_MERGE_THREADS),
+                           dim3(zkdev::MSM_MERGE_THREADS), 0, st, (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy,
+                           (const uint32_t*)cnt.as<uint32_t>(), (const uint32_t*)toff.as<uint32_t>(),
+                           (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg, heavy_blocks, light_buckets,
+                           merge_inline);
             // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
-            if (few)
-                ZK_LAUNCH(zkdev::k_msm_merge_light<DF>, grid(nb), dim3(64), 0, st, (const uint32_t*)cnt.as<uint32_t>(),
-                          (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb,
-                          merge_inline, seg);
             ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
                       toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, few ? 0u : merge_inline, seg);
             ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
@@ -517,11 +532,13 @@ struct MsmGroup {
                 while ((1u << nbits) < T) nbits++;
                 while ((1u << (log2_2l - 1)) < L) log2_2l++;
                 const uint32_t nblk = (T + zkdev::MSM_BITSUM_NODES - 1) / zkdev::MSM_BITSUM_NODES;
-                DPoint* part = red_t.as<DPoint>();   // (nbits + 1) * nblk <= T partials per job
-                ZK_LAUNCH_SYNC(zkdev::k_msm_bitsum<DF>, dim3(nblk, nbits + 1, (unsigned)nj), dim3(64), 0, st,
-                          (const DPoint*)R, L, (const DPoint*)Wa, part, T, nbits);
-                ZK_LAUNCH_SYNC(zkdev::k_msm_bitsum_fold<DF>, dim3(nbits + 1, (unsigned)nj), dim3(zkdev::MSM_MERGE_THREADS), 0, st,
-                          (const DPoint*)part, Wb, nblk);
+                const uint32_t nlow = std::min(nbits, zkdev::MSM_BITSUM_LOG);
+                const uint32_t n_planes = nlow + (nbits > nlow ? 1u : 0u) + 1u;   // bit planes | block sums U | W
+                DPoint* part = red_t.as<DPoint>();   // n_planes * nblk <= T partials per job
+                ZK_LAUNCH_SYNC(zkdev::k_msm_bitsum<DF>, dim3(nblk, n_planes, (unsigned)nj), dim3(64), 0, st, (const DPoint*)R, L,
+                               (const DPoint*)Wa, part, T, nbits);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_bitsum_fold<DF>, dim3(nbits + 1, (unsigned)nj), dim3(64), 0, st, (const DPoint*)part, Wb,
+                               nblk, nbits, n_planes);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_bitsum_combine<DF>, dim3((unsigned)nj), dim3(64), 0, st, (const DPoint*)Wb, Rnext, nbits,
                                log2_2l);
                 in = Rnext;
