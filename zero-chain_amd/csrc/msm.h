@@ -53,9 +53,18 @@ template <class F> struct MsmOcc;
 #ifndef ZK_OCC_G2_RED
 #define ZK_OCC_G2_RED 2
 #endif
-template <> struct MsmOcc<Fq> { static constexpr int acc = ZK_OCC_G1_ACC, red = ZK_OCC_G1_RED; };
-template <> struct MsmOcc<Fq2> { static constexpr int acc = ZK_OCC_G2_ACC, red = ZK_OCC_G2_RED; };
-template <> struct MsmOcc<Fq2x> { static constexpr int acc = ZK_OCC_G2_ACC, red = ZK_OCC_G2_RED; };
+// `tail`: the kernels of the few-jobs reduction tail (k_msm_bitsum*) are chains of dependent point
+// additions run by one wave per SIMD at most - occupancy buys nothing there, spilled registers cost
+// latency - so they take the whole register file.
+#ifndef ZK_OCC_G1_TAIL
+#define ZK_OCC_G1_TAIL 2
+#endif
+#ifndef ZK_OCC_G2_TAIL
+#define ZK_OCC_G2_TAIL 1
+#endif
+template <> struct MsmOcc<Fq> { static constexpr int acc = ZK_OCC_G1_ACC, red = ZK_OCC_G1_RED, tail = ZK_OCC_G1_TAIL; };
+template <> struct MsmOcc<Fq2> { static constexpr int acc = ZK_OCC_G2_ACC, red = ZK_OCC_G2_RED, tail = ZK_OCC_G2_TAIL; };
+template <> struct MsmOcc<Fq2x> { static constexpr int acc = ZK_OCC_G2_ACC, red = ZK_OCC_G2_RED, tail = ZK_OCC_G2_TAIL; };
 
 // Longest run of points one accumulation thread walks (`seg`, a launch parameter): 256 when
 // thousands of jobs fill the machine (fewer task partials to merge in the reduction), 64 for a
@@ -599,7 +608,12 @@ k_msm_suffix_buckets(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restri
                      const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base,
                      XYZZ<F>* __restrict__ R, uint32_t nb, uint32_t L, uint32_t merge_inline, uint32_t seg) {
     const uint32_t T = nb / L;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroup (x, y) runs on XCD (y * gridDim.x + x) mod 8: with 8 workgroups per job the plain
+    // mapping hands XCD 0 the lowest buckets of EVERY job - the ones with several task partials
+    // (small top digits of the recoding) - and the launch waits for that XCD with the other SEs half
+    // idle (SQ_BUSY_CYCLES / duration = 50 %).  Rotating the node range by the job index spreads them.
+    const uint32_t bx = (blockIdx.x + blockIdx.y) % gridDim.x;
+    uint32_t t = bx * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const uint32_t job = blockIdx.y;
     const size_t b0 = (size_t)job * nb + (size_t)t * L;
@@ -669,7 +683,7 @@ k_msm_segsum(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ init, X
 // tree in LDS (14 KB, so all blocks of a launch are resident at once: one chain of 14 additions).
 constexpr uint32_t MSM_BITSUM_LOG = 9, MSM_BITSUM_NODES = 1u << MSM_BITSUM_LOG;
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+__global__ void __launch_bounds__(64, MsmOcc<F>::tail)
 k_msm_bitsum(const XYZZ<F>* __restrict__ S, uint32_t s_stride, const XYZZ<F>* __restrict__ W, XYZZ<F>* __restrict__ part,
              uint32_t T, uint32_t nbits) {
     ZK_SHARED XYZZ<F> sm[64];
@@ -695,7 +709,7 @@ k_msm_bitsum(const XYZZ<F>* __restrict__ S, uint32_t s_stride, const XYZZ<F>* __
 // k_msm_bitsum_fold: grid (nbits + 1, jobs), one wave; Y[job][j] = plane sum over the blocks
 // (j < nbits: the nodes with bit j set; j = nbits: W).
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+__global__ void __launch_bounds__(64, MsmOcc<F>::tail)
 k_msm_bitsum_fold(const XYZZ<F>* __restrict__ part, XYZZ<F>* __restrict__ Y, uint32_t nblk, uint32_t nbits, uint32_t n_planes) {
     ZK_SHARED XYZZ<F> sm[64];
     const uint32_t tid = threadIdx.x, j = blockIdx.x, job = blockIdx.y;
@@ -718,7 +732,7 @@ k_msm_bitsum_fold(const XYZZ<F>* __restrict__ part, XYZZ<F>* __restrict__ Y, uin
 // folded pairwise (step s adds 2^(2^s) times the upper neighbour), which keeps the unavoidable
 // nbits doublings but only log2(nbits) additions on the critical path.
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+__global__ void __launch_bounds__(64, MsmOcc<F>::tail)
 k_msm_bitsum_combine(const XYZZ<F>* __restrict__ Y, XYZZ<F>* __restrict__ out, uint32_t nbits, uint32_t dbl) {
     ZK_SHARED XYZZ<F> sm[64];
     const uint32_t tid = threadIdx.x, job = blockIdx.x;

@@ -878,12 +878,17 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     // icoset fft: ifft (natural -> bit-reversed), * g^-i / m, Montgomery factor dropped; in place
     // inside the merged scalar vectors
     ZK_TRY(P->ntt.chain(cvec, (uint32_t)np, cstride, true, true, nullptr, P->ntt.s2.as<uint32_t>()));
+    // job order: all C' jobs, then all A jobs.  Workgroup i of a launch runs on XCD i mod 8 and the
+    // sort is one workgroup per job: alternating A, C' (a fifth against four fifths of the scalars)
+    // put every large job on the odd XCDs.  Largest first also keeps the tail of the launch short.
+    for (size_t p = 0; p < np; p++) {
+        MsmJob jc = {cvec + p * (size_t)cstride * 8, P->map_c.as<int32_t>(), cstride, 0, npts1, 0};
+        P->jobs1.push_back(jc);
+    }
     for (size_t p = 0; p < np; p++) {
         const uint32_t* w = wit + p * wstride * 8;
         MsmJob ja = {w, P->map_a.as<int32_t>(), nv + 3, P->off_a, npts1, 0};
-        MsmJob jc = {cvec + p * (size_t)cstride * 8, P->map_c.as<int32_t>(), cstride, 0, npts1, 0};
         P->jobs1.push_back(ja);
-        P->jobs1.push_back(jc);
     }
     ZK_TRY(P->g1.enqueue(P->jobs1, P->res1, g_stream));
     ZK_TRY(P->g1.collect(g_stream));
@@ -895,7 +900,7 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     if (nthreads > np) nthreads = (unsigned)np;
     auto work = [&](size_t lo, size_t hi) {
         for (size_t p = lo; p < hi; p++)
-            fold_proof(P->res1[2 * p + 1], P->res1[2 * p], P->res2[p], &rsv[p * 8 + 4], proofs_out + (first + p) * 192);
+            fold_proof(P->res1[p], P->res1[np + p], P->res2[p], &rsv[p * 8 + 4], proofs_out + (first + p) * 192);
     };
     if (nthreads <= 1) {
         work(0, np);
