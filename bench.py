@@ -43,7 +43,7 @@ import numpy as np
 import torch
 
 N_IN, N_AUX, N_CON = 23, 19955, 19974   # confidential_transfer.rs:383-386 (+ derived aux count)
-KERNEL_NAMES = ("msm_accumulate_g1", "msm_accumulate_g2", "msm_sort_lds", "msm_sort_coarse", "msm_sort_fine", "msm_task_sort",
+KERNEL_NAMES = ("msm_accumulate_g1", "msm_accumulate_g2", "msm_sort_lds", "msm_sort_coarse", "msm_sort_fine", "proof_fold", "msm_task_sort",
                 "msm_reduce_g1", "msm_reduce_g2", "msm_sum", "ntt_pass_dif", "ntt_pass_dit", "h_pointwise")
 HBM_PEAK_GBPS = 8000.0
 WORKLOAD_R1CS = [None]

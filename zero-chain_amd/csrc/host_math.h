@@ -288,6 +288,7 @@ inline Point<F> pmul(const Point<F>& a, const uint64_t k[4]) {
 template <class F>
 inline Affine<F> to_affine(const Point<F>& p) {
     if (p.is_inf()) return Affine<F>::inf();
+    if (p.zz == F::one() && p.zzz == F::one()) return Affine<F>{p.x, p.y};   // already normalised (GPU fold)
     F izzz = fq_inv(p.zzz);
     F izz = p.zz.sqr() * izzz.sqr();
     return Affine<F>{p.x * izz, p.y * izzz};

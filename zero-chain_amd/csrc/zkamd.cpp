@@ -14,6 +14,7 @@
 #include <vector>
 #include <map>
 #include <thread>
+#include <chrono>
 #include <algorithm>
 #include <new>
 
@@ -341,6 +342,7 @@ struct MsmGroup {
     size_t n_points = 0;
     DevBuf table;
     DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, blockbase, coarse, tbase, rank, pairs, tsums, red_r, red_w, red_t, result;
+    DPoint* res_dev = nullptr;
     std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
 
@@ -374,9 +376,10 @@ struct MsmGroup {
 
     // jobs[i].pair_base is filled in here.  Everything, including the copy of the results (one XYZZ
     // per job) into `out`, is enqueued on `st`; collect() waits for it.
-    zk_status enqueue(std::vector<MsmJob>& jobs, std::vector<HPoint>& out, hipStream_t st) {
+    zk_status enqueue(std::vector<MsmJob>& jobs, std::vector<HPoint>& out, hipStream_t st, bool to_host = true) {
         const size_t nj = jobs.size();
         out.resize(nj);
+        res_dev = nullptr;
         if (!nj) return ZK_OK;
         const char* seg_env = getenv("ZKAMD_MSM_SEG");
         const uint32_t seg_forced = seg_env && atoi(seg_env) > 0 && atoi(seg_env) <= (int)zkdev::MSM_SEG_MAX
@@ -565,11 +568,26 @@ struct MsmGroup {
                 n = n_out;
             }
         }
+        res_dev = in;   // one XYZZ per job, valid until the next enqueue on this group
+        if (!to_host) {
+            HIP_TRY(hipGetLastError());
+            return ZK_OK;
+        }
         ZK_TRY(result.ensure(nj * sizeof(HPoint)));
         ZK_LAUNCH(zkdev::k_export_xyzz<DF>, dim3((unsigned)((nj + 63) / 64)), dim3(64), 0, st, (const DPoint*)in,
                   result.as<uint32_t>(), (uint32_t)nj);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out.data(), result.p, nj * sizeof(HPoint), hipMemcpyDeviceToHost, st));
+        return ZK_OK;
+    }
+    // out[i] = affine form of src[i] (host layout, zz = zzz = 1), enqueued on st
+    zk_status normalize_to_host(const DPoint* src, size_t n, HPoint* out, DevBuf& stage, hipStream_t st) {
+        if (!n) return ZK_OK;
+        ZK_TRY(stage.ensure(n * sizeof(HPoint)));
+        ZK_LAUNCH(zkdev::k_xyzz_normalize_export<DF>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, src, stage.as<uint32_t>(),
+                  (uint32_t)n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, stage.p, n * sizeof(HPoint), hipMemcpyDeviceToHost, st));
         return ZK_OK;
     }
     zk_status collect(hipStream_t st) {
@@ -664,7 +682,7 @@ struct zk_params {
     DevBuf map_a, map_b2, map_c;
     uint32_t map_nv = 0;
     // workspaces
-    DevBuf abc, wit, cvec, tail, stage_a, stage_b, stage_c, stage_w;
+    DevBuf abc, wit, cvec, tail, stage_a, stage_b, stage_c, stage_w, fold_tbl, fold_c, fold_a1, fold_c1, fold_b2;
     std::vector<MsmJob> jobs1, jobs2;
     std::vector<HG1> res1;
     std::vector<HG2> res2;
@@ -806,14 +824,11 @@ zk_status ensure_maps(zk_params* P, uint32_t n_in, uint32_t n_aux, const uint8_t
 // complete, the alpha and r*delta terms rode along in the A multiexp) and
 // C' = h + l + r*(beta_1 + sum_B1) from the merged multiexp,
 //   C = s*A + C'   ==  rs*delta + s*alpha + r*beta_1 + s*sum_A + r*sum_B1 + h + l.
-void fold_proof(const HG1& cprime, const HG1& a, const HG2& b2, const uint64_t s[4], uint8_t* out) {
-    HG1 c = zkhost::padd(zkhost::pmul(a, s), cprime);
-    zkhost::g1_to_compressed(zkhost::to_affine(a), out);
-    zkhost::g2_to_compressed(zkhost::to_affine(b2), out + 48);
-    zkhost::g1_to_compressed(zkhost::to_affine(c), out + 144);
-}
+// (prove_chunk: the fold and the three into_affine run on the GPU, k_xyzz_scale_add /
+// k_xyzz_normalize_export; the host encodes the 192 bytes.)
 
 zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t first, const uint8_t* rs, uint8_t* proofs_out) {
+    const auto t_begin = std::chrono::steady_clock::now();
     const uint32_t n_in = bt->n_inputs, n_aux = bt->n_aux, nv = n_in + n_aux, n_rows = bt->n_rows;
     const size_t m = P->m;
     const bool mont = (bt->flags & ZK_FR_MONTGOMERY) != 0;
@@ -854,7 +869,8 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     hipStream_t side = getenv("ZKAMD_NO_OVERLAP") ? g_stream : g_stream2;
     HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
     HIP_TRY(hipStreamWaitEvent(side, g_ev_fork, 0));
-    ZK_TRY(P->g2.enqueue(P->jobs2, P->res2, side));
+    ZK_TRY(P->g2.enqueue(P->jobs2, P->res2, side, false));
+    ZK_TRY(P->g2.normalize_to_host(P->g2.res_dev, np, P->res2.data(), P->fold_b2, side));   // B in affine form
     // ---- H pipeline (create_proof step 3)
     ZK_TRY(P->abc.ensure(3 * np * m * 32));
     uint32_t* A = P->abc.as<uint32_t>();
@@ -890,17 +906,39 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
         MsmJob ja = {w, P->map_a.as<int32_t>(), nv + 3, P->off_a, npts1, 0};
         P->jobs1.push_back(ja);
     }
-    ZK_TRY(P->g1.enqueue(P->jobs1, P->res1, g_stream));
+    ZK_TRY(P->g1.enqueue(P->jobs1, P->res1, g_stream, false));
+    // ---- final fold on the GPU: C = s * A + C' (k_xyzz_scale_add), A and C to affine form; the host
+    // only encodes.  (On the host the fold was 0.47 ms per proof with the GPU idle: 8 % of the step.)
+    {
+        typedef zkdev::XYZZ<zkdev::Fq> DP1;
+        ProfScope ps("proof_fold", g_stream);
+        ZK_TRY(P->fold_tbl.ensure(np * 15 * sizeof(DP1)));
+        ZK_TRY(P->fold_c.ensure(np * sizeof(DP1)));
+        const DP1* cprime = P->g1.res_dev;
+        const DP1* a = P->g1.res_dev + np;
+        ZK_LAUNCH(zkdev::k_xyzz_scale_add<zkdev::Fq>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, a, cprime,
+                  (const uint32_t*)P->tail.as<uint32_t>() + 16, 24u, P->fold_tbl.as<DP1>(), P->fold_c.as<DP1>(), (uint32_t)np);
+        ZK_TRY(P->g1.normalize_to_host(a, np, P->res1.data() + np, P->fold_a1, g_stream));
+        ZK_TRY(P->g1.normalize_to_host(P->fold_c.as<DP1>(), np, P->res1.data(), P->fold_c1, g_stream));
+    }
+    const bool trace_host = getenv("ZKAMD_TRACE_HOST") != nullptr;
+    const auto t_wait = std::chrono::steady_clock::now();
     ZK_TRY(P->g1.collect(g_stream));
     ZK_TRY(P->g2.collect(side));
-    // ---- final fold + encoding (host, one thread per slice of the chunk)
+    const auto t_enc = std::chrono::steady_clock::now();
+    // ---- encoding (host, one thread per slice of the chunk): res1[p] = C, res1[np + p] = A, res2[p] = B
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
     if (nthreads > 32) nthreads = 32;
     if (nthreads > np) nthreads = (unsigned)np;
     auto work = [&](size_t lo, size_t hi) {
         for (size_t p = lo; p < hi; p++)
-            fold_proof(P->res1[p], P->res1[np + p], P->res2[p], &rsv[p * 8 + 4], proofs_out + (first + p) * 192);
+        {
+            uint8_t* out = proofs_out + (first + p) * 192;
+            zkhost::g1_to_compressed(zkhost::to_affine(P->res1[np + p]), out);
+            zkhost::g2_to_compressed(zkhost::to_affine(P->res2[p]), out + 48);
+            zkhost::g1_to_compressed(zkhost::to_affine(P->res1[p]), out + 144);
+        }
     };
     if (nthreads <= 1) {
         work(0, np);
@@ -908,6 +946,13 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
         std::vector<std::thread> ths;
         for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, np * t / nthreads, np * (t + 1) / nthreads);
         for (auto& th : ths) th.join();
+    }
+    if (trace_host) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[zkamd] chunk of %zu: enqueue %.2f ms, wait for the GPU %.2f ms, host encoding %.2f ms\n", np,
+                std::chrono::duration<double, std::milli>(t_wait - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_enc - t_wait).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_enc).count());
     }
     return ZK_OK;
 }
