@@ -107,6 +107,32 @@ struct DevBuf {
     }
 };
 
+// page-locked host memory: asynchronous copies into pageable memory block the calling thread until
+// the copy has run, which would serialise whatever is enqueued after them on other streams
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    PinBuf() {}
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    zk_status ensure(size_t bytes) {
+        if (bytes <= cap) return ZK_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        if (hipHostMalloc(&p, bytes) != hipSuccess) {
+            p = nullptr;
+            return fail(ZK_ERR_OUT_OF_MEMORY, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+        }
+        cap = bytes;
+        return ZK_OK;
+    }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
 // ------------------------------------------------------------------------------------------
 // HIP-event profiling of named kernels (zk_profile_*)
 // ------------------------------------------------------------------------------------------
@@ -343,6 +369,7 @@ struct MsmGroup {
     DevBuf table;
     DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, blockbase, coarse, tbase, rank, pairs, tsums, red_r, red_w, red_t, result;
     DPoint* res_dev = nullptr;
+    PinBuf pin_jobs;
     std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
 
@@ -436,8 +463,12 @@ struct MsmGroup {
         ZK_TRY(red_r.ensure(nj * ((size_t)nb + 2 * (size_t)T) * sizeof(DPoint)));   // suffix sums: level 1 | two upper-level areas
         ZK_TRY(red_w.ensure(2 * nj * (size_t)T * sizeof(DPoint)));  // W of the nodes (ping-pong halves)
         ZK_TRY(red_t.ensure(nj * (size_t)T * sizeof(DPoint)));      // 2M * sum R' of the level being built
-        HIP_TRY(hipMemcpyAsync(jobs_d.p, jobs.data(), nj * sizeof(MsmJob), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(tbase.p, tbase_h.data(), nj * 4, hipMemcpyHostToDevice, st));
+        // job descriptors through page-locked staging (collect() separates consecutive launch sets)
+        ZK_TRY(pin_jobs.ensure(nj * (sizeof(MsmJob) + 4)));
+        memcpy(pin_jobs.p, jobs.data(), nj * sizeof(MsmJob));
+        memcpy((uint8_t*)pin_jobs.p + nj * sizeof(MsmJob), tbase_h.data(), nj * 4);
+        HIP_TRY(hipMemcpyAsync(jobs_d.p, pin_jobs.p, nj * sizeof(MsmJob), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(tbase.p, (const uint8_t*)pin_jobs.p + nj * sizeof(MsmJob), nj * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 2) * 4, st));
         uint32_t* lenhist = hist.as<uint32_t>();
         uint32_t* cursor = lenhist + n_class;
@@ -683,6 +714,7 @@ struct zk_params {
     uint32_t map_nv = 0;
     // workspaces
     DevBuf abc, wit, cvec, tail, stage_a, stage_b, stage_c, stage_w, fold_tbl, fold_c, fold_a1, fold_c1, fold_b2;
+    PinBuf pin_g1, pin_g2, pin_tail;   // affine A, C / B of a chunk; [1 | r | s] per proof
     std::vector<MsmJob> jobs1, jobs2;
     std::vector<HG1> res1;
     std::vector<HG2> res2;
@@ -836,7 +868,9 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     const size_t wstride = (size_t)(nv + 3);
     ZK_TRY(P->wit.ensure(np * wstride * 32));
     uint32_t* wit = P->wit.as<uint32_t>();
-    std::vector<uint8_t> tail(np * 96, 0);
+    ZK_TRY(P->pin_tail.ensure(np * 96));
+    uint8_t* tail = P->pin_tail.as<uint8_t>();
+    memset(tail, 0, np * 96);
     std::vector<uint64_t> rsv(np * 8);
     for (size_t p = 0; p < np; p++) {
         const uint8_t* rr = rs + (first + p) * 64;
@@ -848,7 +882,7 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
         memcpy(&tail[p * 96 + 32], rr, 64);
     }
     ZK_TRY(P->tail.ensure(np * 96));
-    HIP_TRY(hipMemcpyAsync(P->tail.p, tail.data(), np * 96, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(P->tail.p, tail, np * 96, hipMemcpyHostToDevice, g_stream));
     const uint32_t cstride = (uint32_t)(m + n_aux + nv + 1);
     ZK_TRY(P->cvec.ensure(np * (size_t)cstride * 32));
     uint32_t* cvec = P->cvec.as<uint32_t>();
@@ -870,7 +904,9 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
     HIP_TRY(hipStreamWaitEvent(side, g_ev_fork, 0));
     ZK_TRY(P->g2.enqueue(P->jobs2, P->res2, side, false));
-    ZK_TRY(P->g2.normalize_to_host(P->g2.res_dev, np, P->res2.data(), P->fold_b2, side));   // B in affine form
+    ZK_TRY(P->pin_g2.ensure(np * sizeof(HG2)));
+    ZK_TRY(P->pin_g1.ensure(2 * np * sizeof(HG1)));
+    ZK_TRY(P->g2.normalize_to_host(P->g2.res_dev, np, P->pin_g2.as<HG2>(), P->fold_b2, side));   // B in affine form
     // ---- H pipeline (create_proof step 3)
     ZK_TRY(P->abc.ensure(3 * np * m * 32));
     uint32_t* A = P->abc.as<uint32_t>();
@@ -918,15 +954,15 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
         const DP1* a = P->g1.res_dev + np;
         ZK_LAUNCH(zkdev::k_xyzz_scale_add<zkdev::Fq>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, a, cprime,
                   (const uint32_t*)P->tail.as<uint32_t>() + 16, 24u, P->fold_tbl.as<DP1>(), P->fold_c.as<DP1>(), (uint32_t)np);
-        ZK_TRY(P->g1.normalize_to_host(a, np, P->res1.data() + np, P->fold_a1, g_stream));
-        ZK_TRY(P->g1.normalize_to_host(P->fold_c.as<DP1>(), np, P->res1.data(), P->fold_c1, g_stream));
+        ZK_TRY(P->g1.normalize_to_host(a, np, P->pin_g1.as<HG1>() + np, P->fold_a1, g_stream));
+        ZK_TRY(P->g1.normalize_to_host(P->fold_c.as<DP1>(), np, P->pin_g1.as<HG1>(), P->fold_c1, g_stream));
     }
     const bool trace_host = getenv("ZKAMD_TRACE_HOST") != nullptr;
     const auto t_wait = std::chrono::steady_clock::now();
     ZK_TRY(P->g1.collect(g_stream));
     ZK_TRY(P->g2.collect(side));
     const auto t_enc = std::chrono::steady_clock::now();
-    // ---- encoding (host, one thread per slice of the chunk): res1[p] = C, res1[np + p] = A, res2[p] = B
+    // ---- encoding (host, one thread per slice of the chunk): pin_g1[p] = C, pin_g1[np + p] = A, pin_g2[p] = B
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
     if (nthreads > 32) nthreads = 32;
@@ -935,9 +971,9 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
         for (size_t p = lo; p < hi; p++)
         {
             uint8_t* out = proofs_out + (first + p) * 192;
-            zkhost::g1_to_compressed(zkhost::to_affine(P->res1[np + p]), out);
-            zkhost::g2_to_compressed(zkhost::to_affine(P->res2[p]), out + 48);
-            zkhost::g1_to_compressed(zkhost::to_affine(P->res1[p]), out + 144);
+            zkhost::g1_to_compressed(zkhost::to_affine(P->pin_g1.as<HG1>()[np + p]), out);
+            zkhost::g2_to_compressed(zkhost::to_affine(P->pin_g2.as<HG2>()[p]), out + 48);
+            zkhost::g1_to_compressed(zkhost::to_affine(P->pin_g1.as<HG1>()[p]), out + 144);
         }
     };
     if (nthreads <= 1) {
