@@ -73,7 +73,7 @@ constexpr uint32_t MSM_SEG_MAX = 256;
 constexpr uint32_t MSM_NPOS = 255;  // table slices: 2^k * P for k = 0 .. 254
 // buckets with more than `merge_inline` (8) task partials are merged by k_msm_merge_heavy, one
 // workgroup each; the others by the level-1 thread of the reduction (many jobs) or by one thread
-// per bucket ahead of it (k_msm_merge_light: few jobs, where level 1 is a latency chain)
+// per bucket in the trailing workgroups of the same launch (few jobs, where level 1 is a latency chain)
 
 // upper bound on the non-zero digits of one scalar: digits are >= c positions apart, 0 .. 254
 __host__ ZK_DI uint32_t msm_max_digits(uint32_t c) { return 254 / c + 2; }
@@ -342,8 +342,8 @@ k_msm_task_offsets(uint32_t* toff, const uint32_t* __restrict__ bin_tbase, uint3
 
 // Passes 1-3 fused for jobs whose bucket histogram fits LDS (every per-proof job): one workgroup
 // per job counts the digits in an LDS histogram, scans it in place (writing cnt / off / toff for
-// the later passes) and scatters the pairs with LDS tickets.  No global atomics, no rank array:
-// the three-kernel path above spends its time on ~10^8 returning global atomics per chunk.
+// the later passes) and scatters the pairs with LDS tickets.  No global atomics at all; the
+// two-level path above is for histograms that do not fit.
 #ifdef ZK_EMU
 constexpr uint32_t MSM_SORT_THREADS = 64;     // the test-only emulation runs one OS thread per GPU thread
 #else

@@ -4,7 +4,7 @@
 // un-vendored bellman 0.1.0 crate; restated in SURVEY.md Appendix A):
 //   create_proof step 3  (EvaluationDomain H pipeline)   -> ntt.h kernels, NttPlan below
 //   create_proof step 4  (8 x multiexp)                  -> msm.h kernels, MsmGroup below
-//   create_proof step 6  (final fold, into_affine)       -> fold_proof() below (host)
+//   create_proof step 6  (final fold, into_affine)       -> k_xyzz_scale_add / k_xyzz_normalize_export (msm.h)
 //   Parameters::read                                     -> Params::load below
 //   Proof::write                                         -> host_math.h g1/g2_to_compressed
 #include <stdio.h>
