@@ -797,15 +797,45 @@ ZK_DI Affine<F> to_affine(const XYZZ<F>& p) {
     return Affine<F>{mul(p.x, izz), mul(p.y, izzz)};
 }
 
+// One thread per base point walks the doubling chain in extended-Jacobian form and brings the slices
+// to affine form MSM_TABLE_CHUNK at a time with ONE field inversion per chunk (Montgomery's trick:
+// prefix products of the zzz, one inversion, back-substitution) - ~54 field products per table entry
+// instead of one Fermat inversion (~590) each.  `scratch` holds 5 field elements per chunk slot and
+// point, [slot][field][point].  Points at infinity (legal bases, mapped out) and - for unchecked keys
+// - a chain that runs into infinity are carried through as (0, 0).
+constexpr uint32_t MSM_TABLE_CHUNK = 16;
 template <class F>
 __global__ void __launch_bounds__(128)
-k_msm_build_table(Affine<F>* table, uint32_t n, uint32_t npos) {
+k_msm_build_table(Affine<F>* table, uint32_t n, uint32_t npos, F* scratch) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine<F> p = table[i];   // slice 0 was uploaded by the host
-    for (uint32_t k = 1; k < npos; k++) {
-        if (!p.is_inf()) p = to_affine(mdbl(p));   // 2-torsion does not exist in G1 / G2: y != 0
-        table[(size_t)k * n + i] = p;
+    const Affine<F> p0 = table[i];   // slice 0 was uploaded by the host
+    XYZZ<F> cur = p0.is_inf() ? XYZZ<F>::inf() : XYZZ<F>{p0.x, p0.y, F::one(), F::one()};
+    auto slot = [&](uint32_t j, uint32_t f) -> F& { return scratch[((size_t)j * 5 + f) * n + i]; };
+    for (uint32_t k0 = 1; k0 < npos; k0 += MSM_TABLE_CHUNK) {
+        const uint32_t nc = npos - k0 < MSM_TABLE_CHUNK ? npos - k0 : MSM_TABLE_CHUNK;
+        F run = F::one();
+        for (uint32_t j = 0; j < nc; j++) {
+            cur = xdbl(cur);
+            slot(j, 0) = cur.x;
+            slot(j, 1) = cur.y;
+            slot(j, 2) = cur.zz;
+            slot(j, 3) = cur.zzz;
+            slot(j, 4) = run;                                   // product of the zzz before this one
+            if (!cur.is_inf()) run = mul(run, cur.zzz);
+        }
+        F inv_run = inv(run);
+        for (uint32_t j = nc; j-- > 0;) {
+            const XYZZ<F> q{slot(j, 0), slot(j, 1), slot(j, 2), slot(j, 3)};
+            Affine<F> a{F::zero(), F::zero()};
+            if (!q.is_inf()) {
+                const F izzz = mul(inv_run, slot(j, 4));
+                inv_run = mul(inv_run, q.zzz);
+                const F izz = mul(sqr(q.zz), sqr(izzz));       // zz^2 / zzz^2 = 1 / zz
+                a = Affine<F>{mul(q.x, izz), mul(q.y, izzz)};
+            }
+            table[(size_t)(k0 + j) * n + i] = a;
+        }
     }
 }
 

@@ -394,10 +394,14 @@ struct MsmGroup {
             HIP_TRY(hipStreamSynchronize(g_stream));
         }
         if (checked) ZK_TRY((check_points_dev<HF, DF>(table.as<DAffine>(), n_points, what)));
-        ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3(blocks), dim3(128), 0, g_stream, table.as<DAffine>(),
-                  (uint32_t)n_points, zkdev::MSM_NPOS);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        {
+            DevBuf scratch;   // chunk of un-normalised slices + prefix products, freed after the build
+            ZK_TRY(scratch.ensure((size_t)zkdev::MSM_TABLE_CHUNK * 5 * sizeof(DF) * n_points));
+            ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3(blocks), dim3(128), 0, g_stream, table.as<DAffine>(),
+                      (uint32_t)n_points, zkdev::MSM_NPOS, scratch.as<DF>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(g_stream));
+        }
         return ZK_OK;
     }
 
