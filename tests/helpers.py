@@ -69,6 +69,27 @@ def g2_of(k):
 
 
 @functools.lru_cache(maxsize=None)
+def anonymous_case(n_witnesses=1, seed=1):
+    """The reference's anonymous-transfer circuit (oracle/anonymous_circuit.py: 12 members, 105 inputs,
+    evaluation domain 2^16), a synthetic CRS from known toxic waste and `n_witnesses` satisfying
+    assignments.  Returns (r1cs, [assignment], Params(scalars), pk bytes)."""
+    from oracle import anonymous_circuit as ac
+    E = g.Bls12Engine()
+    r1cs, asgs = None, []
+    for i in range(n_witnesses):
+        cs = ac.synthesize(ac.make_witness(seed + i, amount=10 + i, balance=100 + 3 * i))
+        assert cs.which_is_unsatisfied() is None
+        if r1cs is None:
+            r1cs = cs.to_r1cs()
+        asg = g.assign(E, r1cs, cs.inputs, cs.aux)
+        assert g.is_satisfied(E, asg)
+        asgs.append(asg)
+    P = g.generate_parameters(E, r1cs, *TOXIC, scalars_only=True)
+    pk = params_io.write_parameters_from_scalars(P.sc, r1cs.n_in, threads=8)
+    return r1cs, asgs, P, pk
+
+
+@functools.lru_cache(maxsize=None)
 def transfer_case(n_witnesses=1, seed=1):
     """The reference's confidential-transfer circuit (oracle/transfer_circuit.py, fingerprint-checked
     against core/proofs/src/circuit/confidential_transfer.rs:383-386), a synthetic CRS from known

@@ -143,6 +143,29 @@ def test_transfer_circuit_from_witness(gpu_lib):
         params.close()
 
 
+def test_anonymous_circuit_from_witness(gpu_lib):
+    """The reference's second circuit (anonymous transfer: 50 514 constraints, 105 inputs, evaluation
+    domain 2^16) through the same kernels: proofs from the variable assignments, bit-exact against the
+    discrete-log oracle."""
+    import zero_chain_amd as zk
+    r1, asgs, P, pk = helpers.anonymous_case(2)
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices(r1.n_in, r1.n_aux, r1.constraints, lib=gpu_lib)
+    try:
+        assert params.info["log_domain"] == 16 and params.info["n_ic"] == 105
+        rs = [(23 + i, 999983 * (i + 1)) for i in range(3)]
+        batch = [asgs[i % len(asgs)] for i in range(3)]
+        proofs = zk.create_proofs_from_witness(mats, params, [a.inputs + a.aux for a in batch], rs)
+        for a, (r, s), pf in zip(batch, rs, proofs):
+            assert pf.write() == helpers.expected_proof_trapdoor(P, a, r, s)
+        # and through the assignment boundary (zk_prove)
+        pf = zk.create_proof(helpers.to_assignment(zk, asgs[1]), params, 5, 7)
+        assert pf.write() == helpers.expected_proof_trapdoor(P, asgs[1], 5, 7)
+    finally:
+        mats.close()
+        params.close()
+
+
 def test_transfer_prove_from_statements(gpu_lib, monkeypatch):
     """zk_transfer_prove_batch: native witness calculator (host) -> A z, B z, C z (GPU) -> create_proof,
     from the ten private values of each statement; proofs equal the trapdoor proofs of the oracle's
