@@ -181,6 +181,25 @@ zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_
 zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
                                   const uint8_t* rs, uint8_t* proofs_out);
 
+/* The value half of AnonymousTransfer::synthesize (core/proofs/src/circuit/anonymous_transfer.rs:56-337,
+ * anonimity_set.rs; ANONIMITY_SIZE = 12, constants.rs:1): the private values of the instance (:40-54) ->
+ * the variable assignment bellman's ProvingAssignment would hold, [105 inputs | 50429 aux].  Scalars are
+ * FsRepr::write_le bytes, points edwards::Point::write bytes; member i of the anonymity set owns
+ * enc_keys[i], left_ciphertexts[i] and its encrypted balance (left, right).  Prove with
+ * zk_prove_batch_witness over the circuit's matrices (zk_r1cs_load). */
+#define ZK_ANONYMOUS_SIZE 12
+#define ZK_ANONYMOUS_N_INPUTS 105
+#define ZK_ANONYMOUS_N_AUX 50429
+typedef struct {
+    uint32_t amount, remaining_balance, s_index, t_index;
+    uint8_t randomness[32], alpha[32], dec_key[32];
+    uint8_t proof_generation_key[32], g_epoch[32];
+    uint8_t enc_keys[ZK_ANONYMOUS_SIZE][32], left_ciphertexts[ZK_ANONYMOUS_SIZE][32];
+    uint8_t enc_balances_left[ZK_ANONYMOUS_SIZE][32], enc_balances_right[ZK_ANONYMOUS_SIZE][32];
+} zk_anonymous_statement;
+/* witness_out: n x (105 + 50429) x 32 bytes; plain little-endian, or Montgomery limbs with ZK_FR_MONTGOMERY */
+zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out);
+
 /* ------------------------------------------------------------------------------------------
  * Stand-alone kernels (micro-benchmark / test entries)
  * ------------------------------------------------------------------------------------------ */

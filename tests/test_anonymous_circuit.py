@@ -73,3 +73,42 @@ def test_two_oracles_agree_on_a_proof():
     got = cp.create_proof(helpers.le(a0.a), helpers.le(a0.b), helpers.le(a0.c), helpers.le(a0.inputs), helpers.le(a0.aux),
                           bytes(a0.a_aux_density), bytes(a0.b_input_density), bytes(a0.b_aux_density), bls.fr_le(r), bls.fr_le(s), 8)
     assert got == helpers.expected_proof_trapdoor(P, a0, r, s)
+
+
+# ---- the product's native witness calculator (zk_anonymous_witness: host code of libzkamd.so, no GPU
+# needed) against the oracle circuit
+def test_native_witness_matches_oracle_vector():
+    import zero_chain_amd as zk
+    lib = zk.load_library()
+    ws = [ac.make_witness(s, amount=10 + s, balance=1000 + 13 * s) for s in (1, 2, 5)]
+    ws.append(ac.make_witness(8, amount=0, balance=0))
+    ws.append(ac.make_witness(9, amount=0xFFFFFFFE, balance=0xFFFFFFFE))
+    sts = zk.anonymous_statements([ac.statement_dict(w) for w in ws])
+    nv = 105 + 50429
+    plain = zk.anonymous_witness(sts, lib=lib)
+    mont = zk.anonymous_witness(sts, montgomery=True, lib=lib)
+    for i, w in enumerate(ws):
+        cs = ac.synthesize(w)
+        assert cs.which_is_unsatisfied() is None
+        want = cs.inputs + cs.aux
+        got = zk.bytes_to_scalars(plain[i * nv * 32:(i + 1) * nv * 32])
+        assert got == want, "statement %d differs at variable %d" % (i, next(j for j in range(nv) if got[j] != want[j]))
+        gm = zk.bytes_to_scalars(mont[i * nv * 32:(i + 1) * nv * 32])
+        assert [bls.fr_from_mont(x) for x in gm[:200]] == want[:200]
+
+
+def test_native_witness_rejects_bad_statements():
+    import zero_chain_amd as zk
+    lib = zk.load_library()
+    d = ac.statement_dict(ac.make_witness(1))
+    with pytest.raises(zk.ZkError) as e:
+        zk.anonymous_witness(zk.anonymous_statements([dict(d, s_index=12)]), lib=lib)
+    assert e.value.variant == "InvalidArgument" and "index" in str(e.value)
+    keys = list(d["enc_keys"])
+    keys[7] = bytes([0xff] * 32)                                 # y >= r: not in the field
+    with pytest.raises(zk.ZkError) as e:
+        zk.anonymous_witness(zk.anonymous_statements([dict(d, enc_keys=keys)]), lib=lib)
+    assert e.value.variant == "InvalidArgument" and "enc_keys[7]" in str(e.value)
+    with pytest.raises(zk.ZkError) as e:
+        zk.anonymous_witness(zk.anonymous_statements([dict(d, dec_key=jj.FS_MOD)]), lib=lib)
+    assert e.value.variant == "InvalidArgument" and "dec_key" in str(e.value)

@@ -24,7 +24,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
                    ZK_NTT_OUT_BITREV)
 
 __all__ = ["Parameters", "Proof", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
-           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness",
+           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "anonymous_statements", "anonymous_witness",
            "transfer_prove_batch", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
@@ -321,6 +321,37 @@ def transfer_witness(statements, montgomery=False, lib=None):
     n = len(statements)
     out = np.zeros(n * (TRANSFER_N_INPUTS + TRANSFER_N_AUX) * 32, dtype=np.uint8)
     lib.check(lib.zk_transfer_witness(statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
+    return out
+
+
+ANONYMOUS_SIZE, ANONYMOUS_N_INPUTS, ANONYMOUS_N_AUX = 12, 105, 50429
+
+
+def anonymous_statements(items):
+    """items: dicts with amount, remaining_balance, s_index, t_index (ints), randomness, alpha, dec_key (Fs
+    ints), proof_generation_key, g_epoch (32-byte Jubjub encodings) and enc_keys, left_ciphertexts,
+    enc_balances_left, enc_balances_right (12 encodings each) -> ctypes array of zk_anonymous_statement."""
+    arr = (_lib.AnonymousStatement * len(items))()
+    for st, it in zip(arr, items):
+        st.amount, st.remaining_balance, st.s_index, st.t_index = it["amount"], it["remaining_balance"], it["s_index"], it["t_index"]
+        for name in ("randomness", "alpha", "dec_key"):
+            getattr(st, name)[:] = int(it[name]).to_bytes(32, "little")
+        for name in ("proof_generation_key", "g_epoch"):
+            getattr(st, name)[:] = bytes(it[name])
+        for name in ("enc_keys", "left_ciphertexts", "enc_balances_left", "enc_balances_right"):
+            if len(it[name]) != ANONYMOUS_SIZE:
+                raise ValueError("%s: expected %d members" % (name, ANONYMOUS_SIZE))
+            for k, enc in enumerate(it[name]):
+                getattr(st, name)[k][:] = bytes(enc)
+    return arr
+
+
+def anonymous_witness(statements, montgomery=False, lib=None):
+    """zk_anonymous_witness: the (105 + 50429) x 32-byte variable assignment of every statement."""
+    lib = lib or _lib.load()
+    n = len(statements)
+    out = np.zeros(n * (ANONYMOUS_N_INPUTS + ANONYMOUS_N_AUX) * 32, dtype=np.uint8)
+    lib.check(lib.zk_anonymous_witness(statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
     return out
 
 

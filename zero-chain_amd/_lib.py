@@ -52,6 +52,12 @@ class TransferStatement(C.Structure):
                                               "enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch")]
 
 
+class AnonymousStatement(C.Structure):
+    _fields_ = [("amount", C.c_uint32), ("remaining_balance", C.c_uint32), ("s_index", C.c_uint32), ("t_index", C.c_uint32)] + \
+               [(n, C.c_uint8 * 32) for n in ("randomness", "alpha", "dec_key", "proof_generation_key", "g_epoch")] + \
+               [(n, (C.c_uint8 * 32) * 12) for n in ("enc_keys", "left_ciphertexts", "enc_balances_left", "enc_balances_right")]
+
+
 class BatchDev(C.Structure):
     _fields_ = [("n_rows", C.c_uint32), ("n_inputs", C.c_uint32), ("n_aux", C.c_uint32), ("flags", C.c_uint32),
                 ("d_a", C.c_void_p), ("d_b", C.c_void_p), ("d_c", C.c_void_p), ("d_wit", C.c_void_p),
@@ -75,6 +81,7 @@ _PROTOS = {
     "zk_transfer_witness": (C.c_int32, [C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_transfer_prove_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TransferStatement), C.c_void_p,
                                             C.c_void_p]),
+    "zk_anonymous_witness": (C.c_int32, [C.POINTER(AnonymousStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_msm_create": (C.c_int32, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_msm_run": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zk_msm_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),

@@ -109,8 +109,8 @@ inline const Tables& tables() {
 struct Wit {
     std::vector<Fr> inputs, aux;
     Wit() {
-        inputs.reserve(23);
-        aux.reserve(19955);
+        inputs.reserve(128);
+        aux.reserve(51200);
         inputs.push_back(Fr::one());
     }
     void alloc(const Fr& v) { aux.push_back(v); }
@@ -311,6 +311,106 @@ inline void synthesize(const Statement& s, Wit& w) {
     (void)bi_right;   // eq_edwards_points allocates nothing; an inconsistent statement simply does not verify
     w.inputize(s.enc_balance_left);
     w.inputize(s.enc_balance_right);
+    // rvk_inputize (utils.rs:71-123)
+    witness_point(w, s.pgk);
+    assert_not_small_order(w, s.pgk);
+    Bits alpha_bits = field_into_boolean_vec_le(w, s.alpha);
+    JPoint alpha_g = fixed_base_multiplication(w, alpha_bits);
+    JPoint rvk = point_add(w, s.pgk, alpha_g);
+    assert_not_small_order(w, rvk);
+    w.inputize(rvk);
+    // g_epoch_nonce_inputize (utils.rs:125-154)
+    witness_point(w, s.g_epoch);
+    JPoint nonce = point_mul(w, s.g_epoch, dec_key_bits);
+    w.inputize(s.g_epoch);
+    w.inputize(nonce);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The anonymous-transfer circuit (core/proofs/src/circuit/anonymous_transfer.rs:56-337,
+// anonimity_set.rs), values only, in the allocation order of oracle/anonymous_circuit.py.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t ANON_SIZE = 12;   // core/proofs/src/constants.rs:1
+
+// EdwardsPoint::conditionally_select: x', y' = the point, or the neutral element (0, 1)
+inline JPoint cond_select(Wit& w, const JPoint& p, bool on) {
+    const JPoint sel = on ? p : JPoint{Fr::zero(), Fr::one()};
+    w.alloc(sel.x);
+    w.alloc(sel.y);
+    return sel;
+}
+// Binary::edwards_add_fold (anonimity_set.rs:155-185): per member [x', y'] [the six values of the
+// addition into the running sum]; the sums are brought to affine form together.
+inline JPoint add_fold(Wit& w, const uint8_t* bins, const JPoint* points, size_t n) {
+    std::vector<EPoint> run(n);
+    for (size_t i = 0; i < n; i++) {
+        const EPoint sel = bins[i] ? to_ext(points[i]) : ext_zero();
+        run[i] = ext_add(i ? run[i - 1] : ext_zero(), sel);
+    }
+    std::vector<JPoint> sums(n);
+    batch_to_affine(run.data(), sums.data(), n);
+    const JPoint neutral{Fr::zero(), Fr::one()};
+    for (size_t i = 0; i < n; i++) {
+        const JPoint sel = cond_select(w, points[i], bins[i] != 0);
+        size_t at = w.reserve_aux(6);
+        fill_add(&w.aux[at], i ? sums[i - 1] : neutral, sel, sums[i]);
+    }
+    return sums[n - 1];
+}
+
+struct AnonStatement {
+    uint32_t amount, remaining_balance, s_index, t_index;
+    uint64_t randomness[4], alpha[4], dec_key[4];   // Fs, plain little-endian limbs
+    JPoint pgk, g_epoch;
+    JPoint enc_keys[ANON_SIZE], left_ciphertexts[ANON_SIZE], balance_left[ANON_SIZE], balance_right[ANON_SIZE];
+};
+
+inline void synthesize_anonymous(const AnonStatement& s, Wit& w) {
+    const JPoint neutral{Fr::zero(), Fr::one()};
+    witness_point(w, neutral);                                                   // zero_p
+    Bits amount_bits = u32_into_bit_vec_le(w, s.amount);
+    JPoint amount_g = fixed_base_multiplication(w, amount_bits);
+    Bits remaining_bits = u32_into_bit_vec_le(w, s.remaining_balance);
+    JPoint remaining_g = fixed_base_multiplication(w, remaining_bits);
+    Bits dec_key_bits = field_into_boolean_vec_le(w, s.dec_key);
+    uint8_t s_bins[ANON_SIZE], t_bins[ANON_SIZE], xor_st[ANON_SIZE], nor_st[ANON_SIZE];
+    for (size_t i = 0; i < ANON_SIZE; i++) w.alloc(fr_u64(s_bins[i] = (i == s.s_index)));
+    for (size_t i = 0; i < ANON_SIZE; i++) w.alloc(fr_u64(t_bins[i] = (i == s.t_index)));
+    for (size_t i = 0; i < ANON_SIZE; i++) witness_point(w, s.enc_keys[i]);
+    add_fold(w, s_bins, s.enc_keys, ANON_SIZE);                                  // sum s_i y_i
+    fixed_base_multiplication(w, dec_key_bits);                                  // sk * G
+    Bits randomness_bits = field_into_boolean_vec_le(w, s.randomness);
+    JPoint keys_mul_random[ANON_SIZE];
+    for (size_t i = 0; i < ANON_SIZE; i++) keys_mul_random[i] = point_mul(w, s.enc_keys[i], randomness_bits);
+    for (size_t i = 0; i < ANON_SIZE; i++) witness_point(w, s.left_ciphertexts[i]);
+    JPoint fold_t = add_fold(w, t_bins, keys_mul_random, ANON_SIZE);
+    point_add(w, fold_t, amount_g);
+    add_fold(w, t_bins, s.left_ciphertexts, ANON_SIZE);
+    for (size_t i = 0; i < ANON_SIZE; i++) w.alloc(fr_u64(xor_st[i] = s_bins[i] ^ t_bins[i]));
+    add_fold(w, xor_st, keys_mul_random, ANON_SIZE);
+    add_fold(w, xor_st, s.left_ciphertexts, ANON_SIZE);
+    for (size_t i = 0; i < ANON_SIZE; i++) w.alloc(fr_u64(nor_st[i] = !s_bins[i] && !t_bins[i]));
+    for (size_t i = 0; i < ANON_SIZE; i++) {                                     // Binary::conditionally_equals
+        cond_select(w, s.left_ciphertexts[i], nor_st[i] != 0);
+        cond_select(w, keys_mul_random[i], nor_st[i] != 0);
+    }
+    for (size_t i = 0; i < ANON_SIZE; i++) w.inputize(s.enc_keys[i]);
+    for (size_t i = 0; i < ANON_SIZE; i++) w.inputize(s.left_ciphertexts[i]);
+    // balance integrity
+    for (size_t i = 0; i < ANON_SIZE; i++) witness_point(w, s.balance_left[i]);
+    JPoint added_lefts[ANON_SIZE];
+    for (size_t i = 0; i < ANON_SIZE; i++) added_lefts[i] = point_add(w, s.balance_left[i], s.left_ciphertexts[i]);
+    add_fold(w, s_bins, added_lefts, ANON_SIZE);
+    for (size_t i = 0; i < ANON_SIZE; i++) witness_point(w, s.balance_right[i]);
+    JPoint right_fold = add_fold(w, s_bins, s.balance_right, ANON_SIZE);
+    Bits randomness_bits2 = field_into_boolean_vec_le(w, s.randomness);          // allocated a second time (anonymous_transfer.rs:273)
+    JPoint right_ciphertext = fixed_base_multiplication(w, randomness_bits2);
+    JPoint cr_d = point_add(w, right_fold, right_ciphertext);
+    JPoint cr_d_mul_sk = point_mul(w, cr_d, dec_key_bits);
+    point_add(w, remaining_g, cr_d_mul_sk);
+    for (size_t i = 0; i < ANON_SIZE; i++) w.inputize(s.balance_left[i]);
+    for (size_t i = 0; i < ANON_SIZE; i++) w.inputize(s.balance_right[i]);
+    w.inputize(right_ciphertext);
     // rvk_inputize (utils.rs:71-123)
     witness_point(w, s.pgk);
     assert_not_small_order(w, s.pgk);

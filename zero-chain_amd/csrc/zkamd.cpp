@@ -1282,11 +1282,12 @@ zk_status transfer_decode(const zk_transfer_statement& in, size_t index, zkwit::
     return ZK_OK;
 }
 
-zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* out) {
-    if ((!st || !out) && n) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+// n statements -> n variable assignments on the host cores.  decode(i, &statement) / synth(statement, wit).
+template <class Stmt, class Decode, class Synth>
+zk_status witness_batch(size_t n, size_t n_inputs, size_t n_aux, uint32_t flags, uint8_t* out, Decode&& decode, Synth&& synth) {
     if (n == 0) return ZK_OK;
     (void)zkwit::tables();   // build the window tables before the threads start
-    const size_t nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX;
+    const size_t nv = n_inputs + n_aux;
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads == 0) nthreads = 1;
     if (nthreads > 64) nthreads = 64;
@@ -1296,16 +1297,16 @@ zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t f
     const bool mont = (flags & ZK_FR_MONTGOMERY) != 0;
     auto work = [&](unsigned t) {
         for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
-            zkwit::Statement s;
-            zk_status rc = transfer_decode(st[i], i, &s);
+            Stmt s;
+            zk_status rc = decode(i, &s);
             if (rc != ZK_OK) {
                 sts[t] = rc;
                 msgs[t] = g_err;
                 return;
             }
             zkwit::Wit w;
-            zkwit::synthesize(s, w);
-            if (w.inputs.size() != ZK_TRANSFER_N_INPUTS || w.aux.size() != ZK_TRANSFER_N_AUX) {
+            synth(s, w);
+            if (w.inputs.size() != n_inputs || w.aux.size() != n_aux) {
                 sts[t] = ZK_ERR_INVALID_ARGUMENT;
                 msgs[t] = "internal: witness size mismatch";
                 return;
@@ -1330,6 +1331,60 @@ zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t f
     for (unsigned t = 0; t < nthreads; t++)
         if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
     return ZK_OK;
+}
+
+zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* out) {
+    if ((!st || !out) && n) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    return witness_batch<zkwit::Statement>(
+        n, ZK_TRANSFER_N_INPUTS, ZK_TRANSFER_N_AUX, flags, out,
+        [&](size_t i, zkwit::Statement* s) { return transfer_decode(st[i], i, s); },
+        [](const zkwit::Statement& s, zkwit::Wit& w) { zkwit::synthesize(s, w); });
+}
+
+zk_status decode_fs(const uint8_t* b, uint64_t (&v)[4], size_t index, const char* what) {
+    static const uint64_t FS[4] = ZK_JUBJUB_FS_MODULUS_64;
+    load_scalar_le(b, v);
+    for (int i = 3; i >= 0; i--) {
+        if (v[i] < FS[i]) return ZK_OK;
+        if (v[i] > FS[i]) break;
+    }
+    return fail(ZK_ERR_INVALID_ARGUMENT, "statement " + std::to_string(index) + ": " + what + " is not a canonical Fs scalar");
+}
+zk_status decode_jubjub(const uint8_t* b, zkwit::JPoint* p, size_t index, const std::string& what) {
+    if (!zkwit::decode_point(b, p))
+        return fail(ZK_ERR_INVALID_ARGUMENT, "statement " + std::to_string(index) + ": " + what + " is not a Jubjub point");
+    return ZK_OK;
+}
+
+zk_status anonymous_decode(const zk_anonymous_statement& in, size_t index, zkwit::AnonStatement* out) {
+    if (in.s_index >= ZK_ANONYMOUS_SIZE || in.t_index >= ZK_ANONYMOUS_SIZE)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "statement " + std::to_string(index) + ": member index out of range");
+    out->amount = in.amount;
+    out->remaining_balance = in.remaining_balance;
+    out->s_index = in.s_index;
+    out->t_index = in.t_index;
+    ZK_TRY(decode_fs(in.randomness, out->randomness, index, "randomness"));
+    ZK_TRY(decode_fs(in.alpha, out->alpha, index, "alpha"));
+    ZK_TRY(decode_fs(in.dec_key, out->dec_key, index, "dec_key"));
+    ZK_TRY(decode_jubjub(in.proof_generation_key, &out->pgk, index, "proof_generation_key"));
+    ZK_TRY(decode_jubjub(in.g_epoch, &out->g_epoch, index, "g_epoch"));
+    for (size_t k = 0; k < ZK_ANONYMOUS_SIZE; k++) {
+        const std::string m = "[" + std::to_string(k) + "]";
+        ZK_TRY(decode_jubjub(in.enc_keys[k], &out->enc_keys[k], index, "enc_keys" + m));
+        ZK_TRY(decode_jubjub(in.left_ciphertexts[k], &out->left_ciphertexts[k], index, "left_ciphertexts" + m));
+        ZK_TRY(decode_jubjub(in.enc_balances_left[k], &out->balance_left[k], index, "enc_balances_left" + m));
+        ZK_TRY(decode_jubjub(in.enc_balances_right[k], &out->balance_right[k], index, "enc_balances_right" + m));
+    }
+    return ZK_OK;
+}
+
+zk_status anonymous_witness(const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* out) {
+    if ((!st || !out) && n) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    static_assert(zkwit::ANON_SIZE == ZK_ANONYMOUS_SIZE, "anonymity set size");
+    return witness_batch<zkwit::AnonStatement>(
+        n, ZK_ANONYMOUS_N_INPUTS, ZK_ANONYMOUS_N_AUX, flags, out,
+        [&](size_t i, zkwit::AnonStatement* s) { return anonymous_decode(st[i], i, s); },
+        [](const zkwit::AnonStatement& s, zkwit::Wit& w) { zkwit::synthesize_anonymous(s, w); });
 }
 
 }  // namespace
@@ -1601,6 +1656,9 @@ zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const
 
 zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
     return transfer_witness(st, n, flags, witness_out);
+}
+zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
+    return anonymous_witness(st, n, flags, witness_out);
 }
 zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
                                   const uint8_t* rs, uint8_t* proofs_out) {
