@@ -17,7 +17,8 @@ inputs, 19 955 aux variables -> 19 997 rows -> domain 2^15, constraint-system ha
 and checked against that fingerprint) - under a synthetic CRS (fixed toxic waste; the reference's
 proving keys are missing blobs).  Witnesses: 8 different transfer statements (keys, amounts,
 balances from a seeded stream) cycled through the batch, every proof with its own r, s.
-Every proof of the last step is checked against the oracle before the line is printed.
+One proof per distinct witness and the last proof of the last step are checked against the oracle
+before the line is printed (`config.proofs_checked_vs_oracle`).
 
 The JSON line carries, besides the contract fields:
   roofline      dominant kernel (G1 bucket accumulation): algorithmic bytes (128 B per multiexp
