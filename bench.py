@@ -277,6 +277,18 @@ def main():
         assert got[-1].write() == out[192 * (hb - 1):192 * hb].tobytes()
         pcie["four_chunks"] = {"value": round(4 * hb / dt, 3), "unit": "proofs/s", "proofs": 4 * hb,
                                "note": "chunk k + 1 staged while the GPU proves chunk k"}
+        # one proof at a time (the reference's own call pattern: one create_random_proof per transaction)
+        try:
+            zk.create_proof(pas[0], params, *rs_ints[0])
+            t0 = time.perf_counter()
+            for i in range(5):
+                one = zk.create_proof(pas[i % n_wit], params, *rs_ints[i])
+            dt1 = (time.perf_counter() - t0) / 5
+            assert one.write() == out[192 * 4:192 * 5].tobytes()
+            pcie["single_proof_latency_ms"] = round(dt1 * 1e3, 2)
+        except Exception as exc:   # never lose the bench line over a side measurement
+            pcie["single_proof_latency_ms"] = None
+            pcie["single_proof_error"] = repr(exc)[:200]
         # the same batch from the variable assignments alone (zk_prove_batch_witness): a quarter of the
         # bytes cross PCIe, A z / B z / C z are evaluated on the GPU from the resident constraint matrices
         r1cs = WORKLOAD_R1CS[0]
