@@ -188,6 +188,24 @@ def prover_small(lib, seed, n_in, n_aux, n_con, checked=True, montgomery=False):
         params.close()
 
 
+def prover_blinding_edges(lib, seed=3):
+    """r and s at the ends of the field: s = 0 leaves the fold's accumulator at infinity (C = C'),
+    s = 1 and s = r - 1 make it A and -A, r = 0 removes the delta / B1 terms of A and C'."""
+    r1, asg, P, pk = helpers.small_case(seed, 3, 12, 14)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    R = bls.R_MOD
+    try:
+        pairs = [(0, 0), (0, 5), (7, 0), (1, 1), (R - 1, R - 1), (R - 1, 1), (2, R - 2)]
+        pa = helpers.to_assignment(zk, asg)
+        for r, s in pairs:
+            assert zk.create_proof(pa, params, r, s).write() == helpers.expected_proof_trapdoor(P, asg, r, s), (r, s)
+        proofs = zk.create_proofs([pa] * len(pairs), params, pairs)
+        for (r, s), pf in zip(pairs, proofs):
+            assert pf.write() == helpers.expected_proof_trapdoor(P, asg, r, s), (r, s)
+    finally:
+        params.close()
+
+
 def prover_batch(lib, seed, n_in, n_aux, n_proofs, use_c_oracle=True):
     """One circuit, n different statements / witnesses / (r, s)."""
     E = g.Bls12Engine()

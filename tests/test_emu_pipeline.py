@@ -110,3 +110,8 @@ def test_msm_sliced(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "6")
     pc.msm_golden_vectors(emu_lib, 1, 300, 0, seed=14)
     pc.msm_golden_vectors(emu_lib, 2, 150, 0, seed=15)
+
+
+def test_prover_blinding_edges(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
+    pc.prover_blinding_edges(emu_lib)

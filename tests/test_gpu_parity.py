@@ -111,6 +111,10 @@ def test_prover_small(gpu_lib):
     pc.prover_small(gpu_lib, 7, 4, 300, 330, checked=False, montgomery=True)
 
 
+def test_prover_blinding_edges(gpu_lib):
+    pc.prover_blinding_edges(gpu_lib)
+
+
 def test_prover_batch(gpu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "3")
     pc.prover_batch(gpu_lib, 4, 3, 12, 5)
