@@ -25,7 +25,9 @@
  *   - status codes 1..8 map 1:1 onto bellman's SynthesisError variants
  *     (mirrored in-tree at core/bellman-verifier/src/lib.rs:359-383).
  *   - one handle may be used from one host thread at a time (the reference caller is
- *     single-threaded).
+ *     single-threaded); different handles - on the same or on different GPUs - may be used from
+ *     different threads: streams live in a per-device context, the current device is selected on
+ *     every entry.
  */
 #ifndef ZKAMD_H
 #define ZKAMD_H
@@ -61,6 +63,10 @@ const char* zk_strerror(zk_status st);
 /* Human-readable detail of the last failure on this thread (HIP error string, offending index). */
 const char* zk_last_error(void);
 zk_status zk_device_count(int* count);
+/* Host threads the library may use for its CPU-side legs (witness calculation of zk_transfer_*,
+ * proof encoding).  0 = default: ZKAMD_HOST_THREADS, else the cores of the process's affinity mask.
+ * One process per GPU on a multi-GPU node should pass cores / ranks. */
+void zk_set_host_threads(int n);
 
 /* ------------------------------------------------------------------------------------------
  * Parameters  (bellman groth16::Parameters<Bls12>)

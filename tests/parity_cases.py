@@ -326,5 +326,74 @@ def prover_errors(lib):
                                              bytes(unsat.b_input_density), bytes(unsat.b_aux_density), bls.fr_le(7),
                                              bls.fr_le(9), 1)
         assert got == want
+        # a non-canonical scalar (v + r < 2^256) anywhere in the assignment is refused: the reference cannot
+        # represent such an Fr (FrRepr -> Fr fails, fr.rs:276-289)
+        for field in ("aux", "inputs", "a", "b", "c"):
+            vals = {k: list(getattr(asg, k)) for k in ("a", "b", "c", "inputs", "aux")}
+            idx = 1 if field != "a" else 0
+            if vals[field][idx] + bls.R_MOD >= 1 << 256:
+                continue
+            vals[field][idx] += bls.R_MOD
+            noncanon = zk.ProvingAssignment.from_ints(vals["a"], vals["b"], vals["c"], vals["inputs"], vals["aux"],
+                                                      asg.a_aux_density, asg.b_input_density, asg.b_aux_density)
+            with pytest.raises(zk.ZkError) as e:
+                zk.create_proof(noncanon, params, 1, 1)
+            assert e.value.variant == "InvalidArgument" and "canonical" in str(e.value), field
+        # ... and so is an assignment whose first input is not ONE
+        not_one = zk.ProvingAssignment.from_ints(asg.a, asg.b, asg.c, [2] + list(asg.inputs[1:]), asg.aux, asg.a_aux_density,
+                                                 asg.b_input_density, asg.b_aux_density)
+        with pytest.raises(zk.ZkError) as e:
+            zk.create_proof(not_one, params, 1, 1)
+        assert e.value.variant == "InvalidArgument" and "ONE" in str(e.value)
+        # an assignment whose densities do not match the key's queries belongs to another circuit
+        j = list(asg.a_aux_density).index(True)
+        thin = list(asg.a_aux_density)
+        thin[j] = False
+        other = zk.ProvingAssignment.from_ints(asg.a, asg.b, asg.c, asg.inputs, asg.aux, thin, asg.b_input_density,
+                                               asg.b_aux_density)
+        with pytest.raises(zk.ZkError) as e:
+            zk.create_proof(other, params, 1, 1)
+        assert e.value.variant == "IoError" and "density" in str(e.value)
+        # the prover still works after every refusal
+        assert zk.create_proof(pa, params, 7, 9).write() == helpers.expected_proof_trapdoor(P, asg, 7, 9)
+    finally:
+        params.close()
+    # bellman reads vk.alpha / beta / gamma / delta with a plain into_affine(): infinity is accepted at load, and
+    # create_proof answers a delta at infinity with SynthesisError::UnexpectedIdentity
+    for off, size in ((96 * 2 + 192 * 2, 96), (96 * 3 + 192 * 2, 192)):   # delta_g1, delta_g2
+        ident = bytearray(pk)
+        ident[off:off + size] = bytes([0x40]) + bytes(size - 1)
+        params = zk.Parameters.read(bytes(ident), checked=True, lib=lib)
+        try:
+            with pytest.raises(zk.ZkError) as e:
+                zk.create_proof(helpers.to_assignment(zk, asg), params, 1, 1)
+            assert e.value.variant == "UnexpectedIdentity"
+        finally:
+            params.close()
+    # ... while vk points off the curve are refused even unchecked (the vk is always read checked), and an
+    # infinity inside vk.ic is an error
+    offc = bytearray(pk)
+    offc[95] ^= 1                                     # alpha_g1.y
+    with pytest.raises(zk.ZkError) as e:
+        zk.Parameters.read(bytes(offc), checked=False, lib=lib)
+    assert e.value.variant == "IoError"
+    icinf = bytearray(pk)
+    icinf[864 + 4:864 + 4 + 96] = bytes([0x40]) + bytes(95)
+    with pytest.raises(zk.ZkError) as e:
+        zk.Parameters.read(bytes(icinf), checked=False, lib=lib)
+    assert e.value.variant == "IoError"
+    # alpha_g1 at infinity is a legal (if useless) key: the proof is the one computed without that term
+    al = bytearray(pk)
+    al[0:96] = bytes([0x40]) + bytes(95)
+    params = zk.Parameters.read(bytes(al), checked=False, lib=lib)
+    try:
+        got = zk.create_proof(helpers.to_assignment(zk, asg), params, 7, 9).write()
+        # discrete logs of the proof without the alpha_g1 terms: A - alpha, C - s * alpha
+        a_s, b_s, c_s = g.create_proof_trapdoor(g.Bls12Engine(), P, asg, 7, 9)
+        a_s, c_s = (a_s - P.sc["alpha"]) % bls.R_MOD, (c_s - 9 * P.sc["alpha"]) % bls.R_MOD
+        want = (bls.g1_compressed(bls.G1.to_affine(bls.G1.mul(bls.G1_GEN, a_s))) +
+                bls.g2_compressed(bls.G2.to_affine(bls.G2.mul(bls.G2_GEN, b_s))) +
+                bls.g1_compressed(bls.G1.to_affine(bls.G1.mul(bls.G1_GEN, c_s))))
+        assert got == want
     finally:
         params.close()

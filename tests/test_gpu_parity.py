@@ -228,3 +228,37 @@ def test_transfer_circuit_proof_bit_exact(gpu_lib):
             assert pf.write() == helpers.expected_proof_trapdoor(P, a, ri, si)
     finally:
         params.close()
+
+
+def test_two_handles_two_threads(gpu_lib):
+    """Streams live in a per-device context and the current device is selected on every entry: two handles may
+    be driven from two host threads at once (use_device skipped hipSetDevice for a second thread and
+    handles on different GPUs destroyed each other's streams).  Two keys, two threads, interleaved proofs."""
+    import threading
+    import zero_chain_amd as zk
+    n_dev = C.c_int(0)
+    gpu_lib.check(gpu_lib.zk_device_count(C.byref(n_dev)))
+    cases = [helpers.small_case(11, 2, 30, 33), helpers.small_case(12, 3, 40, 44)]
+    devs = [0, 1 if n_dev.value > 1 else 0]
+    params = [zk.Parameters.read(c[3], checked=False, device=d, lib=gpu_lib) for c, d in zip(cases, devs)]
+    errors = []
+
+    def worker(k):
+        try:
+            r1, asg, P, pk = cases[k]
+            pa = helpers.to_assignment(zk, asg)
+            for i in range(6):
+                r, s = 1000 * k + 2 * i + 1, 1000 * k + 2 * i + 2
+                got = zk.create_proof(pa, params[k], r, s).write()
+                assert got == helpers.expected_proof_trapdoor(P, asg, r, s), (k, i)
+        except BaseException as exc:   # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(exc)))
+
+    ths = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for p in params:
+        p.close()
+    assert not errors, errors

@@ -68,6 +68,7 @@ _PROTOS = {
     "zk_strerror": (C.c_char_p, [C.c_int32]),
     "zk_last_error": (C.c_char_p, []),
     "zk_device_count": (C.c_int32, [C.POINTER(C.c_int)]),
+    "zk_set_host_threads": (None, [C.c_int]),
     "zk_params_load": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_params_get_info": (C.c_int32, [C.c_void_p, C.POINTER(ParamsInfo)]),
     "zk_params_free": (None, [C.c_void_p]),

@@ -25,6 +25,8 @@ def shard_bounds(n_total, rank, world):
 
 
 def owner_of(i, n_total, world):
+    if n_total <= 0 or not (0 <= i < n_total):
+        raise ValueError("proof index %d outside a batch of %d" % (i, n_total))
     return i * world // n_total
 
 
@@ -35,6 +37,11 @@ def gather_proofs(local_proofs, n_total, dist=None, device=None, dst=0):
     whole batch in proof order on `dst`, None elsewhere.  One collective: shards are padded to the
     largest block so a single fixed-size gather is enough (at most 191 B x world of padding)."""
     local = np.frombuffer(bytes(local_proofs), dtype=np.uint8) if not isinstance(local_proofs, np.ndarray) else local_proofs
+    if n_total == 0:   # an empty batch: nothing to exchange (a zero-length gather is backend-dependent)
+        if local.size:
+            raise ValueError("empty batch but %d local bytes" % local.size)
+        rank0 = dist is None or not dist.is_initialized() or dist.get_rank() == dst
+        return b"" if rank0 else None
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         if local.size != n_total * PROOF_SIZE:
             raise ValueError("single-rank gather: expected the whole batch")
@@ -68,6 +75,8 @@ def prove_sharded(params, assignments, rs, dist=None, device=None, dst=0, create
     Returns the list of N Proof objects on `dst`, None elsewhere."""
     from . import _api
     n_total = len(rs)
+    if n_total == 0:
+        return [] if (dist is None or not dist.is_initialized() or dist.get_rank() == dst) else None
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
     lo, hi = shard_bounds(n_total, rank, world)

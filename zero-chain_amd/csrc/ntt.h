@@ -49,13 +49,33 @@ ZK_DI void st_fr(uint32_t* p, const Fr& v) {
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+// x >= r ?  (the reference cannot represent such an Fr: FrRepr -> Fr fails, fr.rs:276-289; the same
+// holds for raw Montgomery limbs).  Kernels that take scalars from the caller raise a flag.
+ZK_DI bool fr_geq_r(const Fr& x) {
+    uint32_t bo = 0, co;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        (void)__builtin_subc(x.l[i], FrCfg::P[i], bo, &co);
+        bo = co;
+    }
+    return bo == 0;
+}
+constexpr uint32_t ZK_BAD_SCALAR = 1u, ZK_BAD_ONE = 2u;
+ZK_DI void raise_flag(uint32_t* bad, uint32_t bit) {
+#ifdef ZK_EMU
+    __atomic_fetch_or(bad, bit, __ATOMIC_RELAXED);
+#else
+    atomicOr(bad, bit);
+#endif
+}
+
 // One pass over a batch of polynomials (blockIdx.y = polynomial).  `tw` holds w^e (Montgomery)
 // for e in [0, n/2).  `pre` / `post` (optional, n entries each) are multiplied into every
 // element at load / store, indexed by the element's global position.  `src` (optional) replaces
 // `data` as the load source for the first pass of a chain.
 __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __restrict__ tw,
-           const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post, NttPass ps) {
+           const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post, NttPass ps, uint32_t* bad = nullptr) {
     ZK_DYN_SHARED(uint32_t, tile);   // [2^g][CW][8]
     const uint32_t k = ps.log_n, g = ps.g, lcw = ps.log_cw;
     const uint32_t rows = 1u << g, cw = 1u << lcw;
@@ -76,6 +96,7 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
         if (src) {
             // first pass of a chain: read the caller's (unpadded) array, zero-extend to n
             v = idx < ps.src_valid ? ld_fr(src + ((size_t)blockIdx.y * ps.src_stride + idx) * 8) : Fr::zero();
+            if (bad && fr_geq_r(v)) raise_flag(bad, ZK_BAD_SCALAR);
         } else {
             v = ld_fr(base + (size_t)idx * 8);
         }
@@ -194,10 +215,11 @@ k_fr_pow_table(uint32_t* out, const uint32_t* __restrict__ base, const uint32_t*
 
 // plain <-> Montgomery conversion of a scalar array (mode 0: to Montgomery, 1: from)
 __global__ void __launch_bounds__(256)
-k_fr_convert(uint32_t* out, const uint32_t* __restrict__ in, uint32_t from, size_t count) {
+k_fr_convert(uint32_t* out, const uint32_t* __restrict__ in, uint32_t from, size_t count, uint32_t* bad = nullptr) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     Fr v = ld_fr(in + i * 8);
+    if (bad && fr_geq_r(v)) raise_flag(bad, ZK_BAD_SCALAR);
     st_fr(out + i * 8, from ? from_mont(v) : to_mont(v));
 }
 
@@ -253,7 +275,7 @@ k_r1cs_eval(R1csMat ma, R1csMat mb, R1csMat mc, const uint32_t* __restrict__ z, 
 // tail[p] = (1, r, s).  Witness scalars are converted out of Montgomery form when `mont` is set.
 __global__ void __launch_bounds__(256)
 k_build_scalars(uint32_t* wit_out, uint32_t* cvec, const uint32_t* __restrict__ wit, const uint32_t* __restrict__ tail,
-                uint32_t nv, uint32_t n_in, uint32_t m, uint32_t cstride, uint32_t mont) {
+                uint32_t nv, uint32_t n_in, uint32_t m, uint32_t cstride, uint32_t mont, uint32_t* bad) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv + 3) return;
     const size_t p = blockIdx.y;
@@ -263,6 +285,12 @@ k_build_scalars(uint32_t* wit_out, uint32_t* cvec, const uint32_t* __restrict__ 
     Fr v;
     if (i < nv) {
         Fr raw = ld_fr(wit + (p * nv + i) * 8);
+        if (fr_geq_r(raw)) {
+            raise_flag(bad, ZK_BAD_SCALAR);
+            raw = Fr::zero();   // the call fails at its end; until then the multiexp recoding must see values < r
+        }
+        if (i == 0 && !(mont ? raw == Fr::one() : (raw.l[0] == 1u && (raw.l[1] | raw.l[2] | raw.l[3] | raw.l[4] | raw.l[5] | raw.l[6] | raw.l[7]) == 0u)))
+            raise_flag(bad, ZK_BAD_ONE);   // bellman: alloc_input(ONE = 1) comes first
         Fr rz;
         if (mont) {
             v = from_mont(raw);

@@ -17,6 +17,10 @@
 #include <chrono>
 #include <algorithm>
 #include <new>
+#include <mutex>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include "../../include/zkamd.h"
 #include "gpu_rt.h"
@@ -31,12 +35,25 @@ using zkdev::NttPass;
 namespace {
 
 thread_local std::string g_err;
-hipStream_t g_stream = nullptr;    // main stream: H pipeline, G1 multiexps, stand-alone entries
-hipStream_t g_stream2 = nullptr;   // side stream: the G2 multiexp of a chunk runs beside the G1 work
-hipStream_t g_copy_stream = nullptr;   // staging copies of the next block of a host batch
-hipEvent_t g_ev_fork = nullptr;
-bool g_stream_init = false;
-int g_device = -1;
+
+// Streams and the fork event live in a per-DEVICE context that is created on first use and kept for
+// the life of the process: handles on different GPUs never tear down each other's streams, and the
+// current device - which HIP keeps per host thread - is selected on every entry (use_device), so a
+// handle may be driven from any thread.  g_stream & co. are the calling thread's view of the context
+// of the device it selected last.
+struct DevCtx {
+    hipStream_t stream = nullptr;    // main stream: H pipeline, G1 multiexps, stand-alone entries
+    hipStream_t stream2 = nullptr;   // side stream: the G2 multiexp of a chunk runs beside the G1 work
+    hipStream_t copy = nullptr;      // staging copies of the next block of a host batch
+    hipEvent_t ev_fork = nullptr;
+};
+std::mutex g_ctx_mu;
+std::map<int, DevCtx*> g_ctxs;
+thread_local hipStream_t g_stream = nullptr;
+thread_local hipStream_t g_stream2 = nullptr;
+thread_local hipStream_t g_copy_stream = nullptr;
+thread_local hipEvent_t g_ev_fork = nullptr;
+thread_local int g_device = -1;
 
 zk_status fail(zk_status st, const std::string& msg) {
     g_err = msg;
@@ -59,25 +76,48 @@ zk_status use_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ZK_ERR_NO_DEVICE, "no HIP device visible");
     if (device < 0 || device >= n) return fail(ZK_ERR_INVALID_ARGUMENT, "device index out of range");
-    if (g_device != device) {
-        HIP_TRY(hipSetDevice(device));
-        if (g_stream_init) {
-            (void)hipStreamDestroy(g_stream);
-            (void)hipStreamDestroy(g_stream2);
-            (void)hipStreamDestroy(g_copy_stream);
-            (void)hipEventDestroy(g_ev_fork);
-            g_stream_init = false;
+    HIP_TRY(hipSetDevice(device));   // per host thread: never skipped
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    DevCtx*& c = g_ctxs[device];
+    if (!c) {
+        DevCtx* fresh = new DevCtx();
+        if (hipStreamCreate(&fresh->stream) != hipSuccess || hipStreamCreate(&fresh->stream2) != hipSuccess ||
+            hipStreamCreateWithFlags(&fresh->copy, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&fresh->ev_fork) != hipSuccess) {
+            delete fresh;
+            g_ctxs.erase(device);
+            return fail(ZK_ERR_DEVICE, "cannot create the streams of device " + std::to_string(device));
         }
-        g_device = device;
+        c = fresh;
     }
-    if (!g_stream_init) {
-        HIP_TRY(hipStreamCreate(&g_stream));
-        HIP_TRY(hipStreamCreate(&g_stream2));
-        HIP_TRY(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&g_ev_fork));
-        g_stream_init = true;
-    }
+    g_stream = c->stream;
+    g_stream2 = c->stream2;
+    g_copy_stream = c->copy;
+    g_ev_fork = c->ev_fork;
+    g_device = device;
     return ZK_OK;
+}
+
+// Host threads the library may use for the CPU-side legs (witness calculation, proof encoding):
+// zk_set_host_threads() / ZKAMD_HOST_THREADS, default = the cores this process may run on.  With one
+// process per GPU on an 8-GPU node every rank must take its share of the cores, not all of them.
+int g_host_threads = 0;
+unsigned host_threads(size_t work_items, unsigned cap) {
+    long n = g_host_threads;
+    if (n <= 0) {
+        if (const char* env = getenv("ZKAMD_HOST_THREADS")) n = atol(env);
+    }
+    if (n <= 0) {
+#if defined(__linux__) && !defined(ZK_EMU)
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+#endif
+        if (n <= 0) n = (long)std::thread::hardware_concurrency();
+    }
+    if (n <= 0) n = 1;
+    if ((unsigned long)n > cap) n = cap;
+    if ((size_t)n > work_items) n = (long)work_items;
+    return n > 0 ? (unsigned)n : 1u;
 }
 
 struct DevBuf {
@@ -140,8 +180,8 @@ struct ProfRec {
     std::string name;
     hipEvent_t a, b;
 };
-bool g_prof = false;
-std::vector<ProfRec> g_recs;
+thread_local bool g_prof = false;
+thread_local std::vector<ProfRec> g_recs;
 
 struct ProfScope {
     bool on;
@@ -265,7 +305,7 @@ struct NttPlan {
     // Run one chain of passes over `batch` polynomials laid out with `stride` elements.
     zk_status chain(uint32_t* data, uint32_t batch, uint32_t stride, bool dif, bool inverse,
                     const uint32_t* pre, const uint32_t* post, const uint32_t* src = nullptr,
-                    uint32_t src_stride = 0, uint32_t src_valid = 0) {
+                    uint32_t src_stride = 0, uint32_t src_valid = 0, uint32_t* bad = nullptr) {
         std::vector<NttPass> ps = passes(log_n, dif, stride);
         const uint32_t* tw = inverse ? tw_inv.as<uint32_t>() : tw_fwd.as<uint32_t>();
         for (size_t i = 0; i < ps.size(); i++) {
@@ -282,7 +322,7 @@ struct NttPlan {
             ProfScope ps_(dif ? "ntt_pass_dif" : "ntt_pass_dit");
             ZK_LAUNCH_SYNC(zkdev::k_ntt_pass, grid, dim3(zkdev::NTT_THREADS), shmem, g_stream, data, s, tw,
                            i == 0 ? pre : (const uint32_t*)nullptr,
-                           i + 1 == ps.size() ? post : (const uint32_t*)nullptr, p);
+                           i + 1 == ps.size() ? post : (const uint32_t*)nullptr, p, i == 0 && s ? bad : (uint32_t*)nullptr);
         }
         if (ps.empty() && (pre || post || src)) return fail(ZK_ERR_INVALID_ARGUMENT, "size-1 transform");
         HIP_TRY(hipGetLastError());
@@ -672,19 +712,22 @@ struct Reader {
     }
 };
 
-zk_status read_g1(Reader& r, HG1A* out, const char* what) {
+// bellman: the query vectors and vk.ic reject the point at infinity in both modes (Parameters::read,
+// VerifyingKey::read); alpha, beta, gamma, delta are read with a plain into_affine(), which accepts it
+// (in-tree twin: core/bellman-verifier/src/lib.rs:310-327) - create_proof then answers a delta at
+// infinity with SynthesisError::UnexpectedIdentity.
+zk_status read_g1(Reader& r, HG1A* out, const char* what, bool allow_inf = false) {
     const uint8_t* b;
     if (!r.take(96, &b)) return fail(ZK_ERR_IO, std::string("unexpected end of parameters in ") + what);
     if (zkhost::g1_from_uncompressed(b, out) != zkhost::DEC_OK) return fail(ZK_ERR_IO, std::string("invalid G1 encoding in ") + what);
-    // bellman Parameters::read: "point at infinity" is an error in both modes
-    if (out->is_inf()) return fail(ZK_ERR_IO, std::string("point at infinity in ") + what);
+    if (!allow_inf && out->is_inf()) return fail(ZK_ERR_IO, std::string("point at infinity in ") + what);
     return ZK_OK;
 }
-zk_status read_g2(Reader& r, HG2A* out, const char* what) {
+zk_status read_g2(Reader& r, HG2A* out, const char* what, bool allow_inf = false) {
     const uint8_t* b;
     if (!r.take(192, &b)) return fail(ZK_ERR_IO, std::string("unexpected end of parameters in ") + what);
     if (zkhost::g2_from_uncompressed(b, out) != zkhost::DEC_OK) return fail(ZK_ERR_IO, std::string("invalid G2 encoding in ") + what);
-    if (out->is_inf()) return fail(ZK_ERR_IO, std::string("point at infinity in ") + what);
+    if (!allow_inf && out->is_inf()) return fail(ZK_ERR_IO, std::string("point at infinity in ") + what);
     return ZK_OK;
 }
 
@@ -719,6 +762,12 @@ struct zk_params {
     // workspaces
     DevBuf abc, wit, cvec, tail, stage_a, stage_b, stage_c, stage_w, fold_tbl, fold_c, fold_a1, fold_c1, fold_b2;
     PinBuf pin_g1, pin_g2, pin_tail;   // affine A, C / B of a chunk; [1 | r | s] per proof
+    // [0]: raised by the kernels of a chunk that read caller scalars (non-canonical value, ONE != 1);
+    // [1]: the same for the conversion pass of zk_prove_batch_witness
+    DevBuf bad;
+    PinBuf pin_bad;
+    // vk points bellman accepts at infinity (VerifyingKey::read does not reject them)
+    bool alpha_g1_inf = false, beta_g1_inf = false, beta_g2_inf = false, delta_g1_inf = false, delta_g2_inf = false;
     std::vector<MsmJob> jobs1, jobs2;
     std::vector<HG1> res1;
     std::vector<HG2> res2;
@@ -738,12 +787,17 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     Reader r{pk, len};
     HG1A alpha_g1, beta_g1, delta_g1, tmp1;
     HG2A beta_g2, gamma_g2, delta_g2, tmp2;
-    ZK_TRY(read_g1(r, &alpha_g1, "vk.alpha_g1"));
-    ZK_TRY(read_g1(r, &beta_g1, "vk.beta_g1"));
-    ZK_TRY(read_g2(r, &beta_g2, "vk.beta_g2"));
-    ZK_TRY(read_g2(r, &gamma_g2, "vk.gamma_g2"));
-    ZK_TRY(read_g1(r, &delta_g1, "vk.delta_g1"));
-    ZK_TRY(read_g2(r, &delta_g2, "vk.delta_g2"));
+    ZK_TRY(read_g1(r, &alpha_g1, "vk.alpha_g1", true));
+    ZK_TRY(read_g1(r, &beta_g1, "vk.beta_g1", true));
+    ZK_TRY(read_g2(r, &beta_g2, "vk.beta_g2", true));
+    ZK_TRY(read_g2(r, &gamma_g2, "vk.gamma_g2", true));
+    ZK_TRY(read_g1(r, &delta_g1, "vk.delta_g1", true));
+    ZK_TRY(read_g2(r, &delta_g2, "vk.delta_g2", true));
+    P->alpha_g1_inf = alpha_g1.is_inf();
+    P->beta_g1_inf = beta_g1.is_inf();
+    P->beta_g2_inf = beta_g2.is_inf();
+    P->delta_g1_inf = delta_g1.is_inf();
+    P->delta_g2_inf = delta_g2.is_inf();
     if (!r.u32be(&P->n_ic)) return fail(ZK_ERR_IO, "unexpected end of parameters (ic length)");
     std::vector<HG1A> ic(P->n_ic);
     if ((size_t)P->n_ic * 96 > r.left) return fail(ZK_ERR_IO, "unexpected end of parameters in vk.ic");
@@ -784,10 +838,14 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     if (m < 2 || (m & (m - 1))) return fail(ZK_ERR_IO, "h query length + 1 is not a power of two");
     P->m = m;
     while (((size_t)1 << P->log_m) < m) P->log_m++;
-    if (checked) {
-        // vk points that never enter a table are checked on the host side of the same kernel
-        ZK_TRY((check_points_host<zkhost::Fq, zkdev::Fq>(ic, "vk.ic")));
-        ZK_TRY((check_points_host<zkhost::Fq2, DevFq2>(std::vector<HG2A>{gamma_g2}, "vk.gamma_g2")));
+    {
+        // the verifying key is validated in BOTH modes (bellman reads it with the checked into_affine())
+        std::vector<HG1A> vk1 = ic;
+        vk1.push_back(alpha_g1);
+        vk1.push_back(beta_g1);
+        vk1.push_back(delta_g1);
+        ZK_TRY((check_points_host<zkhost::Fq, zkdev::Fq>(vk1, "vk (G1: ic | alpha | beta | delta)")));
+        ZK_TRY((check_points_host<zkhost::Fq2, DevFq2>(std::vector<HG2A>{beta_g2, gamma_g2, delta_g2}, "vk (G2: beta | gamma | delta)")));
     }
     // one width per group: the G1 jobs of a proof (H, L, A, B1) average a quarter of the G1 terms
     // two G1 jobs per proof: A, and the merged C' = H + L + r * B1
@@ -819,18 +877,24 @@ zk_status ensure_maps(zk_params* P, uint32_t n_in, uint32_t n_aux, const uint8_t
     for (uint32_t i = 0; i < n_in; i++) ma[i] = (int32_t)i;   // A inputs: full density
     for (uint32_t j = 0; j < n_aux; j++)
         if (a_aux_d[j]) ma[n_in + j] = (int32_t)pa++;
-    if (pa > P->n_a) return fail(ZK_ERR_IO, "a query shorter than the A density (unexpected EOF in bases)");
-    ma[nv] = (int32_t)P->n_a;         // 1 * alpha_g1
-    ma[nv + 1] = (int32_t)P->n_a + 1; // r * delta_g1
+    // bellman's generator emits exactly one `a` entry per input and per dense aux variable (and the
+    // b queries likewise): a different count means the assignment belongs to another circuit than the key
+    if (pa != P->n_a)
+        return fail(ZK_ERR_IO, "the A density of the assignment (" + std::to_string(pa) + ") differs from the key's a query (" +
+                                   std::to_string(P->n_a) + ")");
+    if (!P->alpha_g1_inf) ma[nv] = (int32_t)P->n_a;   // 1 * alpha_g1
+    ma[nv + 1] = (int32_t)P->n_a + 1;                 // r * delta_g1 (never at infinity here: prove_* refuse)
     uint32_t pb = 0;
     for (uint32_t i = 0; i < n_in; i++)
         if (b_in_d[i]) mb1[i] = mb2[i] = (int32_t)pb++;
     for (uint32_t j = 0; j < n_aux; j++)
         if (b_aux_d[j]) mb1[n_in + j] = mb2[n_in + j] = (int32_t)pb++;
-    if (pb > P->n_b1 || pb > P->n_b2) return fail(ZK_ERR_IO, "b query shorter than the B density (unexpected EOF in bases)");
-    mb1[nv] = (int32_t)P->n_b1;       // 1 * beta_g1
-    mb2[nv] = (int32_t)P->n_b2;       // 1 * beta_g2
-    mb2[nv + 2] = (int32_t)P->n_b2 + 1;   // s * delta_g2
+    if (pb != P->n_b1 || pb != P->n_b2)
+        return fail(ZK_ERR_IO, "the B density of the assignment (" + std::to_string(pb) + ") differs from the key's b queries (" +
+                                   std::to_string(P->n_b1) + " in G1, " + std::to_string(P->n_b2) + " in G2)");
+    if (!P->beta_g1_inf) mb1[nv] = (int32_t)P->n_b1;   // 1 * beta_g1
+    if (!P->beta_g2_inf) mb2[nv] = (int32_t)P->n_b2;   // 1 * beta_g2
+    mb2[nv + 2] = (int32_t)P->n_b2 + 1;                // s * delta_g2
     // h coefficients leave the last transform in bit-reversed order; the top coefficient
     // (degree m - 1) is dropped exactly as bellman truncates it
     std::vector<int32_t> mh(P->m);
@@ -844,7 +908,7 @@ zk_status ensure_maps(zk_params* P, uint32_t n_in, uint32_t n_aux, const uint8_t
     for (size_t pos = 0; pos < P->m; pos++) mc.push_back(mh[pos] < 0 ? -1 : (int32_t)(P->off_h + mh[pos]));
     for (uint32_t j = 0; j < n_aux; j++) mc.push_back((int32_t)(P->off_l + j));
     for (uint32_t i = 0; i < nv; i++) mc.push_back(mb1[i] < 0 ? -1 : (int32_t)(P->off_b1 + mb1[i]));
-    mc.push_back((int32_t)(P->off_b1 + P->n_b1));   // r * beta_g1
+    mc.push_back(P->beta_g1_inf ? -1 : (int32_t)(P->off_b1 + P->n_b1));   // r * beta_g1
     ZK_TRY(P->map_a.ensure(ma.size() * 4));
     ZK_TRY(P->map_b2.ensure(mb2.size() * 4));
     ZK_TRY(P->map_c.ensure(mc.size() * 4));
@@ -887,12 +951,16 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     }
     ZK_TRY(P->tail.ensure(np * 96));
     HIP_TRY(hipMemcpyAsync(P->tail.p, tail, np * 96, hipMemcpyHostToDevice, g_stream));
+    ZK_TRY(P->bad.ensure(8));
+    ZK_TRY(P->pin_bad.ensure(8));
+    uint32_t* bad = P->bad.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(bad, 0, 4, g_stream));
     const uint32_t cstride = (uint32_t)(m + n_aux + nv + 1);
     ZK_TRY(P->cvec.ensure(np * (size_t)cstride * 32));
     uint32_t* cvec = P->cvec.as<uint32_t>();
     ZK_LAUNCH(zkdev::k_build_scalars, dim3((nv + 3 + 255) / 256, (unsigned)np), dim3(256), 0, g_stream, wit, cvec,
               (const uint32_t*)bt->d_wit + first * (size_t)nv * 8, P->tail.as<uint32_t>(), nv, n_in, (uint32_t)m, cstride,
-              mont ? 1u : 0u);
+              mont ? 1u : 0u, bad);
     // ---- multiexps (create_proof step 4).  The G2 job only needs the witness scalars: it is
     // enqueued first, on the side stream, and runs beside the H pipeline and the G1 multiexps (its
     // reduction tree is latency-bound with one job per proof; the G1 work fills the machine).
@@ -922,7 +990,7 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
                                (const uint32_t*)bt->d_c + first * (size_t)n_rows * 8};
     uint32_t* dsts[3] = {A, B, C};
     for (int k = 0; k < 3; k++)   // ifft (natural -> bit-reversed), then * g^i / m  (coset shift)
-        ZK_TRY(P->ntt.chain(dsts[k], (uint32_t)np, (uint32_t)m, true, true, nullptr, s1, srcs[k], n_rows, n_rows));
+        ZK_TRY(P->ntt.chain(dsts[k], (uint32_t)np, (uint32_t)m, true, true, nullptr, s1, srcs[k], n_rows, n_rows, bad));
     // coset fft (bit-reversed -> natural) of all three at once
     ZK_TRY(P->ntt.chain(A, (uint32_t)(3 * np), (uint32_t)m, false, false, nullptr, nullptr));
     {
@@ -961,16 +1029,22 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
         ZK_TRY(P->g1.normalize_to_host(a, np, P->pin_g1.as<HG1>() + np, P->fold_a1, g_stream));
         ZK_TRY(P->g1.normalize_to_host(P->fold_c.as<DP1>(), np, P->pin_g1.as<HG1>(), P->fold_c1, g_stream));
     }
+    HIP_TRY(hipMemcpyAsync(P->pin_bad.p, bad, 8, hipMemcpyDeviceToHost, g_stream));
     const bool trace_host = getenv("ZKAMD_TRACE_HOST") != nullptr;
     const auto t_wait = std::chrono::steady_clock::now();
     ZK_TRY(P->g1.collect(g_stream));
     ZK_TRY(P->g2.collect(side));
+    {
+        // the reference cannot even represent these assignments (FrRepr -> Fr fails for values >= r,
+        // fr.rs:276-289; ProvingAssignment starts with alloc_input(ONE = 1))
+        const uint32_t flags = P->pin_bad.as<uint32_t>()[0];
+        if (flags & zkdev::ZK_BAD_SCALAR)
+            return fail(ZK_ERR_INVALID_ARGUMENT, "an assignment scalar (a, b, c, input or aux) is not a canonical field element (>= r)");
+        if (flags & zkdev::ZK_BAD_ONE) return fail(ZK_ERR_INVALID_ARGUMENT, "input 0 of an assignment is not ONE = 1");
+    }
     const auto t_enc = std::chrono::steady_clock::now();
     // ---- encoding (host, one thread per slice of the chunk): pin_g1[p] = C, pin_g1[np + p] = A, pin_g2[p] = B
-    unsigned nthreads = std::thread::hardware_concurrency();
-    if (nthreads == 0) nthreads = 1;
-    if (nthreads > 32) nthreads = 32;
-    if (nthreads > np) nthreads = (unsigned)np;
+    const unsigned nthreads = host_threads(np, 32);
     auto work = [&](size_t lo, size_t hi) {
         for (size_t p = lo; p < hi; p++)
         {
@@ -1001,6 +1075,8 @@ zk_status prove_batch_dev(zk_params* P, size_t n, const zk_batch_dev* bt, const 
     if (!P || !bt || !rs || !proofs_out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return ZK_OK;
     ZK_TRY(use_device(P->device));
+    // bellman create_proof: `if vk.delta_g1.is_zero() || vk.delta_g2.is_zero() { return Err(UnexpectedIdentity) }`
+    if (P->delta_g1_inf || P->delta_g2_inf) return fail(ZK_ERR_UNEXPECTED_IDENTITY, "vk.delta is the point at infinity");
     if (bt->n_inputs == 0) return fail(ZK_ERR_INVALID_ARGUMENT, "n_inputs must include ONE");
     if (bt->n_rows > P->m) return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
     if (bt->n_inputs != P->n_ic) return fail(ZK_ERR_MALFORMED_VERIFYING_KEY, "number of inputs differs from vk.ic");
@@ -1056,7 +1132,8 @@ zk_status prove_batch_host(zk_params* P, size_t n, const zk_assignment* asgs, co
     ZK_TRY(P->stage_b.ensure(slots * hc * rb));
     ZK_TRY(P->stage_c.ensure(slots * hc * rb));
     ZK_TRY(P->stage_w.ensure(slots * hc * nvb));
-    auto stage = [&](size_t slot, size_t first, size_t np) -> zk_status {
+    const hipStream_t copy_stream = g_copy_stream;   // thread-local view: the helper thread gets it by value
+    auto stage = [&, copy_stream](size_t slot, size_t first, size_t np) -> zk_status {
         HIP_TRY(hipSetDevice(P->device));   // the current device is per host thread
         uint8_t* da = (uint8_t*)P->stage_a.p + slot * hc * rb;
         uint8_t* db = (uint8_t*)P->stage_b.p + slot * hc * rb;
@@ -1064,14 +1141,14 @@ zk_status prove_batch_host(zk_params* P, size_t n, const zk_assignment* asgs, co
         uint8_t* dw = (uint8_t*)P->stage_w.p + slot * hc * nvb;
         for (size_t i = 0; i < np; i++) {
             const zk_assignment& x = asgs[first + i];
-            HIP_TRY(hipMemcpyAsync(da + i * rb, x.a, rb, hipMemcpyHostToDevice, g_copy_stream));
-            HIP_TRY(hipMemcpyAsync(db + i * rb, x.b, rb, hipMemcpyHostToDevice, g_copy_stream));
-            HIP_TRY(hipMemcpyAsync(dc + i * rb, x.c, rb, hipMemcpyHostToDevice, g_copy_stream));
-            HIP_TRY(hipMemcpyAsync(dw + i * nvb, x.inputs, (size_t)z.n_inputs * 32, hipMemcpyHostToDevice, g_copy_stream));
+            HIP_TRY(hipMemcpyAsync(da + i * rb, x.a, rb, hipMemcpyHostToDevice, copy_stream));
+            HIP_TRY(hipMemcpyAsync(db + i * rb, x.b, rb, hipMemcpyHostToDevice, copy_stream));
+            HIP_TRY(hipMemcpyAsync(dc + i * rb, x.c, rb, hipMemcpyHostToDevice, copy_stream));
+            HIP_TRY(hipMemcpyAsync(dw + i * nvb, x.inputs, (size_t)z.n_inputs * 32, hipMemcpyHostToDevice, copy_stream));
             HIP_TRY(hipMemcpyAsync(dw + i * nvb + (size_t)z.n_inputs * 32, x.aux, (size_t)z.n_aux * 32, hipMemcpyHostToDevice,
-                                   g_copy_stream));
+                                   copy_stream));
         }
-        HIP_TRY(hipStreamSynchronize(g_copy_stream));
+        HIP_TRY(hipStreamSynchronize(copy_stream));
         return ZK_OK;
     };
     ZK_TRY(stage(0, 0, hc));
@@ -1214,10 +1291,12 @@ zk_status prove_batch_witness(zk_params* P, zk_r1cs* R, size_t n, const uint8_t*
         ZK_TRY(R->z.ensure(np * (size_t)nv * 32));
         ZK_TRY(R->abc.ensure(3 * np * (size_t)n_rows * 32));
         HIP_TRY(hipMemcpyAsync(R->z.p, witness + first * (size_t)nv * 32, np * (size_t)nv * 32, hipMemcpyHostToDevice, g_stream));
+        ZK_TRY(P->bad.ensure(8));
+        HIP_TRY(hipMemsetAsync(P->bad.as<uint32_t>() + 1, 0, 4, g_stream));
         if (!(flags & ZK_FR_MONTGOMERY)) {
             const size_t cnt = np * (size_t)nv;
             ZK_LAUNCH(zkdev::k_fr_convert, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g_stream, R->z.as<uint32_t>(),
-                      (const uint32_t*)R->z.as<uint32_t>(), 0u, cnt);
+                      (const uint32_t*)R->z.as<uint32_t>(), 0u, cnt, P->bad.as<uint32_t>() + 1);
         }
         zkdev::R1csMat mm[3];
         for (int m = 0; m < 3; m++)
@@ -1242,6 +1321,8 @@ zk_status prove_batch_witness(zk_params* P, zk_r1cs* R, size_t n, const uint8_t*
         bt.b_input_density = R->b_input_density.data();
         bt.b_aux_density = R->b_aux_density.data();
         ZK_TRY(prove_batch_dev(P, np, &bt, rs + first * 64, proofs_out + first * 192));
+        if (P->pin_bad.as<uint32_t>()[1] & zkdev::ZK_BAD_SCALAR)
+            return fail(ZK_ERR_INVALID_ARGUMENT, "a witness scalar is not a canonical field element (>= r)");
     }
     return ZK_OK;
 }
@@ -1285,13 +1366,13 @@ zk_status transfer_decode(const zk_transfer_statement& in, size_t index, zkwit::
 // n statements -> n variable assignments on the host cores.  decode(i, &statement) / synth(statement, wit).
 template <class Stmt, class Decode, class Synth>
 zk_status witness_batch(size_t n, size_t n_inputs, size_t n_aux, uint32_t flags, uint8_t* out, Decode&& decode, Synth&& synth) {
+    // decode(i, ...) reports the ABSOLUTE statement index (the callers add their batch offset); threads own
+    // increasing index ranges and stop at their first failure, so the first failing thread holds the
+    // lowest failing statement
     if (n == 0) return ZK_OK;
     (void)zkwit::tables();   // build the window tables before the threads start
     const size_t nv = n_inputs + n_aux;
-    unsigned nthreads = std::thread::hardware_concurrency();
-    if (nthreads == 0) nthreads = 1;
-    if (nthreads > 64) nthreads = 64;
-    if (nthreads > n) nthreads = (unsigned)n;
+    const unsigned nthreads = host_threads(n, 64);
     std::vector<zk_status> sts(nthreads, ZK_OK);
     std::vector<std::string> msgs(nthreads);
     const bool mont = (flags & ZK_FR_MONTGOMERY) != 0;
@@ -1333,11 +1414,11 @@ zk_status witness_batch(size_t n, size_t n_inputs, size_t n_aux, uint32_t flags,
     return ZK_OK;
 }
 
-zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* out) {
+zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* out, size_t index_base = 0) {
     if ((!st || !out) && n) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     return witness_batch<zkwit::Statement>(
         n, ZK_TRANSFER_N_INPUTS, ZK_TRANSFER_N_AUX, flags, out,
-        [&](size_t i, zkwit::Statement* s) { return transfer_decode(st[i], i, s); },
+        [&](size_t i, zkwit::Statement* s) { return transfer_decode(st[i], index_base + i, s); },
         [](const zkwit::Statement& s, zkwit::Wit& w) { zkwit::synthesize(s, w); });
 }
 
@@ -1596,6 +1677,7 @@ const char* zk_strerror(zk_status st) {
     return "unknown status";
 }
 const char* zk_last_error(void) { return g_err.c_str(); }
+void zk_set_host_threads(int n) { g_host_threads = n > 0 ? n : 0; }
 
 zk_status zk_device_count(int* count) {
     if (!count) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1688,7 +1770,7 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
         std::thread producer;
         if (next < n)
             producer = std::thread([&, next] {
-                next_rc = transfer_witness(st + next, std::min(chunk, n - next), ZK_FR_MONTGOMERY, buf[cur ^ 1]);
+                next_rc = transfer_witness(st + next, std::min(chunk, n - next), ZK_FR_MONTGOMERY, buf[cur ^ 1], next);
                 if (next_rc != ZK_OK) next_err = g_err;   // g_err is thread-local
             });
         rc = prove_batch_witness(p, circuit, np, buf[cur], ZK_FR_MONTGOMERY, rs + first * 64, proofs_out + first * 192);
@@ -1801,7 +1883,7 @@ void zk_profile_begin(void) {
     g_prof = true;
 }
 int zk_profile_get(const char* kernel, double* total_ms) {
-    if (g_stream_init) (void)hipStreamSynchronize(g_stream);
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
     int count = 0;
     double tot = 0;
     for (auto& r : g_recs)
@@ -1816,7 +1898,7 @@ int zk_profile_get(const char* kernel, double* total_ms) {
     return count;
 }
 void zk_profile_end(void) {
-    if (g_stream_init) (void)hipStreamSynchronize(g_stream);
+    if (g_stream) (void)hipStreamSynchronize(g_stream);
     for (auto& r : g_recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -1826,7 +1908,8 @@ void zk_profile_end(void) {
 }
 void* zk_stream(void) { return (void*)g_stream; }
 zk_status zk_synchronize(void) {
-    if (g_stream_init) HIP_TRY(hipStreamSynchronize(g_stream));
+    if (g_stream) HIP_TRY(hipStreamSynchronize(g_stream));
+    if (g_stream2) HIP_TRY(hipStreamSynchronize(g_stream2));
     return ZK_OK;
 }
 
