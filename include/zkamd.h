@@ -187,6 +187,19 @@ zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_
 zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
                                   const uint8_t* rs, uint8_t* proofs_out);
 
+/* A stream of statement batches: submit() queues a batch and returns at once; a producer thread computes
+ * its witnesses on the host cores (zk_set_host_threads) while the GPU proves the batch submitted before it;
+ * wait() blocks until everything submitted so far is proved and returns the first failure, if any (the
+ * statement index in its message is relative to the failing submit).  The caller's buffers (statements, rs,
+ * proofs_out) must stay valid until wait() returns, and `p` / `circuit` must not be used by other calls
+ * while batches are in flight.  Batches larger than a device chunk (1024) are cut into chunks. */
+typedef struct zk_pipeline zk_pipeline;
+zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out);
+zk_status zk_pipeline_submit(zk_pipeline* pl, size_t n, const zk_transfer_statement* st, const uint8_t* rs,
+                             uint8_t* proofs_out);
+zk_status zk_pipeline_wait(zk_pipeline* pl);
+void zk_pipeline_free(zk_pipeline* pl);
+
 /* The value half of AnonymousTransfer::synthesize (core/proofs/src/circuit/anonymous_transfer.rs:56-337,
  * anonimity_set.rs; ANONIMITY_SIZE = 12, constants.rs:1): the private values of the instance (:40-54) ->
  * the variable assignment bellman's ProvingAssignment would hold, [105 inputs | 50429 aux].  Scalars are

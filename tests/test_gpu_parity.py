@@ -189,6 +189,26 @@ def test_transfer_prove_from_statements(gpu_lib, monkeypatch):
             cs = tc.synthesize(w)
             asg = g.assign(E, r1, cs.inputs, cs.aux)
             assert pf.write() == helpers.expected_proof_trapdoor(P, asg, r, s)
+        # the same statements as a stream of batches (zk_pipeline): submit returns at once, the witnesses of
+        # the second batch are computed while the GPU proves the first
+        pipe = zk.TransferPipeline(mats, params)
+        try:
+            sts = [zk.transfer_statements([tc.statement_dict(w) for w in part]) for part in (ws[:3], ws[3:], ws[1:2])]
+            for part, prs in zip(sts, (rs[:3], rs[3:], rs[1:2])):
+                pipe.submit(part, prs)
+            streamed = pipe.wait()
+            assert [p.write() for p in streamed] == [p.write() for p in proofs + proofs[1:2]]
+            # a malformed statement fails the stream at wait(), with its index; the stream stays usable
+            bad = tc.statement_dict(ws[0])
+            bad["g_epoch"] = bytes([2]) + bytes(31)
+            pipe.submit(zk.transfer_statements([tc.statement_dict(ws[0]), bad]), rs[:2])
+            with pytest.raises(zk.ZkError) as e:
+                pipe.wait()
+            assert e.value.variant == "InvalidArgument" and "statement 1" in str(e.value)
+            pipe.submit(sts[2], rs[1:2])
+            assert pipe.wait()[0].write() == proofs[1].write()
+        finally:
+            pipe.close()
     finally:
         mats.close()
         params.close()

@@ -25,7 +25,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 
 __all__ = ["Parameters", "Proof", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "anonymous_statements", "anonymous_witness",
-           "transfer_prove_batch", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
+           "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
 
@@ -36,6 +36,11 @@ PROOF_SIZE = 192  # core/proofs/src/constants.rs:3
 
 def load_library():
     return _lib.load()
+
+
+def set_host_threads(n, lib=None):
+    """zk_set_host_threads: host threads for the CPU-side legs (witness calculation, encoding); 0 = default."""
+    (lib or _lib.load()).zk_set_host_threads(int(n))
 
 
 def scalars_to_bytes(values):
@@ -364,6 +369,52 @@ def transfer_prove_batch(matrices, params, statements, rs):
     lib.check(lib.zk_transfer_prove_batch(params._h, matrices._h, n, statements, _ptr(rsb), _ptr(out)))
     ob = out.tobytes()
     return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
+
+
+class TransferPipeline:
+    """zk_pipeline: a stream of statement batches; the witnesses of batch k + 1 are computed on the host cores
+    while the GPU proves batch k.  submit() returns at once, wait() returns the proofs of everything submitted
+    since the last wait, in submission order."""
+
+    def __init__(self, matrices, params):
+        self._lib = params._lib
+        self._keep = (matrices, params)
+        h = C.c_void_p()
+        self._lib.check(self._lib.zk_pipeline_create(params._h, matrices._h, C.byref(h)))
+        self._h = h
+        self._pending = []
+
+    def submit(self, statements, rs):
+        n = len(statements)
+        rsb = rs if isinstance(rs, np.ndarray) else scalars_to_bytes([x for pair in rs for x in pair])
+        out = np.zeros(PROOF_SIZE * n, dtype=np.uint8)
+        self._pending.append((statements, rsb, out))   # the buffers stay alive until wait()
+        self._lib.check(self._lib.zk_pipeline_submit(self._h, n, statements, _ptr(rsb), _ptr(out)))
+        return out
+
+    def wait(self, raw=False):
+        try:
+            self._lib.check(self._lib.zk_pipeline_wait(self._h))
+            if raw:
+                return [out for _, _, out in self._pending]
+            proofs = []
+            for _, _, out in self._pending:
+                ob = out.tobytes()
+                proofs += [Proof(ob[i:i + PROOF_SIZE]) for i in range(0, len(ob), PROOF_SIZE)]
+            return proofs
+        finally:
+            self._pending = []
+
+    def close(self):
+        if self._h:
+            self._lib.zk_pipeline_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ----------------------------------------------------------------------------------------------

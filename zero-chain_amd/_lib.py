@@ -82,6 +82,10 @@ _PROTOS = {
     "zk_transfer_witness": (C.c_int32, [C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_transfer_prove_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TransferStatement), C.c_void_p,
                                             C.c_void_p]),
+    "zk_pipeline_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "zk_pipeline_submit": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(TransferStatement), C.c_void_p, C.c_void_p]),
+    "zk_pipeline_wait": (C.c_int32, [C.c_void_p]),
+    "zk_pipeline_free": (None, [C.c_void_p]),
     "zk_anonymous_witness": (C.c_int32, [C.POINTER(AnonymousStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_msm_create": (C.c_int32, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_msm_run": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),

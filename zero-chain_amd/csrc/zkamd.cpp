@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <new>
 #include <mutex>
+#include <condition_variable>
+#include <deque>
 #if defined(__linux__)
 #include <sched.h>
 #endif
@@ -180,25 +182,32 @@ struct ProfRec {
     std::string name;
     hipEvent_t a, b;
 };
-thread_local bool g_prof = false;
-thread_local std::vector<ProfRec> g_recs;
+// process-wide (the GPU thread of a zk_pipeline records into the same list the caller reads)
+std::mutex g_prof_mu;
+bool g_prof = false;
+std::vector<ProfRec> g_recs;
 
 struct ProfScope {
-    bool on;
+    bool on = false;
     hipStream_t st;
-    size_t idx = 0;
-    ProfScope(const char* name, hipStream_t stream = nullptr) : on(g_prof), st(stream ? stream : g_stream) {
-        if (!on) return;
+    hipEvent_t end = nullptr;
+    ProfScope(const char* name, hipStream_t stream = nullptr) : st(stream ? stream : g_stream) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof) return;
         ProfRec r;
         r.name = name;
-        (void)hipEventCreate(&r.a);
-        (void)hipEventCreate(&r.b);
+        if (hipEventCreate(&r.a) != hipSuccess) return;
+        if (hipEventCreate(&r.b) != hipSuccess) {
+            (void)hipEventDestroy(r.a);
+            return;
+        }
         (void)hipEventRecord(r.a, st);
-        idx = g_recs.size();
+        end = r.b;
+        on = true;
         g_recs.push_back(r);
     }
     ~ProfScope() {
-        if (on) (void)hipEventRecord(g_recs[idx].b, st);
+        if (on) (void)hipEventRecord(end, st);
     }
 };
 
@@ -1782,6 +1791,156 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
     return ZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// zk_pipeline: a stream of statement batches.  zk_transfer_prove_batch overlaps the witnesses of
+// chunk k + 1 with the GPU work of chunk k INSIDE one call; a service that proves batch after batch
+// wants the same overlap ACROSS calls.  submit() queues a batch and returns; a producer thread computes
+// its witnesses (host cores) into one of two page-locked buffers while the GPU thread proves the batch
+// before it; wait() returns when everything submitted so far is proved.
+// ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct zk_pipeline {
+    struct Job {
+        const zk_transfer_statement* st;
+        const uint8_t* rs;
+        uint8_t* out;
+        size_t n, index_base;
+        int slot;
+    };
+    zk_params* P = nullptr;
+    zk_r1cs* R = nullptr;
+    size_t chunk = 1024, nv = 0;
+    PinBuf buf[2];
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> q_wit, q_gpu;
+    bool slot_free[2] = {true, true};
+    size_t in_flight = 0;
+    zk_status err = ZK_OK;
+    std::string err_msg;
+    bool stop = false;
+    std::thread t_wit, t_gpu;
+
+    void fail_with(zk_status st, const std::string& msg) {   // mu held
+        if (err == ZK_OK) {
+            err = st;
+            err_msg = msg;
+        }
+    }
+    void run_wit() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || (!q_wit.empty() && (slot_free[0] || slot_free[1])); });
+                if (stop) return;
+                j = q_wit.front();
+                q_wit.pop_front();
+                j.slot = slot_free[0] ? 0 : 1;
+                slot_free[j.slot] = false;
+                if (err != ZK_OK) {   // a failed stream drains without doing work
+                    q_gpu.push_back(j);
+                    cv.notify_all();
+                    continue;
+                }
+            }
+            zk_status rc = transfer_witness(j.st, j.n, ZK_FR_MONTGOMERY, buf[j.slot].as<uint8_t>(), j.index_base);
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc != ZK_OK) fail_with(rc, g_err);
+            q_gpu.push_back(j);
+            cv.notify_all();
+        }
+    }
+    void run_gpu() {
+        for (;;) {
+            Job j;
+            bool skip;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q_gpu.empty(); });
+                if (stop) return;
+                j = q_gpu.front();
+                q_gpu.pop_front();
+                skip = err != ZK_OK;
+            }
+            zk_status rc = ZK_OK;
+            if (!skip) rc = prove_batch_witness(P, R, j.n, buf[j.slot].as<uint8_t>(), ZK_FR_MONTGOMERY, j.rs, j.out);
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc != ZK_OK) fail_with(rc, g_err);
+            slot_free[j.slot] = true;
+            in_flight--;
+            cv.notify_all();
+        }
+    }
+};
+
+extern "C" {
+
+zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) {
+    if (!p || !circuit || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the transfer circuit's");
+    if (circuit->device != p->device) return fail(ZK_ERR_INVALID_ARGUMENT, "parameters and circuit live on different devices");
+    ZK_TRY(use_device(p->device));
+    zk_pipeline* L = new (std::nothrow) zk_pipeline();
+    if (!L) return fail(ZK_ERR_OUT_OF_MEMORY, "host allocation failed");
+    L->P = p;
+    L->R = circuit;
+    L->nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX;
+    if (const char* env = getenv("ZKAMD_BATCH_CHUNK"))
+        if (atoi(env) > 0) L->chunk = (size_t)atoi(env);
+    for (int k = 0; k < 2; k++) {
+        zk_status rc = L->buf[k].ensure(L->chunk * L->nv * 32);
+        if (rc != ZK_OK) {
+            delete L;
+            return rc;
+        }
+    }
+    (void)zkwit::tables();
+    L->t_wit = std::thread([L] { L->run_wit(); });
+    L->t_gpu = std::thread([L] { L->run_gpu(); });
+    *out = L;
+    return ZK_OK;
+}
+
+zk_status zk_pipeline_submit(zk_pipeline* L, size_t n, const zk_transfer_statement* st, const uint8_t* rs, uint8_t* proofs_out) {
+    if (!L || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    std::lock_guard<std::mutex> lk(L->mu);
+    for (size_t first = 0; first < n; first += L->chunk) {
+        const size_t np = std::min(L->chunk, n - first);
+        L->q_wit.push_back(zk_pipeline::Job{st + first, rs + first * 64, proofs_out + first * 192, np, first, -1});
+        L->in_flight++;
+    }
+    L->cv.notify_all();
+    return ZK_OK;
+}
+
+zk_status zk_pipeline_wait(zk_pipeline* L) {
+    if (!L) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    std::unique_lock<std::mutex> lk(L->mu);
+    L->cv.wait(lk, [&] { return L->in_flight == 0; });
+    const zk_status rc = L->err;
+    if (rc != ZK_OK) g_err = L->err_msg;
+    L->err = ZK_OK;   // the stream is usable again after the failure has been reported
+    L->err_msg.clear();
+    return rc;
+}
+
+void zk_pipeline_free(zk_pipeline* L) {
+    if (!L) return;
+    {
+        std::unique_lock<std::mutex> lk(L->mu);
+        L->cv.wait(lk, [&] { return L->in_flight == 0; });
+        L->stop = true;
+        L->cv.notify_all();
+    }
+    if (L->t_wit.joinable()) L->t_wit.join();
+    if (L->t_gpu.joinable()) L->t_gpu.join();
+    delete L;
+}
+
 zk_status zk_msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
     if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
@@ -1880,10 +2039,12 @@ zk_status zk_debug_field_mul(int field, const uint8_t* a, const uint8_t* b, uint
 
 void zk_profile_begin(void) {
     zk_profile_end();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof = true;
 }
 int zk_profile_get(const char* kernel, double* total_ms) {
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     int count = 0;
     double tot = 0;
     for (auto& r : g_recs)
@@ -1898,7 +2059,8 @@ int zk_profile_get(const char* kernel, double* total_ms) {
     return count;
 }
 void zk_profile_end(void) {
-    if (g_stream) (void)hipStreamSynchronize(g_stream);
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto& r : g_recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
