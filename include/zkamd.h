@@ -220,6 +220,36 @@ typedef struct {
 zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out);
 
 /* ------------------------------------------------------------------------------------------
+ * Verification  (bellman-verifier: prepare_verifying_key / verify_proof, PreparedVerifyingKey IO)
+ * replaces: prepare_verifying_key + verify_proof   core/bellman-verifier/src/verifier.rs:15-63
+ *           (called by the wallet's self-check core/proofs/src/confidential.rs:208-278 and by the
+ *           runtime, modules/zk-system/src/lib.rs:57-108)
+ * A zk_vk is a PreparedVerifyingKey resident on the GPU: e(alpha, beta), the line coefficients of
+ * -gamma and -delta, the doubling tables of ic.
+ *   zk_params_write_vk  VerifyingKey::write of the key inside a loaded Parameters (the first bytes of the
+ *                       parameter file: alpha_g1 | beta_g1 | beta_g2 | gamma_g2 | delta_g1 | delta_g2 | n_ic | ic)
+ *   zk_vk_prepare       VerifyingKey bytes -> prepare_verifying_key (pairing and G2 preparation on the GPU)
+ *   zk_vk_read / write  PreparedVerifyingKey::read / write (core/bellman-verifier/src/lib.rs:175-244; the
+ *                       reference's zface/params/conf_vk.dat is such a file)
+ *   zk_verify_batch     n independent verify_proof calls, one GPU thread per proof: proofs n x 192 bytes
+ *                       (Proof::read: compressed points, curve and subgroup checks), public inputs
+ *                       n x n_inputs x 32 bytes (plain little-endian, WITHOUT the leading ONE).
+ *                       ok_out[i] = 1 iff proof i verifies; a malformed proof or input is 0, not an error.
+ *                       ZK_ERR_MALFORMED_VERIFYING_KEY if n_inputs + 1 != ic length (verifier.rs:38-40).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct zk_vk zk_vk;
+zk_status zk_params_write_vk(const zk_params* p, uint8_t* out, size_t cap, size_t* len);
+zk_status zk_vk_prepare(const uint8_t* vk_bytes, size_t len, int device, zk_vk** out);
+zk_status zk_vk_read(const uint8_t* pvk_bytes, size_t len, int device, zk_vk** out);
+/* out may be NULL to query the length */
+zk_status zk_vk_write(const zk_vk* vk, uint8_t* out, size_t cap, size_t* len);
+zk_status zk_vk_num_inputs(const zk_vk* vk, uint32_t* n_inputs);
+void zk_vk_free(zk_vk* vk);
+zk_status zk_verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
+                          uint8_t* ok_out);
+zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* public_inputs, size_t n_inputs, int* ok);
+
+/* ------------------------------------------------------------------------------------------
  * Stand-alone kernels (micro-benchmark / test entries)
  * ------------------------------------------------------------------------------------------ */
 /* multiexp over G1 / G2: sum_i scalars[i] * bases[i].   replaces bellman multiexp (FullDensity).

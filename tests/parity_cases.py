@@ -2,6 +2,7 @@
 sizes) suites.  Every function takes `lib` (a ZkLib over one build of the C ABI) and compares
 the HIP path's bytes with the oracle's on the same seeded inputs."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -10,7 +11,7 @@ import zero_chain_amd as zk
 from oracle import bls12_381 as bls
 from oracle import cport
 from oracle import groth16 as g
-from oracle import params_io, synth
+from oracle import pairing, params_io, synth
 import helpers
 
 
@@ -397,3 +398,220 @@ def prover_errors(lib):
         assert got == want
     finally:
         params.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# verification (zk_vk_*, zk_verify_*): pairing.h / verify.cpp against the oracle and the reference's fixtures
+# ------------------------------------------------------------------------------------------------
+def _fq12_from_pvk(data):
+    """The leading Fq12 of a PreparedVerifyingKey file as the oracle's w-basis tuple."""
+    c = [int.from_bytes(data[48 * i:48 * i + 48], "big") for i in range(12)]
+    f2 = [(c[2 * i], c[2 * i + 1]) for i in range(6)]     # c0.c0 c0.c1 c0.c2 c1.c0 c1.c1 c1.c2
+    return pairing.tower_to_w(tuple(f2[:3]), tuple(f2[3:]))
+
+
+def _vk_bytes(alpha, beta1, beta2, gamma, delta1, delta2, ic):
+    g1 = lambda p: bls.g1_uncompressed(p)
+    g2 = lambda p: bls.g2_uncompressed(p)
+    return (g1(alpha) + g1(beta1) + g2(beta2) + g2(gamma) + g1(delta1) + g2(delta2) + len(ic).to_bytes(4, "big") +
+            b"".join(g1(p) for p in ic))
+
+
+def verifier_pairing_relic(lib):
+    """prepare_verifying_key computes e(alpha, beta) on the device: with alpha = G1::one(), beta = G2::one() it is
+    the RELIC vector the reference pins its pairing on (core/pairing/src/bls12_381/tests/mod.rs:4-53)."""
+    v = helpers.kats()["kats"]["relic_pairing_fq12"]
+    f2 = [(v[2 * i], v[2 * i + 1]) for i in range(6)]
+    relic = pairing.tower_to_w(tuple(f2[:3]), tuple(f2[3:]))
+    pvk = zk.prepare_verifying_key(_vk_bytes(bls.G1_GEN, bls.G1_GEN, bls.G2_GEN, bls.G2_GEN, bls.G1_GEN, bls.G2_GEN,
+                                             [bls.G1_GEN]), lib=lib)
+    try:
+        assert _fq12_from_pvk(pvk.write()) == relic
+    finally:
+        pvk.close()
+    # bilinearity on other points, against the oracle's pairing: e(3 G1, 5 G2) and an infinity on either side
+    a, b = bls.G1.to_affine(bls.G1.mul(bls.G1_GEN, 3)), bls.G2.to_affine(bls.G2.mul(bls.G2_GEN, 5))
+    pvk = zk.prepare_verifying_key(_vk_bytes(a, bls.G1_GEN, b, bls.G2_GEN, bls.G1_GEN, bls.G2_GEN, [bls.G1_GEN]), lib=lib)
+    try:
+        assert _fq12_from_pvk(pvk.write()) == pairing.fq12_pow(relic, 15) == pairing.pairing(a, b)
+    finally:
+        pvk.close()
+    pvk = zk.prepare_verifying_key(_vk_bytes(None, bls.G1_GEN, b, bls.G2_GEN, bls.G1_GEN, bls.G2_GEN, [bls.G1_GEN]), lib=lib)
+    try:
+        assert _fq12_from_pvk(pvk.write()) == pairing.FQ12_ONE
+    finally:
+        pvk.close()
+
+
+def verifier_pvk_fixtures(lib):
+    """PreparedVerifyingKey::read / write on the reference's own files (harness: core/bellman-verifier/src/lib.rs:
+    427-447 reads, writes and reads again; here the rewritten bytes must equal the file), and the G2 preparation
+    kernel against the coefficient tables inside them: the point -gamma (-delta) is recovered from the first
+    doubling triple of a table (Z = 1: a = 4 y, b = -6 x^2, c = 6 x^3 - 4 y^2), put into a verifying key, and the
+    device must reproduce all 68 triples of the reference bit for bit."""
+    F2 = bls.Fq2Ops
+    for name in ("conf_vk.dat", "verification.params", "anony_vk.dat"):
+        data = open(os.path.join(helpers.GOLDEN, name), "rb").read()
+        pvk = zk.PreparedVerifyingKey.read(data, lib=lib)
+        try:
+            assert pvk.write() == data, name
+            n_ic = int.from_bytes(data[576 + 2 * (4 + 68 * 288 + 1):][:4], "big")
+            assert pvk.n_inputs == n_ic - 1
+        finally:
+            pvk.close()
+        points = []
+        for k in range(2):
+            base = 576 + k * (4 + 68 * 288 + 1)
+            assert int.from_bytes(data[base:base + 4], "big") == 68 and data[base + 4 + 68 * 288] == 0
+            rd = lambda i: (int.from_bytes(data[base + 4 + 96 * i:][:48], "big"), int.from_bytes(data[base + 4 + 96 * i + 48:][:48], "big"))
+            a0, b0, c0 = rd(0), rd(1), rd(2)
+            y = F2.mul(a0, F2.inv((4, 0)))
+            x = F2.mul(F2.add(c0, F2.mul((4, 0), F2.sqr(y))), F2.inv(F2.neg(b0)))
+            assert F2.sqr(y) == F2.add(F2.mul(F2.sqr(x), x), (4, 4)), "recovered point is not on the twist"
+            points.append((x, y))
+        neg = lambda p: (p[0], F2.neg(p[1]))
+        pvk = zk.prepare_verifying_key(_vk_bytes(bls.G1_GEN, bls.G1_GEN, bls.G2_GEN, neg(points[0]), bls.G1_GEN, neg(points[1]),
+                                                 [bls.G1_GEN]), lib=lib)
+        try:
+            mine = pvk.write()
+            lo, hi = 576, 576 + 2 * (4 + 68 * 288 + 1)
+            assert mine[lo:hi] == data[lo:hi], "%s: prepared coefficients differ from the reference's" % name
+        finally:
+            pvk.close()
+
+
+def verifier_small_circuit(lib, seed=5, n_in=3, n_aux=12, n_con=14):
+    """verify_proof on proofs of a small circuit: accepted exactly when the oracle's verifier accepts."""
+    r1, asg, P, pk = helpers.small_case(seed, n_in, n_aux, n_con)
+    E = g.Bls12Engine()
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    pvk = zk.prepare_verifying_key(params)
+    try:
+        assert pvk.n_inputs == n_in - 1
+        # e(alpha, beta) against the oracle
+        sc = P.sc
+        ab = pairing.pairing(bls.G1.to_affine(bls.G1.mul(bls.G1_GEN, sc["alpha"])), bls.G2.to_affine(bls.G2.mul(bls.G2_GEN, sc["beta"])))
+        assert _fq12_from_pvk(pvk.write()) == ab
+        good = [helpers.expected_proof_trapdoor(P, asg, r, s) for r, s in ((3, 5), (0, 0), (bls.R_MOD - 1, 7))]
+        inputs = list(asg.inputs[1:])
+        assert zk.verify_proofs(pvk, good, [inputs] * 3) == [True, True, True]
+        assert zk.verify_proof(pvk, zk.Proof(good[0]), inputs) is True
+        # the prover's own output verifies too
+        mine = zk.create_proof(helpers.to_assignment(zk, asg), params, 11, 13)
+        assert zk.verify_proof(pvk, mine, inputs)
+        # wrong public input, swapped A / C, a proof of other randomness with its C replaced
+        bad_in = [(inputs[0] + 1) % bls.R_MOD] + inputs[1:]
+        swapped = good[0][144:] + good[0][48:144] + good[0][:48]
+        mixed = good[0][:144] + good[1][144:]
+        # malformed encodings: not compressed, x >= q, x with no y on the curve, y-sign flipped (valid point,
+        # wrong proof), a point outside the subgroup is covered by the golden-vector tests of the decoder below
+        raw = bytearray(good[0])
+        raw[0] &= 0x7f
+        big = bytes([0x9f]) + b"\xff" * 47 + good[0][48:]
+        flipped = bytes([good[0][0] ^ 0x20]) + good[0][1:]
+        off = None
+        for k in range(1, 50):   # an x for which x^3 + 4 is not a square
+            x = k
+            if pow((x ** 3 + 4) % bls.Q_MOD, (bls.Q_MOD - 1) // 2, bls.Q_MOD) != 1:
+                off = (x | (1 << 383)).to_bytes(48, "big") + good[0][48:]
+                break
+        noncanon_in = scalars_to_bytes_list([inputs[0] + bls.R_MOD] + inputs[1:]) if inputs[0] + bls.R_MOD < 1 << 256 else None
+        batch = [good[0], swapped, mixed, bytes(raw), big, flipped, off, good[2]]
+        got = zk.verify_proofs(pvk, batch, [inputs] * len(batch))
+        assert got == [True, False, False, False, False, False, False, True], got
+        assert zk.verify_proofs(pvk, [good[0], good[1]], [bad_in, inputs]) == [False, True]
+        if noncanon_in is not None:
+            ib = np.concatenate([noncanon_in, zk.scalars_to_bytes(inputs)])
+            assert zk.verify_proofs(pvk, np.frombuffer(good[0] + good[1], dtype=np.uint8), ib) == [False, True]
+        # infinity encodings are legal points that Proof::read refuses (core/bellman-verifier/src/lib.rs:67-110)
+        inf_a = bytes([0xc0]) + bytes(47) + good[0][48:]
+        inf_b = good[0][:48] + bytes([0xc0]) + bytes(95) + good[0][144:]
+        assert zk.verify_proofs(pvk, [inf_a, inf_b], [inputs, inputs]) == [False, False]
+        # the oracle's verifier agrees on every decodable case
+        opvk = dict(alpha_g1_beta_g2=ab, neg_gamma_g2=bls.G2.mul(bls.G2_GEN, bls.R_MOD - sc["gamma"]),
+                    neg_delta_g2=bls.G2.mul(bls.G2_GEN, bls.R_MOD - sc["delta"]),
+                    ic=[bls.G1.mul(bls.G1_GEN, k) for k in sc["ic"]])
+        for pf, want in ((good[0], True), (swapped, None), (mixed, False)):
+            try:
+                dec = params_io.read_proof(pf)
+            except Exception:
+                continue
+            assert g.verify_proof(E, opvk, dec, inputs) == (want if want is not None else False)
+        # verifier.rs:38-40
+        with pytest.raises(zk.ZkError) as e:
+            zk.verify_proofs(pvk, [good[0]], [inputs + [1]])
+        assert e.value.variant == "MalformedVerifyingKey"
+        assert zk.verify_proofs(pvk, [], []) == []
+    finally:
+        pvk.close()
+        params.close()
+
+
+def scalars_to_bytes_list(values):
+    return zk.scalars_to_bytes(values)
+
+
+def verifier_golden_multiples(lib):
+    """Proofs assembled from the reference's golden multiples k * G (core/pairing/src/bls12_381/tests/*.dat, in the
+    compressed encodings) under the key alpha = G1, beta = gamma = delta = G2, ic = [i G1]:
+        e(a G1, b G2) e(i G1, -G2) e(c G1, -G2) == e(G1, G2)   <=>   a b - i - c == 1   (mod r)
+    so decoder, accumulator, Miller loop, final exponentiation and the comparison are pinned on reference-held
+    bytes; a triple that misses the equation by one is rejected, and so are curve points outside the subgroup."""
+    g1c, g2c = helpers.golden_points("g1_compressed"), helpers.golden_points("g2_compressed")
+    g1u = helpers.golden_points("g1_uncompressed")
+    one2 = bls.g2_uncompressed(bls.G2_GEN)
+    i = 3
+    vk = g1u[1] + g1u[1] + one2 + one2 + g1u[1] + one2 + (1).to_bytes(4, "big") + g1u[i]
+    pvk = zk.prepare_verifying_key(vk, lib=lib)
+    try:
+        cases, want = [], []
+        for a, b in ((5, 7), (2, 3), (1, 6), (17, 15), (255, 1), (5, 1)):
+            c = a * b - i - 1
+            assert 0 < c < 256
+            cases.append(g1c[a] + g2c[b] + g1c[c])
+            want.append(True)
+            cases.append(g1c[a] + g2c[b] + g1c[c + 1])
+            want.append(False)
+        # points on the curve but outside the r-torsion: rejected by the subgroup test of into_affine()
+        for x in range(1, 200):
+            y2 = (x ** 3 + 4) % bls.Q_MOD
+            y = pow(y2, (bls.Q_MOD + 1) // 4, bls.Q_MOD)
+            if y * y % bls.Q_MOD == y2 and bls.G1.mul((x, y), bls.R_MOD) is not None:
+                cases.append(bls.g1_compressed((x, y)) + g2c[7] + g1c[31])
+                want.append(False)
+                break
+        assert zk.verify_proofs(pvk, cases, [[]] * len(cases)) == want
+    finally:
+        pvk.close()
+
+
+def verifier_reference_vectors(lib):
+    """The reference's literal proofs through the decoder: core/primitives/src/proof.rs:89 and the byte_cast proof
+    (core/bellman-verifier/src/lib.rs:392-414) are well-formed (every point decodes and lies in the subgroup: they
+    reach the pairing and are rejected by it, not by the decoder), the proof of
+    modules/encrypted-balances/src/lib.rs:442-450 (a malformed encoding) must not verify under conf_vk.dat."""
+    k = helpers.kats()["kats"]
+    data = open(os.path.join(helpers.GOLDEN, "conf_vk.dat"), "rb").read()
+    pvk = zk.PreparedVerifyingKey.read(data, lib=lib)
+    try:
+        assert pvk.n_inputs == 22
+        from oracle import jubjub as jj
+        w = k["wrong_proof_case"]
+        pts = [jj.read_point(bytes.fromhex(w[n])) for n in ("pkd_addr_alice", "pkd_addr_bob", "enc10_by_alice", "enc10_by_bob",
+                                                           "randomness", "enc1_by_alice")]
+        # balance (left, right), rvk, g_epoch, nonce: the chain state of that test is not in the vector; any points do
+        pts += [pts[2], pts[4], jj.read_point(bytes.fromhex(w["rvk"])), pts[0], jj.read_point(bytes.fromhex(w["nonce"]))]
+        inputs = [c for p in pts for c in p]
+        assert len(inputs) == 22
+        proofs = [bytes.fromhex(w["proof"]), bytes.fromhex(k["valid_proof_hex"])]
+        limbs = k["byte_cast_limbs"]
+        to_int = lambda l: sum(v << (64 * i) for i, v in enumerate(l)) * pow(1 << 384, -1, bls.Q_MOD) % bls.Q_MOD
+        ax, ay, bx0, bx1, by0, by1, cx, cy = (to_int(l) for l in limbs)
+        proofs.append(bls.g1_compressed((ax, ay)) + bls.g2_compressed(((bx0, bx1), (by0, by1))) + bls.g1_compressed((cx, cy)))
+        with pytest.raises(bls.DecodeError):   # 0xc8...: infinity flag with coordinate bits set - Proof::read fails
+            params_io.read_proof(proofs[0])
+        for pf in proofs[1:]:                   # the other two are well-formed: rejected by the pairing, not the decoder
+            params_io.read_proof(pf)
+        assert zk.verify_proofs(pvk, proofs, [inputs] * 3) == [False, False, False]
+    finally:
+        pvk.close()

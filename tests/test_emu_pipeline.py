@@ -115,3 +115,23 @@ def test_msm_sliced(emu_lib, monkeypatch):
 def test_prover_blinding_edges(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
     pc.prover_blinding_edges(emu_lib)
+
+
+def test_verifier_pairing_relic(emu_lib):
+    pc.verifier_pairing_relic(emu_lib)
+
+
+def test_verifier_pvk_fixtures(emu_lib):
+    pc.verifier_pvk_fixtures(emu_lib)
+
+
+def test_verifier_small_circuit(emu_lib):
+    pc.verifier_small_circuit(emu_lib)
+
+
+def test_verifier_reference_vectors(emu_lib):
+    pc.verifier_reference_vectors(emu_lib)
+
+
+def test_verifier_golden_multiples(emu_lib):
+    pc.verifier_golden_multiples(emu_lib)

@@ -282,3 +282,64 @@ def test_two_handles_two_threads(gpu_lib):
     for p in params:
         p.close()
     assert not errors, errors
+
+
+def test_verifier_pairing_relic(gpu_lib):
+    pc.verifier_pairing_relic(gpu_lib)
+
+
+def test_verifier_pvk_fixtures(gpu_lib):
+    pc.verifier_pvk_fixtures(gpu_lib)
+
+
+def test_verifier_small_circuit(gpu_lib):
+    pc.verifier_small_circuit(gpu_lib)
+
+
+def test_verifier_golden_multiples(gpu_lib):
+    pc.verifier_golden_multiples(gpu_lib)
+
+
+def test_verifier_reference_vectors(gpu_lib):
+    pc.verifier_reference_vectors(gpu_lib)
+
+
+def test_full_chunk_1024_every_proof_checked(gpu_lib):
+    """One full 1024-proof chunk of the transfer circuit - the launch shape of the bench (accumulation tasks of up
+    to 256 points, 8 inline task partials per bucket, fan-16 bucket reduction: branches the small batches of the
+    other tests never take) - from statements, through zk_transfer_prove_batch.  EVERY proof is verified by the
+    product's verifier against the public inputs of its statement, a sample is compared byte for byte with the
+    oracle's discrete-log proof, and tampered proofs inside the same batch are rejected."""
+    import zero_chain_amd as zk
+    from oracle import transfer_circuit as tc
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    E = g.Bls12Engine()
+    n_distinct, n = 32, 1024
+    ws = [tc.make_witness(900 + i, amount=1 + 37 * i, fee=i % 5, balance=5000 + 11 * i) for i in range(n_distinct)]
+    items = [tc.statement_dict(ws[i % n_distinct]) for i in range(n)]
+    sts = zk.transfer_statements(items)
+    rng = synth.SplitMix64(2024)
+    rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices(r1.n_in, r1.n_aux, r1.constraints, lib=gpu_lib)
+    pvk = zk.prepare_verifying_key(params)
+    try:
+        proofs = zk.transfer_prove_batch(mats, params, sts, rs)
+        raw = np.frombuffer(b"".join(p.write() for p in proofs), dtype=np.uint8).copy()
+        assert zk.verify_transfer_batch(pvk, sts, raw) == n
+        for i in (0, 1, 517, n - 1):
+            cs = tc.synthesize(ws[i % n_distinct])
+            asg = g.assign(E, r1, cs.inputs, cs.aux)
+            assert proofs[i].write() == helpers.expected_proof_trapdoor(P, asg, *rs[i]), i
+        # proofs swapped between statements with different public inputs, and one flipped bit, are rejected
+        bad = raw.copy()
+        bad[192 * 5:192 * 6], bad[192 * 6:192 * 7] = raw[192 * 6:192 * 7].copy(), raw[192 * 5:192 * 6].copy()
+        bad[192 * 100 + 60] ^= 1
+        w = zk.transfer_witness(sts, lib=gpu_lib).reshape(n, -1)
+        inputs = np.ascontiguousarray(w[:, 32:zk.TRANSFER_N_INPUTS * 32])
+        ok = zk.verify_proofs(pvk, bad, inputs)
+        assert [i for i, v in enumerate(ok) if not v] == [5, 6, 100]
+    finally:
+        pvk.close()
+        mats.close()
+        params.close()

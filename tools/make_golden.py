@@ -12,6 +12,9 @@ fixtures.  Sources (relative to /root/reference):
   core/primitives/src/proof.rs:89                a valid 192-byte proof
   core/bellman-verifier/src/lib.rs:392-414       a valid (A, B, C) as literal Montgomery limbs
   core/bellman-verifier/src/verifier.rs:74-92    DummyEngine Groth16 KAT
+  zface/params/conf_vk.dat, anony_vk.dat, core/bellman-verifier/src/tests/verification.params
+        PreparedVerifyingKey files (copied verbatim: 42 - 50 KB each; harness lib.rs:427-447)
+  modules/encrypted-balances/src/lib.rs:442-450  a 192-byte proof that must NOT verify, with its public points
 """
 import hashlib
 import json
@@ -67,6 +70,16 @@ def main():
     w = [int(x) for x in re.findall(r"Wrapping\((\d+)\)", body)]
     kats["dummy_engine"] = {"alpha_g1_beta_g2": w[0], "neg_gamma_g2": w[1], "neg_delta_g2": w[2], "ic": w[3:5],
                             "proof": w[5:8], "public_input": w[8:9]}
+    for src, dst in (("zface/params/conf_vk.dat", "conf_vk.dat"), ("zface/params/anony_vk.dat", "anony_vk.dat"),
+                     ("core/bellman-verifier/src/tests/verification.params", "verification.params")):
+        data = open(os.path.join(REF, src), "rb").read()
+        with open(os.path.join(OUT, dst), "wb") as f:
+            f.write(data)
+        meta[dst] = {"source": src, "bytes": len(data), "sha256_full": hashlib.sha256(data).hexdigest()}
+    esrc = open(os.path.join(REF, "modules/encrypted-balances/src/lib.rs")).read()
+    body = esrc[esrc.index("fn test_call_with_worng_proof"):]
+    names = re.findall(r"let (\w+): \[u8; \d+\] = hex!\(\"([0-9a-f]+)\"\)", body)
+    kats["wrong_proof_case"] = {k: v for k, v in names[:9]}
     with open(os.path.join(OUT, "reference_kats.json"), "w") as f:
         json.dump({"files": meta, "kats": kats}, f, indent=1)
     print("wrote", os.path.abspath(OUT))

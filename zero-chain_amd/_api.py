@@ -23,7 +23,8 @@ from ._shard import shard_bounds, gather_proofs, prove_sharded
 from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSET, ZK_NTT_IN_BITREV,
                    ZK_NTT_OUT_BITREV)
 
-__all__ = ["Parameters", "Proof", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
+__all__ = ["Parameters", "Proof", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
+           "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "anonymous_statements", "anonymous_witness",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
@@ -185,6 +186,110 @@ class Parameters:
             self.close()
         except Exception:
             pass
+
+
+class PreparedVerifyingKey:
+    """bellman_verifier::PreparedVerifyingKey<Bls12> resident on one GPU (zk_vk): e(alpha, beta), the line
+    coefficients of -gamma and -delta, the doubling tables of ic.
+        PreparedVerifyingKey.read(bytes)      PreparedVerifyingKey::read  (zface/params/conf_vk.dat)
+        prepare_verifying_key(params | bytes) verifier.rs:15-30
+        .write()                              PreparedVerifyingKey::write"""
+
+    def __init__(self, lib, handle):
+        self._lib = lib
+        self._h = handle
+        n = C.c_uint32(0)
+        lib.check(lib.zk_vk_num_inputs(handle, C.byref(n)))
+        self.n_inputs = n.value
+
+    @classmethod
+    def read(cls, reader, device=0, lib=None):
+        lib = lib or _lib.load()
+        buf = _u8(bytes(reader if isinstance(reader, (bytes, bytearray)) else reader.read()))
+        h = C.c_void_p()
+        lib.check(lib.zk_vk_read(_ptr(buf), buf.size, device, C.byref(h)))
+        return cls(lib, h)
+
+    def write(self, writer=None):
+        n = C.c_size_t(0)
+        self._lib.check(self._lib.zk_vk_write(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint8)
+        self._lib.check(self._lib.zk_vk_write(self._h, _ptr(out), out.size, C.byref(n)))
+        data = out.tobytes()
+        if writer is not None:
+            writer.write(data)
+        return data
+
+    def close(self):
+        if self._h:
+            self._lib.zk_vk_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prepare_verifying_key(vk, device=None, lib=None):
+    """verifier.rs:15-30.  `vk`: a Parameters object (its VerifyingKey) or VerifyingKey::write bytes."""
+    if isinstance(vk, Parameters):
+        lib = vk._lib
+        n = C.c_size_t(0)
+        lib.check(lib.zk_params_write_vk(vk._h, None, 0, C.byref(n)))
+        raw = np.zeros(n.value, dtype=np.uint8)
+        lib.check(lib.zk_params_write_vk(vk._h, _ptr(raw), raw.size, C.byref(n)))
+        device = vk.info["device"] if device is None else device
+    else:
+        lib = lib or _lib.load()
+        raw = _u8(bytes(vk))
+        device = 0 if device is None else device
+    h = C.c_void_p()
+    lib.check(lib.zk_vk_prepare(_ptr(raw), raw.size, device, C.byref(h)))
+    return PreparedVerifyingKey(lib, h)
+
+
+def verify_proofs(pvk, proofs, public_inputs):
+    """n independent verify_proof calls on the GPU (zk_verify_batch).  proofs: list of Proof / 192-byte strings
+    (or one n x 192 byte array); public_inputs: per proof the list of Fr values WITHOUT the leading ONE (or one
+    n x n_inputs x 32 byte array, plain little-endian).  Returns a list of bools; raises ZkError
+    MalformedVerifyingKey when the number of inputs does not fit the key (verifier.rs:38-40)."""
+    if isinstance(proofs, np.ndarray):
+        pb = _u8(proofs)
+    else:
+        pb = _u8(b"".join(p.write() if isinstance(p, Proof) else bytes(p) for p in proofs))
+    n = pb.size // PROOF_SIZE
+    if isinstance(public_inputs, np.ndarray):
+        ib = _u8(public_inputs)
+        n_inputs = ib.size // (32 * n) if n else pvk.n_inputs
+    else:
+        n_inputs = len(public_inputs[0]) if n else pvk.n_inputs
+        if any(len(x) != n_inputs for x in public_inputs):
+            raise ValueError("every proof needs the same number of public inputs")
+        flat = [v for x in public_inputs for v in x]
+        ib = scalars_to_bytes(flat) if flat else np.zeros(0, dtype=np.uint8)
+    ok = np.zeros(max(n, 1), dtype=np.uint8)
+    pvk._lib.check(pvk._lib.zk_verify_batch(pvk._h, n, _ptr(pb) if pb.size else None, _ptr(ib) if ib.size else None, n_inputs,
+                                             _ptr(ok)))
+    return [bool(x) for x in ok[:n]]
+
+
+def verify_proof(pvk, proof, public_inputs):
+    """verifier.rs:32-63 for one proof."""
+    return verify_proofs(pvk, [proof], [list(public_inputs)])[0]
+
+
+def verify_transfer_batch(pvk, statements, proofs, lib=None):
+    """Verify a batch of confidential-transfer proofs against the statements they were made from: the 22 public
+    inputs of each statement are recomputed by the native witness calculator (the first values of its assignment).
+    Returns the number of proofs that verify."""
+    lib = lib or pvk._lib
+    n = len(statements)
+    nv = TRANSFER_N_INPUTS + TRANSFER_N_AUX
+    w = transfer_witness(statements, lib=lib).reshape(n, nv * 32)
+    inputs = np.ascontiguousarray(w[:, 32:TRANSFER_N_INPUTS * 32])
+    return sum(verify_proofs(pvk, proofs if isinstance(proofs, np.ndarray) else list(proofs), inputs))
 
 
 class ProvingAssignment:

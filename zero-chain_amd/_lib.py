@@ -87,6 +87,14 @@ _PROTOS = {
     "zk_pipeline_wait": (C.c_int32, [C.c_void_p]),
     "zk_pipeline_free": (None, [C.c_void_p]),
     "zk_anonymous_witness": (C.c_int32, [C.POINTER(AnonymousStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
+    "zk_params_write_vk": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "zk_vk_prepare": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_vk_read": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_vk_write": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "zk_vk_num_inputs": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "zk_vk_free": (None, [C.c_void_p]),
+    "zk_verify_batch": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zk_verify_proof": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "zk_msm_create": (C.c_int32, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_msm_run": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zk_msm_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),

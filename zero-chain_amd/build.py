@@ -35,15 +35,30 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
+TRANSLATION_UNITS = ("zkamd.cpp", "verify.cpp")   # compiled in parallel, linked into one library
+
+
 def build_lib(force=False):
     if not force and not _stale(LIB, _sources()):
         return LIB
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           os.path.join(CSRC, "zkamd.cpp"), "-o", LIB, "-lpthread"]
-    extra = os.environ.get("ZKAMD_HIPCC_FLAGS")
-    if extra:
-        cmd[1:1] = extra.split()
-    _run(cmd)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    extra = (os.environ.get("ZKAMD_HIPCC_FLAGS") or "").split()
+    deps = _sources()
+    procs, objs = [], []
+    for tu in TRANSLATION_UNITS:
+        obj = os.path.join(objdir, tu.replace(".cpp", ".o"))
+        objs.append(obj)
+        if not force and not extra and not _stale(obj, deps):
+            continue
+        cmd = [HIPCC] + extra + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-x", "hip",
+                                 os.path.join(CSRC, tu), "-o", obj]
+        print("+", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-lpthread"])
     return LIB
 
 

@@ -1,0 +1,195 @@
+// Host-side runtime helpers shared by the translation units of libzkamd (zkamd.cpp, verify.cpp):
+// error reporting, the per-device stream contexts, device / page-locked buffers, HIP-event profiling.
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <thread>
+#include <mutex>
+#if defined(__linux__)
+#include <sched.h>
+#endif
+#include "../../include/zkamd.h"
+#include "gpu_rt.h"
+
+namespace zkrt {
+
+inline thread_local std::string g_err;
+
+// Streams and the fork event live in a per-DEVICE context that is created on first use and kept for
+// the life of the process: handles on different GPUs never tear down each other's streams, and the
+// current device - which HIP keeps per host thread - is selected on every entry (use_device), so a
+// handle may be driven from any thread.  g_stream & co. are the calling thread's view of the context
+// of the device it selected last.
+struct DevCtx {
+    hipStream_t stream = nullptr;    // main stream: H pipeline, G1 multiexps, stand-alone entries
+    hipStream_t stream2 = nullptr;   // side stream: the G2 multiexp of a chunk runs beside the G1 work
+    hipStream_t copy = nullptr;      // staging copies of the next block of a host batch
+    hipEvent_t ev_fork = nullptr;
+};
+inline std::mutex g_ctx_mu;
+inline std::map<int, DevCtx*> g_ctxs;
+inline thread_local hipStream_t g_stream = nullptr;
+inline thread_local hipStream_t g_stream2 = nullptr;
+inline thread_local hipStream_t g_copy_stream = nullptr;
+inline thread_local hipEvent_t g_ev_fork = nullptr;
+inline thread_local int g_device = -1;
+
+inline zk_status fail(zk_status st, const std::string& msg) {
+    g_err = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ZK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+#define ZK_TRY(expr)                \
+    do {                            \
+        zk_status s_ = (expr);      \
+        if (s_ != ZK_OK) return s_; \
+    } while (0)
+
+inline zk_status use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ZK_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(ZK_ERR_INVALID_ARGUMENT, "device index out of range");
+    HIP_TRY(hipSetDevice(device));   // per host thread: never skipped
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    DevCtx*& c = g_ctxs[device];
+    if (!c) {
+        DevCtx* fresh = new DevCtx();
+        if (hipStreamCreate(&fresh->stream) != hipSuccess || hipStreamCreate(&fresh->stream2) != hipSuccess ||
+            hipStreamCreateWithFlags(&fresh->copy, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&fresh->ev_fork) != hipSuccess) {
+            delete fresh;
+            g_ctxs.erase(device);
+            return fail(ZK_ERR_DEVICE, "cannot create the streams of device " + std::to_string(device));
+        }
+        c = fresh;
+    }
+    g_stream = c->stream;
+    g_stream2 = c->stream2;
+    g_copy_stream = c->copy;
+    g_ev_fork = c->ev_fork;
+    g_device = device;
+    return ZK_OK;
+}
+
+// Host threads the library may use for the CPU-side legs (witness calculation, proof encoding):
+// zk_set_host_threads() / ZKAMD_HOST_THREADS, default = the cores this process may run on.  With one
+// process per GPU on an 8-GPU node every rank must take its share of the cores, not all of them.
+inline int g_host_threads = 0;
+inline unsigned host_threads(size_t work_items, unsigned cap) {
+    long n = g_host_threads;
+    if (n <= 0) {
+        if (const char* env = getenv("ZKAMD_HOST_THREADS")) n = atol(env);
+    }
+    if (n <= 0) {
+#if defined(__linux__) && !defined(ZK_EMU)
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+#endif
+        if (n <= 0) n = (long)std::thread::hardware_concurrency();
+    }
+    if (n <= 0) n = 1;
+    if ((unsigned long)n > cap) n = cap;
+    if ((size_t)n > work_items) n = (long)work_items;
+    return n > 0 ? (unsigned)n : 1u;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    zk_status ensure(size_t bytes) {
+        if (bytes <= cap) return ZK_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            p = nullptr;
+            return fail(ZK_ERR_OUT_OF_MEMORY, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
+        }
+        cap = bytes;
+        return ZK_OK;
+    }
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+};
+
+// page-locked host memory: asynchronous copies into pageable memory block the calling thread until
+// the copy has run, which would serialise whatever is enqueued after them on other streams
+struct PinBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    PinBuf() {}
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+    zk_status ensure(size_t bytes) {
+        if (bytes <= cap) return ZK_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        if (hipHostMalloc(&p, bytes) != hipSuccess) {
+            p = nullptr;
+            return fail(ZK_ERR_OUT_OF_MEMORY, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+        }
+        cap = bytes;
+        return ZK_OK;
+    }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+// ------------------------------------------------------------------------------------------
+// HIP-event profiling of named kernels (zk_profile_*)
+// ------------------------------------------------------------------------------------------
+struct ProfRec {
+    std::string name;
+    hipEvent_t a, b;
+};
+// process-wide (the GPU thread of a zk_pipeline records into the same list the caller reads)
+inline std::mutex g_prof_mu;
+inline bool g_prof = false;
+inline std::vector<ProfRec> g_recs;
+
+struct ProfScope {
+    bool on = false;
+    hipStream_t st;
+    hipEvent_t end = nullptr;
+    ProfScope(const char* name, hipStream_t stream = nullptr) : st(stream ? stream : g_stream) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof) return;
+        ProfRec r;
+        r.name = name;
+        if (hipEventCreate(&r.a) != hipSuccess) return;
+        if (hipEventCreate(&r.b) != hipSuccess) {
+            (void)hipEventDestroy(r.a);
+            return;
+        }
+        (void)hipEventRecord(r.a, st);
+        end = r.b;
+        on = true;
+        g_recs.push_back(r);
+    }
+    ~ProfScope() {
+        if (on) (void)hipEventRecord(end, st);
+    }
+};
+
+}  // namespace zkrt

@@ -179,7 +179,7 @@ constexpr uint32_t MSM_COARSE_MAX = 1024;      // coarse bins per job
 constexpr uint32_t MSM_FINE_MAX = 2048;        // buckets per coarse bin
 constexpr uint32_t MSM_COARSE_SCALARS = 1024;  // scalars per workgroup of passes 1 and 3 (4 per thread)
 
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_msm_coarse_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse, uint32_t* coarse_cnt,
                    uint32_t* blockbase) {
     ZK_SHARED uint32_t h[MSM_COARSE_MAX];
@@ -200,7 +200,7 @@ k_msm_coarse_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_lo
 }
 
 // exclusive scan of n values per job (n <= a few thousand), one workgroup per job; total[job] = sum
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_msm_coarse_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t* __restrict__ total, uint32_t n) {
     ZK_SHARED uint32_t part[1024];
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
@@ -230,7 +230,7 @@ k_msm_coarse_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, u
 
 // record = (bucket inside its coarse bin, pair);  pair = (table index << 1) | sign,
 // table index = position * n_table + base
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_msm_coarse_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse,
                      const uint32_t* __restrict__ coarse_off, const uint32_t* __restrict__ blockbase, uint2* __restrict__ rec) {
     ZK_SHARED uint32_t h[MSM_COARSE_MAX];
@@ -258,7 +258,7 @@ k_msm_coarse_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_
 
 // grid (coarse bins, jobs).  A bucket with k points is cut into ceil(k / seg) tasks (see below);
 // toff is left relative to the bin's first task, bin_tasks[bin] = tasks of the bin.
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_msm_fine_sort(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, const uint32_t* __restrict__ coarse_cnt,
                 const uint32_t* __restrict__ coarse_off, uint32_t fine, uint32_t nb, uint32_t* cnt, uint32_t* off, uint32_t* toff,
                 uint32_t* bin_tasks, uint32_t* pairs, uint32_t seg) {
@@ -334,7 +334,7 @@ k_msm_fine_sort(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, 
 }
 
 // toff[b] += first task of b's bin; grid (blocks over the buckets, jobs)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_msm_task_offsets(uint32_t* toff, const uint32_t* __restrict__ bin_tbase, uint32_t nb, uint32_t fine_log, uint32_t n_coarse) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < nb) toff[(size_t)blockIdx.y * nb + b] += bin_tbase[(size_t)blockIdx.y * n_coarse + (b >> fine_log)];
@@ -349,7 +349,7 @@ constexpr uint32_t MSM_SORT_THREADS = 64;     // the test-only emulation runs on
 #else
 constexpr uint32_t MSM_SORT_THREADS = 1024;
 #endif
-__global__ void __launch_bounds__(MSM_SORT_THREADS)
+static __global__ void __launch_bounds__(MSM_SORT_THREADS)
 k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* off, uint32_t* toff,
                uint32_t* ntasks, uint32_t* pairs, uint32_t seg) {
     ZK_DYN_SHARED(uint32_t, h);   // [nb] histogram, then running slot cursors
@@ -426,7 +426,7 @@ ZK_DI TaskCut task_cut(uint32_t k, uint32_t seg) {
 }
 
 // Pass 4a: histogram of task lengths (1 .. seg) per job.  One thread per bucket.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t* lenhist, uint32_t nb, uint32_t seg) {
     ZK_SHARED uint32_t h[MSM_SEG_MAX];
     const uint32_t tid = threadIdx.x, job = blockIdx.y;
@@ -444,7 +444,7 @@ k_msm_task_hist(const uint32_t* __restrict__ cnt, uint32_t* lenhist, uint32_t nb
 
 // Pass 4b: first slot of every (length, job) class in the launch-wide task order: longest tasks
 // first, jobs in order inside a length class.  One workgroup.
-__global__ void __launch_bounds__(1024)
+static __global__ void __launch_bounds__(1024)
 k_msm_task_base(const uint32_t* __restrict__ lenhist, uint32_t* base, uint32_t* total, uint32_t nj, uint32_t seg) {
     ZK_SHARED uint32_t part[1024];
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
@@ -474,7 +474,7 @@ k_msm_task_base(const uint32_t* __restrict__ lenhist, uint32_t* base, uint32_t* 
 // Pass 4c: write the task descriptors {first pair, index of the partial sum, length} in that
 // order.  A workgroup reserves a range per length class with one global atomic, its threads
 // take slots inside the range from LDS counters.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff,
                  const uint32_t* __restrict__ task_base, const uint32_t* __restrict__ base, uint32_t* cursor,
                  uint4* sorted, uint32_t* n_heavy, uint32_t* heavy, uint32_t nb, uint32_t nj, uint32_t merge_inline,
@@ -517,7 +517,7 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
 // slices in step.  The single job's lower rate (4.3 G additions/s against 7.0) is 88 % occupancy at
 // the two ends of a 3 ms launch, a 12 % lower issue rate per resident wave and a lower clock.
 template <class F>
-__global__ void __launch_bounds__(128, MsmOcc<F>::acc)
+static __global__ void __launch_bounds__(128, MsmOcc<F>::acc)
 k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
                  const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<F>* __restrict__ tsums) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,7 +542,7 @@ k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict
 // bucket's first partial.
 constexpr uint32_t MSM_MERGE_THREADS = 256;
 template <class F>
-__global__ void __launch_bounds__(MSM_MERGE_THREADS)
+static __global__ void __launch_bounds__(MSM_MERGE_THREADS)
 k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
                   const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb,
                   uint32_t seg, uint32_t heavy_blocks, uint32_t light_buckets, uint32_t merge_inline) {
@@ -603,7 +603,7 @@ k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict
 //
 // k_msm_suffix_buckets: R over the buckets (task partials merged on the fly), in bucket order.
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+static __global__ void __launch_bounds__(64, MsmOcc<F>::red)
 k_msm_suffix_buckets(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restrict__ cnt,
                      const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base,
                      XYZZ<F>* __restrict__ R, uint32_t nb, uint32_t L, uint32_t merge_inline, uint32_t seg) {
@@ -633,7 +633,7 @@ k_msm_suffix_buckets(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restri
 // k_msm_suffix: out[k] = sum_{k' >= k, same segment} in[k' * stride]; n elements per job, segments
 // of `seg`, one thread per segment.
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+static __global__ void __launch_bounds__(64, MsmOcc<F>::red)
 k_msm_suffix(const XYZZ<F>* __restrict__ in, XYZZ<F>* __restrict__ out, uint32_t n, uint32_t seg, uint32_t stride) {
     const uint32_t ns = (n + seg - 1) / seg;
     uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -652,7 +652,7 @@ k_msm_suffix(const XYZZ<F>* __restrict__ in, XYZZ<F>* __restrict__ out, uint32_t
 //     acc = (init ? init[s] : 0) + sum_{first <= k < seg} in[s * seg + k]
 //     out[s] = 2^dbl * acc + (plus_first ? in[s * seg] : 0)
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::red)
+static __global__ void __launch_bounds__(64, MsmOcc<F>::red)
 k_msm_segsum(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ init, XYZZ<F>* __restrict__ out, uint32_t n,
              uint32_t seg, uint32_t first, uint32_t dbl, uint32_t plus_first) {
     const uint32_t ns = (n + seg - 1) / seg;
@@ -683,7 +683,7 @@ k_msm_segsum(const XYZZ<F>* __restrict__ in, const XYZZ<F>* __restrict__ init, X
 // tree in LDS (14 KB, so all blocks of a launch are resident at once: one chain of 14 additions).
 constexpr uint32_t MSM_BITSUM_LOG = 9, MSM_BITSUM_NODES = 1u << MSM_BITSUM_LOG;
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::tail)
+static __global__ void __launch_bounds__(64, MsmOcc<F>::tail)
 k_msm_bitsum(const XYZZ<F>* __restrict__ S, uint32_t s_stride, const XYZZ<F>* __restrict__ W, XYZZ<F>* __restrict__ part,
              uint32_t T, uint32_t nbits) {
     ZK_SHARED XYZZ<F> sm[64];
@@ -709,7 +709,7 @@ k_msm_bitsum(const XYZZ<F>* __restrict__ S, uint32_t s_stride, const XYZZ<F>* __
 // k_msm_bitsum_fold: grid (nbits + 1, jobs), one wave; Y[job][j] = plane sum over the blocks
 // (j < nbits: the nodes with bit j set; j = nbits: W).
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::tail)
+static __global__ void __launch_bounds__(64, MsmOcc<F>::tail)
 k_msm_bitsum_fold(const XYZZ<F>* __restrict__ part, XYZZ<F>* __restrict__ Y, uint32_t nblk, uint32_t nbits, uint32_t n_planes) {
     ZK_SHARED XYZZ<F> sm[64];
     const uint32_t tid = threadIdx.x, j = blockIdx.x, job = blockIdx.y;
@@ -732,7 +732,7 @@ k_msm_bitsum_fold(const XYZZ<F>* __restrict__ part, XYZZ<F>* __restrict__ Y, uin
 // folded pairwise (step s adds 2^(2^s) times the upper neighbour), which keeps the unavoidable
 // nbits doublings but only log2(nbits) additions on the critical path.
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::tail)
+static __global__ void __launch_bounds__(64, MsmOcc<F>::tail)
 k_msm_bitsum_combine(const XYZZ<F>* __restrict__ Y, XYZZ<F>* __restrict__ out, uint32_t nbits, uint32_t dbl) {
     ZK_SHARED XYZZ<F> sm[64];
     const uint32_t tid = threadIdx.x, job = blockIdx.x;
@@ -805,7 +805,7 @@ ZK_DI Affine<F> to_affine(const XYZZ<F>& p) {
 // - a chain that runs into infinity are carried through as (0, 0).
 constexpr uint32_t MSM_TABLE_CHUNK = 16;
 template <class F>
-__global__ void __launch_bounds__(128)
+static __global__ void __launch_bounds__(128)
 k_msm_build_table(Affine<F>* table, uint32_t n, uint32_t npos, F* scratch) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -889,7 +889,7 @@ template <> struct HostWords<Fq2> { static constexpr int N = 24; };
 template <> struct HostWords<Fq2x> { static constexpr int N = 24; };
 
 template <class F>
-__global__ void __launch_bounds__(128)
+static __global__ void __launch_bounds__(128)
 k_import_affine(const uint32_t* __restrict__ src, Affine<F>* dst, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -900,7 +900,7 @@ k_import_affine(const uint32_t* __restrict__ src, Affine<F>* dst, uint32_t n) {
     dst[i] = p;
 }
 template <class F>
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 k_export_xyzz(const XYZZ<F>* __restrict__ src, uint32_t* dst, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -921,7 +921,7 @@ k_export_xyzz(const XYZZ<F>* __restrict__ src, uint32_t* dst, uint32_t n) {
 // words at scalars + i * stride_words); the 15 multiples of A live in a scratch table [15][n].
 // One thread per proof: a latency chain of 252 doublings + ~75 additions.
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::tail)
+static __global__ void __launch_bounds__(64, MsmOcc<F>::tail)
 k_xyzz_scale_add(const XYZZ<F>* __restrict__ A, const XYZZ<F>* __restrict__ B, const uint32_t* __restrict__ scalars,
                  uint32_t stride_words, XYZZ<F>* tbl, XYZZ<F>* __restrict__ out, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -948,7 +948,7 @@ k_xyzz_scale_add(const XYZZ<F>* __restrict__ A, const XYZZ<F>* __restrict__ B, c
 // dst[i] = src[i] in affine form, exported in the host's XYZZ layout with zz = zzz = 1 (all zero for
 // the point at infinity): the host only has to encode it.
 template <class F>
-__global__ void __launch_bounds__(64, MsmOcc<F>::tail)
+static __global__ void __launch_bounds__(64, MsmOcc<F>::tail)
 k_xyzz_normalize_export(const XYZZ<F>* __restrict__ src, uint32_t* dst, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -966,7 +966,7 @@ k_xyzz_normalize_export(const XYZZ<F>* __restrict__ src, uint32_t* dst, uint32_t
 // flags[i] bit0: not on curve, bit1: not in the r-torsion subgroup.  Infinity ((0,0)) passes.
 // The subgroup test is the reference's (ec.rs:142-144): r * P == infinity.
 template <class F>
-__global__ void __launch_bounds__(128)
+static __global__ void __launch_bounds__(128)
 k_check_points(const Affine<F>* __restrict__ pts, uint32_t n, uint32_t do_subgroup, uint32_t* flags) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -73,7 +73,7 @@ ZK_DI void raise_flag(uint32_t* bad, uint32_t bit) {
 // for e in [0, n/2).  `pre` / `post` (optional, n entries each) are multiplied into every
 // element at load / store, indexed by the element's global position.  `src` (optional) replaces
 // `data` as the load source for the first pass of a chain.
-__global__ void __launch_bounds__(NTT_THREADS)
+static __global__ void __launch_bounds__(NTT_THREADS)
 k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __restrict__ tw,
            const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post, NttPass ps, uint32_t* bad = nullptr) {
     ZK_DYN_SHARED(uint32_t, tile);   // [2^g][CW][8]
@@ -153,7 +153,7 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
 // to out[proof * out_stride + e]: the last inverse transform then runs in place inside the
 // per-proof scalar vector of the merged C multiexp.
 // bellman: a.mul_assign(b); a.sub_assign(c); a.divide_by_z_on_coset()  
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_h_pointwise(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
               const uint32_t* __restrict__ zinv, uint32_t* out, uint32_t m, uint32_t out_stride, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,7 +166,7 @@ k_h_pointwise(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, co
 }
 
 // out[i] = in[i] * tab[i]  (optional table) ; used by the stand-alone zk_ntt_fr entry
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_fr_scale(uint32_t* data, const uint32_t* __restrict__ tab, size_t n, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -174,7 +174,7 @@ k_fr_scale(uint32_t* data, const uint32_t* __restrict__ tab, size_t n, size_t co
 }
 
 // out[bitrev(i)] = in[i] (out-of-place)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_fr_bitrev(uint32_t* out, const uint32_t* __restrict__ in, uint32_t log_n, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -200,7 +200,7 @@ ZK_DI Fr fr_pow_u32(Fr base, uint32_t e) {
 //                    mode 2: out[i] = base^i * scale
 // `base`, `scale` are Montgomery; if raw_out the Montgomery factor is stripped from the result
 // (so that multiplying a Montgomery value by the table entry yields a PLAIN value).
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_fr_pow_table(uint32_t* out, const uint32_t* __restrict__ base, const uint32_t* __restrict__ scale,
                uint32_t log_n, uint32_t mode, uint32_t raw_out, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,7 +214,7 @@ k_fr_pow_table(uint32_t* out, const uint32_t* __restrict__ base, const uint32_t*
 }
 
 // plain <-> Montgomery conversion of a scalar array (mode 0: to Montgomery, 1: from)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_fr_convert(uint32_t* out, const uint32_t* __restrict__ in, uint32_t from, size_t count, uint32_t* bad = nullptr) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -226,7 +226,7 @@ k_fr_convert(uint32_t* out, const uint32_t* __restrict__ in, uint32_t from, size
 // out[i] = a[i] * b[i] as raw Montgomery limbs (a*b*R^-1): lets the tests run the reference's
 // literal field KATs (fr.rs:1239-1340, fq.rs:2562-2672) through the device multiplier.
 template <class C>
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 k_field_mul_raw(uint32_t* out, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -249,7 +249,7 @@ struct R1csMat {
     const uint32_t* col;
     const uint32_t* coeff;   // Montgomery
 };
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_r1cs_eval(R1csMat ma, R1csMat mb, R1csMat mc, const uint32_t* __restrict__ z, uint32_t* out, uint32_t n_con,
             uint32_t n_in, uint32_t nv, uint32_t n_rows, size_t out_mat_stride) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -273,7 +273,7 @@ k_r1cs_eval(R1csMat ma, R1csMat mb, R1csMat mc, const uint32_t* __restrict__ z, 
 //   cvec[p]    = [ h (m, written later) | aux (n_aux) | r * z (nv) | r ]  (merged C multiexp:
 //                C' = H + L + r * (B1 + beta_1), one bucket set instead of three)
 // tail[p] = (1, r, s).  Witness scalars are converted out of Montgomery form when `mont` is set.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 k_build_scalars(uint32_t* wit_out, uint32_t* cvec, const uint32_t* __restrict__ wit, const uint32_t* __restrict__ tail,
                 uint32_t nv, uint32_t n_in, uint32_t m, uint32_t cstride, uint32_t mont, uint32_t* bad) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,0 +1,607 @@
+// BLS12-381 optimal-ate pairing and Groth16 verification kernels for gfx950.
+//
+// Row f-3 of the hot-path scope: the step right after the prover - the wallet's self-check of a fresh
+// proof (core/proofs/src/confidential.rs:208-278 check_proof) and the on-chain verify_proof
+// (core/bellman-verifier/src/verifier.rs:32-63):
+//     e(A, B) * e(acc, -gamma) * e(C, -delta) == e(alpha, beta),   acc = ic[0] + sum_i x_i * ic[i + 1]
+// as ONE Miller loop over the three pairs and ONE final exponentiation per proof
+// (core/pairing/src/bls12_381/mod.rs:40-160).  A batch is verified one GPU thread per proof: the work of
+// a proof is a serial chain of ~40 000 Fq products, a thousand proofs are a thousand independent
+// chains - latency-bound work for 16-odd waves that runs beside the prover's kernels on its own stream.
+//
+// Arithmetic: Fq on the saturated 12 x 32-bit Montgomery representation (dev_field.h Fq32 - every value
+// fully reduced, the byte formats of the reference map onto it directly), the tower
+//     Fq2 = Fq[u]/(u^2 + 1),  Fq6 = Fq2[v]/(v^3 - xi),  Fq12 = Fq6[w]/(w^2 - v),  xi = u + 1
+// laid out as the reference serialises it (fq12.rs:29-45: c0 then c1; fq6.rs:30-48; fq2.rs:40-60), so an
+// Fq12 can be compared with PreparedVerifyingKey::alpha_g1_beta_g2 limb for limb.
+//
+// Line coefficients are the triples of the reference's G2Prepared (ec.rs:1625-1683: the coefficient of
+// y_P, the coefficient of x_P, the constant term) in the reference's scaling (doubling / addition steps
+// of eprint 2010/354, Algorithms 26 / 27, as adapted in mod.rs:175-334), so that
+//   * a PreparedVerifyingKey written by the reference (zface/params/conf_vk.dat) is consumed as it is, and
+//   * k_g2_prepare reproduces such a file's coefficients bit for bit (pinned in the tests on the fixture).
+// The final exponentiation computes f^(3 (q^12 - 1) / r), the value the reference's chain computes
+// (mod.rs:102-160; 3 * (q^4 - q^2 + 1) / r == (x - 1)^2 (x + q)(x^2 + q^2 - 1) + 3), through its own chain:
+//   easy part (q^6 - 1)(q^2 + 1), then  a = f^((x-1)^2),  b = a^(x+q),  c = b^(x^2+q^2-1),  c * f^3.
+#pragma once
+#include "msm.h"
+
+namespace zkdev {
+
+#ifdef ZK_EMU
+#define ZK_NOINLINE inline
+#else
+#define ZK_NOINLINE __device__ __attribute__((noinline))
+#endif
+
+typedef Fq2 F2;   // Fq2 over Fq32
+
+ZK_DI F2 f2_conj(const F2& a) { return F2{a.c0, neg(a.c1)}; }
+ZK_DI F2 f2_mul_xi(const F2& a) { return F2{sub(a.c0, a.c1), add(a.c0, a.c1)}; }   // (c0 + c1 u)(1 + u)
+ZK_DI F2 f2_mul_fq(const F2& a, const Fq32& k) { return F2{mul(a.c0, k), mul(a.c1, k)}; }
+ZK_DI F2 f2_mul_u(const F2& a) { return F2{neg(a.c1), a.c0}; }
+ZK_NOINLINE F2 f2_mul(const F2& a, const F2& b) { return mul(a, b); }
+ZK_NOINLINE F2 f2_sqr(const F2& a) { return sqr(a); }
+ZK_DI F2 f2_dbl(const F2& a) { return dbl(a); }
+ZK_DI F2 f2_ld(const uint32_t* p) {
+    F2 r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        r.c0.l[i] = p[i];
+        r.c1.l[i] = p[12 + i];
+    }
+    return r;
+}
+ZK_DI void f2_st(uint32_t* p, const F2& a) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        p[i] = a.c0.l[i];
+        p[12 + i] = a.c1.l[i];
+    }
+}
+ZK_DI Fq32 fq_ld(const uint32_t* p) {
+    Fq32 r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = p[i];
+    return r;
+}
+ZK_DI void fq_st(uint32_t* p, const Fq32& a) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) p[i] = a.l[i];
+}
+
+// a^e for a public 12-word exponent, MSB first
+template <class F>
+ZK_DI F pow12(const F& a, const uint32_t (&e)[12]) {
+    F r = a;
+    bool started = false;
+    for (int i = 11; i >= 0; i--)
+        for (int b = 31; b >= 0; b--) {
+            if (started) r = sqr(r);
+            if ((e[i] >> b) & 1u) {
+                if (started) r = mul(r, a);
+                started = true;
+            }
+        }
+    return r;
+}
+
+// plain value of y > (q - 1) / 2, i.e. y > -y in the reference's ordering (fq.rs:707-713)
+ZK_DI bool fq_lex_largest(const Fq32& y) {
+    const uint32_t half[12] = ZK_FQ_EXP_QM1D2_32;
+    Fq32 p = from_mont(y);
+    for (int i = 11; i >= 0; i--) {
+        if (p.l[i] > half[i]) return true;
+        if (p.l[i] < half[i]) return false;
+    }
+    return false;
+}
+// Fq2 ordering: c1 first, then c0 (fq2.rs:21-30)
+ZK_DI bool f2_lex_largest(const F2& y) { return y.c1.is_zero() ? fq_lex_largest(y.c0) : fq_lex_largest(y.c1); }
+
+// ---------------------------------------------------------------------------------------------
+// Fq6 / Fq12
+// ---------------------------------------------------------------------------------------------
+struct F6 {
+    F2 c0, c1, c2;
+};
+struct F12 {
+    F6 c0, c1;
+};
+
+ZK_DI void f6_add(F6& r, const F6& a, const F6& b) {
+    r.c0 = add(a.c0, b.c0);
+    r.c1 = add(a.c1, b.c1);
+    r.c2 = add(a.c2, b.c2);
+}
+ZK_DI void f6_sub(F6& r, const F6& a, const F6& b) {
+    r.c0 = sub(a.c0, b.c0);
+    r.c1 = sub(a.c1, b.c1);
+    r.c2 = sub(a.c2, b.c2);
+}
+ZK_DI void f6_neg(F6& r, const F6& a) {
+    r.c0 = neg(a.c0);
+    r.c1 = neg(a.c1);
+    r.c2 = neg(a.c2);
+}
+// a * v   (v^3 = xi)
+ZK_DI void f6_mul_v(F6& r, const F6& a) {
+    const F2 t = f2_mul_xi(a.c2), a0 = a.c0, a1 = a.c1;
+    r.c0 = t;
+    r.c1 = a0;
+    r.c2 = a1;
+}
+// Karatsuba over the three coefficients: 6 Fq2 products.  r may alias a or b.
+ZK_NOINLINE void f6_mul(F6& r, const F6& a, const F6& b) {
+    const F2 t0 = f2_mul(a.c0, b.c0), t1 = f2_mul(a.c1, b.c1), t2 = f2_mul(a.c2, b.c2);
+    const F2 s12 = f2_mul(add(a.c1, a.c2), add(b.c1, b.c2));
+    const F2 s01 = f2_mul(add(a.c0, a.c1), add(b.c0, b.c1));
+    const F2 s02 = f2_mul(add(a.c0, a.c2), add(b.c0, b.c2));
+    r.c0 = add(t0, f2_mul_xi(sub(sub(s12, t1), t2)));
+    r.c1 = add(sub(sub(s01, t0), t1), f2_mul_xi(t2));
+    r.c2 = add(sub(sub(s02, t0), t2), t1);
+}
+// a * (b0 + b1 v): 5 products
+ZK_NOINLINE void f6_mul_01(F6& r, const F6& a, const F2& b0, const F2& b1) {
+    const F2 t0 = f2_mul(a.c0, b0), t1 = f2_mul(a.c1, b1);
+    const F2 s12 = f2_mul(add(a.c1, a.c2), b1);
+    const F2 s01 = f2_mul(add(a.c0, a.c1), add(b0, b1));
+    const F2 s02 = f2_mul(add(a.c0, a.c2), b0);
+    r.c0 = add(t0, f2_mul_xi(sub(s12, t1)));
+    r.c1 = sub(sub(s01, t0), t1);
+    r.c2 = add(sub(s02, t0), t1);
+}
+// a * (b1 v): 3 products
+ZK_NOINLINE void f6_mul_1(F6& r, const F6& a, const F2& b1) {
+    const F2 x = f2_mul(a.c2, b1), y = f2_mul(a.c0, b1), z = f2_mul(a.c1, b1);
+    r.c0 = f2_mul_xi(x);
+    r.c1 = y;
+    r.c2 = z;
+}
+ZK_DI void f6_mul_f2(F6& r, const F6& a, const F2& k) {
+    r.c0 = f2_mul(a.c0, k);
+    r.c1 = f2_mul(a.c1, k);
+    r.c2 = f2_mul(a.c2, k);
+}
+// 1 / a:  with A = a0^2 - xi a1 a2, B = xi a2^2 - a0 a1, C = a1^2 - a0 a2 the norm to Fq2 is
+// a0 A + xi (a2 B + a1 C) and a^-1 = (A + B v + C v^2) / norm
+ZK_NOINLINE void f6_inv(F6& r, const F6& a) {
+    const F2 A = sub(f2_sqr(a.c0), f2_mul_xi(f2_mul(a.c1, a.c2)));
+    const F2 B = sub(f2_mul_xi(f2_sqr(a.c2)), f2_mul(a.c0, a.c1));
+    const F2 C = sub(f2_sqr(a.c1), f2_mul(a.c0, a.c2));
+    const F2 n = add(f2_mul(a.c0, A), f2_mul_xi(add(f2_mul(a.c2, B), f2_mul(a.c1, C))));
+    const F2 t = inv(n);
+    r.c0 = f2_mul(A, t);
+    r.c1 = f2_mul(B, t);
+    r.c2 = f2_mul(C, t);
+}
+
+ZK_DI void f12_one(F12& r) {
+    r.c0.c0 = F2::one();
+    r.c0.c1 = r.c0.c2 = r.c1.c0 = r.c1.c1 = r.c1.c2 = F2::zero();
+}
+ZK_DI void f12_conj(F12& r, const F12& a) {   // a^(q^6): w -> -w
+    r.c0 = a.c0;
+    f6_neg(r.c1, a.c1);
+}
+ZK_DI bool f12_eq(const F12& a, const F12& b) {
+    return a.c0.c0 == b.c0.c0 && a.c0.c1 == b.c0.c1 && a.c0.c2 == b.c0.c2 && a.c1.c0 == b.c1.c0 && a.c1.c1 == b.c1.c1 &&
+           a.c1.c2 == b.c1.c2;
+}
+// (a0 + a1 w)(b0 + b1 w) = (a0 b0 + v a1 b1) + ((a0 + a1)(b0 + b1) - a0 b0 - a1 b1) w
+ZK_NOINLINE void f12_mul(F12& r, const F12& a, const F12& b) {
+    F6 aa, bb, s, t;
+    f6_mul(aa, a.c0, b.c0);
+    f6_mul(bb, a.c1, b.c1);
+    f6_add(s, a.c0, a.c1);
+    f6_add(t, b.c0, b.c1);
+    f6_mul(s, s, t);
+    f6_sub(s, s, aa);
+    f6_sub(s, s, bb);
+    f6_mul_v(t, bb);
+    f6_add(r.c0, aa, t);
+    r.c1 = s;
+}
+// (a0 + a1 w)^2 = (a0 + a1)(a0 + v a1) - a0 a1 - v a0 a1  +  2 a0 a1 w
+ZK_NOINLINE void f12_sqr(F12& r, const F12& a) {
+    F6 ab, s, t;
+    f6_mul(ab, a.c0, a.c1);
+    f6_add(s, a.c0, a.c1);
+    f6_mul_v(t, a.c1);
+    f6_add(t, t, a.c0);
+    f6_mul(s, s, t);
+    f6_sub(s, s, ab);
+    f6_mul_v(t, ab);
+    f6_sub(r.c0, s, t);
+    f6_add(r.c1, ab, ab);
+}
+// f * (c0 + c1 v + c4 v w): the line evaluations of the Miller loop (13 Fq2 products instead of 18)
+ZK_NOINLINE void f12_mul_014(F12& f, const F2& c0, const F2& c1, const F2& c4) {
+    F6 aa, bb, s, t;
+    f6_mul_01(aa, f.c0, c0, c1);
+    f6_mul_1(bb, f.c1, c4);
+    f6_add(s, f.c0, f.c1);
+    f6_mul_01(s, s, c0, add(c1, c4));
+    f6_sub(s, s, aa);
+    f6_sub(s, s, bb);
+    f6_mul_v(t, bb);
+    f6_add(f.c0, aa, t);
+    f.c1 = s;
+}
+// 1 / (a0 + a1 w) = (a0 - a1 w) / (a0^2 - v a1^2)
+ZK_NOINLINE void f12_inv(F12& r, const F12& a) {
+    F6 t, u;
+    f6_mul(t, a.c0, a.c0);
+    f6_mul(u, a.c1, a.c1);
+    f6_mul_v(u, u);
+    f6_sub(t, t, u);
+    f6_inv(t, t);
+    f6_mul(r.c0, a.c0, t);
+    f6_mul(u, a.c1, t);
+    f6_neg(r.c1, u);
+}
+// a^(q^k), k = 1 or 2.  In the basis 1, w, ..., w^5 over Fq2 (w^6 = xi; c0.cj sits at w^(2j), c1.cj at
+// w^(2j+1)) the coefficient of w^i becomes conj^k(a_i) * xi^(i (q^k - 1) / 6).  gam: [2][6] Fq2, gam[k-1][i]
+// (computed on the host from xi^((q-1)/6), verify.cpp).
+ZK_NOINLINE void f12_frob(F12& r, const F12& a, int k, const uint32_t* __restrict__ gam) {
+    const uint32_t* g = gam + (size_t)(k - 1) * 6 * 24;
+    const F2* src[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};
+    F2* dst[6] = {&r.c0.c0, &r.c1.c0, &r.c0.c1, &r.c1.c1, &r.c0.c2, &r.c1.c2};
+    for (int i = 0; i < 6; i++) {
+        F2 x = (k & 1) ? f2_conj(*src[i]) : *src[i];
+        if (i) x = f2_mul(x, f2_ld(g + i * 24));
+        *dst[i] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// G2 steps of the Miller loop: running point R = (X, Y, Z) Jacobian on the twist, line coefficients
+// (a, b, c) = (coefficient of y_P, coefficient of x_P, constant), the reference's G2Prepared triple.
+// ---------------------------------------------------------------------------------------------
+struct LineCoef {
+    F2 a, b, c;
+};
+constexpr int PAIRING_NCOEF = 68;   // 63 doublings + 5 additions (bits of |x| / 2 below the top one)
+constexpr uint64_t PAIRING_LOOP = ZK_BLS_X_ABS >> 1;
+
+// R <- 2R; tangent at R.  With E = 3 X^2:  X3 = E^2 - 8 X Y^2, Z3 = 2 Y Z, Y3 = E (4 X Y^2 - X3) - 8 Y^4 and the
+// tangent, cleared of denominators and doubled (the reference's scaling):
+//     a = 2 Z3 Z^2,   b = -2 E Z^2,   c = 6 X^3 - 4 Y^2 = (X + E)^2 - X^2 - E^2 - 4 Y^2
+ZK_NOINLINE void g2_double_step(F2& X, F2& Y, F2& Z, LineCoef& l) {
+    const F2 A = f2_sqr(X), B = f2_sqr(Y), C = f2_sqr(B);
+    const F2 D = f2_dbl(sub(sub(f2_sqr(add(X, B)), A), C));       // 4 X Y^2
+    const F2 E = add(f2_dbl(A), A);
+    const F2 G = f2_sqr(E), zz = f2_sqr(Z);
+    const F2 x3 = sub(G, f2_dbl(D));
+    const F2 z3 = sub(sub(f2_sqr(add(Y, Z)), B), zz);
+    const F2 c8 = f2_dbl(f2_dbl(f2_dbl(C)));
+    const F2 y3 = sub(f2_mul(sub(D, x3), E), c8);
+    l.a = f2_dbl(f2_mul(z3, zz));
+    l.b = neg(f2_dbl(f2_mul(E, zz)));
+    l.c = sub(sub(sub(f2_sqr(add(X, E)), A), G), f2_dbl(f2_dbl(B)));
+    X = x3;
+    Y = y3;
+    Z = z3;
+}
+// R <- R + Q (Q affine); chord through R and Q.  With H = x_Q Z^2 - X, r2 = 2 (y_Q Z^3 - Y):
+//     X3 = r2^2 - 4 H^3 - 8 X H^2,  Z3 = 2 Z H,  Y3 = r2 (4 X H^2 - X3) - 8 Y H^3
+//     a = 2 Z3,   b = -2 r2,   c = 2 r2 x_Q - 2 y_Q Z3
+ZK_NOINLINE void g2_add_step(F2& X, F2& Y, F2& Z, const F2& qx, const F2& qy, LineCoef& l) {
+    const F2 zz = f2_sqr(Z), yy = f2_sqr(qy);
+    const F2 u2 = f2_mul(zz, qx);
+    const F2 s2x2 = f2_mul(sub(sub(f2_sqr(add(qy, Z)), yy), zz), zz);   // 2 y_Q Z^3
+    const F2 H = sub(u2, X), HH = f2_sqr(H);
+    const F2 H4 = f2_dbl(f2_dbl(HH));
+    const F2 H3x4 = f2_mul(H4, H);
+    const F2 r2 = sub(s2x2, f2_dbl(Y));
+    const F2 rq = f2_mul(r2, qx);
+    const F2 V = f2_mul(H4, X);
+    const F2 x3 = sub(sub(f2_sqr(r2), H3x4), f2_dbl(V));
+    const F2 z3 = sub(sub(f2_sqr(add(Z, H)), zz), HH);
+    const F2 y3 = sub(f2_mul(sub(V, x3), r2), f2_dbl(f2_mul(Y, H3x4)));
+    const F2 yz2 = sub(sub(f2_sqr(add(qy, z3)), yy), f2_sqr(z3));       // 2 y_Q Z3
+    l.a = f2_dbl(z3);
+    l.b = neg(f2_dbl(r2));
+    l.c = sub(f2_dbl(rq), yz2);
+    X = x3;
+    Y = y3;
+    Z = z3;
+}
+
+// f <- f * line(P):  constant term at 1, b x_P at v, a y_P at v w  (mod.rs:57-69)
+ZK_DI void ell(F12& f, const LineCoef& l, const Fq32& px, const Fq32& py) {
+    f12_mul_014(f, l.c, f2_mul_fq(l.b, px), f2_mul_fq(l.a, py));
+}
+ZK_DI LineCoef coef_ld(const uint32_t* p) { return LineCoef{f2_ld(p), f2_ld(p + 24), f2_ld(p + 48)}; }
+ZK_DI void coef_st(uint32_t* p, const LineCoef& l) {
+    f2_st(p, l.a);
+    f2_st(p + 24, l.b);
+    f2_st(p + 48, l.c);
+}
+
+// G2Prepared::from_affine (mod.rs:335-359): the 68 coefficient triples of a fixed G2 point, one thread per
+// point.  q: [n][48] words (x.c0, x.c1, y.c0, y.c1; Montgomery), out: [n][68][72] words.
+static __global__ void __launch_bounds__(64, 1)
+k_g2_prepare(const uint32_t* __restrict__ q, uint32_t* __restrict__ out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const F2 qx = f2_ld(q + (size_t)i * 48), qy = f2_ld(q + (size_t)i * 48 + 24);
+    F2 X = qx, Y = qy, Z = F2::one();
+    uint32_t* o = out + (size_t)i * PAIRING_NCOEF * 72;
+    LineCoef l;
+    int idx = 0;
+    for (int b = 61; b >= 0; b--) {
+        g2_double_step(X, Y, Z, l);
+        coef_st(o + (idx++) * 72, l);
+        if ((PAIRING_LOOP >> b) & 1ull) {
+            g2_add_step(X, Y, Z, qx, qy, l);
+            coef_st(o + (idx++) * 72, l);
+        }
+    }
+    g2_double_step(X, Y, Z, l);
+    coef_st(o + idx * 72, l);
+}
+
+// One proof's (or any three pairs') Miller loop.  Per item i:
+//   pair 0: (P0, Q0) with Q0 a variable G2 point - its line coefficients are computed on the fly
+//   pairs 1, 2: (P1, prepared1), (P2, prepared2) with fixed G2 points - coefficient tables shared by all items
+// p0 / p1 / p2: [n][24] words (x, y); q0: [n][48] words; skip: [n] bit k set = pair k is left out (a point at
+// infinity: mod.rs:50-54); f_out: [n] F12.
+static __global__ void __launch_bounds__(64, 1)
+k_miller_loop(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ q0, const uint32_t* __restrict__ p1,
+              const uint32_t* __restrict__ prep1, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ prep2,
+              const uint32_t* __restrict__ skip, F12* __restrict__ f_out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sk = skip[i];
+    const bool on0 = !(sk & 1u), on1 = !(sk & 2u) && p1 && prep1, on2 = !(sk & 4u) && p2 && prep2;
+    Fq32 x0, y0, x1, y1, x2, y2;
+    F2 qx, qy, X, Y, Z;
+    if (on0) {
+        x0 = fq_ld(p0 + (size_t)i * 24);
+        y0 = fq_ld(p0 + (size_t)i * 24 + 12);
+        qx = f2_ld(q0 + (size_t)i * 48);
+        qy = f2_ld(q0 + (size_t)i * 48 + 24);
+        X = qx;
+        Y = qy;
+        Z = F2::one();
+    }
+    if (on1) {
+        x1 = fq_ld(p1 + (size_t)i * 24);
+        y1 = fq_ld(p1 + (size_t)i * 24 + 12);
+    }
+    if (on2) {
+        x2 = fq_ld(p2 + (size_t)i * 24);
+        y2 = fq_ld(p2 + (size_t)i * 24 + 12);
+    }
+    F12 f;
+    f12_one(f);
+    LineCoef l;
+    int idx = 0;
+    for (int b = 61; b >= -1; b--) {
+        // doubling lines of the three pairs (b == -1: the last one, after the loop in mod.rs:93-95)
+        if (on0) {
+            g2_double_step(X, Y, Z, l);
+            ell(f, l, x0, y0);
+        }
+        if (on1) ell(f, coef_ld(prep1 + idx * 72), x1, y1);
+        if (on2) ell(f, coef_ld(prep2 + idx * 72), x2, y2);
+        idx++;
+        if (b < 0) break;
+        if ((PAIRING_LOOP >> b) & 1ull) {
+            if (on0) {
+                g2_add_step(X, Y, Z, qx, qy, l);
+                ell(f, l, x0, y0);
+            }
+            if (on1) ell(f, coef_ld(prep1 + idx * 72), x1, y1);
+            if (on2) ell(f, coef_ld(prep2 + idx * 72), x2, y2);
+            idx++;
+        }
+        f12_sqr(f, f);
+    }
+    f12_conj(f, f);   // the curve parameter is negative
+    f_out[i] = f;
+}
+
+// f^|x| by square and multiply (|x| = 0xd201000000010000: 63 squarings, 5 products), then the conjugate:
+// inside the cyclotomic subgroup (after the easy part) the inverse is the conjugate and x is negative.
+ZK_NOINLINE void f12_exp_x(F12& r, const F12& a) {
+    F12 t = a;
+    for (int b = 62; b >= 0; b--) {
+        f12_sqr(t, t);
+        if ((ZK_BLS_X_ABS >> b) & 1ull) f12_mul(t, t, a);
+    }
+    f12_conj(r, t);
+}
+
+// Final exponentiation f^(3 (q^12 - 1) / r) and the comparison with e(alpha, beta).  One thread per item.
+// want: one F12 (nullptr: no comparison); ok: [n] result of the comparison, AND-ed with valid[i] (0 = the item
+// failed an earlier stage); value_out: optional [n] F12.
+static __global__ void __launch_bounds__(64, 1)
+k_final_exp(const F12* __restrict__ f_in, const uint32_t* __restrict__ gam, const F12* __restrict__ want,
+            const uint32_t* __restrict__ valid, uint32_t* __restrict__ ok, F12* value_out, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (valid && !valid[i]) {
+        if (ok) ok[i] = 0;
+        return;
+    }
+    F12 f = f_in[i], t, u;
+    // easy part: f^((q^6 - 1)(q^2 + 1))
+    f12_conj(t, f);
+    f12_inv(u, f);
+    f12_mul(t, t, u);
+    f12_frob(u, t, 2, gam);
+    f12_mul(f, u, t);
+    // hard part: 3 (q^4 - q^2 + 1) / r = (x - 1)^2 (x + q)(x^2 + q^2 - 1) + 3
+    F12 a, b, c;
+    f12_exp_x(t, f);
+    f12_conj(u, f);
+    f12_mul(a, t, u);          // f^(x - 1)
+    f12_exp_x(t, a);
+    f12_conj(u, a);
+    f12_mul(a, t, u);          // f^((x - 1)^2)
+    f12_exp_x(t, a);
+    f12_frob(u, a, 1, gam);
+    f12_mul(b, t, u);          // a^(x + q)
+    f12_exp_x(t, b);
+    f12_exp_x(t, t);
+    f12_frob(u, b, 2, gam);
+    f12_mul(c, t, u);
+    f12_conj(u, b);
+    f12_mul(c, c, u);          // b^(x^2 + q^2 - 1)
+    f12_sqr(t, f);
+    f12_mul(t, t, f);
+    f12_mul(c, c, t);          // * f^3
+    if (value_out) value_out[i] = c;
+    if (ok) ok[i] = want ? (f12_eq(c, *want) ? 1u : 0u) : 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Proof decoding: compressed G1 / G2 -> affine, with the checks of into_affine() (ec.rs:776-868,
+// :1429-1548): x < q (host), a square root exists, the point lies in the r-torsion subgroup.
+// in: [n][12 | 24] words, PLAIN little-endian x (G2: c0 then c1); flags: bit 0 = infinity, bit 1 = the larger y.
+// out: affine (x, y) Montgomery; st: 0 = ok, 1 = not on the curve, 2 = not in the subgroup, 3 = infinity (a legal
+// encoding of a point that Proof::read then refuses).
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(64, 1)
+k_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out,
+            uint32_t* __restrict__ st, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i] & 1u) {
+        st[i] = 3;
+        return;
+    }
+    const uint32_t e[12] = ZK_FQ_EXP_QP1D4_32;
+    const Fq32 x = to_mont(fq_ld(in + (size_t)i * 12));
+    const Fq32 rhs = add(mul(sqr(x), x), curve_b32());
+    Fq32 y = pow12(rhs, e);                     // q = 3 mod 4
+    if (sqr(y) != rhs) {
+        st[i] = 1;
+        return;
+    }
+    if (fq_lex_largest(y) != ((flags[i] & 2u) != 0)) y = neg(y);
+    // r * P == infinity (ec.rs:142-144)
+    const uint32_t r[8] = ZK_FR_P_32;
+    const Affine<Fq32> p{x, y};
+    XYZZ<Fq32> acc = XYZZ<Fq32>::inf();
+    for (int w = 7; w >= 0; w--)
+        for (int b = 31; b >= 0; b--) {
+            acc = xdbl(acc);
+            if ((r[w] >> b) & 1u) madd(acc, p, false);
+        }
+    if (!acc.is_inf()) {
+        st[i] = 2;
+        return;
+    }
+    fq_st(out + (size_t)i * 24, x);
+    fq_st(out + (size_t)i * 24 + 12, y);
+    st[i] = 0;
+}
+
+// square root in Fq2 (q = 3 mod 4): Algorithm 9 of eprint 2012/685, the one fq2.rs:189-250 follows
+ZK_DI bool f2_sqrt(const F2& a, F2* out) {
+    if (a.is_zero()) {
+        *out = a;
+        return true;
+    }
+    const uint32_t e1[12] = ZK_FQ_EXP_QM3D4_32, e2[12] = ZK_FQ_EXP_QM1D2_32;
+    const F2 minus_one{neg(Fq32::one()), Fq32::zero()};
+    F2 a1 = pow12(a, e1);
+    F2 alpha = mul(sqr(a1), a);
+    const F2 a0 = mul(f2_conj(alpha), alpha);
+    if (a0 == minus_one) return false;
+    F2 x0 = mul(a1, a);
+    if (alpha == minus_one) {
+        *out = f2_mul_u(x0);
+    } else {
+        const F2 b = pow12(add(alpha, F2::one()), e2);
+        *out = mul(b, x0);
+    }
+    return sqr(*out) == a;
+}
+
+static __global__ void __launch_bounds__(64, 1)
+k_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out,
+            uint32_t* __restrict__ st, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flags[i] & 1u) {
+        st[i] = 3;
+        return;
+    }
+    const F2 x{to_mont(fq_ld(in + (size_t)i * 24)), to_mont(fq_ld(in + (size_t)i * 24 + 12))};
+    const F2 rhs = add(mul(sqr(x), x), curve_b((const F2*)nullptr));
+    F2 y;
+    if (!f2_sqrt(rhs, &y)) {
+        st[i] = 1;
+        return;
+    }
+    if (f2_lex_largest(y) != ((flags[i] & 2u) != 0)) y = neg(y);
+    const uint32_t r[8] = ZK_FR_P_32;
+    const Affine<F2> p{x, y};
+    XYZZ<F2> acc = XYZZ<F2>::inf();
+    for (int w = 7; w >= 0; w--)
+        for (int b = 31; b >= 0; b--) {
+            acc = xdbl(acc);
+            if ((r[w] >> b) & 1u) madd(acc, p, false);
+        }
+    if (!acc.is_inf()) {
+        st[i] = 2;
+        return;
+    }
+    f2_st(out + (size_t)i * 48, x);
+    f2_st(out + (size_t)i * 48 + 24, y);
+    st[i] = 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Public-input accumulator  acc = ic[0] + sum_j x_j ic[j]  (verifier.rs:41-45).  ic is a fixed set of bases,
+// so - as in the prover - every doubling 2^k ic[j] is tabulated once (k_msm_build_table) and a scalar
+// multiplication is the sum of the table entries at the set bits: one thread per (proof, input), ~127
+// mixed additions each, then one thread per proof sums the n_ic - 1 products, adds ic[0] and normalises.
+// ---------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(64, 2)
+k_inputs_mul(const Affine<Fq>* __restrict__ table, const uint32_t* __restrict__ scalars, XYZZ<Fq>* __restrict__ part,
+             uint32_t n_ic, uint32_t n_proofs) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ni = n_ic - 1;
+    if (t >= ni * n_proofs) return;
+    const uint32_t p = t / ni, j = t % ni + 1;
+    const uint32_t* s = scalars + ((size_t)p * ni + (j - 1)) * 8;
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    for (uint32_t k = 0; k < 255; k++)
+        if ((s[k >> 5] >> (k & 31)) & 1u) madd(acc, table[(size_t)k * n_ic + j], false);
+    part[t] = acc;
+}
+// out: [n][24] words affine (x, y) in the Fq32 layout; inf[i] = 1 if the accumulator is the point at infinity
+static __global__ void __launch_bounds__(64, 2)
+k_inputs_sum(const Affine<Fq>* __restrict__ table, const XYZZ<Fq>* __restrict__ part, uint32_t* __restrict__ out,
+             uint32_t* __restrict__ inf, uint32_t n_ic, uint32_t n_proofs) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_proofs) return;
+    const uint32_t ni = n_ic - 1;
+    XYZZ<Fq> acc = XYZZ<Fq>::from_affine(table[0]);
+    for (uint32_t j = 0; j < ni; j++) acc = xadd(acc, part[(size_t)p * ni + j]);
+    inf[p] = acc.is_inf() ? 1u : 0u;
+    const Affine<Fq> a = to_affine(acc);
+    fld_export(a.x, out + (size_t)p * 24);
+    fld_export(a.y, out + (size_t)p * 24 + 12);
+}
+
+// skip[i] / valid[i] of a batch from the decode states of A, B, C (st_g1: [2n] = A then C) and the accumulator
+static __global__ void __launch_bounds__(256)
+k_verify_flags(const uint32_t* __restrict__ st_g1, const uint32_t* __restrict__ st_g2, const uint32_t* __restrict__ acc_inf,
+               const uint32_t* __restrict__ host_bad, uint32_t* __restrict__ skip, uint32_t* __restrict__ valid, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = st_g1[i], c = st_g1[n + i], b = st_g2[i];
+    // Proof::read refuses a point at infinity in A, B or C (core/bellman-verifier/src/lib.rs:67-110); an
+    // accumulator at infinity is legal and simply drops out of the Miller loop (mod.rs:50-54)
+    const bool bad = host_bad[i] || a != 0 || b != 0 || c != 0;
+    valid[i] = bad ? 0u : 1u;
+    skip[i] = (bad ? 5u : 0u) | (acc_inf[i] ? 2u : 0u);
+}
+
+}  // namespace zkdev

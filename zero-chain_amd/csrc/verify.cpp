@@ -1,0 +1,528 @@
+// libzkamd, verification half: PreparedVerifyingKey handles and batch verification (include/zkamd.h,
+// "Verification").  Replaces, behind the C ABI:
+//   prepare_verifying_key            core/bellman-verifier/src/verifier.rs:15-30
+//   verify_proof                     core/bellman-verifier/src/verifier.rs:32-63   (call sites: the wallet's
+//                                    check_proof core/proofs/src/confidential.rs:208-278, the runtime's
+//                                    modules/zk-system/src/lib.rs:57-108)
+//   PreparedVerifyingKey::read/write core/bellman-verifier/src/lib.rs:175-236 (zface/params/conf_vk.dat)
+//   Proof::read                      core/bellman-verifier/src/lib.rs:67-110 (compressed points, into_affine)
+// Device side: pairing.h.  Host side here: byte formats, the handle, the launch sequence.
+#include <algorithm>
+#include <new>
+
+#include "host_common.h"
+#include "host_math.h"
+#include "pairing.h"
+
+using namespace zkrt;
+using zkdev::F12;
+
+namespace {
+
+typedef zkhost::Affine<zkhost::Fq> HG1A;
+typedef zkhost::Affine<zkhost::Fq2> HG2A;
+typedef zkdev::Affine<zkdev::Fq> DG1A;    // radix-2^28 form (tables of the input accumulator)
+typedef zkdev::XYZZ<zkdev::Fq> DG1;
+
+struct Reader {
+    const uint8_t* p;
+    size_t left;
+    bool take(size_t n, const uint8_t** out) {
+        if (left < n) return false;
+        *out = p;
+        p += n;
+        left -= n;
+        return true;
+    }
+    bool u32be(uint32_t* v) {
+        const uint8_t* b;
+        if (!take(4, &b)) return false;
+        *v = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+        return true;
+    }
+};
+void put_u32be(std::vector<uint8_t>& o, uint32_t v) {
+    o.push_back((uint8_t)(v >> 24));
+    o.push_back((uint8_t)(v >> 16));
+    o.push_back((uint8_t)(v >> 8));
+    o.push_back((uint8_t)v);
+}
+
+// 48 big-endian bytes (top `mask` bits cleared) -> 12 plain little-endian u32 words; false if >= q
+bool fq_words_from_be(const uint8_t* b, uint32_t* w, uint8_t top_mask) {
+    uint64_t l[6];
+    for (int i = 0; i < 6; i++) {
+        uint64_t v = 0;
+        for (int j = 0; j < 8; j++) {
+            uint8_t byte = b[(5 - i) * 8 + j];
+            if (i == 5 && j == 0) byte &= top_mask;
+            v = (v << 8) | byte;
+        }
+        l[i] = v;
+    }
+    if (zkhost::Fq::geq_p(l)) return false;
+    for (int i = 0; i < 6; i++) {
+        w[2 * i] = (uint32_t)l[i];
+        w[2 * i + 1] = (uint32_t)(l[i] >> 32);
+    }
+    return true;
+}
+// Fq2::read / write (fq2.rs:40-60): c0 then c1, 48 big-endian bytes each, canonical
+bool fq2_read(Reader& r, zkhost::Fq2* out) {
+    const uint8_t* b;
+    if (!r.take(96, &b)) return false;
+    return zkhost::fq_from_be(b, &out->c0) && zkhost::fq_from_be(b + 48, &out->c1);
+}
+void fq2_write(std::vector<uint8_t>& o, const zkhost::Fq2& v) {
+    uint8_t b[96];
+    zkhost::fq_to_be(v.c0, b);
+    zkhost::fq_to_be(v.c1, b + 48);
+    o.insert(o.end(), b, b + 96);
+}
+zkhost::Fq2 fq2_pow(const zkhost::Fq2& a, const uint64_t* e, int n) {
+    zkhost::Fq2 r = zkhost::Fq2::one();
+    for (int i = n - 1; i >= 0; i--)
+        for (int b = 63; b >= 0; b--) {
+            r = r.sqr();
+            if ((e[i] >> b) & 1) r = r * a;
+        }
+    return r;
+}
+
+zk_status read_g1(Reader& r, HG1A* out, const char* what, bool allow_inf) {
+    const uint8_t* b;
+    if (!r.take(96, &b)) return fail(ZK_ERR_IO, std::string("unexpected end of the key in ") + what);
+    if (zkhost::g1_from_uncompressed(b, out) != zkhost::DEC_OK) return fail(ZK_ERR_IO, std::string("invalid G1 encoding in ") + what);
+    if (!allow_inf && out->is_inf()) return fail(ZK_ERR_IO, std::string("point at infinity in ") + what);
+    return ZK_OK;
+}
+zk_status read_g2(Reader& r, HG2A* out, const char* what) {
+    const uint8_t* b;
+    if (!r.take(192, &b)) return fail(ZK_ERR_IO, std::string("unexpected end of the key in ") + what);
+    if (zkhost::g2_from_uncompressed(b, out) != zkhost::DEC_OK) return fail(ZK_ERR_IO, std::string("invalid G2 encoding in ") + what);
+    return ZK_OK;
+}
+
+constexpr size_t COEF_WORDS = (size_t)zkdev::PAIRING_NCOEF * 72;
+constexpr size_t VERIFY_CHUNK = 8192;   // proofs per launch set
+
+}  // namespace
+
+struct zk_vk {
+    int device = 0;
+    uint32_t n_ic = 0;
+    bool gamma_inf = false, delta_inf = false;
+    std::vector<HG1A> ic;
+    std::vector<uint32_t> h_alpha_beta;          // 144 words: the Fq12 in tower order, Montgomery
+    std::vector<uint32_t> h_prep[2];             // 68 x 72 words each (-gamma, -delta); empty = infinity
+    DevBuf ic_table, prep[2], gam, alpha_beta;
+    // per-batch workspaces
+    DevBuf in_g1, in_g2, fl_g1, fl_g2, aff_g1, aff_g2, st_g1, st_g2, scal, part, acc, acc_inf, host_bad, skip, valid, f, ok;
+};
+
+namespace {
+
+zk_status upload(DevBuf& d, const void* src, size_t bytes) {
+    ZK_TRY(d.ensure(bytes ? bytes : 4));
+    if (bytes) HIP_TRY(hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, g_stream));
+    return ZK_OK;
+}
+
+// xi^(i (q^k - 1) / 6) for k = 1, 2 and i = 0 .. 5  (pairing.h f12_frob)
+zk_status upload_frobenius(zk_vk* V) {
+    static const uint64_t e[6] = ZK_FQ_EXP_QM1D6_64;
+    const zkhost::Fq2 xi{zkhost::Fq::one(), zkhost::Fq::one()};
+    const zkhost::Fq2 g = fq2_pow(xi, e, 6);
+    std::vector<zkhost::Fq2> tab(12);
+    zkhost::Fq2 p = zkhost::Fq2::one();
+    for (int i = 0; i < 6; i++) {
+        tab[i] = p;
+        const zkhost::Fq2 conj{p.c0, -p.c1};
+        tab[6 + i] = p * conj;
+        p = p * g;
+    }
+    static_assert(sizeof(zkhost::Fq2) == 96, "Fq2 layout");
+    ZK_TRY(upload(V->gam, tab.data(), tab.size() * sizeof(zkhost::Fq2)));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return ZK_OK;
+}
+
+// on-curve and subgroup validation of decoded key points (into_affine): the prover's kernel
+template <class HF, class DF>
+zk_status check_points(const std::vector<zkhost::Affine<HF>>& pts, const char* what) {
+    if (pts.empty()) return ZK_OK;
+    const size_t n = pts.size();
+    DevBuf stage, d, flags;
+    ZK_TRY(upload(stage, pts.data(), n * sizeof(zkhost::Affine<HF>)));
+    ZK_TRY(d.ensure(n * sizeof(zkdev::Affine<DF>)));
+    ZK_TRY(flags.ensure(4 * n));
+    const unsigned blocks = (unsigned)((n + 127) / 128);
+    ZK_LAUNCH(zkdev::k_import_affine<DF>, dim3(blocks), dim3(128), 0, g_stream, (const uint32_t*)stage.as<uint32_t>(),
+              d.as<zkdev::Affine<DF>>(), (uint32_t)n);
+    ZK_LAUNCH(zkdev::k_check_points<DF>, dim3(blocks), dim3(128), 0, g_stream, (const zkdev::Affine<DF>*)d.as<zkdev::Affine<DF>>(),
+              (uint32_t)n, 1u, flags.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> f(n);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(f.data(), flags.p, 4 * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++)
+        if (f[i])
+            return fail(ZK_ERR_IO, std::string(what) + ": point " + std::to_string(i) +
+                                       (f[i] & 1 ? " is not on the curve" : " is not in the correct subgroup"));
+    return ZK_OK;
+}
+
+// the doubling table of the ic bases: table[k][j] = 2^k ic[j]
+zk_status build_ic_table(zk_vk* V) {
+    const size_t n = V->ic.size();
+    V->n_ic = (uint32_t)n;
+    if (!n) return ZK_OK;
+    ZK_TRY(V->ic_table.ensure(sizeof(DG1A) * n * zkdev::MSM_NPOS));
+    DevBuf stage, scratch;
+    ZK_TRY(upload(stage, V->ic.data(), n * sizeof(HG1A)));
+    const unsigned blocks = (unsigned)((n + 127) / 128);
+    ZK_LAUNCH(zkdev::k_import_affine<zkdev::Fq>, dim3(blocks), dim3(128), 0, g_stream, (const uint32_t*)stage.as<uint32_t>(),
+              V->ic_table.as<DG1A>(), (uint32_t)n);
+    ZK_TRY(scratch.ensure((size_t)zkdev::MSM_TABLE_CHUNK * 5 * sizeof(zkdev::Fq) * n));
+    ZK_LAUNCH(zkdev::k_msm_build_table<zkdev::Fq>, dim3(blocks), dim3(128), 0, g_stream, V->ic_table.as<DG1A>(), (uint32_t)n,
+              zkdev::MSM_NPOS, scratch.as<zkdev::Fq>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return ZK_OK;
+}
+
+zk_status vk_prepare(const uint8_t* bytes, size_t len, int device, zk_vk** out) {
+    ZK_TRY(use_device(device));
+    zk_vk* V = new (std::nothrow) zk_vk();
+    if (!V) return fail(ZK_ERR_OUT_OF_MEMORY, "host allocation failed");
+    struct Guard {
+        zk_vk* p;
+        ~Guard() { delete p; }
+    } guard{V};
+    V->device = device;
+    Reader r{bytes, len};
+    HG1A alpha_g1, beta_g1, delta_g1, tmp;
+    HG2A beta_g2, gamma_g2, delta_g2;
+    // VerifyingKey::read (in-tree twin: core/bellman-verifier/src/lib.rs:305-355): infinity is accepted for the
+    // six named points, rejected inside ic
+    ZK_TRY(read_g1(r, &alpha_g1, "vk.alpha_g1", true));
+    ZK_TRY(read_g1(r, &beta_g1, "vk.beta_g1", true));
+    ZK_TRY(read_g2(r, &beta_g2, "vk.beta_g2"));
+    ZK_TRY(read_g2(r, &gamma_g2, "vk.gamma_g2"));
+    ZK_TRY(read_g1(r, &delta_g1, "vk.delta_g1", true));
+    ZK_TRY(read_g2(r, &delta_g2, "vk.delta_g2"));
+    uint32_t n_ic = 0;
+    if (!r.u32be(&n_ic)) return fail(ZK_ERR_IO, "unexpected end of the key (ic length)");
+    if ((size_t)n_ic * 96 > r.left) return fail(ZK_ERR_IO, "unexpected end of the key in vk.ic");
+    for (uint32_t i = 0; i < n_ic; i++) {
+        ZK_TRY(read_g1(r, &tmp, "vk.ic", false));
+        V->ic.push_back(tmp);
+    }
+    {
+        std::vector<HG1A> g1 = V->ic;
+        g1.push_back(alpha_g1);
+        g1.push_back(beta_g1);
+        g1.push_back(delta_g1);
+        ZK_TRY((check_points<zkhost::Fq, zkdev::Fq>(g1, "vk (G1: ic | alpha | beta | delta)")));
+        ZK_TRY((check_points<zkhost::Fq2, zkdev::Fq2>(std::vector<HG2A>{beta_g2, gamma_g2, delta_g2}, "vk (G2: beta | gamma | delta)")));
+    }
+    ZK_TRY(upload_frobenius(V));
+    ZK_TRY(build_ic_table(V));
+    // neg_gamma_g2, neg_delta_g2 prepared on the GPU
+    V->gamma_inf = gamma_g2.is_inf();
+    V->delta_inf = delta_g2.is_inf();
+    const HG2A neg[2] = {HG2A{gamma_g2.x, -gamma_g2.y}, HG2A{delta_g2.x, -delta_g2.y}};
+    {
+        DevBuf q, co;
+        ZK_TRY(upload(q, neg, sizeof(neg)));
+        ZK_TRY(co.ensure(2 * COEF_WORDS * 4));
+        ZK_LAUNCH(zkdev::k_g2_prepare, dim3(1), dim3(64), 0, g_stream, (const uint32_t*)q.as<uint32_t>(), co.as<uint32_t>(), 2u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        for (int k = 0; k < 2; k++) {
+            if (k == 0 ? V->gamma_inf : V->delta_inf) continue;
+            V->h_prep[k].resize(COEF_WORDS);
+            HIP_TRY(hipMemcpy(V->h_prep[k].data(), co.as<uint32_t>() + k * COEF_WORDS, COEF_WORDS * 4, hipMemcpyDeviceToHost));
+            ZK_TRY(upload(V->prep[k], V->h_prep[k].data(), COEF_WORDS * 4));
+        }
+    }
+    // alpha_g1_beta_g2 = e(alpha, beta)
+    {
+        DevBuf p0, q0, sk, f, val;
+        uint32_t skip = (alpha_g1.is_inf() || beta_g2.is_inf()) ? 1u : 0u;
+        ZK_TRY(upload(p0, &alpha_g1, sizeof(alpha_g1)));
+        ZK_TRY(upload(q0, &beta_g2, sizeof(beta_g2)));
+        ZK_TRY(upload(sk, &skip, 4));
+        ZK_TRY(f.ensure(sizeof(F12)));
+        ZK_TRY(val.ensure(sizeof(F12)));
+        ZK_LAUNCH(zkdev::k_miller_loop, dim3(1), dim3(64), 0, g_stream, (const uint32_t*)p0.as<uint32_t>(),
+                  (const uint32_t*)q0.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                  (const uint32_t*)nullptr, (const uint32_t*)sk.as<uint32_t>(), f.as<F12>(), 1u);
+        ZK_LAUNCH(zkdev::k_final_exp, dim3(1), dim3(64), 0, g_stream, (const F12*)f.as<F12>(), (const uint32_t*)V->gam.as<uint32_t>(),
+                  (const F12*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, val.as<F12>(), 1u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        static_assert(sizeof(F12) == 144 * 4, "Fq12 layout");
+        V->h_alpha_beta.resize(144);
+        HIP_TRY(hipMemcpy(V->h_alpha_beta.data(), val.p, sizeof(F12), hipMemcpyDeviceToHost));
+        ZK_TRY(upload(V->alpha_beta, V->h_alpha_beta.data(), sizeof(F12)));
+    }
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    guard.p = nullptr;
+    *out = V;
+    return ZK_OK;
+}
+
+// PreparedVerifyingKey::read (core/bellman-verifier/src/lib.rs:207-244)
+zk_status vk_read_prepared(const uint8_t* bytes, size_t len, int device, zk_vk** out) {
+    ZK_TRY(use_device(device));
+    zk_vk* V = new (std::nothrow) zk_vk();
+    if (!V) return fail(ZK_ERR_OUT_OF_MEMORY, "host allocation failed");
+    struct Guard {
+        zk_vk* p;
+        ~Guard() { delete p; }
+    } guard{V};
+    V->device = device;
+    Reader r{bytes, len};
+    zkhost::Fq2 c;
+    static_assert(sizeof(zkhost::Fq2) == 24 * 4, "Fq2 layout");
+    V->h_alpha_beta.resize(144);
+    for (int i = 0; i < 6; i++) {   // Fq12::read: c0 (c0, c1, c2), c1 (c0, c1, c2)
+        if (!fq2_read(r, &c)) return fail(ZK_ERR_IO, "alpha_g1_beta_g2: short or not in the field");
+        memcpy(&V->h_alpha_beta[i * 24], &c, 96);
+    }
+    for (int k = 0; k < 2; k++) {   // G2Prepared::read (ec.rs:1655-1683)
+        const char* what = k == 0 ? "neg_gamma_g2" : "neg_delta_g2";
+        uint32_t cnt = 0;
+        if (!r.u32be(&cnt)) return fail(ZK_ERR_IO, std::string(what) + ": unexpected end");
+        if ((size_t)cnt * 288 > r.left) return fail(ZK_ERR_IO, std::string(what) + ": unexpected end");
+        std::vector<uint32_t> co((size_t)cnt * 72);
+        for (uint32_t i = 0; i < cnt * 3; i++) {
+            if (!fq2_read(r, &c)) return fail(ZK_ERR_IO, std::string(what) + ": coefficient not in the field");
+            memcpy(&co[(size_t)i * 24], &c, 96);
+        }
+        const uint8_t* flag;
+        if (!r.take(1, &flag) || *flag > 1) return fail(ZK_ERR_IO, std::string(what) + ": bad infinity flag");
+        const bool inf = *flag == 1;
+        if (!inf && cnt != (uint32_t)zkdev::PAIRING_NCOEF)
+            return fail(ZK_ERR_IO, std::string(what) + ": expected " + std::to_string(zkdev::PAIRING_NCOEF) + " coefficient triples");
+        (k == 0 ? V->gamma_inf : V->delta_inf) = inf;
+        if (!inf) {
+            V->h_prep[k] = co;
+            ZK_TRY(upload(V->prep[k], V->h_prep[k].data(), COEF_WORDS * 4));
+        }
+    }
+    uint32_t n_ic = 0;
+    if (!r.u32be(&n_ic)) return fail(ZK_ERR_IO, "unexpected end of the key (ic length)");
+    if ((size_t)n_ic * 96 > r.left) return fail(ZK_ERR_IO, "unexpected end of the key in ic");
+    HG1A tmp;
+    for (uint32_t i = 0; i < n_ic; i++) {
+        ZK_TRY(read_g1(r, &tmp, "ic", false));
+        V->ic.push_back(tmp);
+    }
+    ZK_TRY((check_points<zkhost::Fq, zkdev::Fq>(V->ic, "ic")));
+    ZK_TRY(upload(V->alpha_beta, V->h_alpha_beta.data(), 144 * 4));
+    ZK_TRY(upload_frobenius(V));
+    ZK_TRY(build_ic_table(V));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    guard.p = nullptr;
+    *out = V;
+    return ZK_OK;
+}
+
+// one element of a Proof: compressed encoding -> plain x words + flags (bit 0 infinity, bit 1 larger y); false =
+// malformed (Proof::read fails: ec.rs:776-868, :1429-1548)
+bool parse_g1_compressed(const uint8_t* b, uint32_t* x, uint32_t* flags) {
+    if (!(b[0] & 0x80)) return false;   // not the compressed form
+    if (b[0] & 0x40) {
+        if (b[0] & 0x3f) return false;
+        for (int i = 1; i < 48; i++)
+            if (b[i]) return false;
+        *flags = 1;
+        memset(x, 0, 48);
+        return true;
+    }
+    *flags = (b[0] & 0x20) ? 2u : 0u;
+    return fq_words_from_be(b, x, 0x1f);
+}
+bool parse_g2_compressed(const uint8_t* b, uint32_t* x, uint32_t* flags) {
+    if (!(b[0] & 0x80)) return false;
+    if (b[0] & 0x40) {
+        if (b[0] & 0x3f) return false;
+        for (int i = 1; i < 96; i++)
+            if (b[i]) return false;
+        *flags = 1;
+        memset(x, 0, 96);
+        return true;
+    }
+    *flags = (b[0] & 0x20) ? 2u : 0u;
+    return fq_words_from_be(b, x + 12, 0x1f) && fq_words_from_be(b + 48, x, 0xff);   // c1 first on the wire
+}
+
+zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t* inputs, uint8_t* ok_out) {
+    const uint32_t ni = V->n_ic - 1;
+    std::vector<uint32_t> g1((size_t)2 * n * 12), g2((size_t)n * 24), f1(2 * n), f2(n), bad(n, 0), sc((size_t)n * ni * 8);
+    static const uint64_t RMOD[4] = ZK_FR_P_64;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* p = proofs + i * 192;
+        bool good = parse_g1_compressed(p, &g1[i * 12], &f1[i]) && parse_g2_compressed(p + 48, &g2[i * 24], &f2[i]) &&
+                    parse_g1_compressed(p + 144, &g1[(n + i) * 12], &f1[n + i]);
+        for (uint32_t j = 0; j < ni && good; j++) {
+            const uint8_t* s = inputs + (i * ni + j) * 32;
+            uint64_t v[4];
+            for (int k = 0; k < 4; k++) {
+                uint64_t w = 0;
+                for (int b = 7; b >= 0; b--) w = (w << 8) | s[k * 8 + b];
+                v[k] = w;
+            }
+            bool lt = false;
+            for (int k = 3; k >= 0; k--) {
+                if (v[k] < RMOD[k]) {
+                    lt = true;
+                    break;
+                }
+                if (v[k] > RMOD[k]) break;
+            }
+            if (!lt) good = false;   // not a canonical Fr: the reference cannot even form the input
+            memcpy(&sc[(i * ni + j) * 8], s, 32);
+        }
+        if (!good) {
+            bad[i] = 1;
+            f1[i] = f1[n + i] = f2[i] = 1;   // decode nothing
+            memset(&sc[i * ni * 8], 0, (size_t)ni * 32);
+        }
+    }
+    ZK_TRY(upload(V->in_g1, g1.data(), g1.size() * 4));
+    ZK_TRY(upload(V->in_g2, g2.data(), g2.size() * 4));
+    ZK_TRY(upload(V->fl_g1, f1.data(), f1.size() * 4));
+    ZK_TRY(upload(V->fl_g2, f2.data(), f2.size() * 4));
+    ZK_TRY(upload(V->host_bad, bad.data(), bad.size() * 4));
+    ZK_TRY(upload(V->scal, sc.data(), sc.size() * 4));
+    ZK_TRY(V->aff_g1.ensure((size_t)2 * n * 96));
+    ZK_TRY(V->aff_g2.ensure(n * 192));
+    ZK_TRY(V->st_g1.ensure(2 * n * 4));
+    ZK_TRY(V->st_g2.ensure(n * 4));
+    ZK_TRY(V->part.ensure((size_t)n * (ni ? ni : 1) * sizeof(DG1)));
+    ZK_TRY(V->acc.ensure(n * 96));
+    ZK_TRY(V->acc_inf.ensure(n * 4));
+    ZK_TRY(V->skip.ensure(n * 4));
+    ZK_TRY(V->valid.ensure(n * 4));
+    ZK_TRY(V->f.ensure(n * sizeof(F12)));
+    ZK_TRY(V->ok.ensure(n * 4));
+    const unsigned b64 = (unsigned)((n + 63) / 64);
+    {
+        ProfScope ps("verify_decode");
+        ZK_LAUNCH(zkdev::k_decode_g2, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->in_g2.as<uint32_t>(),
+                  (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n);
+        ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, g_stream,
+                  (const uint32_t*)V->in_g1.as<uint32_t>(), (const uint32_t*)V->fl_g1.as<uint32_t>(), V->aff_g1.as<uint32_t>(),
+                  V->st_g1.as<uint32_t>(), (uint32_t)(2 * n));
+    }
+    {
+        ProfScope ps("verify_inputs");
+        if (ni)
+            ZK_LAUNCH(zkdev::k_inputs_mul, dim3((unsigned)((n * ni + 63) / 64)), dim3(64), 0, g_stream,
+                      (const DG1A*)V->ic_table.as<DG1A>(), (const uint32_t*)V->scal.as<uint32_t>(), V->part.as<DG1>(), V->n_ic,
+                      (uint32_t)n);
+        ZK_LAUNCH(zkdev::k_inputs_sum, dim3(b64), dim3(64), 0, g_stream, (const DG1A*)V->ic_table.as<DG1A>(),
+                  (const DG1*)V->part.as<DG1>(), V->acc.as<uint32_t>(), V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n);
+    }
+    ZK_LAUNCH(zkdev::k_verify_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, (const uint32_t*)V->st_g1.as<uint32_t>(),
+              (const uint32_t*)V->st_g2.as<uint32_t>(), (const uint32_t*)V->acc_inf.as<uint32_t>(),
+              (const uint32_t*)V->host_bad.as<uint32_t>(), V->skip.as<uint32_t>(), V->valid.as<uint32_t>(), (uint32_t)n);
+    {
+        ProfScope ps("verify_miller");
+        ZK_LAUNCH(zkdev::k_miller_loop, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g1.as<uint32_t>(),
+                  (const uint32_t*)V->aff_g2.as<uint32_t>(), (const uint32_t*)V->acc.as<uint32_t>(),
+                  V->gamma_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[0].as<uint32_t>(),
+                  (const uint32_t*)(V->aff_g1.as<uint32_t>() + n * 24),
+                  V->delta_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[1].as<uint32_t>(),
+                  (const uint32_t*)V->skip.as<uint32_t>(), V->f.as<F12>(), (uint32_t)n);
+    }
+    {
+        ProfScope ps("verify_final");
+        ZK_LAUNCH(zkdev::k_final_exp, dim3(b64), dim3(64), 0, g_stream, (const F12*)V->f.as<F12>(), (const uint32_t*)V->gam.as<uint32_t>(),
+                  (const F12*)V->alpha_beta.as<F12>(), (const uint32_t*)V->valid.as<uint32_t>(), V->ok.as<uint32_t>(), (F12*)nullptr,
+                  (uint32_t)n);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<uint32_t> okv(n);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(okv.data(), V->ok.p, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) ok_out[i] = okv[i] ? 1 : 0;
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+zk_status zk_vk_prepare(const uint8_t* vk_bytes, size_t len, int device, zk_vk** out) {
+    if (!vk_bytes || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    return vk_prepare(vk_bytes, len, device, out);
+}
+zk_status zk_vk_read(const uint8_t* pvk_bytes, size_t len, int device, zk_vk** out) {
+    if (!pvk_bytes || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    return vk_read_prepared(pvk_bytes, len, device, out);
+}
+zk_status zk_vk_write(const zk_vk* vk, uint8_t* out, size_t cap, size_t* len) {
+    if (!vk || !len) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    std::vector<uint8_t> o;
+    zkhost::Fq2 c;
+    for (int i = 0; i < 6; i++) {
+        memcpy(&c, &vk->h_alpha_beta[i * 24], 96);
+        fq2_write(o, c);
+    }
+    for (int k = 0; k < 2; k++) {
+        const bool inf = k == 0 ? vk->gamma_inf : vk->delta_inf;
+        const uint32_t cnt = inf ? 0u : (uint32_t)zkdev::PAIRING_NCOEF;
+        put_u32be(o, cnt);
+        for (uint32_t i = 0; i < cnt * 3; i++) {
+            memcpy(&c, &vk->h_prep[k][(size_t)i * 24], 96);
+            fq2_write(o, c);
+        }
+        o.push_back(inf ? 1 : 0);
+    }
+    put_u32be(o, (uint32_t)vk->ic.size());
+    for (const HG1A& p : vk->ic) {
+        uint8_t b[96];
+        zkhost::g1_to_uncompressed(p, b);
+        o.insert(o.end(), b, b + 96);
+    }
+    *len = o.size();
+    if (out) {
+        if (cap < o.size()) return fail(ZK_ERR_INVALID_ARGUMENT, "output buffer too small");
+        memcpy(out, o.data(), o.size());
+    }
+    return ZK_OK;
+}
+zk_status zk_vk_num_inputs(const zk_vk* vk, uint32_t* n_inputs) {
+    if (!vk || !n_inputs) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *n_inputs = vk->n_ic ? vk->n_ic - 1 : 0;
+    return ZK_OK;
+}
+void zk_vk_free(zk_vk* vk) { delete vk; }
+
+zk_status zk_verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
+                          uint8_t* ok_out) {
+    if (!vk || (n && (!proofs || !ok_out)) || (n && n_inputs && !public_inputs)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    // verifier.rs:38-40
+    if (n_inputs + 1 != vk->ic.size()) return fail(ZK_ERR_MALFORMED_VERIFYING_KEY, "number of public inputs + 1 differs from ic");
+    ZK_TRY(use_device(vk->device));
+    for (size_t first = 0; first < n; first += VERIFY_CHUNK) {
+        const size_t np = std::min(VERIFY_CHUNK, n - first);
+        ZK_TRY(verify_chunk(vk, np, proofs + first * 192, public_inputs + first * n_inputs * 32, ok_out + first));
+    }
+    return ZK_OK;
+}
+zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* public_inputs, size_t n_inputs, int* ok) {
+    if (!ok) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    uint8_t v = 0;
+    zk_status st = zk_verify_batch(vk, 1, proof, public_inputs, n_inputs, &v);
+    *ok = v;
+    return st;
+}
+
+}  // extern "C"

@@ -26,6 +26,7 @@
 
 #include "../../include/zkamd.h"
 #include "gpu_rt.h"
+#include "host_common.h"
 #include "host_math.h"
 #include "ntt.h"
 #include "msm.h"
@@ -36,180 +37,7 @@ using zkdev::NttPass;
 
 namespace {
 
-thread_local std::string g_err;
-
-// Streams and the fork event live in a per-DEVICE context that is created on first use and kept for
-// the life of the process: handles on different GPUs never tear down each other's streams, and the
-// current device - which HIP keeps per host thread - is selected on every entry (use_device), so a
-// handle may be driven from any thread.  g_stream & co. are the calling thread's view of the context
-// of the device it selected last.
-struct DevCtx {
-    hipStream_t stream = nullptr;    // main stream: H pipeline, G1 multiexps, stand-alone entries
-    hipStream_t stream2 = nullptr;   // side stream: the G2 multiexp of a chunk runs beside the G1 work
-    hipStream_t copy = nullptr;      // staging copies of the next block of a host batch
-    hipEvent_t ev_fork = nullptr;
-};
-std::mutex g_ctx_mu;
-std::map<int, DevCtx*> g_ctxs;
-thread_local hipStream_t g_stream = nullptr;
-thread_local hipStream_t g_stream2 = nullptr;
-thread_local hipStream_t g_copy_stream = nullptr;
-thread_local hipEvent_t g_ev_fork = nullptr;
-thread_local int g_device = -1;
-
-zk_status fail(zk_status st, const std::string& msg) {
-    g_err = msg;
-    return st;
-}
-
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess)                                                                  \
-            return fail(ZK_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
-    } while (0)
-#define ZK_TRY(expr)                \
-    do {                            \
-        zk_status s_ = (expr);      \
-        if (s_ != ZK_OK) return s_; \
-    } while (0)
-
-zk_status use_device(int device) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(ZK_ERR_NO_DEVICE, "no HIP device visible");
-    if (device < 0 || device >= n) return fail(ZK_ERR_INVALID_ARGUMENT, "device index out of range");
-    HIP_TRY(hipSetDevice(device));   // per host thread: never skipped
-    std::lock_guard<std::mutex> lock(g_ctx_mu);
-    DevCtx*& c = g_ctxs[device];
-    if (!c) {
-        DevCtx* fresh = new DevCtx();
-        if (hipStreamCreate(&fresh->stream) != hipSuccess || hipStreamCreate(&fresh->stream2) != hipSuccess ||
-            hipStreamCreateWithFlags(&fresh->copy, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&fresh->ev_fork) != hipSuccess) {
-            delete fresh;
-            g_ctxs.erase(device);
-            return fail(ZK_ERR_DEVICE, "cannot create the streams of device " + std::to_string(device));
-        }
-        c = fresh;
-    }
-    g_stream = c->stream;
-    g_stream2 = c->stream2;
-    g_copy_stream = c->copy;
-    g_ev_fork = c->ev_fork;
-    g_device = device;
-    return ZK_OK;
-}
-
-// Host threads the library may use for the CPU-side legs (witness calculation, proof encoding):
-// zk_set_host_threads() / ZKAMD_HOST_THREADS, default = the cores this process may run on.  With one
-// process per GPU on an 8-GPU node every rank must take its share of the cores, not all of them.
-int g_host_threads = 0;
-unsigned host_threads(size_t work_items, unsigned cap) {
-    long n = g_host_threads;
-    if (n <= 0) {
-        if (const char* env = getenv("ZKAMD_HOST_THREADS")) n = atol(env);
-    }
-    if (n <= 0) {
-#if defined(__linux__) && !defined(ZK_EMU)
-        cpu_set_t set;
-        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
-#endif
-        if (n <= 0) n = (long)std::thread::hardware_concurrency();
-    }
-    if (n <= 0) n = 1;
-    if ((unsigned long)n > cap) n = cap;
-    if ((size_t)n > work_items) n = (long)work_items;
-    return n > 0 ? (unsigned)n : 1u;
-}
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    DevBuf() {}
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
-    }
-    zk_status ensure(size_t bytes) {
-        if (bytes <= cap) return ZK_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        if (hipMalloc(&p, bytes) != hipSuccess) {
-            p = nullptr;
-            return fail(ZK_ERR_OUT_OF_MEMORY, "hipMalloc of " + std::to_string(bytes) + " bytes failed");
-        }
-        cap = bytes;
-        return ZK_OK;
-    }
-    template <class T>
-    T* as() const {
-        return reinterpret_cast<T*>(p);
-    }
-};
-
-// page-locked host memory: asynchronous copies into pageable memory block the calling thread until
-// the copy has run, which would serialise whatever is enqueued after them on other streams
-struct PinBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    PinBuf() {}
-    PinBuf(const PinBuf&) = delete;
-    PinBuf& operator=(const PinBuf&) = delete;
-    ~PinBuf() {
-        if (p) (void)hipHostFree(p);
-    }
-    zk_status ensure(size_t bytes) {
-        if (bytes <= cap) return ZK_OK;
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        if (hipHostMalloc(&p, bytes) != hipSuccess) {
-            p = nullptr;
-            return fail(ZK_ERR_OUT_OF_MEMORY, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
-        }
-        cap = bytes;
-        return ZK_OK;
-    }
-    template <class T> T* as() { return reinterpret_cast<T*>(p); }
-};
-
-// ------------------------------------------------------------------------------------------
-// HIP-event profiling of named kernels (zk_profile_*)
-// ------------------------------------------------------------------------------------------
-struct ProfRec {
-    std::string name;
-    hipEvent_t a, b;
-};
-// process-wide (the GPU thread of a zk_pipeline records into the same list the caller reads)
-std::mutex g_prof_mu;
-bool g_prof = false;
-std::vector<ProfRec> g_recs;
-
-struct ProfScope {
-    bool on = false;
-    hipStream_t st;
-    hipEvent_t end = nullptr;
-    ProfScope(const char* name, hipStream_t stream = nullptr) : st(stream ? stream : g_stream) {
-        std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (!g_prof) return;
-        ProfRec r;
-        r.name = name;
-        if (hipEventCreate(&r.a) != hipSuccess) return;
-        if (hipEventCreate(&r.b) != hipSuccess) {
-            (void)hipEventDestroy(r.a);
-            return;
-        }
-        (void)hipEventRecord(r.a, st);
-        end = r.b;
-        on = true;
-        g_recs.push_back(r);
-    }
-    ~ProfScope() {
-        if (on) (void)hipEventRecord(end, st);
-    }
-};
+using namespace zkrt;
 
 // ------------------------------------------------------------------------------------------
 // NTT plan: twiddles and fused scaling tables for one domain size, resident in HBM
@@ -777,6 +605,7 @@ struct zk_params {
     PinBuf pin_bad;
     // vk points bellman accepts at infinity (VerifyingKey::read does not reject them)
     bool alpha_g1_inf = false, beta_g1_inf = false, beta_g2_inf = false, delta_g1_inf = false, delta_g2_inf = false;
+    std::vector<uint8_t> vk_bytes;   // VerifyingKey::write of the key (the head of the parameter file)
     std::vector<MsmJob> jobs1, jobs2;
     std::vector<HG1> res1;
     std::vector<HG2> res2;
@@ -812,6 +641,7 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     if ((size_t)P->n_ic * 96 > r.left) return fail(ZK_ERR_IO, "unexpected end of parameters in vk.ic");
     for (uint32_t i = 0; i < P->n_ic; i++) ZK_TRY(read_g1(r, &ic[i], "vk.ic"));
 
+    P->vk_bytes.assign(pk, pk + (len - r.left));
     std::vector<HG1A> pts1;
     auto read_vec1 = [&](uint32_t* n, uint32_t* off, const char* what) -> zk_status {
         if (!r.u32be(n)) return fail(ZK_ERR_IO, std::string("unexpected end of parameters (length of ") + what + ")");
@@ -1717,6 +1547,15 @@ zk_status zk_params_get_info(const zk_params* p, zk_params_info* info) {
     return ZK_OK;
 }
 void zk_params_free(zk_params* p) { delete p; }
+zk_status zk_params_write_vk(const zk_params* p, uint8_t* out, size_t cap, size_t* len) {
+    if (!p || !len) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *len = p->vk_bytes.size();
+    if (out) {
+        if (cap < p->vk_bytes.size()) return fail(ZK_ERR_INVALID_ARGUMENT, "output buffer too small");
+        memcpy(out, p->vk_bytes.data(), p->vk_bytes.size());
+    }
+    return ZK_OK;
+}
 
 zk_status zk_prove(zk_params* p, const zk_assignment* asg, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[192]) {
     if (!r || !s) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
