@@ -19,7 +19,7 @@ def build_emu(force=False):
     if not force and os.path.exists(EMU_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(EMU_LIB) for d in deps):
         return EMU_LIB
     cxx = CLANGXX if os.path.exists(CLANGXX) else "clang++"
-    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-DZK_EMU=1", "-Wno-psabi", "-x", "c++",
+    cmd = [cxx, "-O2", "-rdynamic", "-std=c++17", "-fPIC", "-shared", "-DZK_EMU=1", "-Wno-psabi", "-x", "c++",
            os.path.join(CSRC, "zkamd.cpp"), os.path.join(CSRC, "verify.cpp"), os.path.join(HERE, "emu_rt.cpp"), "-o", EMU_LIB,
            "-lpthread"]
     print("+", " ".join(cmd), flush=True)

@@ -259,6 +259,144 @@ def gen28_sqr(p, name):
             "clobbers": clob_v + clob_s + ["vcc"]}
 
 
+SPREAD_K = 16   # the fused Fq2 product subtracts a1 as (K p in spread form) - a1: needs a1 < (K - 1) p
+
+
+def spread28(p, M):
+    """M * p as 14 limbs of which the low 13 are lifted by 3 * 2^28 (tools/gen_constants.py: ZK_FQ28_SPREAD_M)."""
+    c = [(M * p >> (28 * i)) & ((1 << 28) - 1) if i < 13 else (M * p) >> (28 * 13) for i in range(14)]
+    sp = [c[0] + (3 << 28)] + [c[i] + (3 << 28) - 3 for i in range(1, 13)] + [c[13] - 3]
+    assert sum(x << (28 * i) for i, x in enumerate(sp)) == M * p and all(0 <= x < (1 << 32) for x in sp)
+    return sp
+
+
+def gen28_mac2(p, name):
+    """c = (x0 * y0 + x1 * y1) * 2^-392 in the radix-2^28 representation: ONE Montgomery reduction for a sum of two
+    products (a column of 28 limb products and 14 reduction products still fits the 64-bit accumulator).
+    x0, y0, y1: limbs <= 2^28 + 8; x1: limbs < 2^30 (an un-normalised limb-wise negation S - y is fine).
+    Custom register contract (the routine is reached with s_swappc_b64 from inline assembly, not through the
+    32-VGPR calling convention): x0 in v[0:13], y0 in v[16:29], x1 in v[32:45], y1 in v[48:61]; result in
+    v[0:13] (exactly normalised, < 2p if the operand magnitudes satisfy |x0||y0| + |x1||y1| < 2^11 p^2).
+    clobbers v[64:79], s[0:17], vcc.  Inputs other than v[0:13] are preserved."""
+    N, B = 14, 28
+    MASK = (1 << B) - 1
+    P = [(p >> (B * j)) & MASK for j in range(N)]
+    inv = (-pow(p, -1, 1 << B)) & MASK
+    x0 = lambda i: "v%d" % i
+    y0 = lambda i: "v%d" % (16 + i)
+    x1 = lambda i: "v%d" % (32 + i)
+    y1 = lambda i: "v%d" % (48 + i)
+    m = lambda i: "v%d" % (64 + i)
+    lo, hi = 78, 79
+    acc = "v[%d:%d]" % (lo, hi)
+    sp = lambda j: "s%d" % j
+    sinv = "s%d" % N
+    dummy = "s[16:17]"
+    e = Emitter()
+    for j in range(N):
+        e.salu_op("s_mov_b32 %s, 0x%08x" % (sp(j), P[j]))
+    e.salu_op("s_mov_b32 %s, 0x%08x" % (sinv, inv))
+    first = True
+    for k in range(2 * N - 1):
+        prods = []
+        for i in range(N):
+            if 0 <= k - i < N:
+                prods.append((x0(i), y0(k - i)))
+                prods.append((x1(i), y1(k - i)))
+        prods += [(m(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
+        for a, b in prods:
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, dummy, a, b, "0" if first else acc))
+            first = False
+        if k < N:
+            e.valu_op("v_mul_lo_u32 %s, v%d, %s" % (m(k), lo, sinv))
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, %s" % (m(k), MASK, m(k)))
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc, dummy, m(k), sp(0), acc))
+        else:
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, v%d" % (x0(k - N), MASK, lo))   # x0[k - N] is dead from column k on
+        e.valu_op("v_alignbit_b32 v%d, v%d, v%d, %d" % (lo, hi, lo, B))
+        e.valu_op("v_lshrrev_b32_e32 v%d, %d, v%d" % (hi, B, hi))
+    e.valu_op("v_mov_b32_e32 %s, v%d" % (x0(N - 1), lo))
+    clob_v = ["v%d" % i for i in range(64, 80)]
+    clob_s = ["s%d" % i for i in range(0, 18)]
+    return {"name": name, "N": N, "lines": e.lines, "valu": e.valu, "nops": e.nops,
+            "clobbers": clob_v + clob_s + ["vcc"]}
+
+
+def gen28_fq2mul(p, name):
+    """Fq2 = Fq[u]/(u^2 + 1) product in the radix-2^28 representation, lazily reduced:
+        c0 = (a0 b0 + (K p - a1) b1) * 2^-392,     c1 = (a0 b1 + a1 b0) * 2^-392
+    4 limb-product groups and TWO Montgomery reductions (Karatsuba over reduced products costs 3 groups, 3
+    reductions and ~10 carry-propagating additions of which two are lazily reduced differences); the two columns
+    accumulate in two independent 64-bit accumulators whose multiply-adds alternate, so a lone wave has two
+    dependency chains to issue from.  K p - a1 is formed limb-wise against the spread form of K p (no limb goes
+    negative, no normalisation: limbs < 2^30 still leave a column below 2^62.5).
+    a0 in v[0:13], a1 in v[16:29], b0 in v[32:45], b1 in v[48:61]; c0 -> v[0:13], c1 -> v[16:29] (exactly
+    normalised, each < 2p for component magnitudes up to 13 p).  clobbers v[64:109], s[0:17], vcc; b0, b1 are
+    preserved."""
+    N, B = 14, 28
+    MASK = (1 << B) - 1
+    P = [(p >> (B * j)) & MASK for j in range(N)]
+    inv = (-pow(p, -1, 1 << B)) & MASK
+    S = spread28(p, SPREAD_K)
+    a0 = lambda i: "v%d" % i
+    a1 = lambda i: "v%d" % (16 + i)
+    b0 = lambda i: "v%d" % (32 + i)
+    b1 = lambda i: "v%d" % (48 + i)
+    n1 = lambda i: "v%d" % (64 + i)
+    m0 = lambda i: "v%d" % (78 + i)
+    m1 = lambda i: "v%d" % (92 + i)
+    lo0, hi0, lo1, hi1 = 106, 107, 108, 109
+    acc0, acc1 = "v[%d:%d]" % (lo0, hi0), "v[%d:%d]" % (lo1, hi1)
+    sp = lambda j: "s%d" % j
+    sinv = "s%d" % N
+    dummy = "s[16:17]"
+    e = Emitter()
+    for j in range(N):
+        e.salu_op("s_mov_b32 %s, 0x%08x" % (sp(j), P[j]))
+    e.salu_op("s_mov_b32 %s, 0x%08x" % (sinv, inv))
+    for j in range(N):
+        e.valu_op("v_sub_u32_e32 %s, 0x%08x, %s" % (n1(j), S[j], a1(j)))
+    first0 = first1 = True
+    for k in range(2 * N - 1):
+        p0, p1 = [], []
+        for i in range(N):
+            if 0 <= k - i < N:
+                p0.append((a0(i), b0(k - i)))
+                p0.append((n1(i), b1(k - i)))
+                p1.append((a0(i), b1(k - i)))
+                p1.append((a1(i), b0(k - i)))
+        p0 += [(m0(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
+        p1 += [(m1(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
+        for t in range(len(p0)):
+            x, y = p0[t]
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc0, dummy, x, y, "0" if first0 else acc0))
+            first0 = False
+            x, y = p1[t]
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc1, dummy, x, y, "0" if first1 else acc1))
+            first1 = False
+        if k < N:
+            e.valu_op("v_mul_lo_u32 %s, v%d, %s" % (m0(k), lo0, sinv))
+            e.valu_op("v_mul_lo_u32 %s, v%d, %s" % (m1(k), lo1, sinv))
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, %s" % (m0(k), MASK, m0(k)))
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, %s" % (m1(k), MASK, m1(k)))
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc0, dummy, m0(k), sp(0), acc0))
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc1, dummy, m1(k), sp(0), acc1))
+        else:
+            # a0[k - N] and a1[k - N] are dead from column k on
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, v%d" % (a0(k - N), MASK, lo0))
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, v%d" % (a1(k - N), MASK, lo1))
+        e.valu_op("v_alignbit_b32 v%d, v%d, v%d, %d" % (lo0, hi0, lo0, B))
+        e.valu_op("v_alignbit_b32 v%d, v%d, v%d, %d" % (lo1, hi1, lo1, B))
+        e.valu_op("v_lshrrev_b32_e32 v%d, %d, v%d" % (hi0, B, hi0))
+        e.valu_op("v_lshrrev_b32_e32 v%d, %d, v%d" % (hi1, B, hi1))
+    e.valu_op("v_mov_b32_e32 %s, v%d" % (a0(N - 1), lo0))
+    e.valu_op("v_mov_b32_e32 %s, v%d" % (a1(N - 1), lo1))
+    clob_v = ["v%d" % i for i in range(64, 110)]
+    clob_s = ["s%d" % i for i in range(0, 18)]
+    return {"name": name, "N": N, "lines": e.lines, "valu": e.valu, "nops": e.nops,
+            "clobbers": clob_v + clob_s + ["vcc"]}
+
+
 def render(spec):
     body = "\\n\\t".join(spec["lines"])
     out = []
@@ -274,7 +412,8 @@ def render(spec):
 
 
 def main():
-    specs = [gen(8, FR_P, "FR"), gen(12, FQ_P, "FQ"), gen28(FQ_P, "FQ28"), gen28(FQ_P, "FQ28D", dual=True), gen28_sqr(FQ_P, "FQ28SQR")]
+    specs = [gen(8, FR_P, "FR"), gen(12, FQ_P, "FQ"), gen28(FQ_P, "FQ28"), gen28(FQ_P, "FQ28D", dual=True), gen28_sqr(FQ_P, "FQ28SQR"),
+             gen28_mac2(FQ_P, "FQ28MAC2"), gen28_fq2mul(FQ_P, "FQ2MUL28")]
     hdr = ["// GENERATED by tools/gen_mul_asm.py - do not edit.",
            "// Hand-scheduled gfx950 Montgomery products (see the generator for the design notes).",
            "#pragma once", ""]

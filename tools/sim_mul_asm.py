@@ -75,7 +75,7 @@ def run28(lines, a_limbs, b_limbs):
     return _run_regs(lines, {**{i: a_limbs[i] for i in range(14)}, **{16 + i: b_limbs[i] for i in range(14)}}, 14)
 
 
-def _run_regs(lines, init, nout):
+def _run_regs(lines, init, nout, capture=None):
     class R(dict):
         pass
     # same interpreter as run(), on an explicit register file
@@ -115,11 +115,17 @@ def _run_regs(lines, init, nout):
         elif op == "v_alignbit_b32": setv(ops[0], (((val(ops[1]) << 32) | val(ops[2])) >> val(ops[3])) & M32)
         elif op == "v_lshrrev_b32_e32": setv(ops[0], val(ops[2]) >> val(ops[1]))
         elif op == "v_lshlrev_b32_e32": setv(ops[0], (val(ops[2]) << val(ops[1])) & M32)
+        elif op == "v_sub_u32_e32":
+            t = val(ops[1]) - val(ops[2])
+            assert t >= 0, "limb-wise negation went negative"
+            setv(ops[0], t)
         elif op == "v_lshl_add_u64":
             t = (val(ops[1]) << val(ops[2])) + val(ops[3])
             assert t < 2**64, "64-bit add overflow"
             setv(ops[0], t)
         else: raise SystemExit("unknown op " + ln)
+    if capture is not None:
+        capture.update(v)
     return [v[i] for i in range(nout)]
 
 
@@ -167,7 +173,84 @@ def main28(dual=False):
     print(spec["name"], "ok:", len(cases), "products;", spec["valu"], "VALU,", spec["nops"], "wait states")
 
 
+def _weak(rnd, l):
+    """a weakly normalised form of the same value: some limbs up to 2^28 + 8"""
+    l = list(l)
+    for i in range(13):
+        if rnd.random() < 0.5 and l[i] < 8 and l[i + 1] > 0:
+            l[i] += 1 << 28
+            l[i + 1] -= 1
+    return l
+
+
+def main28_mac2():
+    rnd = random.Random(5)
+    p = g.FQ_P
+    spec = g.gen28_mac2(p, "FQ28MAC2")
+    Rinv = pow(1 << 392, -1, p)
+    lim = lambda x: [(x >> (28 * i)) & ((1 << 28) - 1) if i < 13 else x >> (28 * 13) for i in range(14)]
+    val = lambda l: sum(x << (28 * i) for i, x in enumerate(l))
+    S = g.spread28(p, 14)
+    cases = [(0, 0, 0, 0), (1, 1, 1, 1), (13 * p, 13 * p, 12 * p, 13 * p), (2 * p - 1, p - 1, 13 * p - 1, 2 * p - 1)]
+    cases += [tuple(rnd.randrange(13 * p) for _ in range(4)) for _ in range(300)]
+    for x0, y0, x1, y1 in cases:
+        l = [_weak(rnd, lim(v)) for v in (x0, y0, x1, y1)]
+        if rnd.random() < 0.5:   # x1 as an un-normalised limb-wise negation 14 p - x1 (limbs < 2^30)
+            l[2] = [S[i] - l[2][i] for i in range(14)]
+            assert all(0 <= t < (1 << 30) for t in l[2])
+        init = {}
+        for blk, limbs in enumerate(l):
+            for i in range(14):
+                init[16 * blk + i] = limbs[i]
+        keep = dict(init)
+        out_regs = _run_regs_full(spec["lines"], init)
+        out = [out_regs[i] for i in range(14)]
+        got = val(out)
+        assert all(x < (1 << 28) for x in out[:13])
+        assert got % p == (val(l[0]) * val(l[1]) + val(l[2]) * val(l[3])) * Rinv % p and got < 2 * p
+        assert all(out_regs[r] == keep[r] for r in keep if r >= 16), "an input other than x0 was modified"
+    print(spec["name"], "ok:", len(cases), "sums of two products;", spec["valu"], "VALU,", spec["nops"], "wait states")
+
+
+def main28_fq2mul():
+    rnd = random.Random(7)
+    p = g.FQ_P
+    spec = g.gen28_fq2mul(p, "FQ2MUL28")
+    Rinv = pow(1 << 392, -1, p)
+    lim = lambda x: [(x >> (28 * i)) & ((1 << 28) - 1) if i < 13 else x >> (28 * 13) for i in range(14)]
+    val = lambda l: sum(x << (28 * i) for i, x in enumerate(l))
+    cases = [(0, 0, 0, 0), (1, 0, 0, 1), (13 * p, 13 * p, 13 * p, 13 * p), (2 * p - 1, 14 * p, p - 1, 2 * p - 1)]
+    cases += [tuple(rnd.randrange(13 * p) for _ in range(4)) for _ in range(300)]
+    for vals in cases:
+        l = [_weak(rnd, lim(v)) for v in vals]
+        init = {}
+        for blk, limbs in enumerate(l):
+            for i in range(14):
+                init[16 * blk + i] = limbs[i]
+        keep = dict(init)
+        out_regs = _run_regs_full(spec["lines"], init)
+        c0 = [out_regs[i] for i in range(14)]
+        c1 = [out_regs[16 + i] for i in range(14)]
+        a0, a1, b0, b1 = (val(x) for x in l)
+        assert all(x < (1 << 28) for x in c0[:13] + c1[:13])
+        assert val(c0) % p == (a0 * b0 - a1 * b1) * Rinv % p and val(c0) < 2 * p
+        assert val(c1) % p == (a0 * b1 + a1 * b0) * Rinv % p and val(c1) < 2 * p
+        assert all(out_regs[r] == keep[r] for r in keep if r >= 32), "b0 / b1 were modified"
+    print(spec["name"], "ok:", len(cases), "Fq2 products;", spec["valu"], "VALU,", spec["nops"], "wait states")
+
+
+def _run_regs_full(lines, init):
+    """_run_regs returning the whole register file"""
+    regs = {}
+    class Cap(dict):
+        pass
+    out = _run_regs(lines, init, 0, capture=regs)
+    return regs
+
+
 if __name__ == "__main__":
+    main28_mac2()
+    main28_fq2mul()
     main()
     main28()
     main28(dual=True)

@@ -47,6 +47,13 @@ struct alignas(16) XYZZ {
 // (sqr_b<K>: square of a value whose components are < K p; wr(): weak reduction to < 3 p.  Both
 //  are no-ops except on Fq2x, whose Karatsuba / complex-squaring operands are range-limited.)
 
+// x0 y0 - x1 y1 for x1 < B p.  On the lazily reduced Fq28 this is ONE fused routine with one Montgomery
+// reduction (dev_field.h mul_sub2); the other fields take two products and a subtraction.
+template <int B, class F>
+ZK_DI F mul_sub2(const F& x0, const F& y0, const F& x1, const F& y1) {
+    return sub_b<F::MO>(mul(x0, y0), mul(x1, y1));
+}
+
 // bound of a value after wr(): F::WB where wr() reduces, unchanged where it is the identity
 template <class F>
 constexpr int wrb(int b) { return b < F::WB ? b : F::WB; }
@@ -63,7 +70,7 @@ ZK_DI XYZZ<F> mdbl(const Affine<F>& p) {
     F m = add(dbl(xx), xx);                                     // < 3 MO
     F x3 = sub_b<2 * MO>(sqr_b<3 * MO>(m), dbl(s));             // < 3 MO + 1
     F t = wr(sub_b<3 * MO + 1>(s, x3));
-    F y3 = sub_b<MO>(mul(m, t), mul(w, p.y));                   // < 2 MO + 1
+    F y3 = mul_sub2<MO>(m, t, w, p.y);                          // < 2 MO + 1
     return XYZZ<F>{x3, y3, v, w};
 }
 
@@ -81,7 +88,7 @@ ZK_DI XYZZ<F> xdbl(const XYZZ<F>& a) {
     F m = add(dbl(xx), xx);
     F x3 = sub_b<2 * MO>(sqr_b<3 * MO>(m), dbl(s));
     F t = wr(sub_b<3 * MO + 1>(s, x3));
-    F y3 = sub_b<MO>(mul(m, t), mul(w, ay));
+    F y3 = mul_sub2<MO>(m, t, w, ay);
     return XYZZ<F>{x3, y3, mul(v, a.zz), mul(w, a.zzz)};
 }
 
@@ -113,7 +120,7 @@ ZK_DI void madd(XYZZ<F>& acc, const Affine<F>& p, bool negate) {
     }
     F x3 = sub_b<2 * MO>(sub_b<MO>(sqr_b<MO + BY + 1>(r), ppp), dbl(q));   // < 4 MO + 2 = BX
     F t = wr(sub_b<BX>(q, x3));
-    F y3 = sub_b<MO>(mul(r, t), mul(acc.y, ppp));               // < 2 MO + 1 = BY
+    F y3 = mul_sub2<BY>(r, t, acc.y, ppp);                      // < 2 MO + 1 = BY
     acc.x = x3;
     acc.y = y3;
     acc.zz = zz3;
@@ -142,7 +149,7 @@ ZK_DI XYZZ<F> xadd(const XYZZ<F>& a, const XYZZ<F>& b) {
     }
     F x3 = sub_b<2 * MO>(sub_b<MO>(sqr_b<2 * MO + 1>(r), ppp), dbl(q));
     F t = wr(sub_b<BX>(q, x3));
-    F y3 = sub_b<MO>(mul(r, t), mul(s1, ppp));
+    F y3 = mul_sub2<MO>(r, t, s1, ppp);
     return XYZZ<F>{x3, y3, zz3, mul(mul(a.zzz, b.zzz), ppp)};
 }
 

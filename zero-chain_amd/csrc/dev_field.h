@@ -461,7 +461,9 @@ static inline long double fq28_ratio(const uint32_t* l) {
     }
     return v / p;
 }
-#define ZK_FQ28_CHECK(cond) do { if (!(cond)) { fprintf(stderr, "Fq28 bound violated: %s (%s:%d)\n", #cond, __FILE__, __LINE__); abort(); } } while (0)
+#include <execinfo.h>
+#define ZK_FQ28_CHECK(cond) do { if (!(cond)) { fprintf(stderr, "Fq28 bound violated: %s (%s:%d)\n", #cond, __FILE__, __LINE__); \
+    void* bt_[32]; backtrace_symbols_fd(bt_, backtrace(bt_, 32), 2); abort(); } } while (0)
 #else
 #define ZK_FQ28_CHECK(cond) do { } while (0)
 #endif
@@ -572,6 +574,111 @@ ZK_DI Fq28 sqr(const Fq28& a) {
     return r;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused routines with a custom register contract (mul_asm.h FQ28MAC2 / FQ2MUL28).  Four 14-limb operands
+// do not fit the 32 VGPRs the calling convention passes in registers, so these are `naked` functions
+// reached with s_swappc_b64 from an inline-assembly statement that names the operand registers and the
+// clobbers itself: v[0:15], v[16:31], v[32:47], v[48:63] in, v[0:15] (and v[16:31]) out.
+//   mac2:    c = (x0 y0 + x1 y1) 2^-392        one Montgomery reduction for a sum of two products
+//   fq2mul:  c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0   (x 2^-392): 4 limb-product groups, 2 reductions
+// ---------------------------------------------------------------------------------------------
+// plain C++ of the same column schedule (the emulation build, ZK_MUL_CXX): bit-identical results
+ZK_DI u32x16 mac2_cxx(u32x16 x0, u32x16 y0, u32x16 x1, u32x16 y1) {
+    uint32_t m[14];
+    u32x16 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) {
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+            if (k - i >= 0 && k - i < 14) {
+                acc += (uint64_t)x0[i] * y0[k - i];
+                acc += (uint64_t)x1[i] * y1[k - i];
+            }
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+            if (k - i >= 0 && k - i < 14 && (k >= 14 || i < k)) acc += (uint64_t)m[i] * Fq28Consts::P[k - i];
+        if (k < 14) {
+            m[k] = ((uint32_t)acc * Fq28Consts::INV) & FQ28_MASK;
+            acc += (uint64_t)m[k] * Fq28Consts::P[0];
+        } else {
+            r[k - 14] = (uint32_t)acc & FQ28_MASK;
+        }
+        acc >>= 28;
+    }
+    r[13] = (uint32_t)acc;
+    r[14] = 0;
+    r[15] = 0;
+    return r;
+}
+constexpr int FQ2_SPREAD_K = 16;   // tools/gen_mul_asm.py SPREAD_K: the fused Fq2 product negates a1 against 16 p
+
+#if defined(ZK_EMU) || defined(ZK_MUL_CXX)
+ZK_DI void mac2_raw(u32x16& x0, const u32x16& y0, const u32x16& x1, const u32x16& y1) { x0 = mac2_cxx(x0, y0, x1, y1); }
+ZK_DI void fq2mul_raw(u32x16& a0, u32x16& a1, const u32x16& b0, const u32x16& b1) {
+    u32x16 n1;
+#pragma unroll
+    for (int i = 0; i < 14; i++) n1[i] = Fq28Spread<FQ2_SPREAD_K>::V[i] - a1[i];
+    n1[14] = n1[15] = 0;
+    const u32x16 c0 = mac2_cxx(a0, b0, n1, b1), c1 = mac2_cxx(a0, b1, a1, b0);
+    a0 = c0;
+    a1 = c1;
+}
+#else
+extern "C" __device__ __attribute__((naked, noinline, used)) void zk_fq28_mac2() {
+    asm volatile(ZK_MUL_ASM_FQ28MAC2 "s_setpc_b64 s[30:31]");
+}
+extern "C" __device__ __attribute__((naked, noinline, used)) void zk_fq2mul28() {
+    asm volatile(ZK_MUL_ASM_FQ2MUL28 "s_setpc_b64 s[30:31]");
+}
+#define ZK_ASM_CALL(fn)                                   \
+    "s_getpc_b64 s[18:19]\n\t"                            \
+    "s_add_u32 s18, s18, " fn "@rel32@lo+4\n\t"           \
+    "s_addc_u32 s19, s19, " fn "@rel32@hi+12\n\t"         \
+    "s_swappc_b64 s[30:31], s[18:19]"
+ZK_DI void mac2_raw(u32x16& x0, const u32x16& y0, const u32x16& x1, const u32x16& y1) {
+    asm(ZK_ASM_CALL("zk_fq28_mac2")
+        : "+{v[0:15]}"(x0)
+        : "{v[16:31]}"(y0), "{v[32:47]}"(x1), "{v[48:63]}"(y1)
+        : ZK_MUL_ASM_FQ28MAC2_CLOBBERS, "s18", "s19", "s30", "s31");
+}
+ZK_DI void fq2mul_raw(u32x16& a0, u32x16& a1, const u32x16& b0, const u32x16& b1) {
+    asm(ZK_ASM_CALL("zk_fq2mul28")
+        : "+{v[0:15]}"(a0), "+{v[16:31]}"(a1)
+        : "{v[32:47]}"(b0), "{v[48:63]}"(b1)
+        : ZK_MUL_ASM_FQ2MUL28_CLOBBERS, "s18", "s19", "s30", "s31");
+}
+#endif
+
+ZK_DI u32x16 fq28_vec(const Fq28& a) {
+    u32x16 v;
+#pragma unroll
+    for (int j = 0; j < 14; j++) v[j] = a.l[j];
+    v[14] = v[15] = 0;
+    return v;
+}
+ZK_DI Fq28 fq28_unvec(const u32x16& v) {
+    Fq28 r;
+#pragma unroll
+    for (int j = 0; j < 14; j++) r.l[j] = v[j];
+    return r;
+}
+// x0 y0 - x1 y1 for x1 < B p, with ONE reduction: the subtrahend enters as the limb-wise (B + 1) p - x1, left
+// un-normalised (limbs < 2^30, which the routine tolerates in that operand).  Result exactly normalised, < 2p
+// as long as |x0||y0| + (B + 1)|y1| < 2^11.
+template <int B>
+ZK_DI Fq28 mul_sub2(const Fq28& x0, const Fq28& y0, const Fq28& x1, const Fq28& y1) {
+    static_assert(B + 1 >= 2 && B + 1 <= 64, "no spread constant for this bound");
+    ZK_FQ28_CHECK(fq28_ratio(x1.l) < (long double)B);
+    ZK_FQ28_CHECK(fq28_ratio(x0.l) * fq28_ratio(y0.l) + (long double)(B + 1) * fq28_ratio(y1.l) < 2000.0L);
+    u32x16 a = fq28_vec(x0), n;
+#pragma unroll
+    for (int j = 0; j < 14; j++) n[j] = Fq28Spread<B + 1>::V[j] - x1.l[j];
+    n[14] = n[15] = 0;
+    mac2_raw(a, fq28_vec(y0), n, fq28_vec(y1));
+    return fq28_unvec(a);
+}
+
 // the unique representative in [0, p), exactly normalised (rare paths: export, equality)
 ZK_DI Fq28 canon(const Fq28& a) {
     Fq28 t = mul(a, Fq28::one());   // < 2p, exact limbs
@@ -676,21 +783,23 @@ ZK_DI bool fq28_is_zero_lazy(const Fq28& x) {
 ZK_DI Fq28 wr(const Fq28& a) { return a; }
 
 // ---------------------------------------------------------------------------------------------
-// Fq2 = Fq[u]/(u^2 + 1) over the radix-2^28 representation (G2 under -DZK_G2_RADIX28; measured
-// slower than the saturated Fq2 for register-pressure reasons, see zkamd.cpp).  fq2.rs:90-182.
-// Karatsuba leaves lazily reduced differences: a product's components are < 5 p and < 7 p
-// (MO = 7) provided the operands' component bounds A, B satisfy (2A)(2B) < 2^11.3, i.e. A B <= 625;
-// a square needs A <= 24.  Where the curve formulas exceed that, they call wr() (weak reduction of
-// both components, ~200 instructions) - twice per mixed addition.
+// Fq2 = Fq[u]/(u^2 + 1) over the radix-2^28 representation: the G2 field of the MSM kernels.  fq2.rs:90-182.
+// The product is the fused routine above (4 limb-product groups, 2 reductions): both components of a
+// product are exactly normalised and < 2p, so an Fq2x obeys the same magnitude bookkeeping as a G1
+// coordinate (MO = 2, no weak reductions anywhere: the curve formulas' largest operands are 13 p against
+// the 15 p the routine's internal negation allows).  A square is two base-field products,
+// (a0 + a1)(a0 - a1) and 2 a0 a1.
+// (Round 1 ran G2 on the saturated 12 x 32-bit Fq2 below: Karatsuba over three reduced products, 659
+// instructions each plus carry-chain additions, with scratch spills - 100 ms per 1024-proof launch.)
 // ---------------------------------------------------------------------------------------------
 struct Fq2x {
-    static constexpr int MO = 7;
-    static constexpr int WB = 3;   // components after wr()
+    static constexpr int MO = 2;
+    static constexpr int WB = 64;   // wr() is the identity
     Fq28 c0, c1;
     ZK_DI static Fq2x zero() { return Fq2x{Fq28::zero(), Fq28::zero()}; }
     ZK_DI static Fq2x one() { return Fq2x{Fq28::one(), Fq28::zero()}; }
-    // (components are lazily reduced: the test normalises first; c1 is only looked at when c0 is zero)
-    ZK_DI bool is_zero_norm() const { return fq28_is_zero_lazy(c0) && fq28_is_zero_lazy(c1); }
+    // zero test of an EXACTLY normalised value (a product, a constant, a table entry)
+    ZK_DI bool is_zero_norm() const { return c0.is_zero_norm() && c1.is_zero_norm(); }
 };
 ZK_DI Fq2x add(const Fq2x& a, const Fq2x& b) { return Fq2x{add(a.c0, b.c0), add(a.c1, b.c1)}; }
 ZK_DI Fq2x dbl(const Fq2x& a) { return add(a, a); }
@@ -698,23 +807,23 @@ template <int B>
 ZK_DI Fq2x sub_b(const Fq2x& a, const Fq2x& b) { return Fq2x{sub_b<B>(a.c0, b.c0), sub_b<B>(a.c1, b.c1)}; }
 template <int B>
 ZK_DI Fq2x neg_b(const Fq2x& a) { return Fq2x{neg_b<B>(a.c0), neg_b<B>(a.c1)}; }
-ZK_DI Fq2x wr(const Fq2x& a) { return Fq2x{fq28_wred(a.c0), fq28_wred(a.c1)}; }
-ZK_DI bool is_zero_full(const Fq2x& a) { return a.is_zero_norm(); }
+ZK_DI Fq2x wr(const Fq2x& a) { return a; }
+ZK_DI bool is_zero_full(const Fq2x& a) { return is_zero_full(a.c0) && is_zero_full(a.c1); }
 ZK_DI Fq2x mul(const Fq2x& a, const Fq2x& b) {
-    Fq28 aa = mul(a.c0, b.c0);                                  // < 2
-    Fq28 bb = mul(a.c1, b.c1);
-    Fq28 o = mul(add(a.c0, a.c1), add(b.c0, b.c1));
-    return Fq2x{sub_b<2>(aa, bb), sub_b<4>(o, add(aa, bb))};    // < 5, < 7
+    ZK_FQ28_CHECK(fq28_ratio(a.c1.l) < (long double)(FQ2_SPREAD_K - 1));
+    ZK_FQ28_CHECK(fq28_ratio(a.c0.l) * fq28_ratio(b.c0.l) + (long double)FQ2_SPREAD_K * fq28_ratio(b.c1.l) < 2000.0L);
+    ZK_FQ28_CHECK(fq28_ratio(a.c0.l) * fq28_ratio(b.c1.l) + fq28_ratio(a.c1.l) * fq28_ratio(b.c0.l) < 2000.0L);
+    u32x16 a0 = fq28_vec(a.c0), a1 = fq28_vec(a.c1);
+    fq2mul_raw(a0, a1, fq28_vec(b.c0), fq28_vec(b.c1));
+    return Fq2x{fq28_unvec(a0), fq28_unvec(a1)};
 }
-template <int A>   // A = bound of the operand's components (needed for the difference a0 - a1)
+template <int A>   // A = bound of the operand's components (for the difference a0 - a1)
 ZK_DI Fq2x sqr_b(const Fq2x& a) {
-    static_assert(A <= 24, "operand of an Fq2 square out of range: weak-reduce it first");
-    Fq28 ab = mul(a.c0, a.c1);
-    Fq28 s = mul(add(a.c0, a.c1), sub_b<A>(a.c0, a.c1));
-    return Fq2x{s, dbl(ab)};                                    // < 2, < 4
+    static_assert(A <= 30, "operand of an Fq2 square out of range");
+    return Fq2x{mul(add(a.c0, a.c1), sub_b<A>(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
 }
-// square of a product / table entry / imported value (components < 8 p)
-ZK_DI Fq2x sqr(const Fq2x& a) { return sqr_b<8>(a); }
+// square of a product / table entry / imported value / negated product (components < 4 p)
+ZK_DI Fq2x sqr(const Fq2x& a) { return sqr_b<4>(a); }
 
 // The same interface on the saturated representation (G2 still runs on it): bounds are ignored,
 // every value is fully reduced.

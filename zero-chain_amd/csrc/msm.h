@@ -516,10 +516,9 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
 // registers), and sorting every task's pairs by table index so that all lanes sweep the doubling
 // slices in step.  The single job's lower rate (4.3 G additions/s against 7.0) is 88 % occupancy at
 // the two ends of a 3 ms launch, a 12 % lower issue rate per resident wave and a lower clock.
-template <class F>
-static __global__ void __launch_bounds__(128, MsmOcc<F>::acc)
-k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
-                 const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<F>* __restrict__ tsums) {
+template <class F, int OCC>
+ZK_DI void msm_accumulate_body(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                               const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<F>* __restrict__ tsums) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total[0]) return;
     const uint4 d = sorted[t];
@@ -531,6 +530,20 @@ k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict
         madd(acc, p, (pr & 1u) != 0);
     }
     tsums[d.y] = acc;
+}
+template <class F>
+static __global__ void __launch_bounds__(128, MsmOcc<F>::acc)
+k_msm_accumulate(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                 const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<F>* __restrict__ tsums) {
+    msm_accumulate_body<F, MsmOcc<F>::acc>(table, pairs, sorted, total, tsums);
+}
+// the same at one wave per SIMD: the whole register file (256 VGPRs + 256 AGPRs) for one wave, i.e. an Fq2
+// accumulator (112 registers) plus the fused product's working set without scratch traffic
+template <class F>
+static __global__ void __launch_bounds__(128, 1)
+k_msm_accumulate_wide(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                      const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<F>* __restrict__ tsums) {
+    msm_accumulate_body<F, 1>(table, pairs, sorted, total, tsums);
 }
 
 // Pass 5b: buckets cut into many tasks.  Scalars are not uniform where it matters: the LAST digit
@@ -777,10 +790,9 @@ ZK_DI Fq28 inv(const Fq28& a) { return fq_pow_qm2(a); }
 ZK_DI Fq32 inv(const Fq32& a) { return fq_pow_qm2(a); }
 ZK_DI Fq2x inv(const Fq2x& a) {
     // fq2.rs:160-176
-    Fq28 n = add(sqr(wr(a).c0), sqr(wr(a).c1));
+    Fq28 n = add(sqr(a.c0), sqr(a.c1));
     Fq28 t = inv(n);
-    Fq2x w = wr(a);
-    return Fq2x{mul(w.c0, t), neg_b<2>(mul(w.c1, t))};
+    return Fq2x{mul(a.c0, t), neg_b<2>(mul(a.c1, t))};
 }
 ZK_DI Fq2 inv(const Fq2& a) {
     // fq2.rs:160-176

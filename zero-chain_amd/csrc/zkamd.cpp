@@ -414,8 +414,14 @@ struct MsmGroup {
         }
         {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
-            ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
-                      table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
+            // G2: one wave per SIMD with the whole register file unless ZKAMD_G2_ACC_OCC=2 (A/B switch)
+            static const bool wide_g2 = !(getenv("ZKAMD_G2_ACC_OCC") && atoi(getenv("ZKAMD_G2_ACC_OCC")) == 2);
+            if (zkdev::HostWords<DF>::N > 12 && wide_g2)
+                ZK_LAUNCH(zkdev::k_msm_accumulate_wide<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
+                          table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
+            else
+                ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
+                          table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
         }
         DPoint* R = red_r.as<DPoint>();
         DPoint* Wa = red_w.as<DPoint>();
@@ -513,14 +519,12 @@ struct MsmGroup {
 };
 
 typedef MsmGroup<zkhost::Fq, zkdev::Fq> MsmG1;
-// G2 stays on 12 x 32-bit limbs.  Fq2 over the radix-2^28 representation (dev_field.h Fq2x, with weak
-// reductions; parity-green under -DZK_G2_RADIX28) measured SLOWER: 113-118 ms per 1024-proof launch
-// against 99 ms - an XYZZ accumulator is 112 registers, so the kernel either spills (2 waves / SIMD) or
-// runs one wave / SIMD, where the product's dependent multiply-add chain is exposed.
-#ifdef ZK_G2_RADIX28
-typedef zkdev::Fq2x DevFq2;
-#else
+// G2 runs on Fq2 over the radix-2^28 representation with the fused lazy-reduction product (dev_field.h
+// Fq2x).  -DZK_G2_SATURATED selects round 1's saturated 12 x 32-bit Fq2 (A/B measurements).
+#ifdef ZK_G2_SATURATED
 typedef zkdev::Fq2 DevFq2;
+#else
+typedef zkdev::Fq2x DevFq2;
 #endif
 typedef MsmGroup<zkhost::Fq2, DevFq2> MsmG2;
 typedef zkhost::Affine<zkhost::Fq> HG1A;
