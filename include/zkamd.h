@@ -186,6 +186,11 @@ typedef struct {
 zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out);
 zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
                                   const uint8_t* rs, uint8_t* proofs_out);
+/* zk_transfer_prove_batch and zk_pipeline compute the witnesses ON THE GPU (one thread per statement and gadget,
+ * the assignment never leaves HBM; ZKAMD_WITNESS=host selects the host calculator instead).  This entry returns
+ * what that generator produces - same format as zk_transfer_witness - so that the two can be compared. */
+zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement* st, size_t n, uint32_t flags,
+                                  uint8_t* witness_out);
 
 /* A stream of statement batches: submit() queues a batch and returns at once; a producer thread computes
  * its witnesses on the host cores (zk_set_host_threads) while the GPU proves the batch submitted before it;

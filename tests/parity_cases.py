@@ -615,3 +615,39 @@ def verifier_reference_vectors(lib):
         assert zk.verify_proofs(pvk, proofs, [inputs] * 3) == [False, False, False]
     finally:
         pvk.close()
+
+
+def witness_gpu_matches_host(lib, n_extra=3):
+    """The GPU witness generator (witness_gpu.h, zk_transfer_witness_gpu) against the host calculator
+    (zk_transfer_witness, itself compared with the fingerprint-checked oracle circuit in test_transfer_circuit.py):
+    every one of the 19 978 values of every statement, plain and Montgomery; malformed statements are reported
+    with the same message and the statement's index."""
+    from oracle import jubjub as jj
+    from oracle import transfer_circuit as tc
+    ws = [tc.make_witness(70 + s, amount=10 + s, fee=s % 3, balance=1000 + 13 * s) for s in range(n_extra)]
+    ws.append(tc.make_witness(8, amount=0, fee=0, balance=0))
+    ws.append(tc.make_witness(9, amount=0xFFFFFFFE, fee=0, balance=0xFFFFFFFE))
+    r1 = tc.synthesize(ws[0]).to_r1cs()
+    mats = zk.ConstraintMatrices(r1.n_in, r1.n_aux, r1.constraints, lib=lib)
+    try:
+        items = [tc.statement_dict(w) for w in ws]
+        sts = zk.transfer_statements(items)
+        nv = zk.TRANSFER_N_INPUTS + zk.TRANSFER_N_AUX
+        for mont in (False, True):
+            host = zk.transfer_witness(sts, montgomery=mont, lib=lib).reshape(len(ws), nv, 32)
+            dev = zk.transfer_witness_gpu(mats, sts, montgomery=mont).reshape(len(ws), nv, 32)
+            diff = np.argwhere((host != dev).any(axis=2))
+            assert len(diff) == 0, "statement %d, variable %d differs (%d in all)" % (diff[0][0], diff[0][1], len(diff))
+        d = items[0]
+        y = 2
+        while jj.get_for_y(y, False) is not None:
+            y += 1
+        for bad, what in ((dict(d, g_epoch=bytes([0xff] * 32)), "g_epoch"), (dict(d, randomness=jj.FS_MOD), "randomness"),
+                          (dict(d, enc_key_recipient=y.to_bytes(32, "little")), "enc_key_recipient"),
+                          (dict(d, dec_key_sender=jj.FS_MOD + 5, alpha=jj.FS_MOD), "alpha")):
+            for run in (lambda s: zk.transfer_witness(s, lib=lib), lambda s: zk.transfer_witness_gpu(mats, s)):
+                with pytest.raises(zk.ZkError) as e:
+                    run(zk.transfer_statements([items[1], bad, items[2]]))
+                assert e.value.variant == "InvalidArgument" and "statement 1" in str(e.value) and what in str(e.value), str(e.value)
+    finally:
+        mats.close()

@@ -135,3 +135,7 @@ def test_verifier_reference_vectors(emu_lib):
 
 def test_verifier_golden_multiples(emu_lib):
     pc.verifier_golden_multiples(emu_lib)
+
+
+def test_witness_gpu_matches_host(emu_lib):
+    pc.witness_gpu_matches_host(emu_lib, n_extra=1)

@@ -343,3 +343,7 @@ def test_full_chunk_1024_every_proof_checked(gpu_lib):
         pvk.close()
         mats.close()
         params.close()
+
+
+def test_witness_gpu_matches_host(gpu_lib):
+    pc.witness_gpu_matches_host(gpu_lib, n_extra=6)

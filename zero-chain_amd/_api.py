@@ -25,7 +25,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 
 __all__ = ["Parameters", "Proof", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
-           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "anonymous_statements", "anonymous_witness",
+           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "anonymous_statements", "anonymous_witness",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
@@ -431,6 +431,15 @@ def transfer_witness(statements, montgomery=False, lib=None):
     n = len(statements)
     out = np.zeros(n * (TRANSFER_N_INPUTS + TRANSFER_N_AUX) * 32, dtype=np.uint8)
     lib.check(lib.zk_transfer_witness(statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
+    return out
+
+
+def transfer_witness_gpu(matrices, statements, montgomery=False):
+    """zk_transfer_witness_gpu: the assignments the GPU witness generator produces (same format as transfer_witness)."""
+    lib = matrices._lib
+    n = len(statements)
+    out = np.zeros(n * (TRANSFER_N_INPUTS + TRANSFER_N_AUX) * 32, dtype=np.uint8)
+    lib.check(lib.zk_transfer_witness_gpu(matrices._h, statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
     return out
 
 

@@ -80,6 +80,7 @@ _PROTOS = {
     "zk_r1cs_free": (None, [C.c_void_p]),
     "zk_prove_batch_witness": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "zk_transfer_witness": (C.c_int32, [C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
+    "zk_transfer_witness_gpu": (C.c_int32, [C.c_void_p, C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_transfer_prove_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TransferStatement), C.c_void_p,
                                             C.c_void_p]),
     "zk_pipeline_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),

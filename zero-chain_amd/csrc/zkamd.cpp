@@ -31,6 +31,7 @@
 #include "ntt.h"
 #include "msm.h"
 #include "transfer_witness.h"
+#include "witness_gpu.h"
 
 using zkdev::MsmJob;
 using zkdev::NttPass;
@@ -1037,12 +1038,21 @@ struct zk_r1cs {
     uint32_t n_in = 0, n_aux = 0, n_con = 0;
     DevBuf row_ptr[3], col[3], coeff[3];
     std::vector<uint8_t> a_aux_density, b_input_density, b_aux_density;
-    DevBuf z, abc;   // per-chunk workspaces: Montgomery assignment, row evaluations
-    // pinned host buffer of zk_transfer_prove_batch (witness vectors of one chunk); never zero-filled
+    // per-chunk workspaces: Montgomery assignment (two: the witness kernels fill one while the prover reads the
+    // other), row evaluations
+    DevBuf z[2], abc;
+    // GPU witness generator of the transfer circuit (witness_gpu.h)
+    DevBuf wit_st[2], wit_bad[2], wit_pts, wit_table, wit_consts, wit_scratch;
+    PinBuf pin_st[2], pin_bad[2];
+    hipEvent_t wit_done[2] = {nullptr, nullptr};
+    bool wit_ready = false;
+    // pinned host buffer of zk_transfer_prove_batch in host-witness mode (witness vectors of one chunk)
     void* host_z = nullptr;
     size_t host_z_cap = 0;
     ~zk_r1cs() {
         if (host_z) (void)hipHostFree(host_z);
+        for (int k = 0; k < 2; k++)
+            if (wit_done[k]) (void)hipEventDestroy(wit_done[k]);
     }
     zk_status host_ensure(size_t bytes) {
         if (bytes <= host_z_cap) return ZK_OK;
@@ -1118,6 +1128,42 @@ zk_status r1cs_load(uint32_t n_in, uint32_t n_aux, uint32_t n_con, const zk_csr*
     return ZK_OK;
 }
 
+// row evaluations + create_proof of the np assignments in R->z[slot] (Montgomery form)
+zk_status prove_from_z(zk_params* P, zk_r1cs* R, size_t np, int slot, const uint8_t* rs, uint8_t* proofs_out) {
+    const uint32_t nv = R->n_in + R->n_aux, n_rows = R->n_con + R->n_in;
+    ZK_TRY(R->abc.ensure(3 * np * (size_t)n_rows * 32));
+    zkdev::R1csMat mm[3];
+    for (int m = 0; m < 3; m++)
+        mm[m] = zkdev::R1csMat{R->row_ptr[m].as<uint32_t>(), R->col[m].as<uint32_t>(), R->coeff[m].as<uint32_t>()};
+    {
+        ProfScope ps("r1cs_eval");
+        ZK_LAUNCH(zkdev::k_r1cs_eval, dim3((n_rows + 255) / 256, 3, (unsigned)np), dim3(256), 0, g_stream, mm[0], mm[1], mm[2],
+                  (const uint32_t*)R->z[slot].as<uint32_t>(), R->abc.as<uint32_t>(), R->n_con, R->n_in, nv, n_rows,
+                  np * (size_t)n_rows);
+    }
+    HIP_TRY(hipGetLastError());
+    zk_batch_dev bt;
+    bt.n_rows = n_rows;
+    bt.n_inputs = R->n_in;
+    bt.n_aux = R->n_aux;
+    bt.flags = ZK_FR_MONTGOMERY;
+    bt.d_a = R->abc.as<uint32_t>();
+    bt.d_b = R->abc.as<uint32_t>() + np * (size_t)n_rows * 8;
+    bt.d_c = R->abc.as<uint32_t>() + 2 * np * (size_t)n_rows * 8;
+    bt.d_wit = R->z[slot].p;
+    bt.a_aux_density = R->a_aux_density.data();
+    bt.b_input_density = R->b_input_density.data();
+    bt.b_aux_density = R->b_aux_density.data();
+    return prove_batch_dev(P, np, &bt, rs, proofs_out);
+}
+
+size_t batch_chunk() {
+    size_t chunk = 1024;
+    const char* env = getenv("ZKAMD_BATCH_CHUNK");
+    if (env && atoi(env) > 0) chunk = (size_t)atoi(env);
+    return chunk;
+}
+
 zk_status prove_batch_witness(zk_params* P, zk_r1cs* R, size_t n, const uint8_t* witness, uint32_t flags, const uint8_t* rs,
                               uint8_t* proofs_out) {
     if (!P || !R || !witness || !rs || !proofs_out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
@@ -1126,44 +1172,19 @@ zk_status prove_batch_witness(zk_params* P, zk_r1cs* R, size_t n, const uint8_t*
     ZK_TRY(use_device(P->device));
     const uint32_t nv = R->n_in + R->n_aux, n_rows = R->n_con + R->n_in;
     if (n_rows > P->m) return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
-    size_t chunk = 1024;
-    const char* env = getenv("ZKAMD_BATCH_CHUNK");
-    if (env && atoi(env) > 0) chunk = (size_t)atoi(env);
+    const size_t chunk = batch_chunk();
     for (size_t first = 0; first < n; first += chunk) {
         const size_t np = std::min(chunk, n - first);
-        ZK_TRY(R->z.ensure(np * (size_t)nv * 32));
-        ZK_TRY(R->abc.ensure(3 * np * (size_t)n_rows * 32));
-        HIP_TRY(hipMemcpyAsync(R->z.p, witness + first * (size_t)nv * 32, np * (size_t)nv * 32, hipMemcpyHostToDevice, g_stream));
+        ZK_TRY(R->z[0].ensure(np * (size_t)nv * 32));
+        HIP_TRY(hipMemcpyAsync(R->z[0].p, witness + first * (size_t)nv * 32, np * (size_t)nv * 32, hipMemcpyHostToDevice, g_stream));
         ZK_TRY(P->bad.ensure(8));
         HIP_TRY(hipMemsetAsync(P->bad.as<uint32_t>() + 1, 0, 4, g_stream));
         if (!(flags & ZK_FR_MONTGOMERY)) {
             const size_t cnt = np * (size_t)nv;
-            ZK_LAUNCH(zkdev::k_fr_convert, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g_stream, R->z.as<uint32_t>(),
-                      (const uint32_t*)R->z.as<uint32_t>(), 0u, cnt, P->bad.as<uint32_t>() + 1);
+            ZK_LAUNCH(zkdev::k_fr_convert, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g_stream, R->z[0].as<uint32_t>(),
+                      (const uint32_t*)R->z[0].as<uint32_t>(), 0u, cnt, P->bad.as<uint32_t>() + 1);
         }
-        zkdev::R1csMat mm[3];
-        for (int m = 0; m < 3; m++)
-            mm[m] = zkdev::R1csMat{R->row_ptr[m].as<uint32_t>(), R->col[m].as<uint32_t>(), R->coeff[m].as<uint32_t>()};
-        {
-            ProfScope ps("r1cs_eval");
-            ZK_LAUNCH(zkdev::k_r1cs_eval, dim3((n_rows + 255) / 256, 3, (unsigned)np), dim3(256), 0, g_stream, mm[0], mm[1], mm[2],
-                      (const uint32_t*)R->z.as<uint32_t>(), R->abc.as<uint32_t>(), R->n_con, R->n_in, nv, n_rows,
-                      np * (size_t)n_rows);
-        }
-        HIP_TRY(hipGetLastError());
-        zk_batch_dev bt;
-        bt.n_rows = n_rows;
-        bt.n_inputs = R->n_in;
-        bt.n_aux = R->n_aux;
-        bt.flags = ZK_FR_MONTGOMERY;
-        bt.d_a = R->abc.as<uint32_t>();
-        bt.d_b = R->abc.as<uint32_t>() + np * (size_t)n_rows * 8;
-        bt.d_c = R->abc.as<uint32_t>() + 2 * np * (size_t)n_rows * 8;
-        bt.d_wit = R->z.p;
-        bt.a_aux_density = R->a_aux_density.data();
-        bt.b_input_density = R->b_input_density.data();
-        bt.b_aux_density = R->b_aux_density.data();
-        ZK_TRY(prove_batch_dev(P, np, &bt, rs + first * 64, proofs_out + first * 192));
+        ZK_TRY(prove_from_z(P, R, np, 0, rs + first * 64, proofs_out + first * 192));
         if (P->pin_bad.as<uint32_t>()[1] & zkdev::ZK_BAD_SCALAR)
             return fail(ZK_ERR_INVALID_ARGUMENT, "a witness scalar is not a canonical field element (>= r)");
     }
@@ -1263,6 +1284,80 @@ zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t f
         n, ZK_TRANSFER_N_INPUTS, ZK_TRANSFER_N_AUX, flags, out,
         [&](size_t i, zkwit::Statement* s) { return transfer_decode(st[i], index_base + i, s); },
         [](const zkwit::Statement& s, zkwit::Wit& w) { zkwit::synthesize(s, w); });
+}
+
+// ---- the same on the GPU (witness_gpu.h): np statements -> R->z[slot], enqueued on `stream`
+bool witness_on_host() {
+    const char* env = getenv("ZKAMD_WITNESS");
+    return env && !strcmp(env, "host");
+}
+zk_status witness_gpu_init(zk_r1cs* R) {
+    if (R->wit_ready) return ZK_OK;
+    static_assert(sizeof(zkwitdev::Stmt) == sizeof(zk_transfer_statement), "statement layout");
+    const zkwit::Tables& t = zkwit::tables();
+    static_assert(sizeof(zkwit::JPoint) == 64, "Jubjub point layout");
+    ZK_TRY(R->wit_table.ensure(84 * 8 * sizeof(zkwit::JPoint)));
+    HIP_TRY(hipMemcpy(R->wit_table.p, t.win.data(), 84 * 8 * sizeof(zkwit::JPoint), hipMemcpyHostToDevice));
+    const zkhost::Fr dd[2] = {zkwit::edwards_d(), zkwit::edwards_d().dbl()};
+    ZK_TRY(R->wit_consts.ensure(sizeof(dd)));
+    HIP_TRY(hipMemcpy(R->wit_consts.p, dd, sizeof(dd), hipMemcpyHostToDevice));
+    for (int k = 0; k < 2; k++)
+        if (!R->wit_done[k]) HIP_TRY(hipEventCreate(&R->wit_done[k]));
+    R->wit_ready = true;
+    return ZK_OK;
+}
+zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_t np, int slot, hipStream_t stream) {
+    ZK_TRY(witness_gpu_init(R));
+    const size_t nv = zkwitdev::NV;
+    ZK_TRY(R->z[slot].ensure(np * nv * 32));
+    ZK_TRY(R->wit_st[slot].ensure(np * sizeof(zkwitdev::Stmt)));
+    ZK_TRY(R->wit_bad[slot].ensure(np * 4));
+    ZK_TRY(R->pin_st[slot].ensure(np * sizeof(zkwitdev::Stmt)));
+    ZK_TRY(R->pin_bad[slot].ensure(np * 4));
+    ZK_TRY(R->wit_pts.ensure(np * (size_t)zkwitdev::P_COUNT * 64));
+    ZK_TRY(R->wit_scratch.ensure((size_t)zkwitdev::L1_ROLES * zkwitdev::SCRATCH_SLOTS * np * 32));
+    memcpy(R->pin_st[slot].p, st, np * sizeof(zkwitdev::Stmt));
+    HIP_TRY(hipMemcpyAsync(R->wit_st[slot].p, R->pin_st[slot].p, np * sizeof(zkwitdev::Stmt), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(R->wit_bad[slot].p, 0, np * 4, stream));
+    zkwitdev::Ctx c;
+    c.z = R->z[slot].as<uint32_t>();
+    c.st = R->wit_st[slot].as<zkwitdev::Stmt>();
+    c.pts = R->wit_pts.as<uint32_t>();
+    c.table = R->wit_table.as<uint32_t>();
+    c.consts = R->wit_consts.as<uint32_t>();
+    c.scratch = R->wit_scratch.as<uint32_t>();
+    c.bad = R->wit_bad[slot].as<uint32_t>();
+    c.n = (uint32_t)np;
+    const unsigned b64 = (unsigned)((np + 63) / 64);
+    {
+        ProfScope ps("witness_gpu", stream);
+        ZK_LAUNCH(zkwitdev::k_wit_decode, dim3((unsigned)((np * 5 + 63) / 64)), dim3(64), 0, stream, c);
+        ZK_LAUNCH(zkwitdev::k_wit_level1, dim3(b64, zkwitdev::L1_ROLES), dim3(64), 0, stream, c);
+        ZK_LAUNCH(zkwitdev::k_wit_level2, dim3(b64, zkwitdev::L2_ROLES), dim3(64), 0, stream, c);
+        ZK_LAUNCH(zkwitdev::k_wit_level3, dim3(b64), dim3(64), 0, stream, c);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(R->pin_bad[slot].p, R->wit_bad[slot].p, np * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(R->wit_done[slot], stream));
+    return ZK_OK;
+}
+// waits for the witness kernels of `slot`; a malformed statement is reported with its absolute index
+zk_status witness_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base) {
+    HIP_TRY(hipEventSynchronize(R->wit_done[slot]));
+    const uint32_t* bad = R->pin_bad[slot].as<uint32_t>();
+    static const char* const points[5] = {"proof_generation_key", "enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch"};
+    static const char* const scalars[3] = {"randomness", "alpha", "dec_key_sender"};
+    for (size_t i = 0; i < np; i++) {
+        if (!bad[i]) continue;
+        const std::string who = "statement " + std::to_string(index_base + i) + ": ";
+        // the order the host calculator checks them in (transfer_decode)
+        for (int k = 0; k < 3; k++)
+            if (bad[i] & (1u << (8 + k))) return fail(ZK_ERR_INVALID_ARGUMENT, who + scalars[k] + " is not a canonical Fs scalar");
+        for (int k = 0; k < 5; k++)
+            if (bad[i] & (2u << k)) return fail(ZK_ERR_INVALID_ARGUMENT, who + points[k] + " is not a Jubjub point");
+        return fail(ZK_ERR_INVALID_ARGUMENT, who + "malformed");
+    }
+    return ZK_OK;
 }
 
 zk_status decode_fs(const uint8_t* b, uint64_t (&v)[4], size_t index, const char* what) {
@@ -1599,14 +1694,30 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
     if (!p || !circuit || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
         return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the transfer circuit's");
+    if (circuit->device != p->device) return fail(ZK_ERR_INVALID_ARGUMENT, "parameters and circuit live on different devices");
+    if (n == 0) return ZK_OK;
     const size_t nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX;
-    size_t chunk = 1024;
-    const char* env = getenv("ZKAMD_BATCH_CHUNK");
-    if (env && atoi(env) > 0) chunk = (size_t)atoi(env);
+    const size_t chunk = batch_chunk();
     zk_status rc = use_device(p->device);
     if (rc != ZK_OK) return rc;
-    // two pinned buffers: the witnesses of chunk k + 1 are computed on the host cores while the GPU
-    // proves chunk k
+    if ((size_t)circuit->n_con + circuit->n_in > p->m)
+        return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
+    if (!witness_on_host()) {
+        // witnesses on the GPU (witness_gpu.h), on the side stream of the copy engine: the kernels of chunk k + 1
+        // are latency-bound chains for a few hundred waves and run beside the multiexps of chunk k
+        int slot = 0;
+        ZK_TRY(witness_gpu_enqueue(circuit, st, std::min(chunk, n), slot, g_copy_stream));
+        for (size_t first = 0; first < n; first += chunk) {
+            const size_t np = std::min(chunk, n - first), next = first + chunk;
+            ZK_TRY(witness_gpu_finish(circuit, np, slot, first));
+            if (next < n) ZK_TRY(witness_gpu_enqueue(circuit, st + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream));
+            ZK_TRY(prove_from_z(p, circuit, np, slot, rs + first * 64, proofs_out + first * 192));
+            slot ^= 1;
+        }
+        return ZK_OK;
+    }
+    // ZKAMD_WITNESS=host: the host calculator (transfer_witness.h) on the host cores; two pinned buffers, the
+    // witnesses of chunk k + 1 are computed while the GPU proves chunk k
     const size_t cap = std::min(chunk, n) * nv * 32;
     rc = circuit->host_ensure(2 * cap);
     if (rc != ZK_OK) return rc;
@@ -1630,6 +1741,30 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
         if (rc != ZK_OK) return rc;
         if (next_rc != ZK_OK) return fail(next_rc, next_err);
         cur ^= 1;
+    }
+    return ZK_OK;
+}
+
+// The witness vectors the GPU generator produces, copied back to the host: lets the tests compare it with the
+// host calculator (zk_transfer_witness) element by element.  witness_out: n x (23 + 19955) x 32 bytes.
+zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
+    if (!circuit || (n && (!st || !witness_out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the transfer circuit's");
+    ZK_TRY(use_device(circuit->device));
+    const size_t nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX, chunk = batch_chunk();
+    for (size_t first = 0; first < n; first += chunk) {
+        const size_t np = std::min(chunk, n - first);
+        ZK_TRY(witness_gpu_enqueue(circuit, st + first, np, 0, g_stream));
+        ZK_TRY(witness_gpu_finish(circuit, np, 0, first));
+        if (!(flags & ZK_FR_MONTGOMERY)) {
+            const size_t cnt = np * nv;
+            ZK_LAUNCH(zkdev::k_fr_convert, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g_stream, circuit->z[0].as<uint32_t>(),
+                      (const uint32_t*)circuit->z[0].as<uint32_t>(), 1u, cnt, (uint32_t*)nullptr);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipMemcpy(witness_out + first * nv * 32, circuit->z[0].p, np * nv * 32, hipMemcpyDeviceToHost));
     }
     return ZK_OK;
 }
@@ -1695,6 +1830,68 @@ struct zk_pipeline {
             cv.notify_all();
         }
     }
+    // GPU-witness mode: one thread.  The witness kernels of the job behind the current one are enqueued (side
+    // stream, other assignment buffer) before the current job is proved, so they run beside its multiexps.
+    void run_gpu_witness() {
+        Job cur{}, nxt{};
+        bool have_cur = false;
+        int slot = 0;
+        if (use_device(P->device) != ZK_OK) return;
+        const hipStream_t wstream = g_copy_stream;
+        auto start = [&](Job& j, int s) -> zk_status {
+            j.slot = s;
+            return witness_gpu_enqueue(R, j.st, j.n, s, wstream);
+        };
+        for (;;) {
+            zk_status rc = ZK_OK;
+            if (!have_cur) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q_wit.empty(); });
+                if (stop) return;
+                cur = q_wit.front();
+                q_wit.pop_front();
+                const bool skip = err != ZK_OK;
+                lk.unlock();
+                cur.slot = slot;
+                if (!skip) rc = start(cur, slot);
+            }
+            bool have_nxt = false;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!q_wit.empty()) {
+                    nxt = q_wit.front();
+                    q_wit.pop_front();
+                    have_nxt = true;
+                }
+            }
+            bool skip;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                skip = err != ZK_OK;
+            }
+            zk_status rc_next = ZK_OK;
+            if (have_nxt && !skip && rc == ZK_OK) rc_next = start(nxt, cur.slot ^ 1);
+            if (!skip && rc == ZK_OK) rc = witness_gpu_finish(R, cur.n, cur.slot, cur.index_base);
+            if (!skip && rc == ZK_OK) rc = prove_from_z(P, R, cur.n, cur.slot, cur.rs, cur.out);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (rc != ZK_OK) fail_with(rc, g_err);
+                else if (rc_next != ZK_OK) fail_with(rc_next, g_err);
+                in_flight--;
+                cv.notify_all();
+            }
+            if (rc != ZK_OK || rc_next != ZK_OK) (void)hipDeviceSynchronize();   // nothing of a failed job stays in flight
+            if (have_nxt) {
+                nxt.slot = cur.slot ^ 1;
+                cur = nxt;
+                have_cur = true;
+                slot = cur.slot;
+            } else {
+                have_cur = false;
+                slot = cur.slot ^ 1;
+            }
+        }
+    }
     void run_gpu() {
         for (;;) {
             Job j;
@@ -1734,16 +1931,24 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
     L->nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX;
     if (const char* env = getenv("ZKAMD_BATCH_CHUNK"))
         if (atoi(env) > 0) L->chunk = (size_t)atoi(env);
-    for (int k = 0; k < 2; k++) {
-        zk_status rc = L->buf[k].ensure(L->chunk * L->nv * 32);
-        if (rc != ZK_OK) {
-            delete L;
-            return rc;
-        }
+    if ((size_t)circuit->n_con + circuit->n_in > p->m) {
+        delete L;
+        return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
     }
     (void)zkwit::tables();
-    L->t_wit = std::thread([L] { L->run_wit(); });
-    L->t_gpu = std::thread([L] { L->run_gpu(); });
+    if (!witness_on_host()) {
+        L->t_gpu = std::thread([L] { L->run_gpu_witness(); });
+    } else {
+        for (int k = 0; k < 2; k++) {
+            zk_status rc = L->buf[k].ensure(L->chunk * L->nv * 32);
+            if (rc != ZK_OK) {
+                delete L;
+                return rc;
+            }
+        }
+        L->t_wit = std::thread([L] { L->run_wit(); });
+        L->t_gpu = std::thread([L] { L->run_gpu(); });
+    }
     *out = L;
     return ZK_OK;
 }
