@@ -221,7 +221,7 @@ def main():
     t0 = time.time()
     r1cs, P, pk = build_circuit_and_key(host_threads, rank, barrier)
     params = zk.Parameters.read(pk, checked=False, device=dev_index, lib=lib)
-    mats = zk.ConstraintMatrices(r1cs.n_in, r1cs.n_aux, r1cs.constraints, device=dev_index, lib=lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(device=dev_index, lib=lib)   # emitted natively (transfer_r1cs.h)
     # this rank's block of the B * world distinct statements of a step (the same statements every step,
     # fresh (r, s) per step and proof)
     lo = rank * B

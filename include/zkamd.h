@@ -159,6 +159,14 @@ typedef struct {
 zk_status zk_r1cs_load(uint32_t n_inputs, uint32_t n_aux, uint32_t n_constraints, const zk_csr* a, const zk_csr* b,
                        const zk_csr* c, int device, zk_r1cs** out);
 void zk_r1cs_free(zk_r1cs* r);
+/* The constraint system of the reference's confidential-transfer circuit, emitted natively by the library (the
+ * structure half of ConfidentialTransfer::synthesize, core/proofs/src/circuit/confidential_transfer.rs:61-305):
+ * zk_transfer_r1cs_load = zk_r1cs_load of those matrices.  zk_transfer_r1cs_fingerprint returns the counts and
+ * the blake2s hash of the normalised system as the reference's circuit test defines it
+ * (core/proofs/src/circuit/test.rs:228-251); the reference pins 19 974 constraints, 23 inputs and
+ * d23c92fb60ee547d45118e160679929cfa186957280673af62f09fa12d401784 (confidential_transfer.rs:383-386). */
+zk_status zk_transfer_r1cs_load(int device, zk_r1cs** out);
+zk_status zk_transfer_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs, uint32_t* n_aux, uint32_t* n_constraints);
 /* witness: n x (n_inputs + n_aux) x 32 bytes on the HOST (plain, or Montgomery limbs with
  * ZK_FR_MONTGOMERY in flags); rs: n x 64; proofs_out: n x 192. */
 zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const uint8_t* witness, uint32_t flags,

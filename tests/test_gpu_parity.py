@@ -321,7 +321,7 @@ def test_full_chunk_1024_every_proof_checked(gpu_lib):
     rng = synth.SplitMix64(2024)
     rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
     params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
-    mats = zk.ConstraintMatrices(r1.n_in, r1.n_aux, r1.constraints, lib=gpu_lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)   # the natively emitted matrices (transfer_r1cs.h)
     pvk = zk.prepare_verifying_key(params)
     try:
         proofs = zk.transfer_prove_batch(mats, params, sts, rs)

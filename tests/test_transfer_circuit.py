@@ -120,3 +120,12 @@ def test_native_witness_rejects_bad_statements():
     with pytest.raises(zk.ZkError) as e:
         zk.transfer_witness(zk.transfer_statements([bad]), lib=lib)
     assert e.value.variant == "InvalidArgument"
+
+
+def test_native_r1cs_emitter_has_the_reference_fingerprint():
+    """The product's own constraint-system emitter (csrc/transfer_r1cs.h, zk_transfer_r1cs_*) against the
+    reference's pin (confidential_transfer.rs:383-386): counts and the blake2s hash of circuit/test.rs:228-251."""
+    import zero_chain_amd as zk
+    digest, n_in, n_aux, n_con = zk.transfer_r1cs_fingerprint(_product_lib())
+    assert (n_con, n_in) == (tc.REFERENCE_NUM_CONSTRAINTS, tc.REFERENCE_NUM_INPUTS) and n_aux == 19955
+    assert digest == tc.REFERENCE_HASH

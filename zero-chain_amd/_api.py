@@ -25,7 +25,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 
 __all__ = ["Parameters", "Proof", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
-           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "anonymous_statements", "anonymous_witness",
+           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_statements", "anonymous_witness",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
@@ -356,6 +356,17 @@ class ConstraintMatrices:
     being computed on the device.  `constraints`: list of (A, B, C), each a list of
     (variable index, coefficient) with inputs first (ONE = 0), aux variable j at n_inputs + j."""
 
+    @classmethod
+    def transfer_circuit(cls, device=0, lib=None):
+        """The reference's confidential-transfer circuit, emitted natively by the library (zk_transfer_r1cs_load)."""
+        self = cls.__new__(cls)
+        self._lib = lib or _lib.load()
+        self.n_inputs, self.n_aux = TRANSFER_N_INPUTS, TRANSFER_N_AUX
+        h = C.c_void_p()
+        self._lib.check(self._lib.zk_transfer_r1cs_load(device, C.byref(h)))
+        self._h = h
+        return self
+
     def __init__(self, n_inputs, n_aux, constraints, device=0, lib=None):
         self._lib = lib or _lib.load()
         self.n_inputs, self.n_aux = n_inputs, n_aux
@@ -409,6 +420,16 @@ def create_proofs_from_witness(matrices, params, witnesses, rs, montgomery=False
 
 
 TRANSFER_N_INPUTS, TRANSFER_N_AUX = 23, 19955
+
+
+def transfer_r1cs_fingerprint(lib=None):
+    """(blake2s hex digest, n_inputs, n_aux, n_constraints) of the natively emitted transfer circuit, the digest as
+    core/proofs/src/circuit/test.rs:228-251 defines it."""
+    lib = lib or _lib.load()
+    out = np.zeros(32, dtype=np.uint8)
+    a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    lib.check(lib.zk_transfer_r1cs_fingerprint(_ptr(out), C.byref(a), C.byref(b), C.byref(c)))
+    return out.tobytes().hex(), a.value, b.value, c.value
 
 
 def transfer_statements(items):

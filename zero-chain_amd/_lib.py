@@ -78,6 +78,8 @@ _PROTOS = {
     "zk_r1cs_load": (C.c_int32, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Csr), C.POINTER(Csr), C.POINTER(Csr), C.c_int,
                                  C.POINTER(C.c_void_p)]),
     "zk_r1cs_free": (None, [C.c_void_p]),
+    "zk_transfer_r1cs_load": (C.c_int32, [C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_transfer_r1cs_fingerprint": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "zk_prove_batch_witness": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "zk_transfer_witness": (C.c_int32, [C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_transfer_witness_gpu": (C.c_int32, [C.c_void_p, C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),

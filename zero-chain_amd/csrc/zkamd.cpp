@@ -32,6 +32,7 @@
 #include "msm.h"
 #include "transfer_witness.h"
 #include "witness_gpu.h"
+#include "transfer_r1cs.h"
 
 using zkdev::MsmJob;
 using zkdev::NttPass;
@@ -1038,6 +1039,9 @@ struct zk_r1cs {
     uint32_t n_in = 0, n_aux = 0, n_con = 0;
     DevBuf row_ptr[3], col[3], coeff[3];
     std::vector<uint8_t> a_aux_density, b_input_density, b_aux_density;
+    // host copy of the matrices (the parameter generator transposes them): CSR, Montgomery coefficients
+    std::vector<uint32_t> h_row_ptr[3], h_col[3];
+    std::vector<zkhost::Fr> h_coeff[3];
     // per-chunk workspaces: Montgomery assignment (two: the witness kernels fill one while the prover reads the
     // other), row evaluations
     DevBuf z[2], abc;
@@ -1109,6 +1113,14 @@ zk_status r1cs_load(uint32_t n_in, uint32_t n_aux, uint32_t n_con, const zk_csr*
                 else
                     R->b_input_density[v] = 1;
             }
+        }
+        R->h_row_ptr[m].assign(M->row_ptr, M->row_ptr + n_con + 1);
+        R->h_col[m].assign(M->col, M->col + nnz);
+        R->h_coeff[m].resize(nnz);
+        for (uint32_t k = 0; k < nnz; k++) {
+            zkhost::Fr c;
+            load_scalar_le(M->coeff + (size_t)k * 32, c.l);
+            R->h_coeff[m][k] = c.to_mont();
         }
         ZK_TRY(R->row_ptr[m].ensure(((size_t)n_con + 1) * 4));
         ZK_TRY(R->col[m].ensure((size_t)(nnz ? nnz : 1) * 4));
@@ -1678,6 +1690,42 @@ zk_status zk_r1cs_load(uint32_t n_inputs, uint32_t n_aux, uint32_t n_constraints
     return r1cs_load(n_inputs, n_aux, n_constraints, mats, device, out);
 }
 void zk_r1cs_free(zk_r1cs* r) { delete r; }
+
+// the natively emitted constraint system of the transfer circuit (transfer_r1cs.h), built once per process
+static const zkr1cs::System& transfer_system_cached() {
+    static const zkr1cs::System sys = zkr1cs::transfer_system();
+    return sys;
+}
+zk_status zk_transfer_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs, uint32_t* n_aux, uint32_t* n_constraints) {
+    const zkr1cs::System& sys = transfer_system_cached();
+    if (hash_out) sys.fingerprint(hash_out);
+    if (n_inputs) *n_inputs = sys.n_inputs;
+    if (n_aux) *n_aux = sys.n_aux;
+    if (n_constraints) *n_constraints = sys.n_constraints;
+    return ZK_OK;
+}
+zk_status zk_transfer_r1cs_load(int device, zk_r1cs** out) {
+    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const zkr1cs::System& sys = transfer_system_cached();
+    if (sys.n_inputs != ZK_TRANSFER_N_INPUTS || sys.n_aux != ZK_TRANSFER_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "internal: emitted system has the wrong shape");
+    std::vector<uint8_t> coeff[3];
+    zk_csr mats[3];
+    for (int m = 0; m < 3; m++) {
+        const zkr1cs::Csr& M = sys.m[m];
+        coeff[m].resize(M.coeff.size() * 32 + 32);
+        for (size_t k = 0; k < M.coeff.size(); k++) {
+            const zkhost::Fr p = M.coeff[k].from_mont();
+            memcpy(&coeff[m][k * 32], p.l, 32);
+        }
+        mats[m].row_ptr = M.row_ptr.data();
+        mats[m].col = M.col.data();
+        mats[m].coeff = coeff[m].data();
+    }
+    const zk_csr* ptrs[3] = {&mats[0], &mats[1], &mats[2]};
+    return r1cs_load(sys.n_inputs, sys.n_aux, sys.n_constraints, ptrs, device, out);
+}
 zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const uint8_t* witness, uint32_t flags,
                                  const uint8_t* rs, uint8_t* proofs_out) {
     return prove_batch_witness(p, circuit, n, witness, flags, rs, proofs_out);
