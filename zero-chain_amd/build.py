@@ -35,7 +35,21 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-TRANSLATION_UNITS = ("zkamd.cpp", "verify.cpp")   # compiled in parallel, linked into one library
+TRANSLATION_UNITS = ("zkamd.cpp", "verify.cpp", "witness.cpp")   # compiled in parallel, linked into one library
+
+
+def _deps(path, seen=None):
+    """The file and every local header it includes, transitively (so a translation unit is only recompiled when
+    something it really reads has changed)."""
+    import re
+    seen = seen if seen is not None else set()
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
 
 
 def build_lib(force=False):
@@ -44,12 +58,11 @@ def build_lib(force=False):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     extra = (os.environ.get("ZKAMD_HIPCC_FLAGS") or "").split()
-    deps = _sources()
     procs, objs = [], []
     for tu in TRANSLATION_UNITS:
         obj = os.path.join(objdir, tu.replace(".cpp", ".o"))
         objs.append(obj)
-        if not force and not extra and not _stale(obj, deps):
+        if not force and not extra and not _stale(obj, sorted(_deps(os.path.join(CSRC, tu)))):
             continue
         cmd = [HIPCC] + extra + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-x", "hip",
                                  os.path.join(CSRC, tu), "-o", obj]

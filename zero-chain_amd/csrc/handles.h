@@ -1,0 +1,52 @@
+// Handle types shared by the translation units of libzkamd.
+#pragma once
+#include <vector>
+#include "host_common.h"
+#include "host_math.h"
+
+// ------------------------------------------------------------------------------------------
+// zk_r1cs: the fixed constraint matrices of a circuit, resident on the GPU
+// ------------------------------------------------------------------------------------------
+struct zk_r1cs {
+    int device = 0;
+    uint32_t n_in = 0, n_aux = 0, n_con = 0;
+    zkrt::DevBuf row_ptr[3], col[3], coeff[3];
+    std::vector<uint8_t> a_aux_density, b_input_density, b_aux_density;
+    // host copy of the matrices (the parameter generator transposes them): CSR, Montgomery coefficients
+    std::vector<uint32_t> h_row_ptr[3], h_col[3];
+    std::vector<zkhost::Fr> h_coeff[3];
+    // per-chunk workspaces: Montgomery assignment (two: the witness kernels fill one while the prover reads the
+    // other), row evaluations
+    zkrt::DevBuf z[2], abc;
+    // GPU witness generator of the transfer circuit (witness_gpu.h)
+    zkrt::DevBuf wit_st[2], wit_bad[2], wit_pts, wit_table, wit_consts, wit_scratch;
+    zkrt::PinBuf pin_st[2], pin_bad[2];
+    hipEvent_t wit_done[2] = {nullptr, nullptr};
+    bool wit_ready = false;
+    // pinned host buffer of zk_transfer_prove_batch in host-witness mode (witness vectors of one chunk)
+    void* host_z = nullptr;
+    size_t host_z_cap = 0;
+    ~zk_r1cs() {
+        if (host_z) (void)hipHostFree(host_z);
+        for (int k = 0; k < 2; k++)
+            if (wit_done[k]) (void)hipEventDestroy(wit_done[k]);
+    }
+    zk_status host_ensure(size_t bytes) {
+        if (bytes <= host_z_cap) return ZK_OK;
+        if (host_z) (void)hipHostFree(host_z);
+        host_z = nullptr;
+        host_z_cap = 0;
+        if (hipHostMalloc(&host_z, bytes) != hipSuccess) {
+            host_z = nullptr;
+            return zkrt::fail(ZK_ERR_OUT_OF_MEMORY, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
+        }
+        host_z_cap = bytes;
+        return ZK_OK;
+    }
+};
+
+
+// GPU witness generator of the transfer circuit (witness.cpp): np statements -> R->z[slot], enqueued on `stream`;
+// finish() waits for it and reports a malformed statement with its absolute index
+zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_t np, int slot, hipStream_t stream);
+zk_status witness_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base);

@@ -31,7 +31,7 @@
 #include "ntt.h"
 #include "msm.h"
 #include "transfer_witness.h"
-#include "witness_gpu.h"
+#include "handles.h"
 #include "transfer_r1cs.h"
 
 using zkdev::MsmJob;
@@ -1031,47 +1031,6 @@ zk_status prove_batch_host(zk_params* P, size_t n, const zk_assignment* asgs, co
 
 }  // namespace
 
-// ------------------------------------------------------------------------------------------
-// zk_r1cs: the fixed constraint matrices of a circuit, resident on the GPU
-// ------------------------------------------------------------------------------------------
-struct zk_r1cs {
-    int device = 0;
-    uint32_t n_in = 0, n_aux = 0, n_con = 0;
-    DevBuf row_ptr[3], col[3], coeff[3];
-    std::vector<uint8_t> a_aux_density, b_input_density, b_aux_density;
-    // host copy of the matrices (the parameter generator transposes them): CSR, Montgomery coefficients
-    std::vector<uint32_t> h_row_ptr[3], h_col[3];
-    std::vector<zkhost::Fr> h_coeff[3];
-    // per-chunk workspaces: Montgomery assignment (two: the witness kernels fill one while the prover reads the
-    // other), row evaluations
-    DevBuf z[2], abc;
-    // GPU witness generator of the transfer circuit (witness_gpu.h)
-    DevBuf wit_st[2], wit_bad[2], wit_pts, wit_table, wit_consts, wit_scratch;
-    PinBuf pin_st[2], pin_bad[2];
-    hipEvent_t wit_done[2] = {nullptr, nullptr};
-    bool wit_ready = false;
-    // pinned host buffer of zk_transfer_prove_batch in host-witness mode (witness vectors of one chunk)
-    void* host_z = nullptr;
-    size_t host_z_cap = 0;
-    ~zk_r1cs() {
-        if (host_z) (void)hipHostFree(host_z);
-        for (int k = 0; k < 2; k++)
-            if (wit_done[k]) (void)hipEventDestroy(wit_done[k]);
-    }
-    zk_status host_ensure(size_t bytes) {
-        if (bytes <= host_z_cap) return ZK_OK;
-        if (host_z) (void)hipHostFree(host_z);
-        host_z = nullptr;
-        host_z_cap = 0;
-        if (hipHostMalloc(&host_z, bytes) != hipSuccess) {
-            host_z = nullptr;
-            return fail(ZK_ERR_OUT_OF_MEMORY, "hipHostMalloc of " + std::to_string(bytes) + " bytes failed");
-        }
-        host_z_cap = bytes;
-        return ZK_OK;
-    }
-};
-
 namespace {
 
 zk_status r1cs_load(uint32_t n_in, uint32_t n_aux, uint32_t n_con, const zk_csr* const mats[3], int device, zk_r1cs** out) {
@@ -1298,78 +1257,9 @@ zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t f
         [](const zkwit::Statement& s, zkwit::Wit& w) { zkwit::synthesize(s, w); });
 }
 
-// ---- the same on the GPU (witness_gpu.h): np statements -> R->z[slot], enqueued on `stream`
 bool witness_on_host() {
     const char* env = getenv("ZKAMD_WITNESS");
     return env && !strcmp(env, "host");
-}
-zk_status witness_gpu_init(zk_r1cs* R) {
-    if (R->wit_ready) return ZK_OK;
-    static_assert(sizeof(zkwitdev::Stmt) == sizeof(zk_transfer_statement), "statement layout");
-    const zkwit::Tables& t = zkwit::tables();
-    static_assert(sizeof(zkwit::JPoint) == 64, "Jubjub point layout");
-    ZK_TRY(R->wit_table.ensure(84 * 8 * sizeof(zkwit::JPoint)));
-    HIP_TRY(hipMemcpy(R->wit_table.p, t.win.data(), 84 * 8 * sizeof(zkwit::JPoint), hipMemcpyHostToDevice));
-    const zkhost::Fr dd[2] = {zkwit::edwards_d(), zkwit::edwards_d().dbl()};
-    ZK_TRY(R->wit_consts.ensure(sizeof(dd)));
-    HIP_TRY(hipMemcpy(R->wit_consts.p, dd, sizeof(dd), hipMemcpyHostToDevice));
-    for (int k = 0; k < 2; k++)
-        if (!R->wit_done[k]) HIP_TRY(hipEventCreate(&R->wit_done[k]));
-    R->wit_ready = true;
-    return ZK_OK;
-}
-zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_t np, int slot, hipStream_t stream) {
-    ZK_TRY(witness_gpu_init(R));
-    const size_t nv = zkwitdev::NV;
-    ZK_TRY(R->z[slot].ensure(np * nv * 32));
-    ZK_TRY(R->wit_st[slot].ensure(np * sizeof(zkwitdev::Stmt)));
-    ZK_TRY(R->wit_bad[slot].ensure(np * 4));
-    ZK_TRY(R->pin_st[slot].ensure(np * sizeof(zkwitdev::Stmt)));
-    ZK_TRY(R->pin_bad[slot].ensure(np * 4));
-    ZK_TRY(R->wit_pts.ensure(np * (size_t)zkwitdev::P_COUNT * 64));
-    ZK_TRY(R->wit_scratch.ensure((size_t)zkwitdev::L1_ROLES * zkwitdev::SCRATCH_SLOTS * np * 32));
-    memcpy(R->pin_st[slot].p, st, np * sizeof(zkwitdev::Stmt));
-    HIP_TRY(hipMemcpyAsync(R->wit_st[slot].p, R->pin_st[slot].p, np * sizeof(zkwitdev::Stmt), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemsetAsync(R->wit_bad[slot].p, 0, np * 4, stream));
-    zkwitdev::Ctx c;
-    c.z = R->z[slot].as<uint32_t>();
-    c.st = R->wit_st[slot].as<zkwitdev::Stmt>();
-    c.pts = R->wit_pts.as<uint32_t>();
-    c.table = R->wit_table.as<uint32_t>();
-    c.consts = R->wit_consts.as<uint32_t>();
-    c.scratch = R->wit_scratch.as<uint32_t>();
-    c.bad = R->wit_bad[slot].as<uint32_t>();
-    c.n = (uint32_t)np;
-    const unsigned b64 = (unsigned)((np + 63) / 64);
-    {
-        ProfScope ps("witness_gpu", stream);
-        ZK_LAUNCH(zkwitdev::k_wit_decode, dim3((unsigned)((np * 5 + 63) / 64)), dim3(64), 0, stream, c);
-        ZK_LAUNCH(zkwitdev::k_wit_level1, dim3(b64, zkwitdev::L1_ROLES), dim3(64), 0, stream, c);
-        ZK_LAUNCH(zkwitdev::k_wit_level2, dim3(b64, zkwitdev::L2_ROLES), dim3(64), 0, stream, c);
-        ZK_LAUNCH(zkwitdev::k_wit_level3, dim3(b64), dim3(64), 0, stream, c);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(R->pin_bad[slot].p, R->wit_bad[slot].p, np * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipEventRecord(R->wit_done[slot], stream));
-    return ZK_OK;
-}
-// waits for the witness kernels of `slot`; a malformed statement is reported with its absolute index
-zk_status witness_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base) {
-    HIP_TRY(hipEventSynchronize(R->wit_done[slot]));
-    const uint32_t* bad = R->pin_bad[slot].as<uint32_t>();
-    static const char* const points[5] = {"proof_generation_key", "enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch"};
-    static const char* const scalars[3] = {"randomness", "alpha", "dec_key_sender"};
-    for (size_t i = 0; i < np; i++) {
-        if (!bad[i]) continue;
-        const std::string who = "statement " + std::to_string(index_base + i) + ": ";
-        // the order the host calculator checks them in (transfer_decode)
-        for (int k = 0; k < 3; k++)
-            if (bad[i] & (1u << (8 + k))) return fail(ZK_ERR_INVALID_ARGUMENT, who + scalars[k] + " is not a canonical Fs scalar");
-        for (int k = 0; k < 5; k++)
-            if (bad[i] & (2u << k)) return fail(ZK_ERR_INVALID_ARGUMENT, who + points[k] + " is not a Jubjub point");
-        return fail(ZK_ERR_INVALID_ARGUMENT, who + "malformed");
-    }
-    return ZK_OK;
 }
 
 zk_status decode_fs(const uint8_t* b, uint64_t (&v)[4], size_t index, const char* what) {
