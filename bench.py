@@ -37,7 +37,6 @@ The JSON line carries, besides the contract fields:
 """
 import argparse
 import ctypes as C
-import hashlib
 import json
 import os
 import pickle
@@ -109,12 +108,12 @@ def make_statements(lo, hi, procs):
     return items
 
 
-def build_circuit_and_key(threads, rank, barrier):
-    """The reference's confidential-transfer R1CS (restated in oracle/transfer_circuit.py, checked against the
-    reference's fingerprint) and a synthetic CRS for it (fixed toxic waste; the reference's proving keys are
-    missing blobs).  Rank 0 writes the key once, the other ranks read it."""
+def build_circuit(threads):
+    """The reference's confidential-transfer R1CS as the ORACLE restates it (oracle/transfer_circuit.py, checked
+    against the reference's fingerprint) with the discrete logs of a synthetic CRS for it (fixed toxic waste; the
+    reference's proving keys are missing blobs): the checker's side.  The product emits its own matrices
+    (zk_transfer_r1cs_load) and generates its own parameter file (zk_generate_parameters) from the same toxic waste."""
     from oracle import groth16 as g
-    from oracle import params_io
     from oracle import transfer_circuit as tc
     import helpers
     E = g.Bls12Engine()
@@ -123,15 +122,7 @@ def build_circuit_and_key(threads, rank, barrier):
     assert cs.hash() == tc.REFERENCE_HASH and len(cs.constraints) == N_CON and len(cs.inputs) == N_IN
     r1cs = cs.to_r1cs()
     P = g.generate_parameters(E, r1cs, *helpers.TOXIC, scalars_only=True)
-    os.makedirs(CACHE, exist_ok=True)
-    path = os.path.join(CACHE, "transfer_pk_%s.bin" % hashlib.sha256(repr(helpers.TOXIC).encode()).hexdigest()[:12])
-    if rank == 0 and not os.path.exists(path):
-        pk = params_io.write_parameters_from_scalars(P.sc, N_IN, threads=min(64, threads))
-        tmp = path + ".%d" % os.getpid()
-        open(tmp, "wb").write(pk)
-        os.replace(tmp, path)
-    barrier()
-    return r1cs, P, open(path, "rb").read()
+    return r1cs, P
 
 
 def oracle_proof(P, r1cs, st_index, r, s):
@@ -219,9 +210,14 @@ def main():
 
     B, K, W = args.batch, args.steps, args.warmup
     t0 = time.time()
-    r1cs, P, pk = build_circuit_and_key(host_threads, rank, barrier)
-    params = zk.Parameters.read(pk, checked=False, device=dev_index, lib=lib)
+    r1cs, P = build_circuit(host_threads)
     mats = zk.ConstraintMatrices.transfer_circuit(device=dev_index, lib=lib)   # emitted natively (transfer_r1cs.h)
+    digest, _, _, _ = zk.transfer_r1cs_fingerprint(lib)
+    assert digest == "d23c92fb60ee547d45118e160679929cfa186957280673af62f09fa12d401784"   # confidential_transfer.rs:384
+    t_setup = time.time()
+    pk = zk.generate_parameters(mats, *helpers.TOXIC)   # bellman generate_parameters on the GPU (setup.cpp)
+    keygen_s = time.time() - t_setup
+    params = zk.Parameters.read(pk, checked=False, device=dev_index, lib=lib)
     # this rank's block of the B * world distinct statements of a step (the same statements every step,
     # fresh (r, s) per step and proof)
     lo = rank * B
@@ -426,7 +422,7 @@ def main():
                    "parallelism": "dp%d (independent proofs, contiguous blocks, %s gather of 192 B/proof/step)" % (world, "gloo" if one_gpu else "RCCL"),
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
                    "proofs_checked_vs_oracle": checked, "proofs_checked_from_other_ranks": cross_rank,
-                   "proofs_verified_by_product_verifier": verified, "verify_ms": None if verify_ms is None else round(verify_ms, 1), "setup_s": round(setup_s, 2)},
+                   "proofs_verified_by_product_verifier": verified, "verify_ms": None if verify_ms is None else round(verify_ms, 1), "setup_s": round(setup_s, 2), "generate_parameters_s": round(keygen_s, 2)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "secondary": secondary, "micro": micro,
     }
     print(json.dumps(line), flush=True)

@@ -233,6 +233,21 @@ typedef struct {
 zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out);
 
 /* ------------------------------------------------------------------------------------------
+ * Parameter generation  (bellman groth16::generate_parameters(circuit, g1, g2, alpha, beta, gamma, delta, tau))
+ * replaces: generate_random_parameters   reference calls: core/proofs/src/setup.rs:28-31, 59-62
+ * The circuit is the R1CS held by `circuit` (zk_r1cs_load / zk_transfer_r1cs_load); the per-input rows
+ * Input(i) * 0 = 0 are appended as bellman's generator appends them.  g1 / g2: the generators (uncompressed; bellman
+ * draws them at random, any generators do), the five trapdoor scalars: 32 bytes little-endian plain < r.
+ * out receives Parameters::write bytes (zk_params_load reads them back); out may be NULL to query the length.
+ * Lagrange coefficients by the prover's NTT, QAP evaluation and all fixed-base multiplications on the GPU.
+ * ZK_ERR_UNCONSTRAINED_VARIABLE as bellman (an aux variable whose L query is the identity),
+ * ZK_ERR_UNEXPECTED_IDENTITY for gamma = 0 or delta = 0.
+ * ------------------------------------------------------------------------------------------ */
+zk_status zk_generate_parameters(zk_r1cs* circuit, const uint8_t g1[96], const uint8_t g2[192], const uint8_t alpha[32],
+                                 const uint8_t beta[32], const uint8_t gamma[32], const uint8_t delta[32],
+                                 const uint8_t tau[32], uint8_t* out, size_t cap, size_t* len);
+
+/* ------------------------------------------------------------------------------------------
  * Verification  (bellman-verifier: prepare_verifying_key / verify_proof, PreparedVerifyingKey IO)
  * replaces: prepare_verifying_key + verify_proof   core/bellman-verifier/src/verifier.rs:15-63
  *           (called by the wallet's self-check core/proofs/src/confidential.rs:208-278 and by the

@@ -20,7 +20,7 @@ def build_emu(force=False):
         return EMU_LIB
     cxx = CLANGXX if os.path.exists(CLANGXX) else "clang++"
     cmd = [cxx, "-O2", "-rdynamic", "-std=c++17", "-fPIC", "-shared", "-DZK_EMU=1", "-Wno-psabi", "-x", "c++",
-           os.path.join(CSRC, "zkamd.cpp"), os.path.join(CSRC, "verify.cpp"), os.path.join(CSRC, "witness.cpp"), os.path.join(HERE, "emu_rt.cpp"), "-o", EMU_LIB,
+           os.path.join(CSRC, "zkamd.cpp"), os.path.join(CSRC, "verify.cpp"), os.path.join(CSRC, "witness.cpp"), os.path.join(CSRC, "setup.cpp"), os.path.join(HERE, "emu_rt.cpp"), "-o", EMU_LIB,
            "-lpthread"]
     print("+", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

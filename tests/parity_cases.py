@@ -651,3 +651,53 @@ def witness_gpu_matches_host(lib, n_extra=3):
                 assert e.value.variant == "InvalidArgument" and "statement 1" in str(e.value) and what in str(e.value), str(e.value)
     finally:
         mats.close()
+
+
+def setup_matches_oracle(lib, seed=21, n_in=3, n_aux=17, n_con=20):
+    """zk_generate_parameters against the oracle's restatement of bellman's generator
+    (oracle.groth16.generate_parameters + Parameters::write): byte-identical parameter files for explicit toxic
+    waste; a key made by the product then proves and verifies through the product's own prover and verifier."""
+    E = g.Bls12Engine()
+    r1, inputs, aux = synth.random_r1cs(seed, n_in, n_aux, n_con)
+    mats = zk.ConstraintMatrices(r1.n_in, r1.n_aux, r1.constraints, lib=lib)
+    try:
+        toxic = helpers.TOXIC
+        want = params_io.write_parameters(g.generate_parameters(E, r1, *toxic))
+        got = zk.generate_parameters(mats, *toxic)
+        assert got == want
+        # the same key through the scalar-only oracle path the other tests use
+        assert got == helpers.small_case(seed, n_in, n_aux, n_con)[3]
+        # generate_random_parameters: the five Fr::rand draws of bellman, in its order
+        rng = zk.XorShiftRng([0x3dbe6259, 0x8d313d76, 0x3237db17, 0xe5bc0654])
+        rng2 = zk.XorShiftRng([0x3dbe6259, 0x8d313d76, 0x3237db17, 0xe5bc0654])
+        drawn = [zk.fr_rand(rng2) for _ in range(5)]
+        rnd = zk.generate_random_parameters(mats, rng)
+        assert rnd == params_io.write_parameters(g.generate_parameters(E, r1, *drawn))
+        params = zk.Parameters.read(rnd, checked=True, lib=lib)
+        pvk = zk.prepare_verifying_key(params)
+        try:
+            asg = g.assign(E, r1, inputs, aux)
+            pf = zk.create_proof(helpers.to_assignment(zk, asg), params, 5, 6)
+            assert zk.verify_proof(pvk, pf, list(asg.inputs[1:]))
+            assert not zk.verify_proof(pvk, pf, [(asg.inputs[1] + 1) % bls.R_MOD] + list(asg.inputs[2:]))
+        finally:
+            pvk.close()
+            params.close()
+        # error behaviour: gamma = 0 (bellman: UnexpectedIdentity), a trapdoor scalar >= r
+        with pytest.raises(zk.ZkError) as e:
+            zk.generate_parameters(mats, toxic[0], toxic[1], 0, toxic[3], toxic[4])
+        assert e.value.variant == "UnexpectedIdentity"
+        with pytest.raises(zk.ZkError) as e:
+            zk.generate_parameters(mats, bls.R_MOD, *toxic[1:])
+        assert e.value.variant == "InvalidArgument"
+    finally:
+        mats.close()
+    # an aux variable that appears in no constraint: UnconstrainedVariable, as bellman's generator
+    cons = [tuple([(v, c) for v, c in lc] for lc in con) for con in r1.constraints]
+    loose = zk.ConstraintMatrices(r1.n_in, r1.n_aux + 1, cons, lib=lib)
+    try:
+        with pytest.raises(zk.ZkError) as e:
+            zk.generate_parameters(loose, *helpers.TOXIC)
+        assert e.value.variant == "UnconstrainedVariable"
+    finally:
+        loose.close()

@@ -139,3 +139,7 @@ def test_verifier_golden_multiples(emu_lib):
 
 def test_witness_gpu_matches_host(emu_lib):
     pc.witness_gpu_matches_host(emu_lib, n_extra=1)
+
+
+def test_setup_matches_oracle(emu_lib):
+    pc.setup_matches_oracle(emu_lib)

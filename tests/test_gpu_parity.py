@@ -347,3 +347,23 @@ def test_full_chunk_1024_every_proof_checked(gpu_lib):
 
 def test_witness_gpu_matches_host(gpu_lib):
     pc.witness_gpu_matches_host(gpu_lib, n_extra=6)
+
+
+def test_setup_matches_oracle(gpu_lib):
+    pc.setup_matches_oracle(gpu_lib)
+
+
+def test_setup_transfer_circuit_byte_identical(gpu_lib):
+    """generate_parameters for the reference's transfer circuit from the natively emitted matrices: the 10 MB
+    parameter file equals the oracle's (bellman's generator restated, same toxic waste) byte for byte."""
+    import zero_chain_amd as zk
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
+    try:
+        t0 = time.time()
+        got = zk.generate_parameters(mats, *helpers.TOXIC)
+        dt = time.time() - t0
+        assert len(got) == len(pk) and got == pk
+        print("generate_parameters(transfer circuit): %.2f s, %d bytes" % (dt, len(got)))
+    finally:
+        mats.close()

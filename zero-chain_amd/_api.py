@@ -23,7 +23,7 @@ from ._shard import shard_bounds, gather_proofs, prove_sharded
 from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSET, ZK_NTT_IN_BITREV,
                    ZK_NTT_OUT_BITREV)
 
-__all__ = ["Parameters", "Proof", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
+__all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_statements", "anonymous_witness",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
@@ -186,6 +186,38 @@ class Parameters:
             self.close()
         except Exception:
             pass
+
+
+G1_GENERATOR = bytes.fromhex(
+    "17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb"
+    "08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1")
+G2_GENERATOR = bytes.fromhex(
+    "13e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+    "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8"
+    "0606c4a02ea734cc32acd2b02bc28b99cb3e287e85a763af267492ab572e99ab3f370d275cec1da1aaa9075ff05f79be"
+    "0ce5d527727d6e118cc9cdc6da2e351aadfd9baa8cbdd3a76d429a695160d12c923ac9cc3baca289e193548608b82801")
+
+
+def generate_parameters(matrices, alpha, beta, gamma, delta, tau, g1=None, g2=None):
+    """bellman groth16::generate_parameters for the circuit held by `matrices` (zk_generate_parameters): returns
+    Parameters::write bytes.  g1 / g2 default to the standard generators (core/pairing/src/bls12_381/README.md:45-57)."""
+    lib = matrices._lib
+    sc = [scalars_to_bytes([int(v)]) for v in (alpha, beta, gamma, delta, tau)]
+    b1, b2 = _u8(g1 or G1_GENERATOR, 96), _u8(g2 or G2_GENERATOR, 192)
+    n = C.c_size_t(0)
+    args = [matrices._h, _ptr(b1), _ptr(b2)] + [_ptr(x) for x in sc]
+    lib.check(lib.zk_generate_parameters(*args, None, 0, C.byref(n)))
+    out = np.zeros(n.value, dtype=np.uint8)
+    lib.check(lib.zk_generate_parameters(*args, _ptr(out), out.size, C.byref(n)))
+    return out.tobytes()
+
+
+def generate_random_parameters(matrices, rng, g1=None, g2=None):
+    """generate_random_parameters (core/proofs/src/setup.rs:28-31): the five trapdoor scalars alpha, beta, gamma,
+    delta, tau are drawn with Fr::rand from `rng` in bellman's order.  (bellman also draws the two generators at
+    random; any generators give a valid key, the standard ones are used unless g1 / g2 are given.)"""
+    alpha, beta, gamma, delta, tau = (fr_rand(rng) for _ in range(5))
+    return generate_parameters(matrices, alpha, beta, gamma, delta, tau, g1=g1, g2=g2)
 
 
 class PreparedVerifyingKey:
