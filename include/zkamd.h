@@ -213,6 +213,36 @@ zk_status zk_pipeline_submit(zk_pipeline* pl, size_t n, const zk_transfer_statem
 zk_status zk_pipeline_wait(zk_pipeline* pl);
 void zk_pipeline_free(zk_pipeline* pl);
 
+/* ------------------------------------------------------------------------------------------
+ * gen_proof: the reference's wallet-level entry (ProofBuilder::gen_proof, core/proofs/src/confidential.rs:
+ * 105-172) for a batch of transfers.  Per request: the proof generation key G * sk, the decryption key
+ * Blake2s("zech_bdk", pgk) with its five top bits dropped and the sender's encryption key
+ * (no_std_aliases/keys.rs:132-198), rvk = pgk + alpha G, nonce = dec_key * g_epoch, the proof, the ElGamal
+ * ciphertexts of amount and fee under both keys (elgamal.rs:46-63), check_proof against the prepared verifying key
+ * (confidential.rs:208-278; ZK_ERR_UNSATISFIABLE if a proof does not verify, as the reference) and the packing of
+ * ConfidentialXt (:282-361), rsk = sk + alpha.  randomness / alpha are the two Fs::rand draws of gen_proof,
+ * rs (n x 64 bytes) the two Fr::rand draws of create_random_proof; scalars 32 bytes little-endian, points in the
+ * 32-byte Jubjub encoding.
+ * zk_transfer_derive is the host half alone (request -> statement and rsk); zk_spending_key_from_seed is
+ * SpendingKey::from_seed (keys.rs:45-58).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t amount, fee, remaining_balance, reserved;
+    uint8_t spending_key[32];
+    uint8_t enc_key_recipient[32], enc_balance_left[32], enc_balance_right[32], g_epoch[32];
+    uint8_t randomness[32], alpha[32];
+} zk_transfer_request;
+typedef struct {   /* ConfidentialXt, confidential.rs:349-361 */
+    uint8_t proof[192];
+    uint8_t enc_key_sender[32], enc_key_recipient[32], left_amount_sender[32], left_amount_recipient[32], left_fee[32],
+        right_randomness[32], rsk[32], rvk[32], enc_balance[64], nonce[32];
+} zk_confidential_xt;
+zk_status zk_spending_key_from_seed(const uint8_t* seed, size_t len, uint8_t spending_key_out[32]);
+zk_status zk_transfer_derive(const zk_transfer_request* req, size_t n, zk_transfer_statement* statements_out, uint8_t* rsk_out);
+struct zk_vk;
+zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, struct zk_vk* vk, size_t n, const zk_transfer_request* req,
+                                      const uint8_t* rs, zk_confidential_xt* out);
+
 /* The value half of AnonymousTransfer::synthesize (core/proofs/src/circuit/anonymous_transfer.rs:56-337,
  * anonimity_set.rs; ANONIMITY_SIZE = 12, constants.rs:1): the private values of the instance (:40-54) ->
  * the variable assignment bellman's ProvingAssignment would hold, [105 inputs | 50429 aux].  Scalars are

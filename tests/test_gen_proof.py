@@ -1,0 +1,66 @@
+"""The host half of the gen_proof glue (zk_spending_key_from_seed, zk_transfer_derive: host code of libzkamd.so, no
+GPU needed) against the oracle's restatement (oracle/gen_proof.py) and the one value the reference holds for the
+derivation chain.  The GPU half (proof, ciphertexts, self-check, packing) is tests/test_gpu_parity.py."""
+import pytest
+
+from oracle import gen_proof as og
+from oracle import jubjub as jj
+from oracle import synth
+
+ALICE_SEED = b"Alice" + b" " * 27                                               # modules/encrypted-balances/src/lib.rs:381
+ALICE_ENC_KEY = "fd0c0c0183770c99559bf64df4fe23f77ced9b8b4d02826a282bcd125117dcc2"   # :443 pkd_addr_alice
+BOB_ADDR = "45e66da531088b55dcb3b273ca825454d79d2d1d5c4fa2ba4a12c1fa1ccd6389"        # :383
+G_EPOCH = "0953f47325251a2f479c25527df6d977925bebafde84423b20ae6c903411665a"         # :409
+
+
+def _lib():
+    import zero_chain_amd
+    return zero_chain_amd.load_library()
+
+
+def test_oracle_derivation_reproduces_the_reference_address():
+    sk = og.spending_key_from_seed(ALICE_SEED)
+    _, _, enc_key = og.derive(sk)
+    assert jj.write_point(enc_key).hex() == ALICE_ENC_KEY
+
+
+def reference_request(rng_seed=1):
+    """The transfer of test_call_from_zface (lib.rs:372-420): Alice -> Bob, 100 -> 91, amount 8, fee 1, the balance
+    encrypted with randomness Fs::one(), g_epoch of block height one."""
+    sk = og.spending_key_from_seed(ALICE_SEED)
+    _, _, enc_key = og.derive(sk)
+    bal = og.encrypt(100, 1, enc_key)
+    rng = synth.SplitMix64(rng_seed)
+    return dict(amount=8, fee=1, remaining_balance=91, spending_key=sk, enc_key_recipient=bytes.fromhex(BOB_ADDR),
+                enc_balance_left=jj.write_point(bal[0]), enc_balance_right=jj.write_point(bal[1]), g_epoch=bytes.fromhex(G_EPOCH),
+                randomness=rng.field(jj.FS_MOD), alpha=rng.field(jj.FS_MOD)), bal
+
+
+def test_product_derivation_matches_oracle_and_reference():
+    import zero_chain_amd as zk
+    lib = _lib()
+    assert zk.spending_key_from_seed(ALICE_SEED, lib=lib) == og.spending_key_from_seed(ALICE_SEED)
+    for seed in (b"", b"x", b"Bob" + b" " * 29, bytes(range(200))):
+        assert zk.spending_key_from_seed(seed, lib=lib) == og.spending_key_from_seed(seed)
+    items = []
+    for k in range(3):
+        rq, bal = reference_request(k)
+        if k == 2:
+            rq["spending_key"] = og.spending_key_from_seed(b"another key")
+        items.append((rq, bal))
+    sts, rsks = zk.transfer_derive(zk.transfer_requests([rq for rq, _ in items]), lib=lib)
+    for (rq, bal), st, rsk in zip(items, sts, rsks):
+        pgk, dec_key, enc_key = og.derive(rq["spending_key"])
+        assert bytes(st.proof_generation_key) == jj.write_point(pgk)
+        assert int.from_bytes(bytes(st.dec_key_sender), "little") == dec_key
+        assert rsk == ((rq["spending_key"] + rq["alpha"]) % jj.FS_MOD).to_bytes(32, "little")
+        assert (st.amount, st.fee, st.remaining_balance) == (rq["amount"], rq["fee"], rq["remaining_balance"])
+        assert bytes(st.enc_key_recipient) == rq["enc_key_recipient"] and bytes(st.g_epoch) == rq["g_epoch"]
+        assert bytes(st.enc_balance_left) == rq["enc_balance_left"] and bytes(st.enc_balance_right) == rq["enc_balance_right"]
+    # Alice's statement carries the key whose encryption key is the reference's address
+    _, dk, ek = og.derive(items[0][0]["spending_key"])
+    assert jj.write_point(ek).hex() == ALICE_ENC_KEY and int.from_bytes(bytes(sts[0].dec_key_sender), "little") == dk
+    bad = dict(items[0][0], spending_key=jj.FS_MOD)
+    with pytest.raises(zk.ZkError) as e:
+        zk.transfer_derive(zk.transfer_requests([items[1][0], bad]), lib=lib)
+    assert e.value.variant == "InvalidArgument" and "request 1" in str(e.value) and "spending_key" in str(e.value)

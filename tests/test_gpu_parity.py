@@ -367,3 +367,63 @@ def test_setup_transfer_circuit_byte_identical(gpu_lib):
         print("generate_parameters(transfer circuit): %.2f s, %d bytes" % (dt, len(got)))
     finally:
         mats.close()
+
+
+def test_gen_proof_confidential_xt(gpu_lib):
+    """zk_transfer_gen_proof_batch = the reference's gen_proof (core/proofs/src/confidential.rs:105-172): every field
+    of ConfidentialXt against the oracle's restatement (oracle/gen_proof.py: keys, ElGamal, rvk, rsk, nonce) and the
+    proof against the discrete-log proof of the same statement; an inconsistent request fails the self-check with
+    Unsatisfiable, as check_proof does.  The first request is the transfer of the reference's test_call_from_zface
+    (modules/encrypted-balances/src/lib.rs:372-420: Alice -> Bob, 100 -> 91, amount 8, fee 1)."""
+    import zero_chain_amd as zk
+    from oracle import gen_proof as og
+    from oracle import jubjub as jj
+    from oracle import transfer_circuit as tc
+    import test_gen_proof as tg
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    E = g.Bls12Engine()
+    items, bals = [], []
+    for k in range(3):
+        rq, bal = tg.reference_request(k + 1)
+        if k:
+            sk = og.spending_key_from_seed(b"sender %d" % k)
+            _, _, ek = og.derive(sk)
+            bal = og.encrypt(500 + k, 7 + k, ek)
+            rq.update(spending_key=sk, amount=20 + k, fee=k, remaining_balance=500 + k - 20 - k - k,
+                      enc_balance_left=jj.write_point(bal[0]), enc_balance_right=jj.write_point(bal[1]))
+        items.append(rq)
+        bals.append(bal)
+    rs = [(11 + i, 23 + 5 * i) for i in range(len(items))]
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
+    pvk = zk.prepare_verifying_key(params)
+    try:
+        xts = zk.gen_proofs(params, mats, pvk, zk.transfer_requests(items), rs)
+        for rq, bal, xt, (r, s) in zip(items, bals, xts, rs):
+            want, stmt = og.gen_xt_fields(rq["spending_key"], rq["amount"], rq["fee"], rq["remaining_balance"],
+                                          jj.read_point(rq["enc_key_recipient"]), bal, jj.read_point(rq["g_epoch"]),
+                                          rq["randomness"], rq["alpha"])
+            for f, v in want.items():
+                assert xt[f] == v, f
+            cs = tc.synthesize(stmt)
+            assert cs.which_is_unsatisfied() is None
+            asg = g.assign(E, r1, cs.inputs, cs.aux)
+            assert xt["proof"] == helpers.expected_proof_trapdoor(P, asg, r, s)
+        # the reference's own draw order through the single-transfer mirror
+        rng = zk.XorShiftRng([0x3dbe6259, 0x8d313d76, 0x3237db17, 0xe5bc0654])
+        one = zk.gen_proof(params, mats, pvk, 8, 1, 91, items[0]["spending_key"], items[0]["enc_key_recipient"],
+                           (items[0]["enc_balance_left"], items[0]["enc_balance_right"]), items[0]["g_epoch"], rng)
+        rng2 = zk.XorShiftRng([0x3dbe6259, 0x8d313d76, 0x3237db17, 0xe5bc0654])
+        rnd, alpha = zk.fs_rand(rng2), zk.fs_rand(rng2)
+        want, _ = og.gen_xt_fields(items[0]["spending_key"], 8, 1, 91, jj.read_point(items[0]["enc_key_recipient"]), bals[0],
+                                   jj.read_point(items[0]["g_epoch"]), rnd, alpha)
+        assert all(one[f] == v for f, v in want.items())
+        # 100 -> 90 does not add up: the proof is made (the prover does not check satisfiability) and fails check_proof
+        bad = dict(items[0], remaining_balance=90)
+        with pytest.raises(zk.ZkError) as e:
+            zk.gen_proofs(params, mats, pvk, zk.transfer_requests([items[1], bad]), rs[:2])
+        assert e.value.variant == "Unsatisfiable" and "request 1" in str(e.value)
+    finally:
+        pvk.close()
+        mats.close()
+        params.close()

@@ -25,7 +25,8 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
-           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_statements", "anonymous_witness",
+           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "transfer_requests", "transfer_derive", "gen_proofs", "gen_proof", "XT_FIELDS",
+           "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_statements", "anonymous_witness",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
@@ -485,6 +486,80 @@ def transfer_witness(statements, montgomery=False, lib=None):
     out = np.zeros(n * (TRANSFER_N_INPUTS + TRANSFER_N_AUX) * 32, dtype=np.uint8)
     lib.check(lib.zk_transfer_witness(statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# gen_proof (core/proofs/src/confidential.rs:105-172): requests -> ConfidentialXt
+# ----------------------------------------------------------------------------------------------
+FS_MODULUS = 0x0e7db4ea6533afa906673b0101343b00a6682093ccc81082d0970e5ed6f72cb7
+_FS_R_INV = pow(1 << 256, -1, FS_MODULUS)
+XT_FIELDS = ("proof", "enc_key_sender", "enc_key_recipient", "left_amount_sender", "left_amount_recipient", "left_fee",
+             "right_randomness", "rsk", "rvk", "enc_balance", "nonce")
+
+
+def fs_rand(rng):
+    """Fs::rand (core/jubjub/src/curve/fs.rs:255-268): 4 x next_u64 limbs, four top bits shaved, rejected unless < s;
+    the accepted limbs ARE the Montgomery representation.  Returns the plain integer."""
+    while True:
+        limbs = [rng.next_u64() for _ in range(4)]
+        limbs[3] &= 0xFFFFFFFFFFFFFFFF >> 4
+        v = sum(l << (64 * i) for i, l in enumerate(limbs))
+        if v < FS_MODULUS:
+            return v * _FS_R_INV % FS_MODULUS
+
+
+def spending_key_from_seed(seed, lib=None):
+    """SpendingKey::from_seed (keys.rs:45-58)."""
+    lib = lib or _lib.load()
+    buf = _u8(bytes(seed))
+    out = np.zeros(32, dtype=np.uint8)
+    lib.check(lib.zk_spending_key_from_seed(_ptr(buf), buf.size, _ptr(out)))
+    return int.from_bytes(out.tobytes(), "little")
+
+
+def transfer_requests(items):
+    """items: dicts with amount, fee, remaining_balance (ints), spending_key, randomness, alpha (Fs ints) and
+    enc_key_recipient, enc_balance_left, enc_balance_right, g_epoch (32-byte Jubjub encodings)."""
+    arr = (_lib.TransferRequest * len(items))()
+    for rq, it in zip(arr, items):
+        rq.amount, rq.fee, rq.remaining_balance = it["amount"], it["fee"], it["remaining_balance"]
+        for name in ("spending_key", "randomness", "alpha"):
+            getattr(rq, name)[:] = int(it[name]).to_bytes(32, "little")
+        for name in ("enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch"):
+            getattr(rq, name)[:] = bytes(it[name])
+    return arr
+
+
+def transfer_derive(requests, lib=None):
+    """zk_transfer_derive: (statements, [rsk bytes]) - the host half of gen_proof."""
+    lib = lib or _lib.load()
+    n = len(requests)
+    st = (_lib.TransferStatement * n)()
+    rsk = np.zeros(32 * n, dtype=np.uint8)
+    lib.check(lib.zk_transfer_derive(requests, n, st, _ptr(rsk)))
+    return st, [rsk[32 * i:32 * i + 32].tobytes() for i in range(n)]
+
+
+def gen_proofs(params, matrices, pvk, requests, rs):
+    """zk_transfer_gen_proof_batch: one ConfidentialXt (dict of byte strings, XT_FIELDS) per request; raises ZkError
+    Unsatisfiable when a proof fails the self-check, as the reference's gen_proof."""
+    lib = params._lib
+    n = len(requests)
+    rsb = rs if isinstance(rs, np.ndarray) else scalars_to_bytes([x for pair in rs for x in pair])
+    out = (_lib.ConfidentialXt * n)()
+    lib.check(lib.zk_transfer_gen_proof_batch(params._h, matrices._h, pvk._h, n, requests, _ptr(rsb), out))
+    return [{f: bytes(getattr(x, f)) for f in XT_FIELDS} for x in out]
+
+
+def gen_proof(params, matrices, pvk, amount, fee, remaining_balance, spending_key, enc_key_recipient, encrypted_balance, g_epoch, rng):
+    """ProofBuilder::gen_proof for one transfer, drawing from `rng` in the reference's order: randomness and alpha
+    (Fs::rand), then r and s of create_random_proof (Fr::rand)."""
+    randomness, alpha = fs_rand(rng), fs_rand(rng)
+    r, s = fr_rand(rng), fr_rand(rng)
+    rq = transfer_requests([dict(amount=amount, fee=fee, remaining_balance=remaining_balance, spending_key=spending_key,
+                                 enc_key_recipient=enc_key_recipient, enc_balance_left=encrypted_balance[0],
+                                 enc_balance_right=encrypted_balance[1], g_epoch=g_epoch, randomness=randomness, alpha=alpha)])
+    return gen_proofs(params, matrices, pvk, rq, [(r, s)])[0]
 
 
 def transfer_witness_gpu(matrices, statements, montgomery=False):

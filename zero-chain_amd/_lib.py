@@ -52,6 +52,19 @@ class TransferStatement(C.Structure):
                                               "enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch")]
 
 
+class TransferRequest(C.Structure):
+    _fields_ = [("amount", C.c_uint32), ("fee", C.c_uint32), ("remaining_balance", C.c_uint32), ("reserved", C.c_uint32)] + \
+               [(n, C.c_uint8 * 32) for n in ("spending_key", "enc_key_recipient", "enc_balance_left", "enc_balance_right",
+                                              "g_epoch", "randomness", "alpha")]
+
+
+class ConfidentialXt(C.Structure):
+    _fields_ = [("proof", C.c_uint8 * 192)] + \
+               [(n, C.c_uint8 * 32) for n in ("enc_key_sender", "enc_key_recipient", "left_amount_sender", "left_amount_recipient",
+                                              "left_fee", "right_randomness", "rsk", "rvk")] + \
+               [("enc_balance", C.c_uint8 * 64), ("nonce", C.c_uint8 * 32)]
+
+
 class AnonymousStatement(C.Structure):
     _fields_ = [("amount", C.c_uint32), ("remaining_balance", C.c_uint32), ("s_index", C.c_uint32), ("t_index", C.c_uint32)] + \
                [(n, C.c_uint8 * 32) for n in ("randomness", "alpha", "dec_key", "proof_generation_key", "g_epoch")] + \
@@ -89,6 +102,10 @@ _PROTOS = {
     "zk_pipeline_submit": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(TransferStatement), C.c_void_p, C.c_void_p]),
     "zk_pipeline_wait": (C.c_int32, [C.c_void_p]),
     "zk_pipeline_free": (None, [C.c_void_p]),
+    "zk_spending_key_from_seed": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zk_transfer_derive": (C.c_int32, [C.POINTER(TransferRequest), C.c_size_t, C.POINTER(TransferStatement), C.c_void_p]),
+    "zk_transfer_gen_proof_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TransferRequest), C.c_void_p,
+                                                C.POINTER(ConfidentialXt)]),
     "zk_anonymous_witness": (C.c_int32, [C.POINTER(AnonymousStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_generate_parameters": (C.c_int32, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zk_params_write_vk": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),

@@ -1708,6 +1708,215 @@ zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement*
 }
 
 // ------------------------------------------------------------------------------------------
+// gen_proof: the wallet-level entry of the reference (core/proofs/src/confidential.rs:105-172) for a batch of
+// transfers - key derivation (no_std_aliases/keys.rs:132-198), the statement, create_proof, the ElGamal
+// ciphertexts (elgamal.rs:46-63), the self-check (check_proof, confidential.rs:208-278) and the packing of
+// ConfidentialXt (:282-361).
+// ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+const uint64_t FS_MOD[4] = ZK_JUBJUB_FS_MODULUS_64;
+bool fs_lt_mod(const uint64_t v[4]) {
+    for (int i = 3; i >= 0; i--) {
+        if (v[i] < FS_MOD[i]) return true;
+        if (v[i] > FS_MOD[i]) return false;
+    }
+    return false;
+}
+void fs_sub_mod(uint64_t v[4]) {
+    zkhost::u128 bo = 0;
+    for (int i = 0; i < 4; i++) {
+        zkhost::u128 d = (zkhost::u128)v[i] - FS_MOD[i] - bo;
+        v[i] = (uint64_t)d;
+        bo = (d >> 64) & 1;
+    }
+}
+// (a + b) mod s for a, b < s
+void fs_add(const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    zkhost::u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (zkhost::u128)a[i] + b[i];
+        out[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (!fs_lt_mod(out)) fs_sub_mod(out);   // s < 2^252: the sum never carries out of 256 bits
+}
+// Fs::to_uniform: a little-endian byte string reduced mod s (bit by bit: off the hot path)
+void fs_to_uniform(const uint8_t* le, size_t len, uint64_t out[4]) {
+    uint64_t v[4] = {0, 0, 0, 0};
+    for (size_t i = len; i-- > 0;)
+        for (int b = 7; b >= 0; b--) {
+            for (int k = 3; k > 0; k--) v[k] = (v[k] << 1) | (v[k - 1] >> 63);
+            v[0] = (v[0] << 1) | ((le[i] >> b) & 1u);
+            if (!fs_lt_mod(v)) fs_sub_mod(v);
+        }
+    memcpy(out, v, 32);
+}
+// k * G for the fixed generator, from its 3-bit window tables (k < 2^252)
+zkwit::JPoint jubjub_fixed_mul(const uint64_t k[4]) {
+    const zkwit::Tables& t = zkwit::tables();
+    zkwit::EPoint acc = zkwit::ext_zero();
+    for (int w = 0; w < 84; w++) {
+        const int bit = 3 * w;
+        const uint32_t d = (uint32_t)((k[bit >> 6] >> (bit & 63)) | ((bit & 63) > 61 && (bit >> 6) < 3 ? k[(bit >> 6) + 1] << (64 - (bit & 63)) : 0)) & 7u;
+        if (d) acc = zkwit::ext_add(acc, zkwit::to_ext(t.win[w][d]));
+    }
+    zkwit::JPoint out;
+    zkwit::batch_to_affine(&acc, &out, 1);
+    return out;
+}
+// edwards::Point::write (core/jubjub/src/curve/edwards.rs:190-206): y, little-endian, the parity of x in the top bit
+void jubjub_encode(const zkhost::Fr& x_mont, const zkhost::Fr& y_mont, uint8_t out[32]) {
+    const zkhost::Fr x = x_mont.from_mont(), y = y_mont.from_mont();
+    memcpy(out, y.l, 32);
+    if (x.l[0] & 1) out[31] |= 0x80;
+}
+
+// request -> statement (+ rsk): ProofGenerationKey::from_spending_key, into_decryption_key, SpendingKey::into_rsk
+zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_transfer_statement* st, uint8_t rsk[32]) {
+    uint64_t sk[4], alpha[4], rnd[4];
+    load_scalar_le(rq.spending_key, sk);
+    load_scalar_le(rq.alpha, alpha);
+    load_scalar_le(rq.randomness, rnd);
+    const std::string who = "request " + std::to_string(index) + ": ";
+    if (!fs_lt_mod(sk)) return fail(ZK_ERR_INVALID_ARGUMENT, who + "spending_key is not a canonical Fs scalar");
+    if (!fs_lt_mod(alpha)) return fail(ZK_ERR_INVALID_ARGUMENT, who + "alpha is not a canonical Fs scalar");
+    if (!fs_lt_mod(rnd)) return fail(ZK_ERR_INVALID_ARGUMENT, who + "randomness is not a canonical Fs scalar");
+    const zkwit::JPoint pgk = jubjub_fixed_mul(sk);
+    memset(st, 0, sizeof(*st));
+    st->amount = rq.amount;
+    st->remaining_balance = rq.remaining_balance;
+    st->fee = rq.fee;
+    memcpy(st->randomness, rq.randomness, 32);
+    memcpy(st->alpha, rq.alpha, 32);
+    jubjub_encode(pgk.x, pgk.y, st->proof_generation_key);
+    // keys.rs:166-185: Blake2s("zech_bdk", pgk) with the five top bits dropped
+    static const uint8_t person[8] = {'z', 'e', 'c', 'h', '_', 'b', 'd', 'k'};
+    zkhash::Blake2s h(person);
+    h.update(st->proof_generation_key, 32);
+    h.finish(st->dec_key_sender);
+    st->dec_key_sender[31] &= 0x07;
+    memcpy(st->enc_key_recipient, rq.enc_key_recipient, 32);
+    memcpy(st->enc_balance_left, rq.enc_balance_left, 32);
+    memcpy(st->enc_balance_right, rq.enc_balance_right, 32);
+    memcpy(st->g_epoch, rq.g_epoch, 32);
+    uint64_t r[4];
+    fs_add(sk, alpha, r);   // PrivateKey(sk).randomize(alpha)
+    memcpy(rsk, r, 32);
+    return ZK_OK;
+}
+zk_status transfer_derive(const zk_transfer_request* rq, size_t n, zk_transfer_statement* st, uint8_t* rsk) {
+    if (n == 0) return ZK_OK;
+    (void)zkwit::tables();
+    const unsigned nthreads = host_threads(n, 64);
+    std::vector<zk_status> sts(nthreads, ZK_OK);
+    std::vector<std::string> msgs(nthreads);
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
+            zk_status rc = transfer_derive_one(rq[i], i, &st[i], rsk + i * 32);
+            if (rc != ZK_OK) {
+                sts[t] = rc;
+                msgs[t] = g_err;
+                return;
+            }
+        }
+    };
+    if (nthreads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> ths;
+        for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, t);
+        for (auto& th : ths) th.join();
+    }
+    for (unsigned t = 0; t < nthreads; t++)
+        if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+zk_status zk_spending_key_from_seed(const uint8_t* seed, size_t len, uint8_t spending_key_out[32]) {
+    if ((!seed && len) || !spending_key_out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    // keys.rs:45-58: Blake2b-512 personalised "zech_ExpandSeed_", then Fs::to_uniform
+    static const uint8_t person[16] = {'z', 'e', 'c', 'h', '_', 'E', 'x', 'p', 'a', 'n', 'd', 'S', 'e', 'e', 'd', '_'};
+    zkhash::Blake2b h(person);
+    h.update(seed, len);
+    uint8_t d[64];
+    h.finish(d);
+    uint64_t v[4];
+    fs_to_uniform(d, 64, v);
+    memcpy(spending_key_out, v, 32);
+    return ZK_OK;
+}
+
+zk_status zk_transfer_derive(const zk_transfer_request* req, size_t n, zk_transfer_statement* statements_out, uint8_t* rsk_out) {
+    if (n && (!req || !statements_out || !rsk_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    return transfer_derive(req, n, statements_out, rsk_out);
+}
+
+zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk, size_t n, const zk_transfer_request* req,
+                                      const uint8_t* rs, zk_confidential_xt* out) {
+    if (!p || !circuit || !vk || (n && (!req || !rs || !out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the transfer circuit's");
+    if (circuit->device != p->device) return fail(ZK_ERR_INVALID_ARGUMENT, "parameters and circuit live on different devices");
+    if (n == 0) return ZK_OK;
+    ZK_TRY(use_device(p->device));
+    if ((size_t)circuit->n_con + circuit->n_in > p->m)
+        return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
+    std::vector<zk_transfer_statement> st(n);
+    std::vector<uint8_t> rsk(n * 32), proofs(n * 192), ok(n);
+    ZK_TRY(transfer_derive(req, n, st.data(), rsk.data()));
+    const size_t chunk = batch_chunk(), nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX, n_pub = ZK_TRANSFER_N_INPUTS - 1;
+    PinBuf pin_in;
+    ZK_TRY(pin_in.ensure(std::min(chunk, n) * ZK_TRANSFER_N_INPUTS * 32));
+    std::vector<uint8_t> inputs(n * n_pub * 32);
+    int slot = 0;
+    ZK_TRY(witness_gpu_enqueue(circuit, st.data(), std::min(chunk, n), slot, g_copy_stream));
+    for (size_t first = 0; first < n; first += chunk) {
+        const size_t np = std::min(chunk, n - first), next = first + chunk;
+        ZK_TRY(witness_gpu_finish(circuit, np, slot, first));
+        if (next < n) ZK_TRY(witness_gpu_enqueue(circuit, st.data() + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream));
+        // the 23 public inputs of every statement (the head of its assignment), for check_proof and the packing
+        HIP_TRY(hipMemcpy2DAsync(pin_in.p, ZK_TRANSFER_N_INPUTS * 32, circuit->z[slot].p, nv * 32, ZK_TRANSFER_N_INPUTS * 32, np,
+                                 hipMemcpyDeviceToHost, g_stream));
+        ZK_TRY(prove_from_z(p, circuit, np, slot, rs + first * 64, proofs.data() + first * 192));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        for (size_t i = 0; i < np; i++) {
+            const zkhost::Fr* z = reinterpret_cast<const zkhost::Fr*>(pin_in.as<uint8_t>() + i * ZK_TRANSFER_N_INPUTS * 32);
+            zk_confidential_xt& x = out[first + i];
+            memset(&x, 0, sizeof(x));
+            for (size_t k = 0; k < n_pub; k++) {
+                const zkhost::Fr pl = z[1 + k].from_mont();
+                memcpy(&inputs[((first + i) * n_pub + k) * 32], pl.l, 32);
+            }
+            memcpy(x.proof, proofs.data() + (first + i) * 192, 192);
+            jubjub_encode(z[1], z[2], x.enc_key_sender);
+            jubjub_encode(z[3], z[4], x.enc_key_recipient);
+            jubjub_encode(z[5], z[6], x.left_amount_sender);
+            jubjub_encode(z[7], z[8], x.left_amount_recipient);
+            jubjub_encode(z[9], z[10], x.right_randomness);
+            jubjub_encode(z[11], z[12], x.left_fee);
+            jubjub_encode(z[13], z[14], x.enc_balance);
+            jubjub_encode(z[15], z[16], x.enc_balance + 32);
+            jubjub_encode(z[17], z[18], x.rvk);
+            jubjub_encode(z[21], z[22], x.nonce);
+            memcpy(x.rsk, rsk.data() + (first + i) * 32, 32);
+        }
+        slot ^= 1;
+    }
+    // check_proof: every proof must verify against the public inputs the transaction will carry
+    ZK_TRY(zk_verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data()));
+    for (size_t i = 0; i < n; i++)
+        if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // zk_pipeline: a stream of statement batches.  zk_transfer_prove_batch overlaps the witnesses of
 // chunk k + 1 with the GPU work of chunk k INSIDE one call; a service that proves batch after batch
 // wants the same overlap ACROSS calls.  submit() queues a batch and returns; a producer thread computes
