@@ -6,7 +6,7 @@ cp zero-chain_amd/libzkamd.so /tmp/libzkamd.orig.so
 for v in zero-chain_amd/variants/libzkamd_*.so; do
   name=$(basename $v .so); name=${name#libzkamd_}
   cp $v zero-chain_amd/libzkamd.so
-  timeout 600 python bench.py --no-cpu --no-host-path "$@" > gpurun_out/$TAG/$name.json 2> gpurun_out/$TAG/$name.err
+  timeout 600 python bench.py --no-cpu --no-micro --no-secondary --oracle-checks 1 "$@" > gpurun_out/$TAG/$name.json 2> gpurun_out/$TAG/$name.err
   python - "$name" gpurun_out/$TAG/$name.json <<'PY'
 import json,sys
 try:

@@ -31,7 +31,11 @@ struct DevCtx {
     hipEvent_t ev_fork = nullptr;
 };
 inline std::mutex g_ctx_mu;
-inline std::map<int, DevCtx*> g_ctxs;
+inline std::map<int, DevCtx*> g_ctxs;   // key: device * 16 + lane
+// A worker thread of a zk_pipeline works in its own LANE: a second set of streams on the same device, so
+// that the kernels of two chunks can be in flight at once (the latency- and memory-bound phases of one
+// beside the issue-bound phases of the other).
+inline thread_local int g_lane = 0;
 inline thread_local hipStream_t g_stream = nullptr;
 inline thread_local hipStream_t g_stream2 = nullptr;
 inline thread_local hipStream_t g_copy_stream = nullptr;
@@ -61,14 +65,14 @@ inline zk_status use_device(int device) {
     if (device < 0 || device >= n) return fail(ZK_ERR_INVALID_ARGUMENT, "device index out of range");
     HIP_TRY(hipSetDevice(device));   // per host thread: never skipped
     std::lock_guard<std::mutex> lock(g_ctx_mu);
-    DevCtx*& c = g_ctxs[device];
+    DevCtx*& c = g_ctxs[device * 16 + g_lane];
     if (!c) {
         DevCtx* fresh = new DevCtx();
         if (hipStreamCreate(&fresh->stream) != hipSuccess || hipStreamCreate(&fresh->stream2) != hipSuccess ||
             hipStreamCreateWithFlags(&fresh->copy, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreate(&fresh->ev_fork) != hipSuccess) {
             delete fresh;
-            g_ctxs.erase(device);
+            g_ctxs.erase(device * 16 + g_lane);
             return fail(ZK_ERR_DEVICE, "cannot create the streams of device " + std::to_string(device));
         }
         c = fresh;
@@ -106,14 +110,23 @@ inline unsigned host_threads(size_t work_items, unsigned cap) {
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool owned = true;
     DevBuf() {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
+    }
+    // a read-only view of another buffer (tables shared between the lanes of a pipeline); the owner must outlive it
+    void borrow(const DevBuf& o) {
+        if (p && owned) (void)hipFree(p);
+        p = o.p;
+        cap = o.cap;
+        owned = false;
     }
     zk_status ensure(size_t bytes) {
         if (bytes <= cap) return ZK_OK;
+        if (!owned) return fail(ZK_ERR_INVALID_ARGUMENT, "internal: a borrowed buffer cannot grow");
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;

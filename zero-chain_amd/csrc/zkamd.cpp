@@ -704,6 +704,51 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     return ZK_OK;
 }
 
+// A second handle over the SAME key for another lane of a pipeline: the tables (doubling tables, NTT tables)
+// are borrowed, the per-chunk workspaces are its own.  The original must outlive the clone.
+zk_params* params_clone_for_lane(const zk_params* P) {
+    zk_params* Q = new (std::nothrow) zk_params();
+    if (!Q) return nullptr;
+    Q->device = P->device;
+    Q->n_ic = P->n_ic; Q->n_h = P->n_h; Q->n_l = P->n_l; Q->n_a = P->n_a; Q->n_b1 = P->n_b1; Q->n_b2 = P->n_b2;
+    Q->log_m = P->log_m;
+    Q->m = P->m;
+    Q->off_h = P->off_h; Q->off_l = P->off_l; Q->off_a = P->off_a; Q->off_b1 = P->off_b1;
+    Q->g1.c = P->g1.c; Q->g1.maxd = P->g1.maxd; Q->g1.nb = P->g1.nb; Q->g1.n_points = P->g1.n_points;
+    Q->g1.table.borrow(P->g1.table);
+    Q->g2.c = P->g2.c; Q->g2.maxd = P->g2.maxd; Q->g2.nb = P->g2.nb; Q->g2.n_points = P->g2.n_points;
+    Q->g2.table.borrow(P->g2.table);
+    Q->ntt.log_n = P->ntt.log_n;
+    Q->ntt.n = P->ntt.n;
+    Q->ntt.tw_fwd.borrow(P->ntt.tw_fwd);
+    Q->ntt.tw_inv.borrow(P->ntt.tw_inv);
+    Q->ntt.s1_plain.borrow(P->ntt.s1_plain);
+    Q->ntt.s1_mont.borrow(P->ntt.s1_mont);
+    Q->ntt.s2.borrow(P->ntt.s2);
+    Q->ntt.coset_fwd.borrow(P->ntt.coset_fwd);
+    Q->ntt.coset_inv.borrow(P->ntt.coset_inv);
+    Q->ntt.consts.borrow(P->ntt.consts);
+    Q->alpha_g1_inf = P->alpha_g1_inf; Q->beta_g1_inf = P->beta_g1_inf; Q->beta_g2_inf = P->beta_g2_inf;
+    Q->delta_g1_inf = P->delta_g1_inf; Q->delta_g2_inf = P->delta_g2_inf;
+    Q->vk_bytes = P->vk_bytes;
+    return Q;
+}
+zk_r1cs* r1cs_clone_for_lane(const zk_r1cs* R) {
+    zk_r1cs* Q = new (std::nothrow) zk_r1cs();
+    if (!Q) return nullptr;
+    Q->device = R->device;
+    Q->n_in = R->n_in; Q->n_aux = R->n_aux; Q->n_con = R->n_con;
+    for (int m = 0; m < 3; m++) {
+        Q->row_ptr[m].borrow(R->row_ptr[m]);
+        Q->col[m].borrow(R->col[m]);
+        Q->coeff[m].borrow(R->coeff[m]);
+    }
+    Q->a_aux_density = R->a_aux_density;
+    Q->b_input_density = R->b_input_density;
+    Q->b_aux_density = R->b_aux_density;
+    return Q;
+}
+
 // Build (or reuse) the per-circuit index maps from the density trackers.
 zk_status ensure_maps(zk_params* P, uint32_t n_in, uint32_t n_aux, const uint8_t* a_aux_d, const uint8_t* b_in_d,
                       const uint8_t* b_aux_d) {
@@ -1935,6 +1980,12 @@ struct zk_pipeline {
     };
     zk_params* P = nullptr;
     zk_r1cs* R = nullptr;
+    // lane 1 (ZKAMD_PIPELINE_LANES, default 2): a second worker with its own workspaces and streams over the same
+    // tables - two chunks in flight, the sort / reduction / fold / witness phases of one beside the
+    // accumulation of the other
+    zk_params* P1 = nullptr;
+    zk_r1cs* R1 = nullptr;
+    std::thread t_gpu1;
     size_t chunk = 1024, nv = 0;
     PinBuf buf[2];
     std::mutex mu;
@@ -1979,10 +2030,13 @@ struct zk_pipeline {
     }
     // GPU-witness mode: one thread.  The witness kernels of the job behind the current one are enqueued (side
     // stream, other assignment buffer) before the current job is proved, so they run beside its multiexps.
-    void run_gpu_witness() {
+    void run_gpu_witness(int lane) {
         Job cur{}, nxt{};
         bool have_cur = false;
         int slot = 0;
+        g_lane = lane;
+        zk_params* P = lane ? this->P1 : this->P;
+        zk_r1cs* R = lane ? this->R1 : this->R;
         if (use_device(P->device) != ZK_OK) return;
         const hipStream_t wstream = g_copy_stream;
         auto start = [&](Job& j, int s) -> zk_status {
@@ -2004,8 +2058,9 @@ struct zk_pipeline {
             }
             bool have_nxt = false;
             {
+                // (with two lanes a job is only taken ahead of time if the other lane still finds one)
                 std::lock_guard<std::mutex> lk(mu);
-                if (!q_wit.empty()) {
+                if (q_wit.size() >= (size_t)(P1 ? 2 : 1)) {
                     nxt = q_wit.front();
                     q_wit.pop_front();
                     have_nxt = true;
@@ -2084,7 +2139,23 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
     }
     (void)zkwit::tables();
     if (!witness_on_host()) {
-        L->t_gpu = std::thread([L] { L->run_gpu_witness(); });
+        int lanes = 2;
+        if (const char* env = getenv("ZKAMD_PIPELINE_LANES")) lanes = atoi(env);
+#ifdef ZK_EMU
+        lanes = 1;   // the test-only emulation runs one launch at a time
+#endif
+        if (lanes >= 2) {
+            L->P1 = params_clone_for_lane(p);
+            L->R1 = r1cs_clone_for_lane(circuit);
+            if (!L->P1 || !L->R1) {
+                delete L->P1;
+                delete L->R1;
+                L->P1 = nullptr;
+                L->R1 = nullptr;
+            }
+        }
+        L->t_gpu = std::thread([L] { L->run_gpu_witness(0); });
+        if (L->P1) L->t_gpu1 = std::thread([L] { L->run_gpu_witness(1); });
     } else {
         for (int k = 0; k < 2; k++) {
             zk_status rc = L->buf[k].ensure(L->chunk * L->nv * 32);
@@ -2133,6 +2204,9 @@ void zk_pipeline_free(zk_pipeline* L) {
     }
     if (L->t_wit.joinable()) L->t_wit.join();
     if (L->t_gpu.joinable()) L->t_gpu.join();
+    if (L->t_gpu1.joinable()) L->t_gpu1.join();
+    delete L->P1;
+    delete L->R1;
     delete L;
 }
 
