@@ -245,6 +245,11 @@ def main():
                 gathered.append(zk.gather_proofs(o, B * world, dist=dist, device=gather_dev, dst=0))
         return outs
 
+    # priming (setup, not a warmup step): the second lane of the pipeline allocates its chunk workspaces the
+    # first time it proves, so both lanes are put through one batch before anything is counted
+    for _ in range(2):
+        pipe.submit(sts, rs_bytes[0])
+    pipe.wait(raw=True)
     run_steps(0, W)
     gathered.clear()
     fence()
