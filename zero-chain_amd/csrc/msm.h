@@ -770,20 +770,31 @@ k_msm_bitsum_combine(const XYZZ<F>* __restrict__ Y, XYZZ<F>* __restrict__ out, u
 // ---------------------------------------------------------------------------------------------
 // Table construction: table[k][i] = 2^k * P_i  (affine), k < MSM_NPOS, plus validity checks.
 // ---------------------------------------------------------------------------------------------
-// a^(q - 2) by square-and-multiply, MSB first (off the hot path: table construction only)
+// a^(q - 2) by square-and-multiply, MSB first (off the hot path: table construction, affine conversion).  One
+// out-of-line copy per field with rolled loops: inlined and unrolled over the constant exponent it is 380 call
+// sites per use and most of the library's compile time.
+#ifdef ZK_EMU
+#define ZK_POW_ATTR inline
+#else
+#define ZK_POW_ATTR __device__ __attribute__((noinline))
+#endif
 template <class F>
-ZK_DI F fq_pow_qm2(const F& a) {
+ZK_POW_ATTR F fq_pow_qm2(const F& a) {
     const uint32_t e[12] = ZK_FQ_EXP_QM2_32;
     F r = a;
     bool started = false;
-    for (int i = 11; i >= 0; i--)
+#pragma unroll 1
+    for (int i = 11; i >= 0; i--) {
+        const uint32_t w = e[i];
+#pragma unroll 1
         for (int b = 31; b >= 0; b--) {
             if (started) r = sqr(r);
-            if ((e[i] >> b) & 1u) {
+            if ((w >> b) & 1u) {
                 if (started) r = mul(r, a);
                 started = true;
             }
         }
+    }
     return r;
 }
 ZK_DI Fq28 inv(const Fq28& a) { return fq_pow_qm2(a); }

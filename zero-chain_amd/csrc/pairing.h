@@ -70,19 +70,23 @@ ZK_DI void fq_st(uint32_t* p, const Fq32& a) {
     for (int i = 0; i < 12; i++) p[i] = a.l[i];
 }
 
-// a^e for a public 12-word exponent, MSB first
+// a^e for a public 12-word exponent, MSB first (out of line, rolled loops: see fq_pow_qm2 in msm.h)
 template <class F>
-ZK_DI F pow12(const F& a, const uint32_t (&e)[12]) {
+ZK_POW_ATTR F pow12(const F& a, const uint32_t* e) {
     F r = a;
     bool started = false;
-    for (int i = 11; i >= 0; i--)
+#pragma unroll 1
+    for (int i = 11; i >= 0; i--) {
+        const uint32_t w = e[i];
+#pragma unroll 1
         for (int b = 31; b >= 0; b--) {
             if (started) r = sqr(r);
-            if ((e[i] >> b) & 1u) {
+            if ((w >> b) & 1u) {
                 if (started) r = mul(r, a);
                 started = true;
             }
         }
+    }
     return r;
 }
 

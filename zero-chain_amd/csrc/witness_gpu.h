@@ -127,18 +127,33 @@ ZK_DI Fr fr_u32(uint32_t v) {
     return zkdev::to_mont(x);
 }
 ZK_DI Fr fr_bit(uint32_t b) { return b ? Fr::one() : Fr::zero(); }
-ZK_DI Fr fr_inv(const Fr& a) {
-    const uint32_t e[8] = ZK_FR_EXP_RM2_32;
-    return zkdev::pow_limbs(a, e);
-}
-ZK_DI JP neutral() { return JP{Fr::zero(), Fr::one()}; }
-ZK_DI EP to_ext(const JP& p) { return EP{p.x, p.y, Fr::one(), mul(p.x, p.y)}; }
-
 #ifdef ZK_EMU
 #define ZKW_NOINLINE inline
 #else
 #define ZKW_NOINLINE __device__ __attribute__((noinline))
 #endif
+// a^e for a 256-bit exponent, most significant bit first.  One out-of-line copy with rolled loops: inlined and
+// unrolled (the exponents are constants) it is 256 call sites per use and minutes of compile time.
+ZKW_NOINLINE Fr fr_pow_words(const Fr& a, const uint32_t* e) {
+    Fr r = Fr::one();
+#pragma unroll 1
+    for (int i = 7; i >= 0; i--) {
+        const uint32_t w = e[i];
+#pragma unroll 1
+        for (int b = 31; b >= 0; b--) {
+            r = sqr(r);
+            if ((w >> b) & 1u) r = mul(r, a);
+        }
+    }
+    return r;
+}
+ZK_DI Fr fr_inv(const Fr& a) {
+    const uint32_t e[8] = ZK_FR_EXP_RM2_32;
+    return fr_pow_words(a, e);
+}
+ZK_DI JP neutral() { return JP{Fr::zero(), Fr::one()}; }
+ZK_DI EP to_ext(const JP& p) { return EP{p.x, p.y, Fr::one(), mul(p.x, p.y)}; }
+
 // unified addition, a = -1 (add-2008-hwcd-3 with k = 2 d); d2 = 2 d
 ZKW_NOINLINE EP ext_add(const EP& p, const EP& q, const Fr& d2) {
     const Fr a = mul(sub(p.Y, p.X), sub(q.Y, q.X));
@@ -346,15 +361,6 @@ ZK_DI void inputize(uint32_t* z, uint32_t at, const JP& p) {
 }
 
 // ---- Jubjub point decoding (core/jubjub/src/curve/edwards.rs:92-165): y with the sign of x in the top bit
-ZK_DI Fr fr_pow_words(const Fr& a, const uint32_t (&e)[8]) {
-    Fr r = Fr::one();
-    for (int i = 7; i >= 0; i--)
-        for (int b = 31; b >= 0; b--) {
-            r = sqr(r);
-            if ((e[i] >> b) & 1u) r = mul(r, a);
-        }
-    return r;
-}
 // square root by Tonelli-Shanks (2-adicity 32, non-residue 7: fr.rs:38-55); false if none
 ZK_DI bool fr_sqrt(const Fr& a, Fr* out) {
     if (a.is_zero()) {
