@@ -174,6 +174,14 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+    # The statements of this rank's block are made (or read from the cache) BEFORE any GPU runtime or process group
+    # exists in this process: the generator forks a pool of workers, and forking after HIP / RCCL initialisation is
+    # not safe.
+    cores = usable_cores()
+    host_threads = max(1, cores // world)
+    t_setup0 = time.time()
+    items = make_statements(rank * args.batch, rank * args.batch + args.batch, host_threads)
+
     import numpy as np
     import torch
     # ZK_BENCH_ONE_GPU=1 (check of the N > 1 code path on a 1-GPU box): every rank uses cuda:0 and the
@@ -203,13 +211,11 @@ def main():
     from oracle import bls12_381 as bls
     from oracle import synth
     lib = zk.load_library()
-    # every rank takes its share of the host cores (witness calculation, encoding), not all of them
-    cores = usable_cores()
-    host_threads = max(1, cores // world)
+    # every rank takes its share of the host cores (encoding, the optional host witness calculator), not all of them
     lib.zk_set_host_threads(host_threads)
 
     B, K, W = args.batch, args.steps, args.warmup
-    t0 = time.time()
+    t0 = t_setup0
     r1cs, P = build_circuit(host_threads)
     mats = zk.ConstraintMatrices.transfer_circuit(device=dev_index, lib=lib)   # emitted natively (transfer_r1cs.h)
     digest, _, _, _ = zk.transfer_r1cs_fingerprint(lib)
@@ -221,7 +227,6 @@ def main():
     # this rank's block of the B * world distinct statements of a step (the same statements every step,
     # fresh (r, s) per step and proof)
     lo = rank * B
-    items = make_statements(lo, lo + B, host_threads)
     sts = zk.transfer_statements(items)
     setup_s = time.time() - t0
     rng = synth.SplitMix64(99 + rank)

@@ -147,7 +147,7 @@ def test_transfer_circuit_from_witness(gpu_lib):
         params.close()
 
 
-def test_anonymous_circuit_from_witness(gpu_lib):
+def test_anonymous_circuit_from_witness(gpu_lib, monkeypatch):
     """The reference's second circuit (anonymous transfer: 50 514 constraints, 105 inputs, evaluation
     domain 2^16) through the same kernels: proofs from the variable assignments, bit-exact against the
     discrete-log oracle."""
@@ -165,6 +165,13 @@ def test_anonymous_circuit_from_witness(gpu_lib):
         # and through the assignment boundary (zk_prove)
         pf = zk.create_proof(helpers.to_assignment(zk, asgs[1]), params, 5, 7)
         assert pf.write() == helpers.expected_proof_trapdoor(P, asgs[1], 5, 7)
+        # statement -> proof (zk_anonymous_prove_batch: host witness calculator + GPU), two chunks
+        from oracle import anonymous_circuit as ac
+        monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "2")
+        ws = [ac.make_witness(1 + i, amount=10 + i, balance=100 + 3 * i) for i in range(2)]   # the statements of anonymous_case(2)
+        sts = zk.anonymous_statements([ac.statement_dict(ws[i % 2]) for i in range(3)])
+        got = zk.anonymous_prove_batch(mats, params, sts, rs)
+        assert [p.write() for p in got] == [p.write() for p in proofs]
     finally:
         mats.close()
         params.close()

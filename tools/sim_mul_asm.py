@@ -255,3 +255,28 @@ if __name__ == "__main__":
     main28()
     main28(dual=True)
     main28_sqr()
+
+
+def worst_case_limbs():
+    """Column-accumulator headroom with the un-normalised operands dev_curve.h feeds (sub_raw / neg_raw: limbs up to
+    2^28 + 8 + 0x3fffffff < 2^30.33): FQ28 with such a FIRST operand, FQ28MAC2 with such a y0 and an x1 < 2^30."""
+    p = g.FQ_P
+    big = (1 << 28) + 8 + 0x3fffffff
+    norm = (1 << 28) + 8
+    top = 13 * (p >> 364)            # a top limb worth 13 p
+    a_raw = [big] * 13 + [top]
+    b_norm = [norm] * 13 + [top]
+    spec = g.gen28(p, "FQ28")
+    _run_regs(spec["lines"], {**{i: a_raw[i] for i in range(14)}, **{16 + i: b_norm[i] for i in range(14)}}, 14)
+    spec = g.gen28_mac2(p, "FQ28MAC2")
+    x1_raw = [0x3fffffff] * 13 + [top]
+    init = {}
+    for blk, limbs in enumerate((b_norm, a_raw, x1_raw, b_norm)):   # x0 norm, y0 raw, x1 raw, y1 norm
+        for i in range(14):
+            init[16 * blk + i] = limbs[i]
+    _run_regs(spec["lines"], init, 14)
+    print("worst-case limbs: no 64-bit column overflow in FQ28 (raw first operand) and FQ28MAC2 (raw y0, raw x1)")
+
+
+if __name__ == "__main__":
+    worst_case_limbs()

@@ -26,7 +26,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "transfer_requests", "transfer_derive", "gen_proofs", "gen_proof", "XT_FIELDS",
-           "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_statements", "anonymous_witness",
+           "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_statements", "anonymous_witness", "anonymous_prove_batch",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
@@ -600,6 +600,17 @@ def anonymous_witness(statements, montgomery=False, lib=None):
     out = np.zeros(n * (ANONYMOUS_N_INPUTS + ANONYMOUS_N_AUX) * 32, dtype=np.uint8)
     lib.check(lib.zk_anonymous_witness(statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
     return out
+
+
+def anonymous_prove_batch(matrices, params, statements, rs):
+    """zk_anonymous_prove_batch: statements of the anonymous-transfer circuit -> proofs."""
+    lib = params._lib
+    n = len(statements)
+    rsb = scalars_to_bytes([x for pair in rs for x in pair])
+    out = np.zeros(PROOF_SIZE * n, dtype=np.uint8)
+    lib.check(lib.zk_anonymous_prove_batch(params._h, matrices._h, n, statements, _ptr(rsb), _ptr(out)))
+    ob = out.tobytes()
+    return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
 
 
 def transfer_prove_batch(matrices, params, statements, rs):

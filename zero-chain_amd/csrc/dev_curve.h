@@ -54,6 +54,20 @@ ZK_DI F mul_sub2(const F& x0, const F& y0, const F& x1, const F& y1) {
     return sub_b<F::MO>(mul(x0, y0), mul(x1, y1));
 }
 
+// Lazily normalised helpers: on Fq28 a difference that is consumed once - as the first operand of a product, or
+// by mul_sub2 next to a normalised partner - skips its carry pass (dev_field.h sub_raw); every other field
+// takes the ordinary subtraction.  x3 = a - b - 2 c is one pass with one normalisation where the field has it.
+template <int B, class F>
+ZK_DI F sub_lazy(const F& a, const F& b) { return wr(sub_b<B>(a, b)); }
+template <int B>
+ZK_DI Fq28 sub_lazy(const Fq28& a, const Fq28& b) { return sub_raw<B>(a, b); }
+template <int B, class F>
+ZK_DI F neg_lazy(const F& a) { return neg_b<B>(a); }
+template <int B>
+ZK_DI Fq28 neg_lazy(const Fq28& a) { return neg_raw<B>(a); }
+template <int BB, int BC, class F>
+ZK_DI F sub_sub2(const F& a, const F& b, const F& c) { return sub_b<2 * BC>(sub_b<BB>(a, b), dbl(c)); }
+
 // bound of a value after wr(): F::WB where wr() reduces, unchanged where it is the identity
 template <class F>
 constexpr int wrb(int b) { return b < F::WB ? b : F::WB; }
@@ -96,11 +110,11 @@ ZK_DI XYZZ<F> xdbl(const XYZZ<F>& a) {
 template <class F>
 ZK_DI void madd(XYZZ<F>& acc, const Affine<F>& p, bool negate) {
     constexpr int MO = F::MO, BX = XYZZ<F>::BX, BY = XYZZ<F>::BY;
-    F py = negate ? neg_b<MO>(p.y) : p.y;                       // < MO + 1
     if (acc.is_inf()) {
-        acc = XYZZ<F>{p.x, py, F::one(), F::one()};
+        acc = XYZZ<F>{p.x, negate ? neg_b<MO>(p.y) : p.y, F::one(), F::one()};
         return;
     }
+    F py = negate ? neg_lazy<MO>(p.y) : p.y;                    // < MO + 1; first operand of ONE product
     F u2 = mul(p.x, acc.zz);
     F s2 = mul(py, acc.zzz);
     F pp_ = wr(sub_b<BX>(u2, acc.x));                           // < MO + BX + 1
@@ -112,14 +126,14 @@ ZK_DI void madd(XYZZ<F>& acc, const Affine<F>& p, bool negate) {
     if (zz3.is_zero_norm()) {
         // p.x == acc.x: the same point (double it) or its negative (infinity)
         if (is_zero_full(r)) {
-            acc = mdbl(Affine<F>{p.x, py});
+            acc = mdbl(Affine<F>{p.x, negate ? neg_b<MO>(p.y) : p.y});
         } else {
             acc = XYZZ<F>::inf();
         }
         return;
     }
-    F x3 = sub_b<2 * MO>(sub_b<MO>(sqr_b<MO + BY + 1>(r), ppp), dbl(q));   // < 4 MO + 2 = BX
-    F t = wr(sub_b<BX>(q, x3));
+    F x3 = sub_sub2<MO, MO>(sqr_b<MO + BY + 1>(r), ppp, q);     // r^2 - ppp - 2 q  < 4 MO + 2 = BX
+    F t = sub_lazy<BX>(q, x3);
     F y3 = mul_sub2<BY>(r, t, acc.y, ppp);                      // < 2 MO + 1 = BY
     acc.x = x3;
     acc.y = y3;
@@ -147,8 +161,8 @@ ZK_DI XYZZ<F> xadd(const XYZZ<F>& a, const XYZZ<F>& b) {
         if (is_zero_full(r)) return xdbl(a);
         return XYZZ<F>::inf();
     }
-    F x3 = sub_b<2 * MO>(sub_b<MO>(sqr_b<2 * MO + 1>(r), ppp), dbl(q));
-    F t = wr(sub_b<BX>(q, x3));
+    F x3 = sub_sub2<MO, MO>(sqr_b<2 * MO + 1>(r), ppp, q);
+    F t = sub_lazy<BX>(q, x3);
     F y3 = mul_sub2<MO>(r, t, s1, ppp);
     return XYZZ<F>{x3, y3, zz3, mul(mul(a.zzz, b.zzz), ppp)};
 }

@@ -536,6 +536,35 @@ ZK_DI Fq28 neg_b(const Fq28& a) {
     return sub_b<B>(Fq28::zero(), a);
 }
 
+// The same WITHOUT the weak normalisation (limbs < 2^30.4): allowed where the value is consumed exactly once as
+// the FIRST operand of a product (mul: 14 x 2^58.4 + the reduction's 2^59.8 < 2^64) or as an operand of mul_sub2
+// whose partner is normalised.  Saves the 41-instruction carry pass.
+template <int B>
+ZK_DI Fq28 sub_raw(const Fq28& a, const Fq28& b) {
+    static_assert(B + 1 >= 2 && B + 1 <= 64, "no spread constant for this bound");
+    ZK_FQ28_CHECK(fq28_ratio(b.l) < (long double)B);
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + Fq28Spread<B + 1>::V[i] - b.l[i];
+    return r;
+}
+template <int B>
+ZK_DI Fq28 neg_raw(const Fq28& a) {
+    return sub_raw<B>(Fq28::zero(), a);
+}
+// a - b - 2 c + (BB + 2 BC + 1) p in one pass with one normalisation (x3 = r^2 - ppp - 2 q of a point addition)
+template <int BB, int BC>
+ZK_DI Fq28 sub_sub2(const Fq28& a, const Fq28& b, const Fq28& c) {
+    static_assert(BB + 2 * BC + 1 <= 64, "no spread constant for this bound");
+    ZK_FQ28_CHECK(fq28_ratio(b.l) < (long double)BB && fq28_ratio(c.l) < (long double)BC);
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + Fq28Spread<BB + 2 * BC + 1>::V[i] - b.l[i] - 2u * c.l[i];
+    fq28_wnorm(r.l);
+    ZK_FQ28_CHECK(fq28_ratio(r.l) < 64.0L);
+    return r;
+}
+
 ZK_DI Fq28 mul(const Fq28& a, const Fq28& b) {
     ZK_FQ28_CHECK(fq28_ratio(a.l) * fq28_ratio(b.l) < 2500.0L);
     u32x16 av, bv;
@@ -807,6 +836,10 @@ template <int B>
 ZK_DI Fq2x sub_b(const Fq2x& a, const Fq2x& b) { return Fq2x{sub_b<B>(a.c0, b.c0), sub_b<B>(a.c1, b.c1)}; }
 template <int B>
 ZK_DI Fq2x neg_b(const Fq2x& a) { return Fq2x{neg_b<B>(a.c0), neg_b<B>(a.c1)}; }
+template <int BB, int BC>
+ZK_DI Fq2x sub_sub2(const Fq2x& a, const Fq2x& b, const Fq2x& c) {
+    return Fq2x{sub_sub2<BB, BC>(a.c0, b.c0, c.c0), sub_sub2<BB, BC>(a.c1, b.c1, c.c1)};
+}
 ZK_DI Fq2x wr(const Fq2x& a) { return a; }
 ZK_DI bool is_zero_full(const Fq2x& a) { return is_zero_full(a.c0) && is_zero_full(a.c1); }
 ZK_DI Fq2x mul(const Fq2x& a, const Fq2x& b) {

@@ -1728,6 +1728,54 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
     return ZK_OK;
 }
 
+// Statement -> proof for the anonymous-transfer circuit (core/proofs/src/anonymous.rs:165: create_random_proof of
+// AnonymousTransfer): the native host witness calculator (transfer_witness.h: synthesize_anonymous) on the host cores,
+// the witnesses of chunk k + 1 computed while the GPU proves chunk k.  (The transfer circuit's generator runs on the
+// GPU; this circuit keeps the host calculator - its fingerprint is unpinned by the reference, see DESIGN.md.)
+zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_anonymous_statement* st, const uint8_t* rs,
+                                   uint8_t* proofs_out) {
+    if (!p || !circuit || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (circuit->n_in != ZK_ANONYMOUS_N_INPUTS || circuit->n_aux != ZK_ANONYMOUS_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the anonymous-transfer circuit's");
+    if (n == 0) return ZK_OK;
+    ZK_TRY(use_device(p->device));
+    const size_t nv = ZK_ANONYMOUS_N_INPUTS + ZK_ANONYMOUS_N_AUX;
+    size_t chunk = batch_chunk();
+    if (chunk > 512) chunk = 512;   // domain 2^16: half the proofs of a transfer chunk fill the same workspaces
+    const size_t cap = std::min(chunk, n) * nv * 32;
+    ZK_TRY(circuit->host_ensure(2 * cap));
+    uint8_t* buf[2] = {(uint8_t*)circuit->host_z, (uint8_t*)circuit->host_z + cap};
+    auto witness = [&](size_t first, size_t np, uint8_t* out) -> zk_status {
+        return witness_batch<zkwit::AnonStatement>(
+            np, ZK_ANONYMOUS_N_INPUTS, ZK_ANONYMOUS_N_AUX, ZK_FR_MONTGOMERY, out,
+            [&](size_t i, zkwit::AnonStatement* s) { return anonymous_decode(st[first + i], first + i, s); },
+            [](const zkwit::AnonStatement& s, zkwit::Wit& w) { zkwit::synthesize_anonymous(s, w); });
+    };
+    ZK_TRY(witness(0, std::min(chunk, n), buf[0]));
+    int cur = 0;
+    for (size_t first = 0; first < n; first += chunk) {
+        const size_t np = std::min(chunk, n - first), next = first + chunk;
+        zk_status next_rc = ZK_OK;
+        std::string next_err;
+        std::thread producer;
+        if (next < n)
+            producer = std::thread([&, next] {
+                next_rc = witness(next, std::min(chunk, n - next), buf[cur ^ 1]);
+                if (next_rc != ZK_OK) next_err = g_err;
+            });
+        // prove_batch_witness cuts at its own chunk size: keep the two equal for this call
+        zk_status rc = ZK_OK;
+        for (size_t off = 0; off < np && rc == ZK_OK; off += chunk)
+            rc = prove_batch_witness(p, circuit, std::min(chunk, np - off), buf[cur] + off * nv * 32, ZK_FR_MONTGOMERY,
+                                     rs + (first + off) * 64, proofs_out + (first + off) * 192);
+        if (producer.joinable()) producer.join();
+        if (rc != ZK_OK) return rc;
+        if (next_rc != ZK_OK) return fail(next_rc, next_err);
+        cur ^= 1;
+    }
+    return ZK_OK;
+}
+
 // The witness vectors the GPU generator produces, copied back to the host: lets the tests compare it with the
 // host calculator (zk_transfer_witness) element by element.  witness_out: n x (23 + 19955) x 32 bytes.
 zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
