@@ -320,6 +320,11 @@ zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* pu
 typedef struct zk_msm zk_msm;
 zk_status zk_msm_create(int group /*1 = G1, 2 = G2*/, const uint8_t* bases, size_t n, int window_bits /*0 = auto*/,
                         int checked, int device, zk_msm** out);
+/* The same handle WITHOUT the table of doublings (bases that are used once or a few times: only the n bases stay
+ * resident): a scalar is recoded into odd signed digits of `window_bits` bits at fixed positions (0 = auto), one
+ * bucket set per digit position, the position results folded with doublings - classic variable-base Pippenger. */
+zk_status zk_msm_create_variable(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device,
+                                 zk_msm** out);
 zk_status zk_msm_run(zk_msm* m, const uint8_t* scalars, uint32_t flags, uint8_t* out);
 /* scalars already in HBM (device pointer, n x 32 bytes); out is a host buffer */
 zk_status zk_msm_run_dev(zk_msm* m, const void* d_scalars, uint32_t flags, uint8_t* out);

@@ -89,7 +89,7 @@ def ntt_roundtrip_dev_orders(lib, logn, alloc):
         assert got == [x * pow(ginv, i, bls.R_MOD) % bls.R_MOD for i, x in enumerate(v)]
 
 
-def msm_golden_vectors(lib, group, n, window_bits, seed=1):
+def msm_golden_vectors(lib, group, n, window_bits, seed=1, variable_base=False):
     """Bases = the reference's golden multiples k*G (k = 0..255, index 0 is the point at
     infinity), repeated to length n; sum_i s_i * (k_i G) == (sum_i s_i k_i) G."""
     name = "g1_uncompressed" if group == 1 else "g2_uncompressed"
@@ -104,7 +104,11 @@ def msm_golden_vectors(lib, group, n, window_bits, seed=1):
         ks[7], sc[7] = ks[6], sc[6]        # same base, same scalar: forces the doubling branch
         ks[8] = 0                          # a base at infinity
     bases = b"".join(pts[k] for k in ks)
-    ctx = zk.MultiexpContext(group, bases, window_bits=window_bits, checked=(n <= 64), lib=lib)
+    if variable_base:   # even / odd scalars at the ends of the range, digits that sit on the window boundaries
+        for i, special in enumerate((bls.R_MOD - 2, (1 << 254) + 1, 1 << 200, (1 << 255) % bls.R_MOD, 3)):
+            if 9 + i < n:
+                sc[9 + i] = special
+    ctx = zk.MultiexpContext(group, bases, window_bits=window_bits, checked=(n <= 64), lib=lib, variable_base=variable_base)
     try:
         got = ctx.run(sc)
         want = sum(a * b for a, b in zip(ks, sc)) % bls.R_MOD
@@ -116,6 +120,16 @@ def msm_golden_vectors(lib, group, n, window_bits, seed=1):
         assert ctx.run([0] * n)[0] == 0x40 or n == 0
     finally:
         ctx.close()
+
+
+def msm_variable_base(lib, windows=(2, 3, 5, 8, 11, 13), n=400):
+    """zk_msm_create_variable (classic Pippenger, no table of doublings: regular odd-digit recoding at fixed positions,
+    one job per position) on the golden multiples, for several digit widths, both groups and the auto width."""
+    for w in windows:
+        msm_golden_vectors(lib, 1, n, w, seed=40 + w, variable_base=True)
+    msm_golden_vectors(lib, 2, 120, 4, seed=77, variable_base=True)
+    msm_golden_vectors(lib, 1, 700, 0, seed=78, variable_base=True)
+    msm_golden_vectors(lib, 1, 1, 3, seed=79, variable_base=True)
 
 
 def msm_recoding_stress(lib, windows=range(2, 23)):

@@ -143,3 +143,7 @@ def test_witness_gpu_matches_host(emu_lib):
 
 def test_setup_matches_oracle(emu_lib):
     pc.setup_matches_oracle(emu_lib)
+
+
+def test_msm_variable_base(emu_lib):
+    pc.msm_variable_base(emu_lib, windows=(2, 5, 9), n=150)

@@ -434,3 +434,29 @@ def test_gen_proof_confidential_xt(gpu_lib):
         pvk.close()
         mats.close()
         params.close()
+
+
+def test_msm_variable_base(gpu_lib):
+    pc.msm_variable_base(gpu_lib)
+
+
+def test_msm_variable_base_2p17_vs_table(gpu_lib):
+    """2^17 distinct bases: the variable-base multiexp (no table of doublings) and the resident-table multiexp give the
+    same point (and the C restatement of bellman's algorithm agrees)."""
+    import zero_chain_amd as zk
+    n = 1 << 17
+    rng = np.random.default_rng(5)
+    ks = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    ks[:, 3] >>= 2
+    bases = cport.fixed_base_mul(1, ks.tobytes(), 8)
+    sc = np.random.default_rng(6).integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] >>= 2
+    scb = sc.view(np.uint8).reshape(-1)
+    a = zk.MultiexpContext(1, bases, lib=gpu_lib)
+    b = zk.MultiexpContext(1, bases, lib=gpu_lib, variable_base=True)
+    try:
+        ra, rb = a.run(scb), b.run(scb)
+        assert ra == rb == cport.Bases(1, bases).multiexp(scb.tobytes(), 8)
+    finally:
+        a.close()
+        b.close()

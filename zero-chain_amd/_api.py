@@ -674,15 +674,16 @@ class TransferPipeline:
 class MultiexpContext:
     """Bases resident on the GPU (window tables built once); run() = bellman multiexp, FullDensity."""
 
-    def __init__(self, group, bases, window_bits=0, checked=False, device=0, lib=None):
+    def __init__(self, group, bases, window_bits=0, checked=False, device=0, lib=None, variable_base=False):
+        """variable_base=True: no table of doublings (zk_msm_create_variable): classic Pippenger over the bases."""
         self._lib = lib or _lib.load()
         self.group = {"g1": 1, "g2": 2, 1: 1, 2: 2}[group]
         self.point_size = 96 if self.group == 1 else 192
         b = _u8(bases)
         self.n = b.size // self.point_size
         h = C.c_void_p()
-        self._lib.check(self._lib.zk_msm_create(self.group, _ptr(b), self.n, window_bits, 1 if checked else 0, device,
-                                                C.byref(h)))
+        create = self._lib.zk_msm_create_variable if variable_base else self._lib.zk_msm_create
+        self._lib.check(create(self.group, _ptr(b), self.n, window_bits, 1 if checked else 0, device, C.byref(h)))
         self._h = h
 
     def run(self, scalars, montgomery=False):

@@ -119,6 +119,7 @@ _PROTOS = {
     "zk_anonymous_prove_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AnonymousStatement), C.c_void_p,
                                              C.c_void_p]),
     "zk_msm_create": (C.c_int32, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_msm_create_variable": (C.c_int32, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_msm_run": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zk_msm_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     "zk_msm_free": (None, [C.c_void_p]),

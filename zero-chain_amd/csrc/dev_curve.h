@@ -72,12 +72,12 @@ ZK_DI F sub_sub2(const F& a, const F& b, const F& c) { return sub_b<2 * BC>(sub_
 template <class F>
 constexpr int wrb(int b) { return b < F::WB ? b : F::WB; }
 
-// 2 * (affine p) -> XYZZ     (EFD mdbl-2008-s-1); p not infinity
+// 2 * (affine p) -> XYZZ     (EFD mdbl-2008-s-1); p not infinity.  p.y may be a negated table entry (< MO + 1).
 template <class F>
 ZK_DI XYZZ<F> mdbl(const Affine<F>& p) {
     constexpr int MO = F::MO;
-    F u = dbl(p.y);                                             // < 2 MO
-    F v = sqr_b<2 * MO>(u);
+    F u = dbl(p.y);                                             // < 2 (MO + 1)
+    F v = sqr_b<2 * (MO + 1)>(u);
     F w = mul(u, v);
     F s = mul(p.x, v);
     F xx = sqr_b<MO>(p.x);

@@ -35,6 +35,9 @@ struct MsmJob {
     uint32_t table_base;      // index of [k = 0][0] of this job's bases inside the group table
     uint32_t n_table;         // table entries per slice
     uint32_t pair_base;       // first slot of this job in the rank / pair arrays
+    uint32_t vb_digit;        // 0: width-c NAF over the doubling table (every digit of every scalar);
+                              // k + 1: VARIABLE-BASE mode, this job takes digit k of every scalar (see msm_digits)
+    uint32_t reserved;
 };
 
 // Register budgets.  hipcc sizes a kernel's VGPR allocation from its launch bounds alone (it will
@@ -161,6 +164,67 @@ ZK_DI void msm_wnaf(const uint32_t* __restrict__ sp, uint32_t c, Fn&& f) {
     }
 }
 
+// Variable-base mode (no doubling table: bases that are used once).  A scalar is recoded into ODD signed digits at
+// FIXED positions - the regular recoding: for odd k, d_i = (k_i mod 2^(w+1)) - 2^w with k_(i+1) = (k_i - d_i) / 2^w,
+// which unrolls to k_i = (k >> w i) | 1, so every digit is a function of w + 1 bits of k alone:
+//     d_i = (((k >> w i) & (2^(w+1) - 1)) | 1) - 2^w      (i < W - 1),        d_(W-1) = (k >> w (W - 1)) | 1
+// with w = c - 1 window bits for the kernels' parameter c (odd magnitudes < 2^w: the same 2^(c-2) buckets and the same
+// weights 2 b + 1 as the NAF digits).  An even scalar is replaced by r - s (odd) with every sign flipped.  One job per
+// digit position, all over the SAME bases; the host folds the W job results with w doublings between them.
+ZK_DI bool msm_vb_digit(const uint32_t* __restrict__ sp, uint32_t c, uint32_t digit, uint32_t n_digits, uint32_t* mag, bool* negative) {
+    uint32_t s[9];
+    const uint4* q = reinterpret_cast<const uint4*>(sp);
+    const uint4 lo = q[0], hi = q[1];
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w;
+    s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
+    s[8] = 0;
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) any |= s[i];
+    if (!any) return false;
+    const bool flip = (s[0] & 1u) == 0;
+    if (flip) {   // r - s
+        uint32_t bo = 0, co;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            s[i] = __builtin_subc(MsmConsts::R[i], s[i], bo, &co);
+            bo = co;
+        }
+    }
+    const uint32_t w = c - 1, bit = w * digit, word = bit >> 5, sh = bit & 31;
+    uint32_t lo_w = 0, hi_w = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {   // no dynamically indexed register array
+        if ((uint32_t)i == word) {
+            lo_w = s[i];
+            hi_w = s[i + 1];
+        }
+    }
+    const uint64_t two = (uint64_t)lo_w | ((uint64_t)hi_w << 32);
+    uint32_t t = (uint32_t)(two >> sh);
+    if (digit + 1 < n_digits) {
+        t = (t & ((2u << w) - 1u)) | 1u;
+        const int32_t d = (int32_t)t - (int32_t)(1u << w);
+        *mag = (uint32_t)(d < 0 ? -d : d);
+        *negative = (d < 0) != flip;
+    } else {
+        *mag = t | 1u;   // the bits above the last position: < 2^w by the choice of the digit count
+        *negative = flip;
+    }
+    return true;
+}
+// digits of scalar i of a job, in either mode: f(slot, bit position of the table slice, odd magnitude, negative)
+template <class Fn>
+ZK_DI void msm_digits(const MsmJob& job, uint32_t i, uint32_t c, Fn&& f) {
+    if (job.vb_digit == 0) {
+        msm_wnaf(job.scalars + (size_t)i * 8, c, f);
+    } else {
+        uint32_t mag;
+        bool negative;
+        if (msm_vb_digit(job.scalars + (size_t)i * 8, c, job.vb_digit - 1, job.reserved, &mag, &negative)) f(0u, 0u, mag, negative);
+    }
+}
+
 // Passes 1-3 for jobs whose bucket histogram does NOT fit LDS (one or a few large multiexps,
 // c >= 17): a two-level counting sort that keeps every per-digit atomic in LDS.
 //   coarse bin = bucket >> fine_log  (n_coarse <= 1024 bins of `fine` = 2^fine_log buckets)
@@ -190,8 +254,7 @@ k_msm_coarse_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_lo
     for (uint32_t e = 0; e < MSM_COARSE_SCALARS / 256; e++) {
         const uint32_t i = blockIdx.x * MSM_COARSE_SCALARS + e * 256 + tid;
         if (i >= job.n || (job.map && job.map[i] < 0)) continue;
-        msm_wnaf(job.scalars + (size_t)i * 8, c,
-                 [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[(mag >> 1) >> fine_log], 1u); });
+        msm_digits(job, i, c, [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[(mag >> 1) >> fine_log], 1u); });
     }
     __syncthreads();
     uint32_t* bb = blockbase + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n_coarse;
@@ -248,7 +311,7 @@ k_msm_coarse_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_
         const int32_t pos = job.map ? job.map[i] : (int32_t)i;
         if (pos < 0) continue;
         const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
-        msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
+        msm_digits(job, i, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
             const uint32_t b = mag >> 1;
             const uint32_t slot = atomicAdd(&h[b >> fine_log], 1u);
             jrec[slot] = make_uint2(b & fmask, ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u));
@@ -361,7 +424,7 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
     __syncthreads();
     for (uint32_t i = tid; i < job.n; i += nt) {
         if (job.map && job.map[i] < 0) continue;
-        msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[mag >> 1], 1u); });
+        msm_digits(job, i, c, [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[mag >> 1], 1u); });
     }
     __syncthreads();
     // exclusive scans of the counts (pair slots) and of the task counts; thread t owns buckets [t*per, ..)
@@ -405,7 +468,7 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
         int32_t pos = job.map ? job.map[i] : (int32_t)i;
         if (pos < 0) continue;
         const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
-        msm_wnaf(job.scalars + (size_t)i * 8, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
+        msm_digits(job, i, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
             uint32_t slot = atomicAdd(&h[mag >> 1], 1u);
             jpairs[slot] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
         });

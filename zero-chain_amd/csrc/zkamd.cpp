@@ -252,13 +252,16 @@ struct MsmGroup {
     std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
 
-    zk_status build(const std::vector<HAffine>& pts, uint32_t c_, bool checked, const char* what) {
+    // with_table = false: variable-base mode - only the bases themselves are kept (slice 0), every job takes ONE
+    // digit of every scalar (msm.h msm_digits)
+    zk_status build(const std::vector<HAffine>& pts, uint32_t c_, bool checked, const char* what, bool with_table = true) {
         c = c_;
-        maxd = zkdev::msm_max_digits(c);
+        maxd = with_table ? zkdev::msm_max_digits(c) : 1u;
         nb = 1u << (c - 2);
         n_points = pts.size();
-        if ((uint64_t)n_points * zkdev::MSM_NPOS >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "doubling table too large");
-        size_t tb = sizeof(DAffine) * n_points * zkdev::MSM_NPOS;
+        const uint32_t npos = with_table ? zkdev::MSM_NPOS : 1u;
+        if ((uint64_t)n_points * npos >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "doubling table too large");
+        size_t tb = sizeof(DAffine) * n_points * npos;
         ZK_TRY(table.ensure(tb ? tb : 1));
         bytes = tb;
         if (!n_points) return ZK_OK;
@@ -273,7 +276,7 @@ struct MsmGroup {
             HIP_TRY(hipStreamSynchronize(g_stream));
         }
         if (checked) ZK_TRY((check_points_dev<HF, DF>(table.as<DAffine>(), n_points, what)));
-        {
+        if (with_table) {
             DevBuf scratch;   // chunk of un-normalised slices + prefix products, freed after the build
             ZK_TRY(scratch.ensure((size_t)zkdev::MSM_TABLE_CHUNK * 5 * sizeof(DF) * n_points));
             ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3(blocks), dim3(128), 0, g_stream, table.as<DAffine>(),
@@ -1366,6 +1369,7 @@ struct zk_msm {
     MsmG2 g2;
     DevBuf map, scal, conv;
     bool has_map = false;
+    uint32_t vb_window = 0;   // > 0: variable-base mode with this many bits per digit (no doubling table)
 };
 struct zk_ntt {
     int device = 0;
@@ -1388,7 +1392,8 @@ size_t msm_slice(size_t n) {
     return 0;
 }
 
-zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
+zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out,
+                     bool variable = false) {
     if (group != 1 && group != 2) return fail(ZK_ERR_INVALID_ARGUMENT, "group must be 1 (G1) or 2 (G2)");
     if (!bases && n) return fail(ZK_ERR_INVALID_ARGUMENT, "null bases");
     ZK_TRY(use_device(device));
@@ -1401,8 +1406,26 @@ zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits,
     M->group = group;
     M->device = device;
     M->n = n;
-    M->slice = window_bits > 0 ? 0 : msm_slice(n);
+    M->slice = (window_bits > 0 || variable) ? 0 : msm_slice(n);
     uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(M->slice ? M->slice : n, group);
+    if (variable) {
+        // digits of w bits at fixed positions, 255 / w jobs of 2^(w-1) buckets: minimise  n * 255 / w + beta * 2^(w-1) * 255 / w
+        uint32_t w = window_bits > 0 ? (uint32_t)window_bits : 0u;
+        if (!w) {
+            double best = 1e300;
+            const double beta = group == 2 ? 12.0 : 6.0;
+            for (uint32_t k = 2; k <= 20; k++) {
+                const double cost = (255.0 / k) * ((double)(n ? n : 1) + beta * (double)((size_t)1 << (k - 1)));
+                if (cost < best) {
+                    best = cost;
+                    w = k;
+                }
+            }
+        }
+        if (w < 2 || w > 20) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 20] for the variable-base mode");
+        M->vb_window = w;
+        c = w + 1;   // odd magnitudes < 2^w share the kernels' bucket layout for c = w + 1
+    }
     if (c < 2 || c > 22) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 22]");
     // points at infinity are legal multiexp bases: they are mapped out (map = -1)
     std::vector<int32_t> map(n);
@@ -1415,7 +1438,7 @@ zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits,
             map[i] = pts[i].is_inf() ? -1 : (int32_t)i;
             any_inf |= pts[i].is_inf();
         }
-        ZK_TRY(M->g1.build(pts, c, checked != 0, "bases"));
+        ZK_TRY(M->g1.build(pts, c, checked != 0, "bases", !variable));
     } else {
         std::vector<HG2A> pts(n);
         for (size_t i = 0; i < n; i++) {
@@ -1424,7 +1447,7 @@ zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits,
             map[i] = pts[i].is_inf() ? -1 : (int32_t)i;
             any_inf |= pts[i].is_inf();
         }
-        ZK_TRY(M->g2.build(pts, c, checked != 0, "bases"));
+        ZK_TRY(M->g2.build(pts, c, checked != 0, "bases", !variable));
     }
     if (any_inf) {
         ZK_TRY(M->map.ensure(n * 4));
@@ -1449,6 +1472,32 @@ zk_status msm_run_dev(zk_msm* M, const void* d_scalars, uint32_t flags, uint8_t*
     // a sliced multiexp is a batch of independent jobs over consecutive runs of the bases (their
     // table entries start at `first`; with a map the map already holds absolute positions)
     std::vector<MsmJob> jobs;
+    if (M->vb_window) {
+        // one job per digit position, all over the same bases; result = sum_k 2^(w k) R_k
+        const uint32_t w = M->vb_window, nd = (255 + w - 1) / w;
+        for (uint32_t k = 0; k < nd; k++) {
+            MsmJob j = {sc, M->has_map ? M->map.as<int32_t>() : nullptr, (uint32_t)M->n, 0u, (uint32_t)M->n, 0, k + 1, nd};
+            jobs.push_back(j);
+        }
+        auto fold = [&](auto& res, auto zero) {
+            auto acc = zero;
+            for (size_t k = res.size(); k-- > 0;) {
+                for (uint32_t d = 0; d < w; d++) acc = zkhost::pdbl(acc);
+                acc = zkhost::padd(acc, res[k]);
+            }
+            return acc;
+        };
+        if (M->group == 1) {
+            std::vector<HG1> res;
+            ZK_TRY(M->g1.run(jobs, res));
+            zkhost::g1_to_uncompressed(zkhost::to_affine(fold(res, HG1::inf())), out);
+        } else {
+            std::vector<HG2> res;
+            ZK_TRY(M->g2.run(jobs, res));
+            zkhost::g2_to_uncompressed(zkhost::to_affine(fold(res, HG2::inf())), out);
+        }
+        return ZK_OK;
+    }
     const size_t sl = M->slice ? M->slice : M->n;
     for (size_t first = 0; first < M->n; first += sl) {
         const uint32_t cnt = (uint32_t)std::min(sl, M->n - first);
@@ -2262,6 +2311,11 @@ zk_status zk_msm_create(int group, const uint8_t* bases, size_t n, int window_bi
     if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     return msm_create(group, bases, n, window_bits, checked, device, out);
+}
+zk_status zk_msm_create_variable(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
+    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    return msm_create(group, bases, n, window_bits, checked, device, out, true);
 }
 zk_status zk_msm_run(zk_msm* m, const uint8_t* scalars, uint32_t flags, uint8_t* out) { return msm_run(m, scalars, flags, out); }
 zk_status zk_msm_run_dev(zk_msm* m, const void* d_scalars, uint32_t flags, uint8_t* out) { return msm_run_dev(m, d_scalars, flags, out); }
