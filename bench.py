@@ -161,11 +161,21 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="statements per GPU per step (BASELINE config 4: 1024)")
     ap.add_argument("--no-micro", action="store_true")
+    ap.add_argument("--micro-only", action="store_true",
+                    help="only the 2^20 multiexp / NTT figures (BASELINE configs 2 and 3), printed as their own JSON object: "
+                         "the command the profiles of those kernels are taken with; not the driver's line")
     ap.add_argument("--no-secondary", action="store_true", help="skip the witness-resident secondary measurement")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--oracle-checks", type=int, default=6, help="proofs per rank compared with the oracle's proof")
     args = ap.parse_args()
 
+    if args.micro_only:
+        import torch
+        torch.cuda.set_device(0)
+        import zero_chain_amd as zk
+        lib = zk.load_library()
+        print(json.dumps({"micro": run_micro(lib, zk, torch.device("cuda", 0))}), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))

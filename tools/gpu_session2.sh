@@ -33,6 +33,18 @@ if [ "${DO_PMC:-0}" = "1" ]; then
     find $OUT/pmc_$name -type f -size +2M -delete
   done
 fi
+if [ "${DO_MICRO_PROF:-0}" = "1" ]; then
+  # the 2^20 multiexp (resident table and variable-base) and the 2^20 NTT pair: kernel trace + the counter passes
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/micro_prof -o trace -- python bench.py --micro-only > $OUT/micro_prof.json 2> $OUT/micro_prof.err; echo "micro prof rc=$?"
+  for f in $(find $OUT/micro_prof -name '*kernel_stats.csv'); do head -30 $f | cut -c1-200; done
+  find $OUT/micro_prof -type f ! -name '*stats*.csv' -delete
+  for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
+    name=$(echo $ctr | cut -d' ' -f1)
+    timeout 600 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/micro_pmc_$name -o pmc -- python bench.py --micro-only > $OUT/micro_pmc_$name.json 2> $OUT/micro_pmc_$name.err; echo "micro pmc $name rc=$?"
+    python tools/pmc_summary.py $OUT/micro_pmc_$name > $OUT/micro_pmc_$name.summary.txt 2>&1; head -30 $OUT/micro_pmc_$name.summary.txt
+    find $OUT/micro_pmc_$name -type f -size +2M -delete
+  done
+fi
 if [ -n "${EXTRA_CMD:-}" ]; then
   bash -c "$EXTRA_CMD" > $OUT/extra.log 2>&1; echo "extra rc=$?"; tail -30 $OUT/extra.log
 fi

@@ -21,7 +21,7 @@
 namespace zkdev {
 
 constexpr int NTT_MAX_G = 8;        // stages per pass
-constexpr int NTT_TILE_ELEMS = 2048;  // 64 KiB of LDS per workgroup
+constexpr int NTT_TILE_LOG = 10;   // 2^10 elements = 32 KiB of LDS per workgroup: 4 workgroups = 4 waves per SIMD on a CU
 constexpr int NTT_THREADS = 256;
 
 struct NttPass {
@@ -69,14 +69,37 @@ ZK_DI void raise_flag(uint32_t* bad, uint32_t bit) {
 #endif
 }
 
+// LDS tile layout: two planes of 16 bytes per element (limbs 0..3 | limbs 4..7), so that a wave's
+// ds_read_b128 of consecutive elements covers every bank once (an array of 32-byte elements read as
+// two b128 halves leaves every other quad of banks idle: 2-way conflicts).
+ZK_DI Fr ld_tile(const uint32_t* tile, uint32_t tile_elems, uint32_t e) {
+    Fr r;
+    const uint4 a = *reinterpret_cast<const uint4*>(tile + (size_t)e * 4);
+    const uint4 b = *reinterpret_cast<const uint4*>(tile + ((size_t)tile_elems + e) * 4);
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+ZK_DI void st_tile(uint32_t* tile, uint32_t tile_elems, uint32_t e, const Fr& v) {
+    *reinterpret_cast<uint4*>(tile + (size_t)e * 4) = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    *reinterpret_cast<uint4*>(tile + ((size_t)tile_elems + e) * 4) = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
 // One pass over a batch of polynomials (blockIdx.y = polynomial).  `tw` holds w^e (Montgomery)
 // for e in [0, n/2).  `pre` / `post` (optional, n entries each) are multiplied into every
 // element at load / store, indexed by the element's global position.  `src` (optional) replaces
 // `data` as the load source for the first pass of a chain.
-static __global__ void __launch_bounds__(NTT_THREADS)
+//
+// Occupancy is what this kernel is sensitive to: the Montgomery product is one long dependent
+// multiply-add chain per lane, so a SIMD needs ~4 waves to keep issuing.  Measured on MI355X (7 x 1024
+// transforms of 2^15, serial): 2^11-element tiles at 2 waves/SIMD 24.8 ms, 2^10-element tiles at 4
+// waves/SIMD 21.3 ms.  Taking two stages per LDS round trip (radix-4 groups in registers: half the LDS
+// traffic and barriers, the same products, since w^(n/4) is no cheaper than any other twiddle in a prime
+// field) measured 22.1 ms at the same occupancy and 26.4 ms at 2 waves/SIMD: rejected.
+static __global__ void __launch_bounds__(NTT_THREADS, 4)
 k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __restrict__ tw,
            const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post, NttPass ps, uint32_t* bad = nullptr) {
-    ZK_DYN_SHARED(uint32_t, tile);   // [2^g][CW][8]
+    ZK_DYN_SHARED(uint32_t, tile);   // 2 planes x [2^g][CW][4]
     const uint32_t k = ps.log_n, g = ps.g, lcw = ps.log_cw;
     const uint32_t rows = 1u << g, cw = 1u << lcw;
     // s = log2 of the smallest butterfly half-distance (in elements) handled by this pass
@@ -85,12 +108,13 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
     const uint32_t col0 = blockIdx.x << lcw;
     const uint32_t tid = threadIdx.x;
     const uint32_t tile_elems = rows << lcw;
+    const uint32_t smask = (1u << s) - 1;
 
     // ---- load tile (row-major over m, columns fastest => coalesced segments)
     for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
         uint32_t c = e & (cw - 1), m = e >> lcw;
         uint32_t col = col0 + c;
-        uint32_t hi = col >> s, lo = col & ((1u << s) - 1);
+        uint32_t hi = col >> s, lo = col & smask;
         uint32_t idx = (hi << (s + g)) | (m << s) | lo;
         Fr v;
         if (src) {
@@ -101,12 +125,12 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
             v = ld_fr(base + (size_t)idx * 8);
         }
         if (pre) v = mul(v, ld_fr(pre + (size_t)idx * 8));
-        st_fr(tile + e * 8, v);
+        st_tile(tile, tile_elems, e, v);
     }
     __syncthreads();
 
-    const uint32_t nbf = tile_elems >> 1;
     for (uint32_t j = 0; j < g; j++) {
+        const uint32_t nbf = tile_elems >> 1;
         // position (within m) of the bit that separates the two butterfly inputs
         const uint32_t pos = ps.dif ? (g - 1 - j) : j;
         const uint32_t half = 1u << pos;
@@ -115,24 +139,22 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
         for (uint32_t b = tid; b < nbf; b += NTT_THREADS) {
             uint32_t c = b & (cw - 1), mm = b >> lcw;
             uint32_t m = ((mm >> pos) << (pos + 1)) | (mm & (half - 1));
-            uint32_t col = col0 + c;
-            uint32_t lo = col & ((1u << s) - 1);
+            uint32_t lo = (col0 + c) & smask;
             // i mod d, d = half * 2^s
             uint32_t imod = ((m & (half - 1)) << s) | lo;
             uint32_t e = imod << tsh;
-            uint32_t* px = tile + ((m << lcw) | c) * 8;
-            uint32_t* py = tile + (((m + half) << lcw) | c) * 8;
-            Fr x = ld_fr(px), y = ld_fr(py);
+            const uint32_t ax = (m << lcw) | c, ay = ((m + half) << lcw) | c;
+            Fr x = ld_tile(tile, tile_elems, ax), y = ld_tile(tile, tile_elems, ay);
             if (ps.dif) {
                 Fr u = add(x, y);
                 Fr v = sub(x, y);
                 if (e) v = mul(v, ld_fr(tw + (size_t)e * 8));
-                st_fr(px, u);
-                st_fr(py, v);
+                st_tile(tile, tile_elems, ax, u);
+                st_tile(tile, tile_elems, ay, v);
             } else {
                 if (e) y = mul(y, ld_fr(tw + (size_t)e * 8));
-                st_fr(px, add(x, y));
-                st_fr(py, sub(x, y));
+                st_tile(tile, tile_elems, ax, add(x, y));
+                st_tile(tile, tile_elems, ay, sub(x, y));
             }
         }
         __syncthreads();
@@ -141,9 +163,9 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
     for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
         uint32_t c = e & (cw - 1), m = e >> lcw;
         uint32_t col = col0 + c;
-        uint32_t hi = col >> s, lo = col & ((1u << s) - 1);
+        uint32_t hi = col >> s, lo = col & smask;
         uint32_t idx = (hi << (s + g)) | (m << s) | lo;
-        Fr v = ld_fr(tile + e * 8);
+        Fr v = ld_tile(tile, tile_elems, e);
         if (post) v = mul(v, ld_fr(post + (size_t)idx * 8));
         st_fr(base + (size_t)idx * 8, v);
     }

@@ -77,7 +77,7 @@ struct NttPlan {
             p.log_n = k;
             p.t0 = t0;
             p.g = base + (i < extra ? 1 : 0);
-            uint32_t lcw = 11 - p.g;
+            uint32_t lcw = zkdev::NTT_TILE_LOG - p.g;
             if (lcw > k - p.g) lcw = k - p.g;
             p.log_cw = lcw;
             p.dif = dif ? 1 : 0;
