@@ -248,7 +248,7 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, struct zk_
  * the variable assignment bellman's ProvingAssignment would hold, [105 inputs | 50429 aux].  Scalars are
  * FsRepr::write_le bytes, points edwards::Point::write bytes; member i of the anonymity set owns
  * enc_keys[i], left_ciphertexts[i] and its encrypted balance (left, right).  Prove with
- * zk_prove_batch_witness over the circuit's matrices (zk_r1cs_load). */
+ * zk_prove_batch_witness over the circuit's matrices (zk_anonymous_r1cs_load). */
 #define ZK_ANONYMOUS_SIZE 12
 #define ZK_ANONYMOUS_N_INPUTS 105
 #define ZK_ANONYMOUS_N_AUX 50429
@@ -266,6 +266,36 @@ zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint3
  * the GPU, over the matrices loaded with zk_r1cs_load. */
 zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_anonymous_statement* st,
                                    const uint8_t* rs, uint8_t* proofs_out);
+/* The constraint system of that circuit, emitted natively (the structure half of AnonymousTransfer::synthesize):
+ * zk_anonymous_r1cs_load = zk_r1cs_load of its matrices; the fingerprint is defined as for the transfer circuit
+ * (core/proofs/src/circuit/test.rs:228-251).  The reference holds NO pin for it: the figures next to its test
+ * (anonymous_transfer.rs:446-451: 50 634 constraints, 625c4b5d...ea37) are commented out and stale against the
+ * source beside them, which has 50 514 constraints. */
+zk_status zk_anonymous_r1cs_load(int device, zk_r1cs** out);
+zk_status zk_anonymous_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs, uint32_t* n_aux, uint32_t* n_constraints);
+/* gen_proof of the anonymous transfer (ProofBuilder::gen_proof, core/proofs/src/anonymous.rs:97-183): the key
+ * derivations of the confidential entry, the anonymity set assembled with the sender at s_index, the recipient at
+ * t_index and the ten decoys in their order elsewhere (:117-126), MultiCiphertexts::<Anonymous>::encrypt
+ * (crypto_components.rs:168-220: -amount under the sender's key, +amount under the recipient's, zero under every
+ * decoy's, one randomness), the proof, check_proof over the 104 public coordinates (:200-262; ZK_ERR_UNSATISFIABLE if
+ * it fails) and the packing of AnonymousXt (:277-352).  enc_balances_* are indexed by set member.
+ * zk_anonymous_derive is the host half alone (request -> statement and rsk). */
+typedef struct {
+    uint32_t amount, remaining_balance, s_index, t_index;
+    uint8_t spending_key[32];
+    uint8_t enc_key_recipient[32], enc_keys_decoy[ZK_ANONYMOUS_SIZE - 2][32];
+    uint8_t enc_balances_left[ZK_ANONYMOUS_SIZE][32], enc_balances_right[ZK_ANONYMOUS_SIZE][32];
+    uint8_t g_epoch[32];
+    uint8_t randomness[32], alpha[32];
+} zk_anonymous_request;
+typedef struct {   /* AnonymousXt, anonymous.rs:344-352 */
+    uint8_t proof[192];
+    uint8_t enc_keys[ZK_ANONYMOUS_SIZE][32], left_ciphertexts[ZK_ANONYMOUS_SIZE][32];
+    uint8_t right_ciphertext[32], nonce[32], rsk[32], rvk[32];
+} zk_anonymous_xt;
+zk_status zk_anonymous_derive(const zk_anonymous_request* req, size_t n, zk_anonymous_statement* statements_out, uint8_t* rsk_out);
+zk_status zk_anonymous_gen_proof_batch(zk_params* p, zk_r1cs* circuit, struct zk_vk* vk, size_t n, const zk_anonymous_request* req,
+                                       const uint8_t* rs, zk_anonymous_xt* out);
 
 /* ------------------------------------------------------------------------------------------
  * Parameter generation  (bellman groth16::generate_parameters(circuit, g1, g2, alpha, beta, gamma, delta, tau))

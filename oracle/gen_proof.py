@@ -52,3 +52,29 @@ def gen_xt_fields(spending_key, amount, fee, remaining_balance, enc_key_recipien
               "enc_balance": w(enc_balance[0]) + w(enc_balance[1]), "nonce": w(nonce)}
     statement = TransferWitness(amount, remaining_balance, randomness, alpha, pgk, dec_key, enc_key_recipient, enc_balance, fee, g_epoch)
     return fields, statement
+
+
+def gen_anonymous_xt_fields(spending_key, amount, remaining_balance, s_index, t_index, enc_key_recipient, enc_keys_decoy, enc_balances,
+                            g_epoch, randomness, alpha):
+    """core/proofs/src/anonymous.rs:97-183, 277-352: everything of AnonymousXt except the proof, plus the circuit
+    statement (anonymous_circuit.AnonymousWitness).  The set: sender at s_index, recipient at t_index, decoys in order
+    elsewhere (:117-126); MultiCiphertexts::<Anonymous>::encrypt (crypto_components.rs:168-220): -amount under the
+    sender's key (neg_encrypt, elgamal.rs:66-82), +amount under the recipient's, zero under the decoys'."""
+    from .anonymous_circuit import ANONIMITY_SIZE, AnonymousWitness
+    g = jj.note_commitment_randomness_generator()
+    pgk, dec_key, enc_key_sender = derive(spending_key)
+    decoys = list(enc_keys_decoy)
+    keys = [enc_key_sender if i == s_index else enc_key_recipient if i == t_index else decoys.pop(0) for i in range(ANONIMITY_SIZE)]
+    neg = lambda p: ((-p[0]) % jj.R, p[1])
+    amount_g = jj.mul(g, amount)
+    left = []
+    for i, y in enumerate(keys):
+        ry = jj.mul(y, randomness)
+        left.append(jj.add(neg(amount_g), ry) if i == s_index else jj.add(amount_g, ry) if i == t_index else ry)
+    rvk = jj.add(pgk, jj.mul(g, alpha))
+    w = jj.write_point
+    fields = {"enc_keys": [w(k) for k in keys], "left_ciphertexts": [w(c) for c in left], "right_ciphertext": w(jj.mul(g, randomness)),
+              "nonce": w(jj.mul(g_epoch, dec_key)), "rsk": ((spending_key + alpha) % jj.FS_MOD).to_bytes(32, "little"), "rvk": w(rvk)}
+    statement = AnonymousWitness(amount, remaining_balance, s_index, t_index, randomness, alpha, pgk, dec_key, keys, left,
+                                 list(enc_balances), g_epoch)
+    return fields, statement

@@ -112,3 +112,15 @@ def test_native_witness_rejects_bad_statements():
     with pytest.raises(zk.ZkError) as e:
         zk.anonymous_witness(zk.anonymous_statements([dict(d, dec_key=jj.FS_MOD)]), lib=lib)
     assert e.value.variant == "InvalidArgument" and "dec_key" in str(e.value)
+
+
+def test_native_r1cs_emitter_matches_oracle_system(anon_cs):
+    """The product's own emitter of this circuit (csrc/transfer_r1cs.h: anonymous_system, zk_anonymous_r1cs_*)
+    against the oracle's system: counts and the blake2s fingerprint of circuit/test.rs:228-251 over the normalised
+    matrices (every coefficient of every row enters the hash).  No reference-held pin exists for this circuit."""
+    import zero_chain_amd as zk
+    _, cs = anon_cs
+    digest, n_in, n_aux, n_con = zk.anonymous_r1cs_fingerprint(zk.load_library())
+    assert (n_in, n_aux, n_con) == (len(cs.inputs), len(cs.aux), len(cs.constraints)) == (105, 50429, 50514)
+    assert digest == cs.hash()
+    assert digest != ac.REFERENCE_HASH          # the stale commented-out figure

@@ -64,3 +64,64 @@ def test_product_derivation_matches_oracle_and_reference():
     with pytest.raises(zk.ZkError) as e:
         zk.transfer_derive(zk.transfer_requests([items[1][0], bad]), lib=lib)
     assert e.value.variant == "InvalidArgument" and "request 1" in str(e.value) and "spending_key" in str(e.value)
+
+
+# ---- the anonymous transfer (core/proofs/src/anonymous.rs:97-183)
+def anonymous_request(seed, amount=10, balance=100):
+    """A request shaped like the reference's test (anonymous.rs:439-490): twelve members, the sender's balance
+    encrypted under its own key, random balances for everyone else."""
+    rng = synth.SplitMix64(seed)
+    g = jj.note_commitment_randomness_generator()
+    fs = lambda: rng.field(jj.FS_MOD)
+    sk = og.spending_key_from_seed(b"anonymous sender %d" % seed)
+    _, _, enc_key_sender = og.derive(sk)
+    s_index = rng.below(12)
+    t_index = (s_index + 1 + rng.below(11)) % 12
+    recipient = jj.mul(g, fs())
+    decoys = [jj.mul(g, fs()) for _ in range(10)]
+    rest = list(decoys)
+    keys = [enc_key_sender if i == s_index else recipient if i == t_index else rest.pop(0) for i in range(12)]
+    bals = []
+    for i, y in enumerate(keys):
+        value = balance if i == s_index else rng.below(1 << 32)
+        rb = fs()
+        bals.append((jj.add(jj.mul(g, value), jj.mul(y, rb)), jj.mul(g, rb)))
+    w = jj.write_point
+    rq = dict(amount=amount, remaining_balance=balance - amount, s_index=s_index, t_index=t_index, spending_key=sk,
+              enc_key_recipient=w(recipient), enc_keys_decoy=[w(d) for d in decoys], enc_balances_left=[w(b[0]) for b in bals],
+              enc_balances_right=[w(b[1]) for b in bals], g_epoch=w(jj.mul(g, fs())), randomness=fs(), alpha=fs())
+    return rq, recipient, decoys, bals
+
+
+def anonymous_expected(rq, recipient, decoys, bals):
+    return og.gen_anonymous_xt_fields(rq["spending_key"], rq["amount"], rq["remaining_balance"], rq["s_index"], rq["t_index"], recipient,
+                                      decoys, bals, jj.read_point(rq["g_epoch"]), rq["randomness"], rq["alpha"])
+
+
+def test_anonymous_derivation_matches_oracle():
+    """zk_anonymous_derive: the statement the product derives from a request (keys, the assembled set, the twelve left
+    ciphertexts) against the oracle's restatement of anonymous.rs:113-150, and that statement satisfies the circuit."""
+    import zero_chain_amd as zk
+    from oracle import anonymous_circuit as ac
+    lib = _lib()
+    cases = [anonymous_request(1), anonymous_request(2, amount=0, balance=0), anonymous_request(3, amount=0xFFFFFFFE, balance=0xFFFFFFFE)]
+    sts, rsks = zk.anonymous_derive(zk.anonymous_requests([c[0] for c in cases]), lib=lib)
+    for (rq, recipient, decoys, bals), st, rsk in zip(cases, sts, rsks):
+        want, stmt = anonymous_expected(rq, recipient, decoys, bals)
+        d = ac.statement_dict(stmt)
+        assert (st.amount, st.remaining_balance, st.s_index, st.t_index) == (d["amount"], d["remaining_balance"], d["s_index"], d["t_index"])
+        for name in ("randomness", "alpha", "dec_key"):
+            assert int.from_bytes(bytes(getattr(st, name)), "little") == d[name], name
+        for name in ("proof_generation_key", "g_epoch"):
+            assert bytes(getattr(st, name)) == d[name], name
+        for name in ("enc_keys", "left_ciphertexts", "enc_balances_left", "enc_balances_right"):
+            assert [bytes(e) for e in getattr(st, name)] == d[name], name
+        assert [bytes(e) for e in st.enc_keys] == want["enc_keys"] and [bytes(e) for e in st.left_ciphertexts] == want["left_ciphertexts"]
+        assert rsk == want["rsk"]
+    assert ac.synthesize(anonymous_expected(*cases[0])[1]).which_is_unsatisfied() is None
+    rq = cases[0][0]
+    for bad, what in ((dict(rq, t_index=rq["s_index"]), "s_index"), (dict(rq, s_index=12), "s_index"),
+                      (dict(rq, spending_key=jj.FS_MOD), "spending_key"), (dict(rq, enc_key_recipient=bytes([0xff] * 32)), "enc_key_recipient")):
+        with pytest.raises(zk.ZkError) as e:
+            zk.anonymous_derive(zk.anonymous_requests([cases[1][0], bad]), lib=lib)
+        assert e.value.variant == "InvalidArgument" and "request 1" in str(e.value) and what in str(e.value)

@@ -172,6 +172,13 @@ def test_anonymous_circuit_from_witness(gpu_lib, monkeypatch):
         sts = zk.anonymous_statements([ac.statement_dict(ws[i % 2]) for i in range(3)])
         got = zk.anonymous_prove_batch(mats, params, sts, rs)
         assert [p.write() for p in got] == [p.write() for p in proofs]
+        # the same over the natively emitted matrices (zk_anonymous_r1cs_load): no oracle on the product's path
+        native = zk.ConstraintMatrices.anonymous_circuit(lib=gpu_lib)
+        try:
+            got = zk.anonymous_prove_batch(native, params, sts, rs)
+            assert [p.write() for p in got] == [p.write() for p in proofs]
+        finally:
+            native.close()
     finally:
         mats.close()
         params.close()
@@ -434,6 +441,47 @@ def test_gen_proof_confidential_xt(gpu_lib):
         pvk.close()
         mats.close()
         params.close()
+
+
+def test_gen_proof_anonymous_xt(gpu_lib):
+    """zk_anonymous_gen_proof_batch = the reference's anonymous gen_proof (core/proofs/src/anonymous.rs:97-183): every
+    field of AnonymousXt against the oracle's restatement, the proof against the discrete-log proof of the derived
+    statement, over the natively emitted matrices and a key made by the product's generate_parameters; an
+    inconsistent request fails check_proof with Unsatisfiable."""
+    import zero_chain_amd as zk
+    from oracle import anonymous_circuit as ac
+    import test_gen_proof as tg
+    cases = [tg.anonymous_request(1), tg.anonymous_request(2, amount=77, balance=5000)]
+    E = g.Bls12Engine()
+    mats = zk.ConstraintMatrices.anonymous_circuit(lib=gpu_lib)
+    params = pvk = None
+    try:
+        params = zk.Parameters.read(zk.generate_parameters(mats, *helpers.TOXIC), checked=False, lib=gpu_lib)
+        pvk = zk.prepare_verifying_key(params)
+        rs = [(31 + i, 77 + 3 * i) for i in range(len(cases))]
+        xts = zk.anonymous_gen_proofs(params, mats, pvk, zk.anonymous_requests([c[0] for c in cases]), rs)
+        r1 = P = None
+        for case, xt, (r, s) in zip(cases, xts, rs):
+            want, stmt = tg.anonymous_expected(*case)
+            for f, v in want.items():
+                assert xt[f] == v, f
+            cs = ac.synthesize(stmt)
+            assert cs.which_is_unsatisfied() is None
+            if r1 is None:
+                r1 = cs.to_r1cs()
+                P = g.generate_parameters(E, r1, *helpers.TOXIC, scalars_only=True)
+            asg = g.assign(E, r1, cs.inputs, cs.aux)
+            assert xt["proof"] == helpers.expected_proof_trapdoor(P, asg, r, s)
+        bad = dict(cases[0][0], remaining_balance=cases[0][0]["remaining_balance"] + 1)
+        with pytest.raises(zk.ZkError) as e:
+            zk.anonymous_gen_proofs(params, mats, pvk, zk.anonymous_requests([cases[1][0], bad]), rs)
+        assert e.value.variant == "Unsatisfiable" and "request 1" in str(e.value)
+    finally:
+        if pvk is not None:
+            pvk.close()
+        if params is not None:
+            params.close()
+        mats.close()
 
 
 def test_msm_variable_base(gpu_lib):

@@ -26,7 +26,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "transfer_requests", "transfer_derive", "gen_proofs", "gen_proof", "XT_FIELDS",
-           "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_statements", "anonymous_witness", "anonymous_prove_batch",
+           "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_prove_batch",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
@@ -400,6 +400,17 @@ class ConstraintMatrices:
         self._h = h
         return self
 
+    @classmethod
+    def anonymous_circuit(cls, device=0, lib=None):
+        """The reference's anonymous-transfer circuit, emitted natively by the library (zk_anonymous_r1cs_load)."""
+        self = cls.__new__(cls)
+        self._lib = lib or _lib.load()
+        self.n_inputs, self.n_aux = ANONYMOUS_N_INPUTS, ANONYMOUS_N_AUX
+        h = C.c_void_p()
+        self._lib.check(self._lib.zk_anonymous_r1cs_load(device, C.byref(h)))
+        self._h = h
+        return self
+
     def __init__(self, n_inputs, n_aux, constraints, device=0, lib=None):
         self._lib = lib or _lib.load()
         self.n_inputs, self.n_aux = n_inputs, n_aux
@@ -453,6 +464,15 @@ def create_proofs_from_witness(matrices, params, witnesses, rs, montgomery=False
 
 
 TRANSFER_N_INPUTS, TRANSFER_N_AUX = 23, 19955
+
+
+def anonymous_r1cs_fingerprint(lib=None):
+    """(blake2s hex digest, n_inputs, n_aux, n_constraints) of the natively emitted anonymous-transfer circuit."""
+    lib = lib or _lib.load()
+    out = np.zeros(32, dtype=np.uint8)
+    a, b, c = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+    lib.check(lib.zk_anonymous_r1cs_fingerprint(_ptr(out), C.byref(a), C.byref(b), C.byref(c)))
+    return out.tobytes().hex(), a.value, b.value, c.value
 
 
 def transfer_r1cs_fingerprint(lib=None):
@@ -611,6 +631,52 @@ def anonymous_prove_batch(matrices, params, statements, rs):
     lib.check(lib.zk_anonymous_prove_batch(params._h, matrices._h, n, statements, _ptr(rsb), _ptr(out)))
     ob = out.tobytes()
     return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
+
+
+def anonymous_requests(items):
+    """items: dicts with amount, remaining_balance, s_index, t_index (ints), spending_key, randomness, alpha (Fs ints),
+    enc_key_recipient, g_epoch (32-byte Jubjub encodings), enc_keys_decoy (10 encodings) and enc_balances_left /
+    enc_balances_right (12 encodings each, by set member)."""
+    arr = (_lib.AnonymousRequest * len(items))()
+    for rq, it in zip(arr, items):
+        rq.amount, rq.remaining_balance, rq.s_index, rq.t_index = it["amount"], it["remaining_balance"], it["s_index"], it["t_index"]
+        for name in ("spending_key", "randomness", "alpha"):
+            getattr(rq, name)[:] = int(it[name]).to_bytes(32, "little")
+        for name in ("enc_key_recipient", "g_epoch"):
+            getattr(rq, name)[:] = bytes(it[name])
+        for name, count in (("enc_keys_decoy", ANONYMOUS_SIZE - 2), ("enc_balances_left", ANONYMOUS_SIZE), ("enc_balances_right", ANONYMOUS_SIZE)):
+            if len(it[name]) != count:
+                raise ValueError("%s: expected %d encodings" % (name, count))
+            for k in range(count):
+                getattr(rq, name)[k][:] = bytes(it[name][k])
+    return arr
+
+
+def anonymous_derive(requests, lib=None):
+    """zk_anonymous_derive: (statements, [rsk bytes]) - the host half of the anonymous gen_proof."""
+    lib = lib or _lib.load()
+    n = len(requests)
+    st = (_lib.AnonymousStatement * n)()
+    rsk = np.zeros(32 * n, dtype=np.uint8)
+    lib.check(lib.zk_anonymous_derive(requests, n, st, _ptr(rsk)))
+    return st, [rsk[32 * i:32 * i + 32].tobytes() for i in range(n)]
+
+
+def anonymous_gen_proofs(params, matrices, pvk, requests, rs):
+    """zk_anonymous_gen_proof_batch: one AnonymousXt per request, as a dict of byte strings (enc_keys and
+    left_ciphertexts: lists of 12); raises ZkError Unsatisfiable when a proof fails the self-check."""
+    lib = params._lib
+    n = len(requests)
+    rsb = rs if isinstance(rs, np.ndarray) else scalars_to_bytes([x for pair in rs for x in pair])
+    out = (_lib.AnonymousXt * n)()
+    lib.check(lib.zk_anonymous_gen_proof_batch(params._h, matrices._h, pvk._h, n, requests, _ptr(rsb), out))
+    res = []
+    for x in out:
+        d = {f: bytes(getattr(x, f)) for f in ("proof", "right_ciphertext", "nonce", "rsk", "rvk")}
+        d["enc_keys"] = [bytes(e) for e in x.enc_keys]
+        d["left_ciphertexts"] = [bytes(e) for e in x.left_ciphertexts]
+        res.append(d)
+    return res
 
 
 def transfer_prove_batch(matrices, params, statements, rs):

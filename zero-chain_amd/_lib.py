@@ -71,6 +71,18 @@ class AnonymousStatement(C.Structure):
                [(n, (C.c_uint8 * 32) * 12) for n in ("enc_keys", "left_ciphertexts", "enc_balances_left", "enc_balances_right")]
 
 
+class AnonymousRequest(C.Structure):
+    _fields_ = [("amount", C.c_uint32), ("remaining_balance", C.c_uint32), ("s_index", C.c_uint32), ("t_index", C.c_uint32),
+                ("spending_key", C.c_uint8 * 32), ("enc_key_recipient", C.c_uint8 * 32), ("enc_keys_decoy", (C.c_uint8 * 32) * 10),
+                ("enc_balances_left", (C.c_uint8 * 32) * 12), ("enc_balances_right", (C.c_uint8 * 32) * 12),
+                ("g_epoch", C.c_uint8 * 32), ("randomness", C.c_uint8 * 32), ("alpha", C.c_uint8 * 32)]
+
+
+class AnonymousXt(C.Structure):
+    _fields_ = [("proof", C.c_uint8 * 192), ("enc_keys", (C.c_uint8 * 32) * 12), ("left_ciphertexts", (C.c_uint8 * 32) * 12)] + \
+               [(n, C.c_uint8 * 32) for n in ("right_ciphertext", "nonce", "rsk", "rvk")]
+
+
 class BatchDev(C.Structure):
     _fields_ = [("n_rows", C.c_uint32), ("n_inputs", C.c_uint32), ("n_aux", C.c_uint32), ("flags", C.c_uint32),
                 ("d_a", C.c_void_p), ("d_b", C.c_void_p), ("d_c", C.c_void_p), ("d_wit", C.c_void_p),
@@ -93,6 +105,11 @@ _PROTOS = {
     "zk_r1cs_free": (None, [C.c_void_p]),
     "zk_transfer_r1cs_load": (C.c_int32, [C.c_int, C.POINTER(C.c_void_p)]),
     "zk_transfer_r1cs_fingerprint": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "zk_anonymous_r1cs_load": (C.c_int32, [C.c_int, C.POINTER(C.c_void_p)]),
+    "zk_anonymous_derive": (C.c_int32, [C.POINTER(AnonymousRequest), C.c_size_t, C.POINTER(AnonymousStatement), C.c_void_p]),
+    "zk_anonymous_gen_proof_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AnonymousRequest), C.c_void_p,
+                                                 C.POINTER(AnonymousXt)]),
+    "zk_anonymous_r1cs_fingerprint": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "zk_prove_batch_witness": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "zk_transfer_witness": (C.c_int32, [C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_transfer_witness_gpu": (C.c_int32, [C.c_void_p, C.POINTER(TransferStatement), C.c_size_t, C.c_uint32, C.c_void_p]),

@@ -393,4 +393,114 @@ inline System transfer_system() {
     return cs;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The anonymous-transfer circuit (core/proofs/src/circuit/anonymous_transfer.rs:56-337 on top of
+// anonimity_set.rs:38-488 and utils.rs), same allocation order as transfer_witness.h: synthesize_anonymous.
+// The reference pins no fingerprint for it (the assertions at anonymous_transfer.rs:446-451 are commented out and
+// stale): the emitted system is checked against oracle/anonymous_circuit.py, statement for statement.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t ANONIMITY_SIZE = 12;   // core/proofs/src/constants.rs:1
+
+// AllocatedBit::xor: (a + a) * b = a + b - c
+inline Bit xor_allocated(System& cs, const Bit& a, const Bit& b) {
+    const Var r = cs.alloc();
+    cs.enforce(lc(a.var).add(a.var), lc(b.var), lc(a.var).add(b.var).sub(r));
+    return Bit{Bit::IS, r, false};
+}
+// utils.rs:10-37
+inline void eq_points(System& cs, const Pt& a, const Pt& b) {
+    cs.enforce(lc(a.x), lc(ONE), lc(b.x));
+    cs.enforce(lc(a.y), lc(ONE), lc(b.y));
+}
+// Binary::new (anonimity_set.rs:41-77): one allocated bit per member
+inline Bits binary(System& cs) {
+    Bits b;
+    for (size_t i = 0; i < ANONIMITY_SIZE; i++) b.push_back(alloc_bit(cs));
+    return b;
+}
+// Binary::edwards_add_fold (anonimity_set.rs:155-185)
+inline Pt add_fold(System& cs, const Bits& bins, const std::vector<Pt>& points, const Pt& zero_p) {
+    Pt acc = zero_p;
+    for (size_t i = 0; i < bins.size(); i++) acc = pt_add(cs, acc, pt_conditionally_select(cs, points[i], bins[i]));
+    return acc;
+}
+inline std::vector<Pt> pt_witness_set(System& cs) {
+    std::vector<Pt> v;
+    for (size_t i = 0; i < ANONIMITY_SIZE; i++) v.push_back(pt_witness(cs));
+    return v;
+}
+
+inline System anonymous_system() {
+    System cs;
+    const Pt zero_p = pt_witness(cs);
+    const Bits amount_bits = u32_into_bit_vec_le(cs);
+    const Pt amount_g = fixed_base_multiplication(cs, amount_bits);
+    const Bits remaining_bits = u32_into_bit_vec_le(cs);
+    const Pt remaining_g = fixed_base_multiplication(cs, remaining_bits);
+    const Bits dec_key_bits = field_into_boolean_vec_le(cs);
+    const Bits s_bins = binary(cs);
+    const Bits t_bins = binary(cs);
+    const std::vector<Pt> enc_key_set = pt_witness_set(cs);
+    const Pt expected_enc_key_sender = add_fold(cs, s_bins, enc_key_set, zero_p);
+    const Pt enc_key_sender = fixed_base_multiplication(cs, dec_key_bits);
+    eq_points(cs, expected_enc_key_sender, enc_key_sender);                 // sk * G = sum s_i y_i
+    // EncKeySet::gen_enc_keys_mul_random (anonimity_set.rs:230-256)
+    const Bits randomness_bits = field_into_boolean_vec_le(cs);
+    std::vector<Pt> enc_keys_mul_random;
+    for (const Pt& y : enc_key_set) enc_keys_mul_random.push_back(pt_mul(cs, y, randomness_bits));
+    const std::vector<Pt> left_set = pt_witness_set(cs);
+    // sum t_i C_i = b_1 G + sum t_i r y_i
+    const Pt fold_t = add_fold(cs, t_bins, enc_keys_mul_random, zero_p);
+    const Pt expected_left_t = pt_add(cs, fold_t, amount_g);
+    const Pt left_t = add_fold(cs, t_bins, left_set, zero_p);
+    eq_points(cs, expected_left_t, left_t);
+    // sum (s_i xor t_i) C_i = sum (s_i xor t_i) r y_i
+    Bits xor_st;
+    for (size_t i = 0; i < ANONIMITY_SIZE; i++) xor_st.push_back(xor_allocated(cs, s_bins[i], t_bins[i]));
+    const Pt fold_keys_xor = add_fold(cs, xor_st, enc_keys_mul_random, zero_p);
+    const Pt fold_left_xor = add_fold(cs, xor_st, left_set, zero_p);
+    eq_points(cs, fold_left_xor, fold_keys_xor);
+    // (1 - s_i)(1 - t_i) C_i = (1 - s_i)(1 - t_i) r y_i   (Binary::nor, conditionally_equals)
+    Bits nor_st;
+    for (size_t i = 0; i < ANONIMITY_SIZE; i++) nor_st.push_back(and_(cs, s_bins[i].negated(), t_bins[i].negated()));
+    for (size_t i = 0; i < ANONIMITY_SIZE; i++) {
+        const Pt ca = pt_conditionally_select(cs, left_set[i], nor_st[i]);
+        const Pt cb = pt_conditionally_select(cs, enc_keys_mul_random[i], nor_st[i]);
+        eq_points(cs, ca, cb);
+    }
+    for (const Pt& q : enc_key_set) pt_inputize(cs, q);
+    for (const Pt& q : left_set) pt_inputize(cs, q);
+    // balance integrity: sum s_i (C_li + C_i) = b_2 G + sk (sum s_i C_ri + D)
+    const std::vector<Pt> left_balance = pt_witness_set(cs);
+    std::vector<Pt> added_lefts;
+    for (size_t i = 0; i < ANONIMITY_SIZE; i++) added_lefts.push_back(pt_add(cs, left_balance[i], left_set[i]));
+    const Pt lh_c = add_fold(cs, s_bins, added_lefts, zero_p);
+    const std::vector<Pt> right_balance = pt_witness_set(cs);
+    const Pt right_fold = add_fold(cs, s_bins, right_balance, zero_p);
+    const Bits randomness_bits2 = field_into_boolean_vec_le(cs);              // allocated a second time
+    const Pt right_ciphertext = fixed_base_multiplication(cs, randomness_bits2);
+    const Pt cr_d = pt_add(cs, right_fold, right_ciphertext);
+    const Pt cr_d_mul_sk = pt_mul(cs, cr_d, dec_key_bits);
+    const Pt rh_c = pt_add(cs, remaining_g, cr_d_mul_sk);
+    eq_points(cs, lh_c, rh_c);
+    for (const Pt& q : left_balance) pt_inputize(cs, q);
+    for (const Pt& q : right_balance) pt_inputize(cs, q);
+    pt_inputize(cs, right_ciphertext);
+    // rvk_inputize (utils.rs:71-123)
+    const Pt pgk = pt_witness(cs);
+    pt_assert_not_small_order(cs, pgk);
+    const Bits alpha_bits = field_into_boolean_vec_le(cs);
+    const Pt alpha_g = fixed_base_multiplication(cs, alpha_bits);
+    const Pt rvk = pt_add(cs, pgk, alpha_g);
+    pt_assert_not_small_order(cs, rvk);
+    pt_inputize(cs, rvk);
+    // g_epoch_nonce_inputize (utils.rs:125-154)
+    const Pt g_epoch = pt_witness(cs);
+    const Pt nonce = pt_mul(cs, g_epoch, dec_key_bits);
+    pt_inputize(cs, g_epoch);
+    pt_inputize(cs, nonce);
+    cs.finish();
+    return cs;
+}
+
 }  // namespace zkr1cs

@@ -1688,12 +1688,7 @@ zk_status zk_transfer_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs,
     if (n_constraints) *n_constraints = sys.n_constraints;
     return ZK_OK;
 }
-zk_status zk_transfer_r1cs_load(int device, zk_r1cs** out) {
-    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
-    *out = nullptr;
-    const zkr1cs::System& sys = transfer_system_cached();
-    if (sys.n_inputs != ZK_TRANSFER_N_INPUTS || sys.n_aux != ZK_TRANSFER_N_AUX)
-        return fail(ZK_ERR_INVALID_ARGUMENT, "internal: emitted system has the wrong shape");
+static zk_status system_load(const zkr1cs::System& sys, int device, zk_r1cs** out) {
     std::vector<uint8_t> coeff[3];
     zk_csr mats[3];
     for (int m = 0; m < 3; m++) {
@@ -1709,6 +1704,35 @@ zk_status zk_transfer_r1cs_load(int device, zk_r1cs** out) {
     }
     const zk_csr* ptrs[3] = {&mats[0], &mats[1], &mats[2]};
     return r1cs_load(sys.n_inputs, sys.n_aux, sys.n_constraints, ptrs, device, out);
+}
+zk_status zk_transfer_r1cs_load(int device, zk_r1cs** out) {
+    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const zkr1cs::System& sys = transfer_system_cached();
+    if (sys.n_inputs != ZK_TRANSFER_N_INPUTS || sys.n_aux != ZK_TRANSFER_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "internal: emitted system has the wrong shape");
+    return system_load(sys, device, out);
+}
+// the anonymous-transfer circuit, emitted the same way
+static const zkr1cs::System& anonymous_system_cached() {
+    static const zkr1cs::System sys = zkr1cs::anonymous_system();
+    return sys;
+}
+zk_status zk_anonymous_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs, uint32_t* n_aux, uint32_t* n_constraints) {
+    const zkr1cs::System& sys = anonymous_system_cached();
+    if (hash_out) sys.fingerprint(hash_out);
+    if (n_inputs) *n_inputs = sys.n_inputs;
+    if (n_aux) *n_aux = sys.n_aux;
+    if (n_constraints) *n_constraints = sys.n_constraints;
+    return ZK_OK;
+}
+zk_status zk_anonymous_r1cs_load(int device, zk_r1cs** out) {
+    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    const zkr1cs::System& sys = anonymous_system_cached();
+    if (sys.n_inputs != ZK_ANONYMOUS_N_INPUTS || sys.n_aux != ZK_ANONYMOUS_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "internal: emitted system has the wrong shape");
+    return system_load(sys, device, out);
 }
 zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const uint8_t* witness, uint32_t flags,
                                  const uint8_t* rs, uint8_t* proofs_out) {
@@ -2052,6 +2076,185 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
         slot ^= 1;
     }
     // check_proof: every proof must verify against the public inputs the transaction will carry
+    ZK_TRY(zk_verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data()));
+    for (size_t i = 0; i < n; i++)
+        if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gen_proof of the anonymous transfer (core/proofs/src/anonymous.rs:97-183, 267-352): the same derivations, the
+// anonymity set assembled around the sender and the recipient, MultiCiphertexts::<Anonymous>::encrypt
+// (crypto_components.rs:168-220: the sender's amount negated, the recipient's positive, zero under every decoy key,
+// one randomness), check_proof over the 104 public coordinates (:200-262) and the packing of AnonymousXt.
+// ------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+// k * p for a point of the statement (double-and-add over the complete addition law; k < 2^252)
+zkwit::EPoint jubjub_var_mul(const zkwit::JPoint& p, const uint64_t k[4]) {
+    zkwit::EPoint acc = zkwit::ext_zero();
+    const zkwit::EPoint base = zkwit::to_ext(p);
+    for (int bit = 251; bit >= 0; bit--) {
+        acc = zkwit::ext_add(acc, acc);
+        if ((k[bit >> 6] >> (bit & 63)) & 1) acc = zkwit::ext_add(acc, base);
+    }
+    return acc;
+}
+
+struct AnonDerived {
+    zkwit::JPoint pub[4 * ZK_ANONYMOUS_SIZE + 4];   // the public points in the order of the circuit's inputs
+};
+
+zk_status anonymous_derive_one(const zk_anonymous_request& rq, size_t index, zk_anonymous_statement* st, uint8_t rsk[32],
+                               AnonDerived* der) {
+    const std::string who = "request " + std::to_string(index) + ": ";
+    if (rq.s_index >= ZK_ANONYMOUS_SIZE || rq.t_index >= ZK_ANONYMOUS_SIZE || rq.s_index == rq.t_index)
+        return fail(ZK_ERR_INVALID_ARGUMENT, who + "s_index and t_index must be two different members of the set");
+    uint64_t sk[4], alpha[4], rnd[4];
+    load_scalar_le(rq.spending_key, sk);
+    load_scalar_le(rq.alpha, alpha);
+    load_scalar_le(rq.randomness, rnd);
+    if (!fs_lt_mod(sk)) return fail(ZK_ERR_INVALID_ARGUMENT, who + "spending_key is not a canonical Fs scalar");
+    if (!fs_lt_mod(alpha)) return fail(ZK_ERR_INVALID_ARGUMENT, who + "alpha is not a canonical Fs scalar");
+    if (!fs_lt_mod(rnd)) return fail(ZK_ERR_INVALID_ARGUMENT, who + "randomness is not a canonical Fs scalar");
+    memset(st, 0, sizeof(*st));
+    st->amount = rq.amount;
+    st->remaining_balance = rq.remaining_balance;
+    st->s_index = rq.s_index;
+    st->t_index = rq.t_index;
+    memcpy(st->randomness, rq.randomness, 32);
+    memcpy(st->alpha, rq.alpha, 32);
+    memcpy(st->g_epoch, rq.g_epoch, 32);
+    const zkwit::JPoint pgk = jubjub_fixed_mul(sk);
+    jubjub_encode(pgk.x, pgk.y, st->proof_generation_key);
+    static const uint8_t person[8] = {'z', 'e', 'c', 'h', '_', 'b', 'd', 'k'};
+    zkhash::Blake2s h(person);
+    h.update(st->proof_generation_key, 32);
+    h.finish(st->dec_key);
+    st->dec_key[31] &= 0x07;
+    uint64_t dk[4];
+    load_scalar_le(st->dec_key, dk);
+    // the set: sender at s_index, recipient at t_index, the decoys in their order everywhere else
+    zkwit::JPoint keys[ZK_ANONYMOUS_SIZE];
+    keys[rq.s_index] = jubjub_fixed_mul(dk);
+    if (!zkwit::decode_point(rq.enc_key_recipient, &keys[rq.t_index]))
+        return fail(ZK_ERR_INVALID_ARGUMENT, who + "enc_key_recipient is not a Jubjub point");
+    for (size_t i = 0, j = 0; i < ZK_ANONYMOUS_SIZE; i++) {
+        if (i == rq.s_index || i == rq.t_index) continue;
+        if (!zkwit::decode_point(rq.enc_keys_decoy[j], &keys[i]))
+            return fail(ZK_ERR_INVALID_ARGUMENT, who + "enc_keys_decoy[" + std::to_string(j) + "] is not a Jubjub point");
+        j++;
+    }
+    zkwit::JPoint g_epoch;
+    if (!zkwit::decode_point(rq.g_epoch, &g_epoch)) return fail(ZK_ERR_INVALID_ARGUMENT, who + "g_epoch is not a Jubjub point");
+    // left ciphertexts v_i G + r y_i, right r G, rvk = pgk + alpha G, nonce = dec_key * g_epoch: one batch to affine
+    uint64_t amt[4] = {rq.amount, 0, 0, 0};
+    const zkwit::JPoint amount_g = jubjub_fixed_mul(amt);
+    const zkwit::JPoint neg_amount_g{zkhost::Fr::zero() - amount_g.x, amount_g.y};
+    zkwit::EPoint proj[ZK_ANONYMOUS_SIZE + 3];
+    for (size_t i = 0; i < ZK_ANONYMOUS_SIZE; i++) {
+        proj[i] = jubjub_var_mul(keys[i], rnd);
+        if (i == rq.s_index) proj[i] = zkwit::ext_add(proj[i], zkwit::to_ext(neg_amount_g));
+        if (i == rq.t_index) proj[i] = zkwit::ext_add(proj[i], zkwit::to_ext(amount_g));
+    }
+    proj[ZK_ANONYMOUS_SIZE] = zkwit::to_ext(jubjub_fixed_mul(rnd));
+    proj[ZK_ANONYMOUS_SIZE + 1] = zkwit::ext_add(zkwit::to_ext(pgk), zkwit::to_ext(jubjub_fixed_mul(alpha)));
+    proj[ZK_ANONYMOUS_SIZE + 2] = jubjub_var_mul(g_epoch, dk);
+    zkwit::JPoint aff[ZK_ANONYMOUS_SIZE + 3];
+    zkwit::batch_to_affine(proj, aff, ZK_ANONYMOUS_SIZE + 3);
+    for (size_t i = 0; i < ZK_ANONYMOUS_SIZE; i++) {
+        jubjub_encode(keys[i].x, keys[i].y, st->enc_keys[i]);
+        jubjub_encode(aff[i].x, aff[i].y, st->left_ciphertexts[i]);
+        memcpy(st->enc_balances_left[i], rq.enc_balances_left[i], 32);
+        memcpy(st->enc_balances_right[i], rq.enc_balances_right[i], 32);
+    }
+    uint64_t r[4];
+    fs_add(sk, alpha, r);   // SpendingKey::into_rsk
+    memcpy(rsk, r, 32);
+    if (der) {
+        for (size_t i = 0; i < ZK_ANONYMOUS_SIZE; i++) {
+            der->pub[i] = keys[i];
+            der->pub[ZK_ANONYMOUS_SIZE + i] = aff[i];
+            const std::string m = "[" + std::to_string(i) + "] is not a Jubjub point";
+            if (!zkwit::decode_point(rq.enc_balances_left[i], &der->pub[2 * ZK_ANONYMOUS_SIZE + i]))
+                return fail(ZK_ERR_INVALID_ARGUMENT, who + "enc_balances_left" + m);
+            if (!zkwit::decode_point(rq.enc_balances_right[i], &der->pub[3 * ZK_ANONYMOUS_SIZE + i]))
+                return fail(ZK_ERR_INVALID_ARGUMENT, who + "enc_balances_right" + m);
+        }
+        der->pub[4 * ZK_ANONYMOUS_SIZE] = aff[ZK_ANONYMOUS_SIZE];           // right ciphertext
+        der->pub[4 * ZK_ANONYMOUS_SIZE + 1] = aff[ZK_ANONYMOUS_SIZE + 1];   // rvk
+        der->pub[4 * ZK_ANONYMOUS_SIZE + 2] = g_epoch;
+        der->pub[4 * ZK_ANONYMOUS_SIZE + 3] = aff[ZK_ANONYMOUS_SIZE + 2];   // nonce
+    }
+    return ZK_OK;
+}
+zk_status anonymous_derive(const zk_anonymous_request* rq, size_t n, zk_anonymous_statement* st, uint8_t* rsk, AnonDerived* der) {
+    if (n == 0) return ZK_OK;
+    (void)zkwit::tables();
+    const unsigned nthreads = host_threads(n, 8);
+    std::vector<zk_status> sts(nthreads, ZK_OK);
+    std::vector<std::string> msgs(nthreads);
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
+            zk_status rc = anonymous_derive_one(rq[i], i, &st[i], rsk + i * 32, der ? &der[i] : nullptr);
+            if (rc != ZK_OK) {
+                sts[t] = rc;
+                msgs[t] = g_err;
+                return;
+            }
+        }
+    };
+    if (nthreads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> ths;
+        for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, t);
+        for (auto& th : ths) th.join();
+    }
+    for (unsigned t = 0; t < nthreads; t++)
+        if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
+    return ZK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+zk_status zk_anonymous_derive(const zk_anonymous_request* req, size_t n, zk_anonymous_statement* statements_out, uint8_t* rsk_out) {
+    if (n && (!req || !statements_out || !rsk_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    return anonymous_derive(req, n, statements_out, rsk_out, nullptr);
+}
+
+zk_status zk_anonymous_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk, size_t n, const zk_anonymous_request* req,
+                                       const uint8_t* rs, zk_anonymous_xt* out) {
+    if (!p || !circuit || !vk || (n && (!req || !rs || !out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return ZK_OK;
+    const size_t n_pts = 4 * ZK_ANONYMOUS_SIZE + 4, n_pub = 2 * n_pts;
+    std::vector<zk_anonymous_statement> st(n);
+    std::vector<AnonDerived> der(n);
+    std::vector<uint8_t> rsk(n * 32), proofs(n * 192), ok(n), inputs(n * n_pub * 32);
+    ZK_TRY(anonymous_derive(req, n, st.data(), rsk.data(), der.data()));
+    ZK_TRY(zk_anonymous_prove_batch(p, circuit, n, st.data(), rs, proofs.data()));
+    for (size_t i = 0; i < n; i++) {
+        zk_anonymous_xt& x = out[i];
+        memset(&x, 0, sizeof(x));
+        memcpy(x.proof, &proofs[i * 192], 192);
+        for (size_t k = 0; k < n_pts; k++) {
+            const zkhost::Fr px = der[i].pub[k].x.from_mont(), py = der[i].pub[k].y.from_mont();
+            memcpy(&inputs[(i * n_pub + 2 * k) * 32], px.l, 32);
+            memcpy(&inputs[(i * n_pub + 2 * k + 1) * 32], py.l, 32);
+        }
+        memcpy(x.enc_keys, st[i].enc_keys, sizeof(x.enc_keys));
+        memcpy(x.left_ciphertexts, st[i].left_ciphertexts, sizeof(x.left_ciphertexts));
+        const zkwit::JPoint* tail = &der[i].pub[4 * ZK_ANONYMOUS_SIZE];
+        jubjub_encode(tail[0].x, tail[0].y, x.right_ciphertext);
+        jubjub_encode(tail[1].x, tail[1].y, x.rvk);
+        jubjub_encode(tail[3].x, tail[3].y, x.nonce);
+        memcpy(x.rsk, &rsk[i * 32], 32);
+    }
+    // check_proof (anonymous.rs:200-262)
     ZK_TRY(zk_verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data()));
     for (size_t i = 0; i < n; i++)
         if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
