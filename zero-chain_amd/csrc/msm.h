@@ -576,8 +576,12 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
 // Pass 5: one thread per task (= at most seg points of one bucket), tasks in length order.
 // Two things measured NOT to matter here, neither in the batched prover (4 GB of tables) nor on one
 // 2^20-point job (30 GB): fetching the next point while the current one is added (28 more live
-// registers), and sorting every task's pairs by table index so that all lanes sweep the doubling
-// slices in step.  The single job's lower rate (4.3 G additions/s against 7.0) is 88 % occupancy at
+// registers; measured again in round 2 as a two-deep pipeline with the pair index two steps ahead: G1
+// 176.6 -> 178.4 ms per launch, G2 93.2 -> 91.2), and sorting every task's pairs by table index so that all
+// lanes sweep the doubling slices in step.  What bounds the issue rate at two waves per SIMD is the product
+// routine itself (66 G products/s at this occupancy against 74.5 at eight waves, profiles/r01f_ubench.txt);
+// three waves per SIMD (168 VGPRs, 88 bytes of scratch per lane) measured 179.6 ms, four (128 VGPRs) 237.7.
+// The single job's lower rate (4.3 G additions/s against 7.0) is 88 % occupancy at
 // the two ends of a 3 ms launch, a 12 % lower issue rate per resident wave and a lower clock.
 template <class F, int OCC>
 ZK_DI void msm_accumulate_body(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
