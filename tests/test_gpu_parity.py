@@ -47,7 +47,7 @@ def test_ntt_small_sizes_python_oracle(gpu_lib):
 
 
 def test_ntt_large_sizes_c_oracle(gpu_lib):
-    pc.ntt_against_oracle(gpu_lib, [15, 16, 17, 20], use_c_oracle=True)
+    pc.ntt_against_oracle(gpu_lib, [15, 16, 17, 18, 19, 20, 21], use_c_oracle=True)
 
 
 def test_ntt_permutation_free_pair_2p20(gpu_lib):

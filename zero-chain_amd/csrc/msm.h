@@ -37,7 +37,7 @@ struct MsmJob {
     uint32_t pair_base;       // first slot of this job in the rank / pair arrays
     uint32_t vb_digit;        // 0: width-c NAF over the doubling table (every digit of every scalar);
                               // k + 1: VARIABLE-BASE mode, this job takes digit k of every scalar (see msm_digits)
-    uint32_t reserved;
+    uint32_t n_digits;        // variable-base mode: digit positions per scalar
 };
 
 // Register budgets.  hipcc sizes a kernel's VGPR allocation from its launch bounds alone (it will
@@ -221,7 +221,7 @@ ZK_DI void msm_digits(const MsmJob& job, uint32_t i, uint32_t c, Fn&& f) {
     } else {
         uint32_t mag;
         bool negative;
-        if (msm_vb_digit(job.scalars + (size_t)i * 8, c, job.vb_digit - 1, job.reserved, &mag, &negative)) f(0u, 0u, mag, negative);
+        if (msm_vb_digit(job.scalars + (size_t)i * 8, c, job.vb_digit - 1, job.n_digits, &mag, &negative)) f(0u, 0u, mag, negative);
     }
 }
 

@@ -23,6 +23,12 @@ namespace zkdev {
 constexpr int NTT_MAX_G = 8;        // stages per pass
 constexpr int NTT_TILE_LOG = 10;   // 2^10 elements = 32 KiB of LDS per workgroup: 4 workgroups = 4 waves per SIMD on a CU
 constexpr int NTT_THREADS = 256;
+// Large transforms (k >= NTT_BIG_LOG): 2^12-element tiles (128 KiB of LDS, one workgroup of 1024 threads = 4 waves
+// per SIMD on a CU) hold 10 stages, so 2^20 takes 2 passes instead of 3 (0.327 -> 0.315 ms per pair).
+// ZKAMD_NTT_SMALL_TILES keeps the small tiles at every size (A/B).  Also measured and dropped: per-stage twiddle
+// tables laid out so that lanes of consecutive columns read consecutive entries (twice the table memory; 0.327 ms
+// and 21.1 ms per chunk, i.e. no change: the strided twiddle gathers are not what the kernel waits for).
+constexpr int NTT_BIG_LOG = 17, NTT_BIG_MAX_G = 10, NTT_BIG_TILE_LOG = 12, NTT_BIG_THREADS = 1024;
 
 struct NttPass {
     uint32_t log_n;    // transform size
@@ -96,7 +102,7 @@ ZK_DI void st_tile(uint32_t* tile, uint32_t tile_elems, uint32_t e, const Fr& v)
 // waves/SIMD 21.3 ms.  Taking two stages per LDS round trip (radix-4 groups in registers: half the LDS
 // traffic and barriers, the same products, since w^(n/4) is no cheaper than any other twiddle in a prime
 // field) measured 22.1 ms at the same occupancy and 26.4 ms at 2 waves/SIMD: rejected.
-static __global__ void __launch_bounds__(NTT_THREADS, 4)
+static __global__ void __launch_bounds__(NTT_BIG_THREADS, 4)
 k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __restrict__ tw,
            const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post, NttPass ps, uint32_t* bad = nullptr) {
     ZK_DYN_SHARED(uint32_t, tile);   // 2 planes x [2^g][CW][4]
@@ -111,7 +117,7 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
     const uint32_t smask = (1u << s) - 1;
 
     // ---- load tile (row-major over m, columns fastest => coalesced segments)
-    for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < tile_elems; e += blockDim.x) {
         uint32_t c = e & (cw - 1), m = e >> lcw;
         uint32_t col = col0 + c;
         uint32_t hi = col >> s, lo = col & smask;
@@ -136,7 +142,7 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
         const uint32_t half = 1u << pos;
         // global stage index and the shift that turns (i mod d) into a twiddle exponent
         const uint32_t tsh = ps.dif ? (ps.t0 + j) : (k - 1 - ps.t0 - j);
-        for (uint32_t b = tid; b < nbf; b += NTT_THREADS) {
+        for (uint32_t b = tid; b < nbf; b += blockDim.x) {
             uint32_t c = b & (cw - 1), mm = b >> lcw;
             uint32_t m = ((mm >> pos) << (pos + 1)) | (mm & (half - 1));
             uint32_t lo = (col0 + c) & smask;
@@ -160,7 +166,7 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
         __syncthreads();
     }
 
-    for (uint32_t e = tid; e < tile_elems; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < tile_elems; e += blockDim.x) {
         uint32_t c = e & (cw - 1), m = e >> lcw;
         uint32_t col = col0 + c;
         uint32_t hi = col >> s, lo = col & smask;

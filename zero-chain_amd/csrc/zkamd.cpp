@@ -67,17 +67,23 @@ struct NttPlan {
     DevBuf scratch;                  // permutation scratch for the stand-alone entry
     size_t bytes = 0;
 
+    static bool big(uint32_t k) {
+        static const bool off = getenv("ZKAMD_NTT_SMALL_TILES") != nullptr;
+        return !off && k >= (uint32_t)zkdev::NTT_BIG_LOG;
+    }
     static std::vector<NttPass> passes(uint32_t k, bool dif, uint32_t stride) {
         std::vector<NttPass> out;
         if (k == 0) return out;
-        uint32_t np = (k + zkdev::NTT_MAX_G - 1) / zkdev::NTT_MAX_G;
+        const uint32_t max_g = big(k) ? zkdev::NTT_BIG_MAX_G : zkdev::NTT_MAX_G;
+        const uint32_t tile_log = big(k) ? zkdev::NTT_BIG_TILE_LOG : zkdev::NTT_TILE_LOG;
+        uint32_t np = (k + max_g - 1) / max_g;
         uint32_t base = k / np, extra = k % np, t0 = 0;
         for (uint32_t i = 0; i < np; i++) {
             NttPass p;
             p.log_n = k;
             p.t0 = t0;
             p.g = base + (i < extra ? 1 : 0);
-            uint32_t lcw = zkdev::NTT_TILE_LOG - p.g;
+            uint32_t lcw = tile_log - p.g;
             if (lcw > k - p.g) lcw = k - p.g;
             p.log_cw = lcw;
             p.dif = dif ? 1 : 0;
@@ -159,7 +165,16 @@ struct NttPlan {
             dim3 grid(cols >> p.log_cw, batch);
             size_t shmem = ((size_t)1 << (p.g + p.log_cw)) * 32;
             ProfScope ps_(dif ? "ntt_pass_dif" : "ntt_pass_dit");
-            ZK_LAUNCH_SYNC(zkdev::k_ntt_pass, grid, dim3(zkdev::NTT_THREADS), shmem, g_stream, data, s, tw,
+#ifndef ZK_EMU
+            if (shmem > 65536) {
+                static bool raised = false;   // more than 64 KiB of dynamic LDS has to be asked for
+                if (!raised) {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(zkdev::k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    raised = true;
+                }
+            }
+#endif
+            ZK_LAUNCH_SYNC(zkdev::k_ntt_pass, grid, dim3(big(log_n) ? zkdev::NTT_BIG_THREADS : zkdev::NTT_THREADS), shmem, g_stream, data, s, tw,
                            i == 0 ? pre : (const uint32_t*)nullptr,
                            i + 1 == ps.size() ? post : (const uint32_t*)nullptr, p, i == 0 && s ? bad : (uint32_t*)nullptr);
         }
@@ -862,7 +877,7 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     const uint32_t npts1 = (uint32_t)P->g1.n_points, npts2 = (uint32_t)P->g2.n_points;
     for (size_t p = 0; p < np; p++) {
         const uint32_t* w = wit + p * wstride * 8;
-        MsmJob j2 = {w, P->map_b2.as<int32_t>(), nv + 3, 0, npts2, 0};
+        MsmJob j2 = {w, P->map_b2.as<int32_t>(), nv + 3, 0, npts2, 0, 0, 0};
         P->jobs2.push_back(j2);
     }
     hipStream_t side = getenv("ZKAMD_NO_OVERLAP") ? g_stream : g_stream2;
@@ -899,12 +914,12 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     // sort is one workgroup per job: alternating A, C' (a fifth against four fifths of the scalars)
     // put every large job on the odd XCDs.  Largest first also keeps the tail of the launch short.
     for (size_t p = 0; p < np; p++) {
-        MsmJob jc = {cvec + p * (size_t)cstride * 8, P->map_c.as<int32_t>(), cstride, 0, npts1, 0};
+        MsmJob jc = {cvec + p * (size_t)cstride * 8, P->map_c.as<int32_t>(), cstride, 0, npts1, 0, 0, 0};
         P->jobs1.push_back(jc);
     }
     for (size_t p = 0; p < np; p++) {
         const uint32_t* w = wit + p * wstride * 8;
-        MsmJob ja = {w, P->map_a.as<int32_t>(), nv + 3, P->off_a, npts1, 0};
+        MsmJob ja = {w, P->map_a.as<int32_t>(), nv + 3, P->off_a, npts1, 0, 0, 0};
         P->jobs1.push_back(ja);
     }
     ZK_TRY(P->g1.enqueue(P->jobs1, P->res1, g_stream, false));
@@ -1502,7 +1517,7 @@ zk_status msm_run_dev(zk_msm* M, const void* d_scalars, uint32_t flags, uint8_t*
     for (size_t first = 0; first < M->n; first += sl) {
         const uint32_t cnt = (uint32_t)std::min(sl, M->n - first);
         MsmJob j = {sc + first * 8, M->has_map ? M->map.as<int32_t>() + first : nullptr, cnt,
-                    M->has_map ? 0u : (uint32_t)first, (uint32_t)M->n, 0};
+                    M->has_map ? 0u : (uint32_t)first, (uint32_t)M->n, 0, 0, 0};
         jobs.push_back(j);
     }
     if (M->group == 1) {
