@@ -104,7 +104,9 @@ def test_anonymous_derivation_matches_oracle():
     import zero_chain_amd as zk
     from oracle import anonymous_circuit as ac
     lib = _lib()
-    cases = [anonymous_request(1), anonymous_request(2, amount=0, balance=0), anonymous_request(3, amount=0xFFFFFFFE, balance=0xFFFFFFFE)]
+    cases = [anonymous_request(1), anonymous_request(2, amount=0, balance=0), anonymous_request(3, amount=0xFFFFFFFE, balance=0xFFFFFFFE),
+             anonymous_request(5, amount=3, balance=40)]
+    assert cases[0][0]["s_index"] > cases[0][0]["t_index"] and cases[3][0]["s_index"] < cases[3][0]["t_index"]   # both insertion orders (anonymous.rs:119-125)
     sts, rsks = zk.anonymous_derive(zk.anonymous_requests([c[0] for c in cases]), lib=lib)
     for (rq, recipient, decoys, bals), st, rsk in zip(cases, sts, rsks):
         want, stmt = anonymous_expected(rq, recipient, decoys, bals)

@@ -451,7 +451,7 @@ def test_gen_proof_anonymous_xt(gpu_lib):
     import zero_chain_amd as zk
     from oracle import anonymous_circuit as ac
     import test_gen_proof as tg
-    cases = [tg.anonymous_request(1), tg.anonymous_request(2, amount=77, balance=5000)]
+    cases = [tg.anonymous_request(1), tg.anonymous_request(5, amount=77, balance=5000)]   # sender after / before the recipient
     E = g.Bls12Engine()
     mats = zk.ConstraintMatrices.anonymous_circuit(lib=gpu_lib)
     params = pvk = None
