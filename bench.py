@@ -108,6 +108,45 @@ def make_statements(lo, hi, procs):
     return items
 
 
+def _make_request(i):
+    """A gen_proof request (wallet-level entry, core/proofs/src/confidential.rs:105-172) with the amounts of statement i:
+    a spending key, the sender's balance encrypted under the key derived from it, a recipient, an epoch generator."""
+    from oracle import gen_proof as og
+    from oracle import jubjub as jj
+    from oracle import synth
+    _, amount, fee, balance = statement_params(i)
+    rng = synth.SplitMix64(0x67656e70 + i)
+    g = jj.note_commitment_randomness_generator()
+    fs = lambda: rng.field(jj.FS_MOD)
+    sk = fs()
+    _, _, enc_key = og.derive(sk)
+    bal = og.encrypt(balance, fs(), enc_key)
+    w = jj.write_point
+    return dict(amount=amount, fee=fee, remaining_balance=balance - amount - fee, spending_key=sk,
+                enc_key_recipient=w(jj.mul(g, fs())), enc_balance_left=w(bal[0]), enc_balance_right=w(bal[1]),
+                g_epoch=w(jj.mul(g, fs())), randomness=fs(), alpha=fs())
+
+
+def make_requests(n, procs):
+    os.makedirs(CACHE, exist_ok=True)
+    path = os.path.join(CACHE, "requests_%d.pkl" % n)
+    if os.path.exists(path):
+        try:
+            return pickle.load(open(path, "rb"))
+        except Exception:
+            pass
+    if procs > 1 and n >= 8:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(procs) as pool:
+            items = pool.map(_make_request, range(n), chunksize=max(1, n // (4 * procs)))
+    else:
+        items = [_make_request(i) for i in range(n)]
+    tmp = path + ".%d" % os.getpid()
+    pickle.dump(items, open(tmp, "wb"))
+    os.replace(tmp, path)
+    return items
+
+
 def build_circuit(threads):
     """The reference's confidential-transfer R1CS as the ORACLE restates it (oracle/transfer_circuit.py, checked
     against the reference's fingerprint) with the discrete logs of a synthetic CRS for it (fixed toxic waste; the
@@ -191,6 +230,7 @@ def main():
     host_threads = max(1, cores // world)
     t_setup0 = time.time()
     items = make_statements(rank * args.batch, rank * args.batch + args.batch, host_threads)
+    req_items = make_requests(args.batch, host_threads) if (world == 1 and not args.no_secondary) else None
 
     import numpy as np
     import torch
@@ -437,6 +477,29 @@ def main():
         secondary["from_witness_vectors"] = {"value": round(B / dt, 3), "unit": "proofs/s",
                                              "note": "zk_prove_batch_witness: witness vectors given, row evaluations + "
                                                      "create_proof on the GPU (kernel-pipeline rate; not the headline)"}
+        # (4) the wallet-level entry as a whole (gen_proof): key derivation on the host, witness generation, proof,
+        # check_proof (the product's verifier on every proof) and the packing of ConfidentialXt
+        try:
+            from oracle import gen_proof as og
+            from oracle import jubjub as jj
+            reqs = zk.transfer_requests(req_items)
+            pvk2 = zk.prepare_verifying_key(params)
+            zk.gen_proofs(params, mats, pvk2, reqs, rs_ints[0])
+            t0 = time.perf_counter()
+            xts = zk.gen_proofs(params, mats, pvk2, reqs, rs_ints[W + K - 1])
+            dt = time.perf_counter() - t0
+            pvk2.close()
+            it = req_items[B - 1]
+            want, _ = og.gen_xt_fields(it["spending_key"], it["amount"], it["fee"], it["remaining_balance"],
+                                       jj.read_point(it["enc_key_recipient"]),
+                                       (jj.read_point(it["enc_balance_left"]), jj.read_point(it["enc_balance_right"])),
+                                       jj.read_point(it["g_epoch"]), it["randomness"], it["alpha"])
+            assert all(xts[B - 1][f] == v for f, v in want.items()), "ConfidentialXt differs from the oracle's"
+            secondary["gen_proof"] = {"value": round(B / dt, 3), "unit": "transactions/s",
+                                      "note": "zk_transfer_gen_proof_batch on %d requests, one call: key derivation, witness "
+                                              "generation, proof, check_proof of every proof, ConfidentialXt" % B}
+        except Exception as exc:
+            secondary["gen_proof"] = {"error": repr(exc)[:200]}
         # (3) the reference's own call pattern: one create_random_proof per transaction
         try:
             pa = helpers.to_assignment(zk, asg0)

@@ -167,10 +167,14 @@ struct NttPlan {
             ProfScope ps_(dif ? "ntt_pass_dif" : "ntt_pass_dit");
 #ifndef ZK_EMU
             if (shmem > 65536) {
-                static bool raised = false;   // more than 64 KiB of dynamic LDS has to be asked for
-                if (!raised) {
+                // more than 64 KiB of dynamic LDS has to be asked for, once per device
+                static std::mutex mu;
+                static uint64_t raised = 0;
+                std::lock_guard<std::mutex> lock(mu);
+                const uint64_t bit = 1ull << (g_device & 63);
+                if (!(raised & bit)) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(zkdev::k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    raised = true;
+                    raised |= bit;
                 }
             }
 #endif
