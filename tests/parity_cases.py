@@ -122,14 +122,14 @@ def msm_golden_vectors(lib, group, n, window_bits, seed=1, variable_base=False):
         ctx.close()
 
 
-def msm_variable_base(lib, windows=(2, 3, 5, 8, 11, 13), n=400):
+def msm_variable_base(lib, windows=(2, 3, 5, 8, 11, 13), n=400, g2_n=120, auto_n=700, g2_w=4, one_w=3):
     """zk_msm_create_variable (classic Pippenger, no table of doublings: regular odd-digit recoding at fixed positions,
     one job per position) on the golden multiples, for several digit widths, both groups and the auto width."""
     for w in windows:
         msm_golden_vectors(lib, 1, n, w, seed=40 + w, variable_base=True)
-    msm_golden_vectors(lib, 2, 120, 4, seed=77, variable_base=True)
-    msm_golden_vectors(lib, 1, 700, 0, seed=78, variable_base=True)
-    msm_golden_vectors(lib, 1, 1, 3, seed=79, variable_base=True)
+    msm_golden_vectors(lib, 2, g2_n, g2_w, seed=77, variable_base=True)
+    msm_golden_vectors(lib, 1, auto_n, 0, seed=78, variable_base=True)
+    msm_golden_vectors(lib, 1, 1, one_w, seed=79, variable_base=True)
 
 
 def msm_recoding_stress(lib, windows=range(2, 23)):
