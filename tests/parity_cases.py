@@ -179,6 +179,26 @@ def msm_edge_cases(lib):
     with pytest.raises(zk.ZkError) as e:
         zk.MultiexpContext(1, bytes([0x80]) + bytes(95), lib=lib)
     assert e.value.variant == "IoError"
+    # the variable-base handle: empty input, one base, non-canonical scalar, window out of range, malformed base
+    for group, size in ((1, 96), (2, 192)):
+        ctx = zk.MultiexpContext(group, b"", lib=lib, variable_base=True)
+        assert ctx.run([]) == bytes([0x40]) + bytes(size - 1)
+        ctx.close()
+        one = helpers.golden_points("g1_uncompressed" if group == 1 else "g2_uncompressed")[1]
+        ctx = zk.MultiexpContext(group, one, lib=lib, variable_base=True)
+        assert ctx.run([0]) == bytes([0x40]) + bytes(size - 1)
+        assert ctx.run([2]) == (helpers.g1_of(2) if group == 1 else helpers.g2_of(2))
+        with pytest.raises(zk.ZkError) as e:
+            ctx.run(np.frombuffer(int(bls.R_MOD).to_bytes(32, "little"), dtype=np.uint8))
+        assert e.value.variant == "InvalidArgument"
+        ctx.close()
+    for w in (1, 21):
+        with pytest.raises(zk.ZkError) as e:
+            zk.MultiexpContext(1, helpers.golden_points("g1_uncompressed")[1], window_bits=w, lib=lib, variable_base=True)
+        assert e.value.variant == "InvalidArgument" and "window_bits" in str(e.value)
+    with pytest.raises(zk.ZkError) as e:
+        zk.MultiexpContext(1, bytes([0x80]) + bytes(95), lib=lib, variable_base=True)
+    assert e.value.variant == "IoError"
 
 
 def prover_small(lib, seed, n_in, n_aux, n_con, checked=True, montgomery=False):
