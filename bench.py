@@ -147,6 +147,69 @@ def make_requests(n, procs):
     return items
 
 
+def _make_anonymous(i):
+    from oracle import anonymous_circuit as ac
+    _, amount, _, balance = statement_params(i)
+    return ac.statement_dict(ac.make_witness(1000 + i, amount=amount, balance=balance))
+
+
+def make_anonymous_statements(n, procs):
+    os.makedirs(CACHE, exist_ok=True)
+    path = os.path.join(CACHE, "anonymous_%d.pkl" % n)
+    if os.path.exists(path):
+        try:
+            return pickle.load(open(path, "rb"))
+        except Exception:
+            pass
+    if procs > 1 and n >= 8:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(procs) as pool:
+            items = pool.map(_make_anonymous, range(n), chunksize=1)
+    else:
+        items = [_make_anonymous(i) for i in range(n)]
+    tmp = path + ".%d" % os.getpid()
+    pickle.dump(items, open(tmp, "wb"))
+    os.replace(tmp, path)
+    return items
+
+
+def run_anonymous(lib, zk, items):
+    """The reference's anonymous transfer (core/proofs/src/anonymous.rs:165), statement -> proof: natively emitted
+    matrices, a key from zk_generate_parameters, the host witness calculator overlapped with the GPU chunk by chunk.
+    Every proof is verified by the product's verifier against the 104 public inputs of its statement."""
+    import numpy as np
+    import helpers
+    from oracle import bls12_381 as bls
+    from oracle import synth
+    n = len(items)
+    mats = zk.ConstraintMatrices.anonymous_circuit(lib=lib)
+    t0 = time.perf_counter()
+    params = zk.Parameters.read(zk.generate_parameters(mats, *helpers.TOXIC), checked=False, lib=lib)
+    keygen_s = time.perf_counter() - t0
+    pvk = zk.prepare_verifying_key(params)
+    sts = zk.anonymous_statements(items)
+    rng = synth.SplitMix64(4242)
+    rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
+    zk.anonymous_prove_batch(mats, params, sts, rs)
+    t0 = time.perf_counter()
+    proofs = zk.anonymous_prove_batch(mats, params, sts, rs)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    wit = zk.anonymous_witness(sts, lib=lib)
+    dtw = time.perf_counter() - t0
+    nv = zk.ANONYMOUS_N_INPUTS + zk.ANONYMOUS_N_AUX
+    inputs = np.ascontiguousarray(wit.reshape(n, nv * 32)[:, 32:zk.ANONYMOUS_N_INPUTS * 32])
+    ok = zk.verify_proofs(pvk, proofs, inputs)
+    assert all(ok), "the verifier rejected %d of %d anonymous proofs" % (n - sum(ok), n)
+    pvk.close()
+    params.close()
+    mats.close()
+    return {"value": round(n / dt, 3), "unit": "proofs/s", "statements": n, "proofs_verified_by_product_verifier": int(sum(ok)),
+            "witness_only_per_s": round(n / dtw, 1), "generate_parameters_s": round(keygen_s, 2),
+            "note": "zk_anonymous_prove_batch: 50 514 constraints, 105 inputs, evaluation domain 2^16; host witness "
+                    "calculator overlapped with the GPU chunk by chunk"}
+
+
 def build_circuit(threads):
     """The reference's confidential-transfer R1CS as the ORACLE restates it (oracle/transfer_circuit.py, checked
     against the reference's fingerprint) with the discrete logs of a synthetic CRS for it (fixed toxic waste; the
@@ -206,6 +269,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the witness-resident secondary measurement")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--oracle-checks", type=int, default=6, help="proofs per rank compared with the oracle's proof")
+    ap.add_argument("--anonymous", type=int, default=0, metavar="N",
+                    help="also time N statements of the reference's second circuit (anonymous transfer, domain 2^16) through "
+                         "zk_anonymous_prove_batch: an extra object `anonymous` in the line (off by default: its statements "
+                         "cost seconds of oracle arithmetic each)")
     args = ap.parse_args()
 
     if args.micro_only:
@@ -231,6 +298,7 @@ def main():
     t_setup0 = time.time()
     items = make_statements(rank * args.batch, rank * args.batch + args.batch, host_threads)
     req_items = make_requests(args.batch, host_threads) if (world == 1 and not args.no_secondary) else None
+    anon_items = make_anonymous_statements(args.anonymous, host_threads) if (world == 1 and args.anonymous > 0) else None
 
     import numpy as np
     import torch
@@ -515,6 +583,12 @@ def main():
     if not args.no_micro and world == 1:
         micro = run_micro(lib, zk, dev)
     pipe.close()
+    anonymous = None
+    if anon_items:
+        try:
+            anonymous = run_anonymous(lib, zk, anon_items)
+        except Exception as exc:
+            anonymous = {"error": repr(exc)[:300]}
 
     line = {
         "metric": "Groth16 proofs/sec (Transfer circuit)", "value": round(total_proofs / elapsed, 3), "unit": "proofs/s",
@@ -535,6 +609,8 @@ def main():
                    "proofs_verified_by_product_verifier": verified, "verify_ms": None if verify_ms is None else round(verify_ms, 1), "setup_s": round(setup_s, 2), "generate_parameters_s": round(keygen_s, 2)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "secondary": secondary, "micro": micro,
     }
+    if anonymous is not None:
+        line["anonymous"] = anonymous
     print(json.dumps(line), flush=True)
 
 
