@@ -397,6 +397,67 @@ def gen28_fq2mul(p, name):
             "clobbers": clob_v + clob_s + ["vcc"]}
 
 
+def gen28_mul2(p, name):
+    """Two INDEPENDENT products in the radix-2^28 representation, c0 = a0 b0 2^-392 and c1 = a1 b1 2^-392, with their
+    multiply-adds alternating between two 64-bit accumulators: two dependency chains for a wave that runs alone on
+    its SIMD (the G2 kernels), where one product at a time leaves issue slots empty.  Used for the two products of
+    an Fq2 square, (a0 + a1)(a0 - a1) and 2 a0 a1.
+    a0 in v[0:13], a1 in v[16:29], b0 in v[32:45], b1 in v[48:61]; c0 -> v[0:13], c1 -> v[16:29] (exactly normalised,
+    < 2p under the operand bounds of the single product).  clobbers v[64:95], s[0:17], vcc; b0, b1 are preserved."""
+    N, B = 14, 28
+    MASK = (1 << B) - 1
+    P = [(p >> (B * j)) & MASK for j in range(N)]
+    inv = (-pow(p, -1, 1 << B)) & MASK
+    a0 = lambda i: "v%d" % i
+    a1 = lambda i: "v%d" % (16 + i)
+    b0 = lambda i: "v%d" % (32 + i)
+    b1 = lambda i: "v%d" % (48 + i)
+    m0 = lambda i: "v%d" % (64 + i)
+    m1 = lambda i: "v%d" % (78 + i)
+    lo0, hi0, lo1, hi1 = 92, 93, 94, 95
+    acc0, acc1 = "v[%d:%d]" % (lo0, hi0), "v[%d:%d]" % (lo1, hi1)
+    sp = lambda j: "s%d" % j
+    sinv = "s%d" % N
+    dummy = "s[16:17]"
+    e = Emitter()
+    for j in range(N):
+        e.salu_op("s_mov_b32 %s, 0x%08x" % (sp(j), P[j]))
+    e.salu_op("s_mov_b32 %s, 0x%08x" % (sinv, inv))
+    first0 = first1 = True
+    for k in range(2 * N - 1):
+        p0 = [(a0(i), b0(k - i)) for i in range(N) if 0 <= k - i < N]
+        p1 = [(a1(i), b1(k - i)) for i in range(N) if 0 <= k - i < N]
+        p0 += [(m0(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
+        p1 += [(m1(i), sp(k - i)) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
+        for t in range(len(p0)):
+            x, y = p0[t]
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc0, dummy, x, y, "0" if first0 else acc0))
+            first0 = False
+            x, y = p1[t]
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc1, dummy, x, y, "0" if first1 else acc1))
+            first1 = False
+        if k < N:
+            e.valu_op("v_mul_lo_u32 %s, v%d, %s" % (m0(k), lo0, sinv))
+            e.valu_op("v_mul_lo_u32 %s, v%d, %s" % (m1(k), lo1, sinv))
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, %s" % (m0(k), MASK, m0(k)))
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, %s" % (m1(k), MASK, m1(k)))
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc0, dummy, m0(k), sp(0), acc0))
+            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (acc1, dummy, m1(k), sp(0), acc1))
+        else:
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, v%d" % (a0(k - N), MASK, lo0))
+            e.valu_op("v_and_b32_e32 %s, 0x%08x, v%d" % (a1(k - N), MASK, lo1))
+        e.valu_op("v_alignbit_b32 v%d, v%d, v%d, %d" % (lo0, hi0, lo0, B))
+        e.valu_op("v_alignbit_b32 v%d, v%d, v%d, %d" % (lo1, hi1, lo1, B))
+        e.valu_op("v_lshrrev_b32_e32 v%d, %d, v%d" % (hi0, B, hi0))
+        e.valu_op("v_lshrrev_b32_e32 v%d, %d, v%d" % (hi1, B, hi1))
+    e.valu_op("v_mov_b32_e32 %s, v%d" % (a0(N - 1), lo0))
+    e.valu_op("v_mov_b32_e32 %s, v%d" % (a1(N - 1), lo1))
+    clob_v = ["v%d" % i for i in range(64, 96)]
+    clob_s = ["s%d" % i for i in range(0, 18)]
+    return {"name": name, "N": N, "lines": e.lines, "valu": e.valu, "nops": e.nops,
+            "clobbers": clob_v + clob_s + ["vcc"]}
+
+
 def render(spec):
     body = "\\n\\t".join(spec["lines"])
     out = []
@@ -413,7 +474,7 @@ def render(spec):
 
 def main():
     specs = [gen(8, FR_P, "FR"), gen(12, FQ_P, "FQ"), gen28(FQ_P, "FQ28"), gen28(FQ_P, "FQ28D", dual=True), gen28_sqr(FQ_P, "FQ28SQR"),
-             gen28_mac2(FQ_P, "FQ28MAC2"), gen28_fq2mul(FQ_P, "FQ2MUL28")]
+             gen28_mac2(FQ_P, "FQ28MAC2"), gen28_fq2mul(FQ_P, "FQ2MUL28"), gen28_mul2(FQ_P, "FQ28MUL2")]
     hdr = ["// GENERATED by tools/gen_mul_asm.py - do not edit.",
            "// Hand-scheduled gfx950 Montgomery products (see the generator for the design notes).",
            "#pragma once", ""]

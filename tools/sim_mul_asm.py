@@ -239,6 +239,34 @@ def main28_fq2mul():
     print(spec["name"], "ok:", len(cases), "Fq2 products;", spec["valu"], "VALU,", spec["nops"], "wait states")
 
 
+def main28_mul2():
+    rnd = random.Random(11)
+    p = g.FQ_P
+    spec = g.gen28_mul2(p, "FQ28MUL2")
+    Rinv = pow(1 << 392, -1, p)
+    lim = lambda x: [(x >> (28 * i)) & ((1 << 28) - 1) if i < 13 else x >> (28 * 13) for i in range(14)]
+    val = lambda l: sum(x << (28 * i) for i, x in enumerate(l))
+    # operand magnitudes of the single product: |a||b| < 2^11.3 p^2 (here up to 45 p x 45 p)
+    cases = [(0, 0, 0, 0), (1, 2, 3, 4), (45 * p, 45 * p, 45 * p, 45 * p), (2 * p - 1, p - 1, 40 * p, 7 * p)]
+    cases += [tuple(rnd.randrange(45 * p) for _ in range(4)) for _ in range(300)]
+    for vals in cases:
+        l = [_weak(rnd, lim(v)) for v in vals]
+        init = {}
+        for blk, limbs in enumerate(l):
+            for i in range(14):
+                init[16 * blk + i] = limbs[i]
+        keep = dict(init)
+        out_regs = _run_regs_full(spec["lines"], init)
+        c0 = [out_regs[i] for i in range(14)]
+        c1 = [out_regs[16 + i] for i in range(14)]
+        a0, a1, b0, b1 = (val(x) for x in l)
+        assert all(x < (1 << 28) for x in c0[:13] + c1[:13])
+        assert val(c0) % p == a0 * b0 * Rinv % p and val(c0) < 2 * p
+        assert val(c1) % p == a1 * b1 * Rinv % p and val(c1) < 2 * p
+        assert all(out_regs[r] == keep[r] for r in keep if r >= 32), "b0 / b1 were modified"
+    print(spec["name"], "ok:", len(cases), "pairs of products;", spec["valu"], "VALU,", spec["nops"], "wait states")
+
+
 def _run_regs_full(lines, init):
     """_run_regs returning the whole register file"""
     regs = {}
@@ -251,6 +279,7 @@ def _run_regs_full(lines, init):
 if __name__ == "__main__":
     main28_mac2()
     main28_fq2mul()
+    main28_mul2()
     main()
     main28()
     main28(dual=True)

@@ -610,6 +610,7 @@ ZK_DI Fq28 sqr(const Fq28& a) {
 // clobbers itself: v[0:15], v[16:31], v[32:47], v[48:63] in, v[0:15] (and v[16:31]) out.
 //   mac2:    c = (x0 y0 + x1 y1) 2^-392        one Montgomery reduction for a sum of two products
 //   fq2mul:  c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0   (x 2^-392): 4 limb-product groups, 2 reductions
+//   mul2:    c0 = a0 b0, c1 = a1 b1                    (x 2^-392): two independent products, interleaved
 // ---------------------------------------------------------------------------------------------
 // plain C++ of the same column schedule (the emulation build, ZK_MUL_CXX): bit-identical results
 ZK_DI u32x16 mac2_cxx(u32x16 x0, u32x16 y0, u32x16 x1, u32x16 y1) {
@@ -653,7 +654,14 @@ ZK_DI void fq2mul_raw(u32x16& a0, u32x16& a1, const u32x16& b0, const u32x16& b1
     a0 = c0;
     a1 = c1;
 }
+ZK_DI void mul2_raw(u32x16& a0, u32x16& a1, const u32x16& b0, const u32x16& b1) {
+    a0 = mul28_cxx(a0, b0);
+    a1 = mul28_cxx(a1, b1);
+}
 #else
+extern "C" __device__ __attribute__((naked, noinline, used)) void zk_fq28_mul2() {
+    asm volatile(ZK_MUL_ASM_FQ28MUL2 "s_setpc_b64 s[30:31]");
+}
 extern "C" __device__ __attribute__((naked, noinline, used)) void zk_fq28_mac2() {
     asm volatile(ZK_MUL_ASM_FQ28MAC2 "s_setpc_b64 s[30:31]");
 }
@@ -676,6 +684,13 @@ ZK_DI void fq2mul_raw(u32x16& a0, u32x16& a1, const u32x16& b0, const u32x16& b1
         : "+{v[0:15]}"(a0), "+{v[16:31]}"(a1)
         : "{v[32:47]}"(b0), "{v[48:63]}"(b1)
         : ZK_MUL_ASM_FQ2MUL28_CLOBBERS, "s18", "s19", "s30", "s31");
+}
+// two independent products a0 b0, a1 b1 on two interleaved accumulator chains (mul_asm.h FQ28MUL2)
+ZK_DI void mul2_raw(u32x16& a0, u32x16& a1, const u32x16& b0, const u32x16& b1) {
+    asm(ZK_ASM_CALL("zk_fq28_mul2")
+        : "+{v[0:15]}"(a0), "+{v[16:31]}"(a1)
+        : "{v[32:47]}"(b0), "{v[48:63]}"(b1)
+        : ZK_MUL_ASM_FQ28MUL2_CLOBBERS, "s18", "s19", "s30", "s31");
 }
 #endif
 
@@ -853,7 +868,14 @@ ZK_DI Fq2x mul(const Fq2x& a, const Fq2x& b) {
 template <int A>   // A = bound of the operand's components (for the difference a0 - a1)
 ZK_DI Fq2x sqr_b(const Fq2x& a) {
     static_assert(A <= 30, "operand of an Fq2 square out of range");
-    return Fq2x{mul(add(a.c0, a.c1), sub_b<A>(a.c0, a.c1)), mul(dbl(a.c0), a.c1)};
+    // (a0 + a1)(a0 - a1) and (2 a0) a1 in ONE routine, their multiply-adds alternating: two dependency chains for
+    // the lone wave per SIMD the G2 kernels run with
+    const Fq28 s = add(a.c0, a.c1), d = sub_b<A>(a.c0, a.c1), t = dbl(a.c0);
+    ZK_FQ28_CHECK(fq28_ratio(s.l) * fq28_ratio(d.l) < 2500.0L);
+    ZK_FQ28_CHECK(fq28_ratio(t.l) * fq28_ratio(a.c1.l) < 2500.0L);
+    u32x16 x0 = fq28_vec(s), x1 = fq28_vec(t);
+    mul2_raw(x0, x1, fq28_vec(d), fq28_vec(a.c1));
+    return Fq2x{fq28_unvec(x0), fq28_unvec(x1)};
 }
 // square of a product / table entry / imported value / negated product (components < 4 p)
 ZK_DI Fq2x sqr(const Fq2x& a) { return sqr_b<4>(a); }
