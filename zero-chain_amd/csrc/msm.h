@@ -577,13 +577,13 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
 // Two things measured NOT to matter here, neither in the batched prover (4 GB of tables) nor on one
 // 2^20-point job (30 GB): fetching the next point while the current one is added (28 more live
 // registers; measured again in round 2 as a two-deep pipeline with the pair index two steps ahead: G1
-// 176.6 -> 178.4 ms per launch, G2 93.2 -> 91.2), and sorting every task's pairs by table index so that all
+// 176.6 -> 178.4 ms per launch, G2 at one wave per SIMD 93.2 -> 91.2: kept there only), and sorting every task's pairs by table index so that all
 // lanes sweep the doubling slices in step.  What bounds the issue rate at two waves per SIMD is the product
 // routine itself (66 G products/s at this occupancy against 74.5 at eight waves, profiles/r01f_ubench.txt);
 // three waves per SIMD (168 VGPRs, 88 bytes of scratch per lane) measured 179.6 ms, four (128 VGPRs) 237.7.
 // The single job's lower rate (4.3 G additions/s against 7.0) is 88 % occupancy at
 // the two ends of a 3 ms launch, a 12 % lower issue rate per resident wave and a lower clock.
-template <class F, int OCC>
+template <class F, int OCC, bool PIPELINED = false>
 ZK_DI void msm_accumulate_body(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
                                const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<F>* __restrict__ tsums) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -591,10 +591,27 @@ ZK_DI void msm_accumulate_body(const Affine<F>* __restrict__ table, const uint32
     const uint4 d = sorted[t];
     const uint32_t o = d.x, n = d.z;
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t k = 0; k < n; k++) {
-        uint32_t pr = pairs[o + k];
+    if (PIPELINED && n) {
+        // one wave per SIMD has nobody to hide a gather behind: the pair index two steps ahead and the table entry
+        // one step ahead are in flight while the current entry is added (steps past the end re-read the last pair)
+        const uint32_t last = n - 1;
+        uint32_t pr = pairs[o];
+        uint32_t pr_n = pairs[o + (1u < last ? 1u : last)];
         Affine<F> p = table[pr >> 1];
-        madd(acc, p, (pr & 1u) != 0);
+        for (uint32_t k = 0; k < n; k++) {
+            const Affine<F> p_n = table[pr_n >> 1];
+            const uint32_t pr_nn = pairs[o + (k + 2 < last ? k + 2 : last)];
+            madd(acc, p, (pr & 1u) != 0);
+            p = p_n;
+            pr = pr_n;
+            pr_n = pr_nn;
+        }
+    } else {
+        for (uint32_t k = 0; k < n; k++) {
+            uint32_t pr = pairs[o + k];
+            Affine<F> p = table[pr >> 1];
+            madd(acc, p, (pr & 1u) != 0);
+        }
     }
     tsums[d.y] = acc;
 }
@@ -610,7 +627,7 @@ template <class F>
 static __global__ void __launch_bounds__(128, 1)
 k_msm_accumulate_wide(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs,
                       const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<F>* __restrict__ tsums) {
-    msm_accumulate_body<F, 1>(table, pairs, sorted, total, tsums);
+    msm_accumulate_body<F, 1, true>(table, pairs, sorted, total, tsums);
 }
 
 // Pass 5b: buckets cut into many tasks.  Scalars are not uniform where it matters: the LAST digit
