@@ -610,6 +610,8 @@ ZK_DI Fq28 sqr(const Fq28& a) {
 // clobbers itself: v[0:15], v[16:31], v[32:47], v[48:63] in, v[0:15] (and v[16:31]) out.
 //   mac2:    c = (x0 y0 + x1 y1) 2^-392        one Montgomery reduction for a sum of two products
 //   fq2mul:  c0 = a0 b0 - a1 b1, c1 = a0 b1 + a1 b0   (x 2^-392): 4 limb-product groups, 2 reductions
+//            (two accumulator chains; four, folded per column with a 64-bit add, measured slower even for a wave
+//            alone on its SIMD: G2 accumulation 90.2 -> 93.1 ms - the routine is bound by issue, not by latency)
 //   mul2:    c0 = a0 b0, c1 = a1 b1                    (x 2^-392): two independent products, interleaved
 // ---------------------------------------------------------------------------------------------
 // plain C++ of the same column schedule (the emulation build, ZK_MUL_CXX): bit-identical results
