@@ -550,11 +550,12 @@ def main():
         try:
             from oracle import gen_proof as og
             from oracle import jubjub as jj
-            reqs = zk.transfer_requests(req_items)
+            reqs = zk.transfer_requests(req_items + req_items)     # two chunks: check_proof of one overlaps the proving of the next
+            rs2 = list(rs_ints[W + K - 1]) + list(rs_ints[0])
             pvk2 = zk.prepare_verifying_key(params)
-            zk.gen_proofs(params, mats, pvk2, reqs, rs_ints[0])
+            zk.gen_proofs(params, mats, pvk2, reqs, rs2)
             t0 = time.perf_counter()
-            xts = zk.gen_proofs(params, mats, pvk2, reqs, rs_ints[W + K - 1])
+            xts = zk.gen_proofs(params, mats, pvk2, reqs, rs2)
             dt = time.perf_counter() - t0
             pvk2.close()
             it = req_items[B - 1]
@@ -563,9 +564,10 @@ def main():
                                        (jj.read_point(it["enc_balance_left"]), jj.read_point(it["enc_balance_right"])),
                                        jj.read_point(it["g_epoch"]), it["randomness"], it["alpha"])
             assert all(xts[B - 1][f] == v for f, v in want.items()), "ConfidentialXt differs from the oracle's"
-            secondary["gen_proof"] = {"value": round(B / dt, 3), "unit": "transactions/s",
-                                      "note": "zk_transfer_gen_proof_batch on %d requests, one call: key derivation, witness "
-                                              "generation, proof, check_proof of every proof, ConfidentialXt" % B}
+            assert all(xts[2 * B - 1][f] == v for f, v in want.items())
+            secondary["gen_proof"] = {"value": round(2 * B / dt, 3), "unit": "transactions/s",
+                                      "note": "zk_transfer_gen_proof_batch on %d requests (two chunks), one call: key derivation, "
+                                              "witness generation, proof, check_proof of every proof, ConfidentialXt" % (2 * B)}
         except Exception as exc:
             secondary["gen_proof"] = {"error": repr(exc)[:200]}
         # (3) the reference's own call pattern: one create_random_proof per transaction

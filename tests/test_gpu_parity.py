@@ -383,7 +383,7 @@ def test_setup_transfer_circuit_byte_identical(gpu_lib):
         mats.close()
 
 
-def test_gen_proof_confidential_xt(gpu_lib):
+def test_gen_proof_confidential_xt(gpu_lib, monkeypatch):
     """zk_transfer_gen_proof_batch = the reference's gen_proof (core/proofs/src/confidential.rs:105-172): every field
     of ConfidentialXt against the oracle's restatement (oracle/gen_proof.py: keys, ElGamal, rvk, rsk, nonce) and the
     proof against the discrete-log proof of the same statement; an inconsistent request fails the self-check with
@@ -437,6 +437,16 @@ def test_gen_proof_confidential_xt(gpu_lib):
         with pytest.raises(zk.ZkError) as e:
             zk.gen_proofs(params, mats, pvk, zk.transfer_requests([items[1], bad]), rs[:2])
         assert e.value.variant == "Unsatisfiable" and "request 1" in str(e.value)
+        # several chunks: check_proof of chunk k runs on its own lane while chunk k + 1 is proved
+        monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "2")
+        again = zk.gen_proofs(params, mats, pvk, zk.transfer_requests(items + items[:2]), rs + rs[:2])
+        assert again[:3] == xts and again[3:] == xts[:2]
+        for where in (0, 2, 4):      # a failing request in the first, a middle and the last chunk
+            reqs = list(items + items[:2])
+            reqs[where] = dict(reqs[where], remaining_balance=reqs[where]["remaining_balance"] + 1)
+            with pytest.raises(zk.ZkError) as e:
+                zk.gen_proofs(params, mats, pvk, zk.transfer_requests(reqs), rs + rs[:2])
+            assert e.value.variant == "Unsatisfiable" and "request %d" % where in str(e.value)
     finally:
         pvk.close()
         mats.close()

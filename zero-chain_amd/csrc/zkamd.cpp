@@ -2043,6 +2043,36 @@ zk_status zk_transfer_derive(const zk_transfer_request* req, size_t n, zk_transf
     return transfer_derive(req, n, statements_out, rsk_out);
 }
 
+}  // extern "C"
+namespace {
+// One verification at a time on a helper thread with its own lane: check_proof of chunk k overlaps the proving of
+// chunk k + 1 (the pairing chains are latency-bound and take a few per cent of the GPU).
+struct AsyncVerifier {
+    std::thread th;
+    zk_status rc = ZK_OK;
+    std::string err;
+    zk_status join() {
+        if (th.joinable()) th.join();
+        if (rc != ZK_OK) return fail(rc, err);
+        return ZK_OK;
+    }
+    ~AsyncVerifier() {
+        if (th.joinable()) th.join();
+    }
+};
+zk_status verify_chunk_async(AsyncVerifier& v, zk_vk* vk, size_t first, size_t end, const uint8_t* proofs, const uint8_t* inputs,
+                             size_t n_pub, uint8_t* ok) {
+    ZK_TRY(v.join());
+    v.th = std::thread([&v, vk, first, end, proofs, inputs, n_pub, ok] {
+        g_lane = 3;
+        v.rc = zk_verify_batch(vk, end - first, proofs + first * 192, inputs + first * n_pub * 32, n_pub, ok + first);
+        if (v.rc != ZK_OK) v.err = g_err;
+    });
+    return ZK_OK;
+}
+}  // namespace
+extern "C" {
+
 zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk, size_t n, const zk_transfer_request* req,
                                       const uint8_t* rs, zk_confidential_xt* out) {
     if (!p || !circuit || !vk || (n && (!req || !rs || !out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
@@ -2060,6 +2090,7 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
     PinBuf pin_in;
     ZK_TRY(pin_in.ensure(std::min(chunk, n) * ZK_TRANSFER_N_INPUTS * 32));
     std::vector<uint8_t> inputs(n * n_pub * 32);
+    AsyncVerifier ver;
     int slot = 0;
     ZK_TRY(witness_gpu_enqueue(circuit, st.data(), std::min(chunk, n), slot, g_copy_stream));
     for (size_t first = 0; first < n; first += chunk) {
@@ -2092,10 +2123,13 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
             jubjub_encode(z[21], z[22], x.nonce);
             memcpy(x.rsk, rsk.data() + (first + i) * 32, 32);
         }
+        // check_proof of this chunk runs on its own lane (streams) while the next chunk is proved
+        if (next < n) ZK_TRY(verify_chunk_async(ver, vk, first, first + np, proofs.data(), inputs.data(), n_pub, ok.data()));
         slot ^= 1;
     }
-    // check_proof: every proof must verify against the public inputs the transaction will carry
-    ZK_TRY(zk_verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data()));
+    // check_proof of the last chunk, then the verdicts of all of them
+    ZK_TRY(verify_chunk_async(ver, vk, n > chunk ? (n - 1) / chunk * chunk : 0, n, proofs.data(), inputs.data(), n_pub, ok.data()));
+    ZK_TRY(ver.join());
     for (size_t i = 0; i < n; i++)
         if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
     return ZK_OK;
