@@ -323,7 +323,9 @@ struct MsmGroup {
         for (size_t k = 0; k < nj; k++) total += (uint64_t)jobs[k].n * maxd;
         // points per accumulation task (msm.h): a task is a serial chain of ~10 us per point, so the
         // long form is for launches that keep the GPU busy for tens of milliseconds anyway
-        const uint32_t seg = seg_forced ? seg_forced : (nj >= 64 && total >= 100000000ull ? 256u : 64u);
+        // ... and the short form (32) is for one proof at a time, where the longest task IS the launch: 5.33 -> 4.80 ms
+        // per proof (at 2^20 points it costs 1 % with the table and doubles the variable-base time: kept at 64 there)
+        const uint32_t seg = seg_forced ? seg_forced : (nj >= 64 && total >= 100000000ull ? 256u : total < 4000000ull ? 32u : 64u);
         total = 0;
         for (size_t k = 0; k < nj; k++) {
             MsmJob& j = jobs[k];
@@ -382,7 +384,9 @@ struct MsmGroup {
         const MsmJob* dj = jobs_d.as<MsmJob>();
         dim3 gridn((max_n + 255) / 256, (unsigned)nj);
         dim3 gridb((nb + 255) / 256, (unsigned)nj);
-        const bool lds_sort = (size_t)nb * 4 <= 65536 && !getenv("ZKAMD_NO_LDS_SORT");
+        // one workgroup per job sorts inside its LDS: right for a thousand jobs per launch, a 0.67 ms serial pass for
+        // the one or two jobs of a proof made alone (4.83 -> 4.17 ms per proof with the many-workgroup sort instead)
+        const bool lds_sort = (size_t)nb * 4 <= 65536 && nj > MSM_FEW_JOBS && !getenv("ZKAMD_NO_LDS_SORT");
         if (lds_sort) {
             // histogram + scan + scatter of a job inside one workgroup's LDS
             ProfScope ps("msm_sort_lds", st);
