@@ -383,6 +383,7 @@ struct Fq28Consts {
     static constexpr uint32_t ONE[14] = ZK_FQ28_ONE;
     static constexpr uint32_t KIN[14] = ZK_FQ28_KIN;
     static constexpr uint32_t KOUT[14] = ZK_FQ28_KOUT;
+    static constexpr uint32_t KINV[14] = ZK_FQ28_KINV;
     static constexpr uint32_t B[14] = ZK_FQ28_B;
     static constexpr uint32_t INV = ZK_FQ28_INV;
 };
@@ -743,7 +744,8 @@ ZK_DI Fq28 canon(const Fq28& a) {
 ZK_DI bool is_zero_full(const Fq28& a) { return mul(a, Fq28::one()).is_zero_norm(); }
 
 // host interchange: 12 x u32 canonical Montgomery (radix 2^384) limbs  <->  Fq28
-ZK_DI Fq28 fq28_import(const uint32_t* h) {
+// 12 x 32-bit words (an integer < 2^384) -> 14 limbs of 28 bits, as they are
+ZK_DI Fq28 fq28_unpack(const uint32_t* h) {
     Fq28 t;
     uint32_t w[13];
 #pragma unroll
@@ -755,8 +757,9 @@ ZK_DI Fq28 fq28_import(const uint32_t* h) {
         uint64_t two = (uint64_t)w[q] | ((uint64_t)w[q + 1] << 32);
         t.l[i] = (uint32_t)(two >> sh) & FQ28_MASK;
     }
-    return mul(t, Fq28::from_const(Fq28Consts::KIN));
+    return t;
 }
+ZK_DI Fq28 fq28_import(const uint32_t* h) { return mul(fq28_unpack(h), Fq28::from_const(Fq28Consts::KIN)); }
 ZK_DI void fq28_export(const Fq28& a, uint32_t* h) {
     Fq28 t = mul(a, Fq28::from_const(Fq28Consts::KOUT));
     // canonical: subtract p once if needed (t < 2p, exact limbs)

@@ -530,8 +530,15 @@ struct MsmGroup {
     zk_status normalize_to_host(const DPoint* src, size_t n, HPoint* out, DevBuf& stage, hipStream_t st) {
         if (!n) return ZK_OK;
         ZK_TRY(stage.ensure(n * sizeof(HPoint)));
-        ZK_LAUNCH(zkdev::k_xyzz_normalize_export<DF>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, src, stage.as<uint32_t>(),
-                  (uint32_t)n);
+        // a handful of points (a proof made alone): the Euclidean inversion, 0.66 -> 0.1 ms of pure latency; a chunk of
+        // proofs: the Fermat chain, whose lanes stay in step (5.0 against 5.5 ms per 1024 proofs)
+        if (n <= 64) {
+            ZK_LAUNCH((zkdev::k_xyzz_normalize_export<DF, true>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, src,
+                      stage.as<uint32_t>(), (uint32_t)n);
+        } else {
+            ZK_LAUNCH((zkdev::k_xyzz_normalize_export<DF, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, src,
+                      stage.as<uint32_t>(), (uint32_t)n);
+        }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out, stage.p, n * sizeof(HPoint), hipMemcpyDeviceToHost, st));
         return ZK_OK;
