@@ -313,7 +313,7 @@ struct MsmGroup {
         out.resize(nj);
         res_dev = nullptr;
         if (!nj) return ZK_OK;
-        const char* seg_env = getenv("ZKAMD_MSM_SEG");
+        const char* seg_env = getenv(zkdev::HostWords<DF>::N == 24 && getenv("ZKAMD_MSM_SEG_G2") ? "ZKAMD_MSM_SEG_G2" : "ZKAMD_MSM_SEG");
         const uint32_t seg_forced = seg_env && atoi(seg_env) > 0 && atoi(seg_env) <= (int)zkdev::MSM_SEG_MAX
                                  ? (uint32_t)atoi(seg_env)
                                  : 0u;
@@ -325,7 +325,11 @@ struct MsmGroup {
         // long form is for launches that keep the GPU busy for tens of milliseconds anyway
         // ... and the short form (32) is for one proof at a time, where the longest task IS the launch: 5.33 -> 4.80 ms
         // per proof (at 2^20 points it costs 1 % with the table and doubles the variable-base time: kept at 64 there)
-        const uint32_t seg = seg_forced ? seg_forced : (nj >= 64 && total >= 100000000ull ? 256u : total < 4000000ull ? 32u : 64u);
+        // (G2, whose additions take three times as long and whose side stream is the critical path of a lone proof: 16,
+        // 3.79 -> 3.53 ms)
+        const bool is_g2 = zkdev::HostWords<DF>::N == 24;
+        const uint32_t seg = seg_forced ? seg_forced
+                                        : (nj >= 64 && total >= 100000000ull ? 256u : total < 4000000ull ? (is_g2 ? 16u : 32u) : 64u);
         total = 0;
         for (size_t k = 0; k < nj; k++) {
             MsmJob& j = jobs[k];
