@@ -185,7 +185,7 @@ def msm_edge_cases(lib):
         assert ctx.run([]) == bytes([0x40]) + bytes(size - 1)
         ctx.close()
         one = helpers.golden_points("g1_uncompressed" if group == 1 else "g2_uncompressed")[1]
-        ctx = zk.MultiexpContext(group, one, lib=lib, variable_base=True)
+        ctx = zk.MultiexpContext(group, one, window_bits=7, lib=lib, variable_base=True)
         assert ctx.run([0]) == bytes([0x40]) + bytes(size - 1)
         assert ctx.run([2]) == (helpers.g1_of(2) if group == 1 else helpers.g2_of(2))
         with pytest.raises(zk.ZkError) as e:
