@@ -2079,7 +2079,7 @@ zk_status verify_chunk_async(AsyncVerifier& v, zk_vk* vk, size_t first, size_t e
                              size_t n_pub, uint8_t* ok) {
     ZK_TRY(v.join());
     v.th = std::thread([&v, vk, first, end, proofs, inputs, n_pub, ok] {
-        g_lane = 3;
+        g_lane = 5;   // not one of the pipeline's lanes (0 .. 3)
         v.rc = zk_verify_batch(vk, end - first, proofs + first * 192, inputs + first * n_pub * 32, n_pub, ok + first);
         if (v.rc != ZK_OK) v.err = g_err;
     });
@@ -2348,12 +2348,14 @@ struct zk_pipeline {
     };
     zk_params* P = nullptr;
     zk_r1cs* R = nullptr;
-    // lane 1 (ZKAMD_PIPELINE_LANES, default 2): a second worker with its own workspaces and streams over the same
-    // tables - two chunks in flight, the sort / reduction / fold / witness phases of one beside the
-    // accumulation of the other
-    zk_params* P1 = nullptr;
-    zk_r1cs* R1 = nullptr;
-    std::thread t_gpu1;
+    // lanes 1 .. (ZKAMD_PIPELINE_LANES, default 2): further workers with their own workspaces and streams over the
+    // same tables - several chunks in flight, the sort / reduction / fold / witness phases of one beside the
+    // accumulation of another
+    static constexpr int MAX_LANES = 4;
+    zk_params* Pl[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    zk_r1cs* Rl[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    std::thread t_lane[MAX_LANES];
+    int n_lanes = 1;
     size_t chunk = 1024, nv = 0;
     PinBuf buf[2];
     std::mutex mu;
@@ -2403,8 +2405,8 @@ struct zk_pipeline {
         bool have_cur = false;
         int slot = 0;
         g_lane = lane;
-        zk_params* P = lane ? this->P1 : this->P;
-        zk_r1cs* R = lane ? this->R1 : this->R;
+        zk_params* P = lane ? this->Pl[lane] : this->P;
+        zk_r1cs* R = lane ? this->Rl[lane] : this->R;
         if (use_device(P->device) != ZK_OK) return;
         const hipStream_t wstream = g_copy_stream;
         auto start = [&](Job& j, int s) -> zk_status {
@@ -2426,9 +2428,9 @@ struct zk_pipeline {
             }
             bool have_nxt = false;
             {
-                // (with two lanes a job is only taken ahead of time if the other lane still finds one)
+                // (with several lanes a job is only taken ahead of time if the other lanes still find one each)
                 std::lock_guard<std::mutex> lk(mu);
-                if (q_wit.size() >= (size_t)(P1 ? 2 : 1)) {
+                if (q_wit.size() >= (size_t)n_lanes) {
                     nxt = q_wit.front();
                     q_wit.pop_front();
                     have_nxt = true;
@@ -2512,18 +2514,21 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
 #ifdef ZK_EMU
         lanes = 1;   // the test-only emulation runs one launch at a time
 #endif
-        if (lanes >= 2) {
-            L->P1 = params_clone_for_lane(p);
-            L->R1 = r1cs_clone_for_lane(circuit);
-            if (!L->P1 || !L->R1) {
-                delete L->P1;
-                delete L->R1;
-                L->P1 = nullptr;
-                L->R1 = nullptr;
+        if (lanes > zk_pipeline::MAX_LANES) lanes = zk_pipeline::MAX_LANES;
+        for (int l = 1; l < lanes; l++) {
+            L->Pl[l] = params_clone_for_lane(p);
+            L->Rl[l] = r1cs_clone_for_lane(circuit);
+            if (!L->Pl[l] || !L->Rl[l]) {   // no room for another set of workspaces: run with the lanes there are
+                delete L->Pl[l];
+                delete L->Rl[l];
+                L->Pl[l] = nullptr;
+                L->Rl[l] = nullptr;
+                break;
             }
+            L->n_lanes = l + 1;
         }
         L->t_gpu = std::thread([L] { L->run_gpu_witness(0); });
-        if (L->P1) L->t_gpu1 = std::thread([L] { L->run_gpu_witness(1); });
+        for (int l = 1; l < L->n_lanes; l++) L->t_lane[l] = std::thread([L, l] { L->run_gpu_witness(l); });
     } else {
         for (int k = 0; k < 2; k++) {
             zk_status rc = L->buf[k].ensure(L->chunk * L->nv * 32);
@@ -2572,9 +2577,11 @@ void zk_pipeline_free(zk_pipeline* L) {
     }
     if (L->t_wit.joinable()) L->t_wit.join();
     if (L->t_gpu.joinable()) L->t_gpu.join();
-    if (L->t_gpu1.joinable()) L->t_gpu1.join();
-    delete L->P1;
-    delete L->R1;
+    for (int l = 1; l < zk_pipeline::MAX_LANES; l++) {
+        if (L->t_lane[l].joinable()) L->t_lane[l].join();
+        delete L->Pl[l];
+        delete L->Rl[l];
+    }
     delete L;
 }
 
