@@ -1188,6 +1188,25 @@ k_xyzz_normalize_export(const XYZZ<F>* __restrict__ src, uint32_t* dst, uint32_t
     fld_export(unit, dst + (size_t)i * 4 * W + 2 * W);
     fld_export(unit, dst + (size_t)i * 4 * W + 3 * W);
 }
+// the same for two arrays in one launch (A and C of a proof made alone: side by side instead of one after the other)
+template <class F, bool GCD>
+static __global__ void __launch_bounds__(64, MsmOcc<F>::tail)
+k_xyzz_normalize_export2(const XYZZ<F>* __restrict__ src0, const XYZZ<F>* __restrict__ src1, uint32_t* dst0, uint32_t* dst1, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n) return;
+    const XYZZ<F>* src = i < n ? src0 : src1;
+    uint32_t* dst = i < n ? dst0 : dst1;
+    if (i >= n) i -= n;
+    constexpr int W = HostWords<F>::N;
+    const XYZZ<F> p = src[i];
+    const bool inf = p.is_inf();
+    const Affine<F> a = to_affine<F, GCD && HostWords<F>::GCD_INV>(p);
+    const F unit = inf ? F::zero() : F::one();
+    fld_export(a.x, dst + (size_t)i * 4 * W);
+    fld_export(a.y, dst + (size_t)i * 4 * W + W);
+    fld_export(unit, dst + (size_t)i * 4 * W + 2 * W);
+    fld_export(unit, dst + (size_t)i * 4 * W + 3 * W);
+}
 
 // flags[i] bit0: not on curve, bit1: not in the r-torsion subgroup.  Infinity ((0,0)) passes.
 // The subgroup test is the reference's (ec.rs:142-144): r * P == infinity.

@@ -555,6 +555,23 @@ struct MsmGroup {
         HIP_TRY(hipMemcpyAsync(out, stage.p, n * sizeof(HPoint), hipMemcpyDeviceToHost, st));
         return ZK_OK;
     }
+    // two arrays of n points each, out0 / out1 on the host; one launch while the pair fits a wave
+    zk_status normalize2_to_host(const DPoint* src0, const DPoint* src1, size_t n, HPoint* out0, HPoint* out1, DevBuf& stage0,
+                                 DevBuf& stage1, hipStream_t st) {
+        if (2 * n > 64) {
+            ZK_TRY(normalize_to_host(src0, n, out0, stage0, st));
+            return normalize_to_host(src1, n, out1, stage1, st);
+        }
+        if (!n) return ZK_OK;
+        ZK_TRY(stage0.ensure(n * sizeof(HPoint)));
+        ZK_TRY(stage1.ensure(n * sizeof(HPoint)));
+        ZK_LAUNCH((zkdev::k_xyzz_normalize_export2<DF, true>), dim3(1), dim3(64), 0, st, src0, src1, stage0.as<uint32_t>(),
+                  stage1.as<uint32_t>(), (uint32_t)n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out0, stage0.p, n * sizeof(HPoint), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out1, stage1.p, n * sizeof(HPoint), hipMemcpyDeviceToHost, st));
+        return ZK_OK;
+    }
     zk_status collect(hipStream_t st) {
         HIP_TRY(hipStreamSynchronize(st));
         return ZK_OK;
@@ -968,8 +985,8 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
         const DP1* a = P->g1.res_dev + np;
         ZK_LAUNCH(zkdev::k_xyzz_scale_add<zkdev::Fq>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, a, cprime,
                   (const uint32_t*)P->tail.as<uint32_t>() + 16, 24u, P->fold_tbl.as<DP1>(), P->fold_c.as<DP1>(), (uint32_t)np);
-        ZK_TRY(P->g1.normalize_to_host(a, np, P->pin_g1.as<HG1>() + np, P->fold_a1, g_stream));
-        ZK_TRY(P->g1.normalize_to_host(P->fold_c.as<DP1>(), np, P->pin_g1.as<HG1>(), P->fold_c1, g_stream));
+        ZK_TRY(P->g1.normalize2_to_host(a, P->fold_c.as<DP1>(), np, P->pin_g1.as<HG1>() + np, P->pin_g1.as<HG1>(), P->fold_a1, P->fold_c1,
+                                        g_stream));
     }
     HIP_TRY(hipMemcpyAsync(P->pin_bad.p, bad, 8, hipMemcpyDeviceToHost, g_stream));
     const bool trace_host = getenv("ZKAMD_TRACE_HOST") != nullptr;
