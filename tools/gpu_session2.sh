@@ -24,6 +24,12 @@ if [ "${DO_PROF:-0}" = "1" ]; then
   for f in $(find $OUT/prof -name '*kernel_stats.csv'); do head -40 $f; done
   find $OUT/prof -type f ! -name '*stats*.csv' -delete
 fi
+if [ "${DO_PROF_SERIAL:-0}" = "1" ]; then
+  # the same command with one lane and no side streams: every launch alone on the GPU (the duration the roofline is priced on)
+  ZKAMD_PIPELINE_LANES=1 ZKAMD_NO_OVERLAP=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_serial -o trace -- python bench.py --no-cpu --no-micro --no-secondary --oracle-checks 1 "$@" > $OUT/prof_serial_bench.json 2> $OUT/prof_serial.err; echo "prof serial rc=$?"
+  for f in $(find $OUT/prof_serial -name '*kernel_stats.csv'); do head -6 $f | cut -c1-200; done
+  find $OUT/prof_serial -type f ! -name '*stats*.csv' -delete
+fi
 if [ "${DO_PMC:-0}" = "1" ]; then
   # HBM traffic and VALU counters, one pass each (FETCH_SIZE and WRITE_SIZE cannot share a pass)
   for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"; do
