@@ -146,4 +146,4 @@ def test_setup_matches_oracle(emu_lib):
 
 
 def test_msm_variable_base(emu_lib):
-    pc.msm_variable_base(emu_lib, windows=(5, 9), n=100, g2_n=40, auto_n=200, g2_w=9, one_w=12)
+    pc.msm_variable_base(emu_lib, windows=(9,), n=60, g2_n=24, auto_n=40, g2_w=9, one_w=6)
