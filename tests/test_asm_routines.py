@@ -42,3 +42,22 @@ def test_every_routine_in_the_single_lane_interpreter(capsys):
     out = capsys.readouterr().out
     for name in ("FR ok", "FQ ok", "FQ28 ok", "FQ28D ok", "FQ28SQR ok", "FQ28MAC2 ok", "FQ2MUL28 ok", "FQ28MUL2 ok"):
         assert name in out
+
+
+def test_madd_loop_header_is_the_generators_output(tmp_path, monkeypatch):
+    g = _load("gen_madd_asm")
+    monkeypatch.setattr(g, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "zero-chain_amd" / "csrc")
+    g.main()
+    fresh = open(tmp_path / "zero-chain_amd" / "csrc" / "madd_asm.h").read()
+    assert fresh == open(os.path.join(ROOT, "zero-chain_amd", "csrc", "madd_asm.h")).read()
+
+
+def test_madd_loop_in_the_single_lane_interpreter(capsys):
+    """The generated G1 accumulation loop (madd_asm.h), run for one lane over whole tasks - loads retired only by
+    s_waitcnt, EXEC masking, 64-bit column accumulators, limb-wise differences - against the affine group law
+    (core/pairing/src/bls12_381/ec.rs:356-444 computes the same sums in Jacobian coordinates); equal and opposite
+    points must come out flagged (ZZ == 0 mod p) for the second pass."""
+    s = _load("sim_madd_asm")
+    s.main(cases=10)
+    assert "MADD_G1 ok" in capsys.readouterr().out

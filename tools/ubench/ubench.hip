@@ -76,6 +76,30 @@ __global__ void k_fma64(uint32_t* out, uint32_t seed, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s;
 }
 template <int ILP>
+__global__ void k_shr64(uint32_t* out, uint32_t seed, int iters) {
+    uint64_t acc[ILP];
+    for (int i = 0; i < ILP; i++) acc[i] = ((uint64_t)(seed + threadIdx.x) << 33) + i + blockIdx.x;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) asm volatile("v_lshrrev_b64 %0, 1, %0" : "+v"(acc[i]));
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s ^= acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+template <int ILP>
+__global__ void k_lshladd64(uint32_t* out, uint32_t seed, int iters) {
+    uint64_t acc[ILP], b = seed + blockIdx.x;
+    for (int i = 0; i < ILP; i++) acc[i] = ((uint64_t)(seed + threadIdx.x) << 33) + i;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < ILP; i++) asm volatile("v_lshl_add_u64 %0, %0, 1, %1" : "+v"(acc[i]) : "v"(b));
+    }
+    uint64_t s = 0;
+    for (int i = 0; i < ILP; i++) s ^= acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+template <int ILP>
 __global__ void k_add32(uint32_t* out, uint32_t seed, int iters) {
     uint32_t acc[ILP];
     uint32_t b = seed * 3 + blockIdx.x;
@@ -223,6 +247,8 @@ int main() {
     RATE("v_mul_hi_u32 (ILP8)", k_mulhi<8>, 8)
     RATE("v_mad_u32_u24 (ILP8)", k_mul24<8>, 8)
     RATE("v_fma_f64 (ILP8)", k_fma64<8>, 8)
+    RATE("v_lshrrev_b64 (ILP8)", k_shr64<8>, 8)
+    RATE("v_lshl_add_u64 (ILP8)", k_lshladd64<8>, 8)
 #define MM(name, kern, chains, wgs) { const int it2 = 256; int nb = cus * wgs; \
     double ms = time_kernel(kern, dim3(nb), dim3(256), 3, out, (const uint32_t*)in, it2); \
     double muls = (double)nb * 256 * it2 * chains; printf("%-36s %8.3f ms  %8.2f Gmul/s\n", name, ms, muls / ms * 1e-6); }
@@ -233,7 +259,9 @@ int main() {
     MM("Fq mul inline, 1 chain, 8 WG/CU", (k_montmul<FqCfg, 1, 1>), 1, 8)
     MM("Fq mul inline, 2 chains, 8 WG/CU", (k_montmul<FqCfg, 2, 1>), 2, 8)
     MM("Fq28 mul asm, 1 chain, 2 WG/CU", (k_montmul28<1>), 1, 2)
+    MM("Fq28 mul asm, 1 chain, 3 WG/CU", (k_montmul28<1>), 1, 3)
     MM("Fq28 mul asm, 1 chain, 4 WG/CU", (k_montmul28<1>), 1, 4)
+    MM("Fq28 mul asm, 1 chain, 6 WG/CU", (k_montmul28<1>), 1, 6)
     MM("Fq28 mul asm, 1 chain, 8 WG/CU", (k_montmul28<1>), 1, 8)
     MM("Fq28 mul asm, 2 chains, 4 WG/CU", (k_montmul28<2>), 2, 4)
     MM("Fq mul asm call, 1 chain, 2 WG/CU", (k_montmul<FqCfg, 1, 0>), 1, 2)

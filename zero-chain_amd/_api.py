@@ -207,10 +207,10 @@ def generate_parameters(matrices, alpha, beta, gamma, delta, tau, g1=None, g2=No
     b1, b2 = _u8(g1 or G1_GENERATOR, 96), _u8(g2 or G2_GENERATOR, 192)
     n = C.c_size_t(0)
     args = [matrices._h, _ptr(b1), _ptr(b2)] + [_ptr(x) for x in sc]
-    lib.check(lib.zk_generate_parameters(*args, None, 0, C.byref(n)))
+    lib.check(lib.zk_generate_parameters(*args, None, 0, C.byref(n)))     # an upper bound, no computation
     out = np.zeros(n.value, dtype=np.uint8)
     lib.check(lib.zk_generate_parameters(*args, _ptr(out), out.size, C.byref(n)))
-    return out.tobytes()
+    return out[:n.value].tobytes()
 
 
 def generate_random_parameters(matrices, rng, g1=None, g2=None):
@@ -292,16 +292,30 @@ def verify_proofs(pvk, proofs, public_inputs):
         pb = _u8(proofs)
     else:
         pb = _u8(b"".join(p.write() if isinstance(p, Proof) else bytes(p) for p in proofs))
+    if pb.size % PROOF_SIZE:
+        raise ValueError("proofs: %d bytes is not a whole number of %d-byte proofs" % (pb.size, PROOF_SIZE))
     n = pb.size // PROOF_SIZE
     if isinstance(public_inputs, np.ndarray):
         ib = _u8(public_inputs)
-        n_inputs = ib.size // (32 * n) if n else pvk.n_inputs
+        if n == 0:
+            if ib.size:
+                raise ValueError("public inputs given for zero proofs")
+            n_inputs = pvk.n_inputs
+        else:
+            if ib.size % (32 * n):
+                raise ValueError("public_inputs: %d bytes do not split into %d rows of 32-byte scalars" % (ib.size, n))
+            n_inputs = ib.size // (32 * n)
     else:
+        if len(public_inputs) != n:
+            raise ValueError("%d proofs but %d lists of public inputs" % (n, len(public_inputs)))
         n_inputs = len(public_inputs[0]) if n else pvk.n_inputs
         if any(len(x) != n_inputs for x in public_inputs):
             raise ValueError("every proof needs the same number of public inputs")
         flat = [v for x in public_inputs for v in x]
         ib = scalars_to_bytes(flat) if flat else np.zeros(0, dtype=np.uint8)
+    # the library reads exactly n * n_inputs scalars and n proofs: nothing shorter may reach it
+    if ib.size != n * n_inputs * 32:
+        raise ValueError("public_inputs: %d bytes, expected %d" % (ib.size, n * n_inputs * 32))
     ok = np.zeros(max(n, 1), dtype=np.uint8)
     pvk._lib.check(pvk._lib.zk_verify_batch(pvk._h, n, _ptr(pb) if pb.size else None, _ptr(ib) if ib.size else None, n_inputs,
                                              _ptr(ok)))

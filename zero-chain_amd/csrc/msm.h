@@ -630,6 +630,70 @@ k_msm_accumulate_wide(const Affine<F>* __restrict__ table, const uint32_t* __res
     msm_accumulate_body<F, 1, true>(table, pairs, sorted, total, tsums);
 }
 
+// Pass 5, G1: the whole loop as ONE generated assembly body (madd_asm.h, tools/gen_madd_asm.py): every product is
+// emitted in place over the registers its operands live in, the modulus stays in SGPRs, 160 VGPRs = three waves per
+// SIMD (the compiled loop above: 198 VGPRs, two waves, ~390 operand moves per addition).  The loop computes the generic
+// madd-2008-s formula only; a step that meets P == +-acc leaves ZZ == 0 (mod p), which every later step preserves, so
+// ONE test per task after the loop queues the task for k_msm_accumulate_redo (the compiled loop with all special
+// cases).  The first point of a task initialises the accumulator here, the assembly adds points 1 .. n - 1.
+#if !defined(ZK_EMU) && !defined(ZK_NO_MADD_ASM)
+#include "madd_asm.h"
+#define ZK_HAVE_MADD_ASM 1
+static __global__ void __launch_bounds__(128, 3)
+k_msm_accumulate_g1asm(const Affine<Fq28>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                       const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq28>* __restrict__ tsums,
+                       uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+    static_assert(ZK_MADD_G1_VGPRS <= 168, "the loop must fit three waves per SIMD");
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total[0]) return;
+    const uint4 d = sorted[t];
+    const uint32_t n = d.z;
+    XYZZ<Fq28> acc = XYZZ<Fq28>::inf();
+    if (n) {
+        const uint32_t* pp = pairs + d.x;
+        const uint32_t pr = pp[0];
+        const Affine<Fq28> p = table[pr >> 1];
+        u32x16 X = fq28_vec(p.x), Y = fq28_vec((pr & 1u) ? neg_b<Fq28::MO>(p.y) : p.y);
+        u32x16 ZZ = fq28_vec(Fq28::one()), ZZZ = ZZ;
+        if (n > 1) {
+            // the loop state rides in the pad registers of the operand blocks
+            const uint64_t pa = (uint64_t)(uintptr_t)pp, ta = (uint64_t)(uintptr_t)table;
+            X[14] = (uint32_t)pa;
+            X[15] = (uint32_t)(pa >> 32);
+            Y[14] = n;
+            ZZ[14] = (uint32_t)ta;
+            ZZ[15] = (uint32_t)(ta >> 32);
+            asm volatile(ZK_MADD_G1_ASM
+                         : "+{v[0:15]}"(X), "+{v[16:31]}"(Y), "+{v[32:47]}"(ZZ), "+{v[48:63]}"(ZZZ)
+                         :
+                         : ZK_MADD_G1_ASM_CLOBBERS);
+        }
+        acc.x = fq28_unvec(X);
+        acc.y = fq28_unvec(Y);
+        acc.zz = fq28_unvec(ZZ);
+        acc.zzz = fq28_unvec(ZZZ);
+        if (n > 1 && acc.zz.is_zero_norm()) redo[atomicAdd(n_redo, 1u)] = t;
+    }
+    tsums[d.y] = acc;
+}
+#endif
+// second pass for the tasks the assembly loop flagged (equal or opposite points met on the way): the compiled loop
+template <class F>
+static __global__ void __launch_bounds__(64, MsmOcc<F>::acc)
+k_msm_accumulate_redo(const Affine<F>* __restrict__ table, const uint32_t* __restrict__ pairs, const uint4* __restrict__ sorted,
+                      const uint32_t* __restrict__ n_redo, const uint32_t* __restrict__ redo, XYZZ<F>* __restrict__ tsums) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_redo[0]; i += gridDim.x * blockDim.x) {
+        const uint4 d = sorted[redo[i]];
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t k = 0; k < d.z; k++) {
+            const uint32_t pr = pairs[d.x + k];
+            const Affine<F> p = table[pr >> 1];
+            madd(acc, p, (pr & 1u) != 0);
+        }
+        tsums[d.y] = acc;
+    }
+}
+
 // Pass 5b: buckets cut into many tasks.  Scalars are not uniform where it matters: the LAST digit
 // of the recoding sits in whatever is left of the 254 bits above the previous digit, so a few small
 // magnitudes collect a large share of all top digits (and boolean witnesses pile up on magnitude 1).

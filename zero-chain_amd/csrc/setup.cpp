@@ -97,6 +97,12 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
     while (((size_t)1 << log_m) < n_rows) log_m++;
     if (log_m > 27) return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "evaluation domain larger than 2^27");
     const size_t m = (size_t)1 << log_m;
+    // length query (out == NULL): an upper bound that needs no computation - every a / b query present (the
+    // query used to run the whole generation and the caller then ran it again to fill the buffer)
+    if (!out) {
+        *len = 864 + 24 + 96 * ((size_t)n_in + (m - 1) + n_aux + 2 * (size_t)nv) + 192 * (size_t)nv;
+        return ZK_OK;
+    }
 
     // ---- the constraint matrices, transposed (per variable: the rows it appears in)
     DevBuf d_colptr[3], d_row[3], d_coeff[3];
@@ -234,9 +240,11 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
     for (uint32_t i = 0; i < nv; i++)
         if (!p_b2[i].is_inf()) put2(p_b2[i]);
     *len = o.size();
-    if (out) {
-        if (cap < o.size()) return fail(ZK_ERR_INVALID_ARGUMENT, "output buffer too small");
-        memcpy(out, o.data(), o.size());
-    }
+    if (cap < o.size()) return fail(ZK_ERR_INVALID_ARGUMENT, "output buffer too small");
+    memcpy(out, o.data(), o.size());
+    // the toxic waste does not outlive the call on the device (the buffers are freed next)
+    for (DevBuf* b : {&consts, &tmp2, &d_vk1, &d_vk2, &eh, &ea, &eb, &eext, &lag})
+        if (b->p) (void)hipMemsetAsync(b->p, 0, b->bytes, g_stream);
+    (void)hipStreamSynchronize(g_stream);
     return ZK_OK;
 }

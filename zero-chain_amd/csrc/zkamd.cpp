@@ -251,6 +251,31 @@ zk_status check_points_host(const std::vector<zkhost::Affine<HF>>& pts, const ch
     return st;
 }
 
+// The G1 accumulation runs the generated assembly loop (msm.h k_msm_accumulate_g1asm) unless ZKAMD_G1_ASM=0 (A/B
+// switch) or the build has none (the x86 emulation build).
+template <class DF>
+static bool g1_asm_loop() { return false; }
+#ifdef ZK_HAVE_MADD_ASM
+template <>
+bool g1_asm_loop<zkdev::Fq28>() {
+    static const bool on = !(getenv("ZKAMD_G1_ASM") && atoi(getenv("ZKAMD_G1_ASM")) == 0);
+    return on;
+}
+#endif
+template <class DF>
+static void launch_g1_asm(const zkdev::Affine<DF>*, const uint32_t*, const uint4*, const uint32_t*, zkdev::XYZZ<DF>*, uint32_t*,
+                          uint32_t*, unsigned, hipStream_t) {}
+#ifdef ZK_HAVE_MADD_ASM
+template <>
+void launch_g1_asm<zkdev::Fq28>(const zkdev::Affine<zkdev::Fq28>* table, const uint32_t* pairs, const uint4* sorted,
+                                const uint32_t* d_total, zkdev::XYZZ<zkdev::Fq28>* tsums, uint32_t* d_nredo, uint32_t* redo,
+                                unsigned blocks, hipStream_t st) {
+    ZK_LAUNCH(zkdev::k_msm_accumulate_g1asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
+    ZK_LAUNCH(zkdev::k_msm_accumulate_redo<zkdev::Fq28>, dim3(256), dim3(64), 0, st, table, pairs, sorted,
+              (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
+}
+#endif
+
 template <class HF, class DF>
 struct MsmGroup {
     typedef zkhost::Affine<HF> HAffine;
@@ -265,7 +290,7 @@ struct MsmGroup {
     uint32_t c = 0, maxd = 0, nb = 0;
     size_t n_points = 0;
     DevBuf table;
-    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, blockbase, coarse, tbase, rank, pairs, tsums, red_r, red_w, red_t, result;
+    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, blockbase, coarse, tbase, rank, pairs, tsums, red_r, red_w, red_t, result, redo;
     DPoint* res_dev = nullptr;
     PinBuf pin_jobs;
     std::vector<uint32_t> tbase_h;
@@ -360,7 +385,7 @@ struct MsmGroup {
         ZK_TRY(toff.ensure(n_buckets * 4));
         ZK_TRY(ntasks.ensure(nj * 4));
         ZK_TRY(tbase.ensure(nj * 4));
-        ZK_TRY(hist.ensure((2 * n_class + 2) * 4));     // [length histogram | placement cursors | total | #heavy]
+        ZK_TRY(hist.ensure((2 * n_class + 3) * 4));     // [length histogram | placement cursors | total | #heavy | #redo]
         const bool few = nj <= MSM_FEW_JOBS;   // latency-optimised bucket reduction (msm.h, passes 5c and 6)
         const uint32_t merge_inline = nj >= 64 || few ? 8u : 2u;
         const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
@@ -388,11 +413,12 @@ struct MsmGroup {
         memcpy((uint8_t*)pin_jobs.p + nj * sizeof(MsmJob), tbase_h.data(), nj * 4);
         HIP_TRY(hipMemcpyAsync(jobs_d.p, pin_jobs.p, nj * sizeof(MsmJob), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(tbase.p, (const uint8_t*)pin_jobs.p + nj * sizeof(MsmJob), nj * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 2) * 4, st));
+        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 3) * 4, st));
         uint32_t* lenhist = hist.as<uint32_t>();
         uint32_t* cursor = lenhist + n_class;
         uint32_t* d_total = cursor + n_class;
         uint32_t* d_nheavy = d_total + 1;
+        uint32_t* d_nredo = d_total + 2;
         const MsmJob* dj = jobs_d.as<MsmJob>();
         dim3 gridn((max_n + 255) / 256, (unsigned)nj);
         dim3 gridb((nb + 255) / 256, (unsigned)nj);
@@ -459,7 +485,12 @@ struct MsmGroup {
             if (zkdev::HostWords<DF>::N > 12 && wide_g2)
                 ZK_LAUNCH(zkdev::k_msm_accumulate_wide<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
                           table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
-            else
+            else if (g1_asm_loop<DF>()) {
+                // G1: the generated assembly loop (msm.h, madd_asm.h), then the compiled loop over the few tasks it flagged
+                ZK_TRY(redo.ensure((size_t)total_tasks * 4));
+                launch_g1_asm(table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>(), d_nredo,
+                              redo.as<uint32_t>(), (unsigned)((total_tasks + 127) / 128), st);
+            } else
                 ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
                           table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
         }
@@ -2007,6 +2038,32 @@ void jubjub_encode(const zkhost::Fr& x_mont, const zkhost::Fr& y_mont, uint8_t o
 }
 
 // request -> statement (+ rsk): ProofGenerationKey::from_spending_key, into_decryption_key, SpendingKey::into_rsk
+// Point<E, Unknown>::as_prime_order (core/jubjub/src/curve/edwards.rs:319-330): [s]P == O for the order s of the
+// prime-order subgroup.  The reference's typed inputs (EncryptionKey::read keys.rs:269-276, Ciphertext::read
+// elgamal.rs:117-133, g_epoch.rs:75) pass through it, so a point with a torsion component is refused by the wallet-level
+// entries here too.  Doubling: dbl-2008-hwcd for a = -1 (4M + 4S).
+bool jubjub_is_prime_order(const zkwit::JPoint& p) {
+    static const uint64_t FS[4] = ZK_JUBJUB_FS_MODULUS_64;
+    using zkhost::Fr;
+    zkwit::EPoint acc = zkwit::ext_zero();
+    const zkwit::EPoint base = zkwit::to_ext(p);
+    for (int bit = 251; bit >= 0; bit--) {
+        const Fr a = acc.X.sqr(), b = acc.Y.sqr(), c = acc.Z.sqr().dbl();
+        const Fr d = Fr::zero() - a;                       // a = -1
+        const Fr e = (acc.X + acc.Y).sqr() - a - b, g = d + b, f = g - c, h = d - b;
+        acc = zkwit::EPoint{e * f, g * h, f * g, e * h};
+        if ((FS[bit >> 6] >> (bit & 63)) & 1) acc = zkwit::ext_add(acc, base);
+    }
+    return acc.X.is_zero() && acc.Y == acc.Z;
+}
+zk_status decode_prime_order(const uint8_t b[32], zkwit::JPoint* out, const std::string& what) {
+    zkwit::JPoint p;
+    if (!zkwit::decode_point(b, &p)) return fail(ZK_ERR_INVALID_ARGUMENT, what + " is not a Jubjub point");
+    if (!jubjub_is_prime_order(p)) return fail(ZK_ERR_INVALID_ARGUMENT, what + " is not in the prime-order subgroup");
+    if (out) *out = p;
+    return ZK_OK;
+}
+
 zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_transfer_statement* st, uint8_t rsk[32]) {
     uint64_t sk[4], alpha[4], rnd[4];
     load_scalar_le(rq.spending_key, sk);
@@ -2030,6 +2087,10 @@ zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_tr
     h.update(st->proof_generation_key, 32);
     h.finish(st->dec_key_sender);
     st->dec_key_sender[31] &= 0x07;
+    ZK_TRY(decode_prime_order(rq.enc_key_recipient, nullptr, who + "enc_key_recipient"));
+    ZK_TRY(decode_prime_order(rq.enc_balance_left, nullptr, who + "enc_balance_left"));
+    ZK_TRY(decode_prime_order(rq.enc_balance_right, nullptr, who + "enc_balance_right"));
+    ZK_TRY(decode_prime_order(rq.g_epoch, nullptr, who + "g_epoch"));
     memcpy(st->enc_key_recipient, rq.enc_key_recipient, 32);
     memcpy(st->enc_balance_left, rq.enc_balance_left, 32);
     memcpy(st->enc_balance_right, rq.enc_balance_right, 32);
@@ -2110,11 +2171,15 @@ struct AsyncVerifier {
 zk_status verify_chunk_async(AsyncVerifier& v, zk_vk* vk, size_t first, size_t end, const uint8_t* proofs, const uint8_t* inputs,
                              size_t n_pub, uint8_t* ok) {
     ZK_TRY(v.join());
-    v.th = std::thread([&v, vk, first, end, proofs, inputs, n_pub, ok] {
-        g_lane = 5;   // not one of the pipeline's lanes (0 .. 3)
-        v.rc = zk_verify_batch(vk, end - first, proofs + first * 192, inputs + first * n_pub * 32, n_pub, ok + first);
-        if (v.rc != ZK_OK) v.err = g_err;
-    });
+    try {
+        v.th = std::thread([&v, vk, first, end, proofs, inputs, n_pub, ok] {
+            g_lane = 5;   // not one of the pipeline's lanes (0 .. 3)
+            v.rc = zk_verify_batch(vk, end - first, proofs + first * 192, inputs + first * n_pub * 32, n_pub, ok + first);
+            if (v.rc != ZK_OK) v.err = g_err;
+        });
+    } catch (const std::system_error& e) {
+        return fail(ZK_ERR_OUT_OF_MEMORY, std::string("cannot start the verification worker: ") + e.what());
+    }
     return ZK_OK;
 }
 }  // namespace
@@ -2239,16 +2304,19 @@ zk_status anonymous_derive_one(const zk_anonymous_request& rq, size_t index, zk_
     // the set: sender at s_index, recipient at t_index, the decoys in their order everywhere else
     zkwit::JPoint keys[ZK_ANONYMOUS_SIZE];
     keys[rq.s_index] = jubjub_fixed_mul(dk);
-    if (!zkwit::decode_point(rq.enc_key_recipient, &keys[rq.t_index]))
-        return fail(ZK_ERR_INVALID_ARGUMENT, who + "enc_key_recipient is not a Jubjub point");
+    ZK_TRY(decode_prime_order(rq.enc_key_recipient, &keys[rq.t_index], who + "enc_key_recipient"));
     for (size_t i = 0, j = 0; i < ZK_ANONYMOUS_SIZE; i++) {
         if (i == rq.s_index || i == rq.t_index) continue;
-        if (!zkwit::decode_point(rq.enc_keys_decoy[j], &keys[i]))
-            return fail(ZK_ERR_INVALID_ARGUMENT, who + "enc_keys_decoy[" + std::to_string(j) + "] is not a Jubjub point");
+        ZK_TRY(decode_prime_order(rq.enc_keys_decoy[j], &keys[i], who + "enc_keys_decoy[" + std::to_string(j) + "]"));
         j++;
     }
     zkwit::JPoint g_epoch;
-    if (!zkwit::decode_point(rq.g_epoch, &g_epoch)) return fail(ZK_ERR_INVALID_ARGUMENT, who + "g_epoch is not a Jubjub point");
+    ZK_TRY(decode_prime_order(rq.g_epoch, &g_epoch, who + "g_epoch"));
+    for (size_t i = 0; i < ZK_ANONYMOUS_SIZE; i++) {
+        const std::string m = "[" + std::to_string(i) + "]";
+        ZK_TRY(decode_prime_order(rq.enc_balances_left[i], nullptr, who + "enc_balances_left" + m));
+        ZK_TRY(decode_prime_order(rq.enc_balances_right[i], nullptr, who + "enc_balances_right" + m));
+    }
     // left ciphertexts v_i G + r y_i, right r G, rvk = pgk + alpha G, nonce = dec_key * g_epoch: one batch to affine
     uint64_t amt[4] = {rq.amount, 0, 0, 0};
     const zkwit::JPoint amount_g = jubjub_fixed_mul(amt);
@@ -2439,7 +2507,19 @@ struct zk_pipeline {
         g_lane = lane;
         zk_params* P = lane ? this->Pl[lane] : this->P;
         zk_r1cs* R = lane ? this->Rl[lane] : this->R;
-        if (use_device(P->device) != ZK_OK) return;
+        if (use_device(P->device) != ZK_OK) {
+            // no context on this lane (stream creation / out of memory): report it and keep DRAINING the queue, so
+            // that wait() and free() never block on jobs nobody will take
+            std::unique_lock<std::mutex> lk(mu);
+            fail_with(ZK_ERR_DEVICE, g_err);
+            for (;;) {
+                cv.wait(lk, [&] { return stop || !q_wit.empty(); });
+                if (stop) return;
+                q_wit.pop_front();
+                in_flight--;
+                cv.notify_all();
+            }
+        }
         const hipStream_t wstream = g_copy_stream;
         auto start = [&](Job& j, int s) -> zk_status {
             j.slot = s;
@@ -2477,6 +2557,8 @@ struct zk_pipeline {
             if (have_nxt && !skip && rc == ZK_OK) rc_next = start(nxt, cur.slot ^ 1);
             if (!skip && rc == ZK_OK) rc = witness_gpu_finish(R, cur.n, cur.slot, cur.index_base);
             if (!skip && rc == ZK_OK) rc = prove_from_z(P, R, cur.n, cur.slot, cur.rs, cur.out);
+            // nothing of a failed job stays in flight when wait() returns: drain the device BEFORE the job is counted done
+            if (rc != ZK_OK || rc_next != ZK_OK) (void)hipDeviceSynchronize();
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (rc != ZK_OK) fail_with(rc, g_err);
@@ -2484,7 +2566,6 @@ struct zk_pipeline {
                 in_flight--;
                 cv.notify_all();
             }
-            if (rc != ZK_OK || rc_next != ZK_OK) (void)hipDeviceSynchronize();   // nothing of a failed job stays in flight
             if (have_nxt) {
                 nxt.slot = cur.slot ^ 1;
                 cur = nxt;
@@ -2559,8 +2640,13 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
             }
             L->n_lanes = l + 1;
         }
-        L->t_gpu = std::thread([L] { L->run_gpu_witness(0); });
-        for (int l = 1; l < L->n_lanes; l++) L->t_lane[l] = std::thread([L, l] { L->run_gpu_witness(l); });
+        try {
+            L->t_gpu = std::thread([L] { L->run_gpu_witness(0); });
+            for (int l = 1; l < L->n_lanes; l++) L->t_lane[l] = std::thread([L, l] { L->run_gpu_witness(l); });
+        } catch (const std::system_error& e) {
+            zk_pipeline_free(L);
+            return fail(ZK_ERR_OUT_OF_MEMORY, std::string("cannot start a pipeline worker: ") + e.what());
+        }
     } else {
         for (int k = 0; k < 2; k++) {
             zk_status rc = L->buf[k].ensure(L->chunk * L->nv * 32);
@@ -2569,8 +2655,13 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
                 return rc;
             }
         }
-        L->t_wit = std::thread([L] { L->run_wit(); });
-        L->t_gpu = std::thread([L] { L->run_gpu(); });
+        try {
+            L->t_wit = std::thread([L] { L->run_wit(); });
+            L->t_gpu = std::thread([L] { L->run_gpu(); });
+        } catch (const std::system_error& e) {
+            zk_pipeline_free(L);
+            return fail(ZK_ERR_OUT_OF_MEMORY, std::string("cannot start a pipeline worker: ") + e.what());
+        }
     }
     *out = L;
     return ZK_OK;
