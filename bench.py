@@ -23,7 +23,8 @@ of every step (RCCL gather, inside the timed region).
 
 Checked before the line is printed: a sample of proofs per rank byte-for-byte against the oracle's
 discrete-log proof of the same statement (and, on rank 0, one proof out of every rank's gathered
-block); ALL proofs of the last step by the product's batch verifier when the library has one.
+block; two proofs of EVERY step of the timed region likewise); ALL K * B proofs of the timed region by the
+product's batch verifier (outside the clock).
 
 The JSON line carries, besides the contract fields:
   roofline      dominant kernel (G1 bucket accumulation): algorithmic bytes (128 B per multiexp
@@ -393,7 +394,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- parity gates
+    # ---- parity gates: EVERY step of the timed region (two pipeline lanes alternate the chunks; VERDICT r2: the
+    # last step alone looks at one lane)
     last = outs[-1]
     last_rs = rs_ints[W + K - 1]
     checked, asg0 = 0, None
@@ -403,17 +405,27 @@ def main():
         assert last[192 * i:192 * (i + 1)].tobytes() == want, "rank %d: proof %d differs from the oracle" % (rank, i)
         asg0 = asg0 or asg
         checked += 1
+    # ... and two proofs of every other step byte-for-byte against the oracle's discrete-log proof
+    per_step = 0 if args.oracle_checks <= 1 else 2
+    for k in range(K - 1):
+        for i in sorted(set([(131 * k + 7) % B, (B - 1 - 17 * k) % B]))[:per_step]:
+            want, _ = oracle_proof(P, r1cs, lo + i, *rs_ints[W + k][i])
+            assert outs[k][192 * i:192 * (i + 1)].tobytes() == want, "rank %d: step %d proof %d differs from the oracle" % (rank, k, i)
+            checked += 1
     verified = None
     verify_ms = None
     if hasattr(zk, "verify_transfer_batch"):
-        # ALL proofs of the last step through the product's verifier (prepare_verifying_key + one verify_proof per
-        # proof on the GPU; public inputs recomputed by the witness calculator from the statements)
+        # ALL K * B proofs of the timed region through the product's verifier (prepare_verifying_key + one verify_proof
+        # per proof on the GPU; public inputs recomputed by the witness calculator from the statements) - outside the clock
         pvk = zk.prepare_verifying_key(params)
+        verified = 0
         t0 = time.perf_counter()
-        verified = zk.verify_transfer_batch(pvk, sts, last)
-        verify_ms = (time.perf_counter() - t0) * 1e3
+        for k in range(K):
+            got = zk.verify_transfer_batch(pvk, sts, outs[k])
+            assert got == B, "rank %d: the verifier accepted %s of the %d proofs of step %d" % (rank, got, B, k)
+            verified += got
+        verify_ms = (time.perf_counter() - t0) * 1e3 / K
         pvk.close()
-        assert verified == B, "rank %d: the verifier accepted %s of %d proofs" % (rank, verified, B)
     cross_rank = 0
     if world > 1 and rank == 0:
         # rank 0's own block sits at the front of every gathered step; one proof out of every other rank's block of
@@ -615,7 +627,7 @@ def main():
                    "parallelism": "dp%d (independent proofs, contiguous blocks, %s gather of 192 B/proof/step)" % (world, "gloo" if one_gpu else "RCCL"),
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
                    "proofs_checked_vs_oracle": checked, "proofs_checked_from_other_ranks": cross_rank,
-                   "proofs_verified_by_product_verifier": verified, "verify_ms": None if verify_ms is None else round(verify_ms, 1), "setup_s": round(setup_s, 2), "generate_parameters_s": round(keygen_s, 2)},
+                   "proofs_verified_by_product_verifier": verified, "verify_ms_per_step": None if verify_ms is None else round(verify_ms, 1), "setup_s": round(setup_s, 2), "generate_parameters_s": round(keygen_s, 2)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "secondary": secondary, "micro": micro,
     }
     if anonymous is not None:

@@ -359,6 +359,46 @@ def test_full_chunk_1024_every_proof_checked(gpu_lib):
         params.close()
 
 
+def test_pipeline_two_lanes_full_chunks_every_proof_checked(gpu_lib, monkeypatch):
+    """The bench's own launch shape: zk_pipeline with TWO lanes - the second lane proves on its
+    own cloned workspaces and streams - fed four submits of one full 1024-statement chunk each, so both lanes take
+    several chunks.  EVERY one of the 4096 proofs is verified by the product's verifier against the public inputs of
+    its statement, proofs of every submit are compared byte for byte with the oracle's discrete-log proof, and the
+    streamed proofs equal the ones zk_transfer_prove_batch makes of the same statements one chunk at a time."""
+    import zero_chain_amd as zk
+    from oracle import transfer_circuit as tc
+    monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "1024")
+    monkeypatch.setenv("ZKAMD_PIPELINE_LANES", "2")
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    E = g.Bls12Engine()
+    n_distinct, n, submits = 32, 1024, 4
+    ws = [tc.make_witness(1700 + i, amount=3 + 41 * i, fee=i % 7, balance=9000 + 13 * i) for i in range(n_distinct)]
+    sts = zk.transfer_statements([tc.statement_dict(ws[i % n_distinct]) for i in range(n)])
+    rng = synth.SplitMix64(777)
+    rs = [[(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)] for _ in range(submits)]
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
+    pvk = zk.prepare_verifying_key(params)
+    pipe = zk.TransferPipeline(mats, params)
+    try:
+        outs = [pipe.submit(sts, zk.scalars_to_bytes([x for pair in step for x in pair])) for step in rs]
+        pipe.wait(raw=True)
+        for k, (o, step) in enumerate(zip(outs, rs)):
+            assert zk.verify_transfer_batch(pvk, sts, o) == n, "submit %d" % k
+            for i in ((97 * k + 5) % n, n - 1 - k):
+                cs = tc.synthesize(ws[i % n_distinct])
+                asg = g.assign(E, r1, cs.inputs, cs.aux)
+                assert o[192 * i:192 * (i + 1)].tobytes() == helpers.expected_proof_trapdoor(P, asg, *step[i]), (k, i)
+        # one lane, one call, the same statements and (r, s): the same bytes
+        serial = zk.transfer_prove_batch(mats, params, sts, rs[2])
+        assert b"".join(p.write() for p in serial) == outs[2].tobytes()
+    finally:
+        pipe.close()
+        pvk.close()
+        mats.close()
+        params.close()
+
+
 def test_witness_gpu_matches_host(gpu_lib):
     pc.witness_gpu_matches_host(gpu_lib, n_extra=6)
 

@@ -17,6 +17,16 @@ reduced radix-2^28 field of dev_field.h with the same magnitude bookkeeping:
     PP = P^2             PPP = P PP               Q = X PP              ZZ' = ZZ PP
     X' = R^2 - PPP - 2Q  Y' = R (Q - X') - Y PPP  ZZZ' = ZZZ PPP
 
+Field representation inside the loop: radix 2^28, 14 limbs, SIGNED and lazily reduced.  A product comes out with
+digits 0..12 in [0, 2^28) and a (possibly slightly negative) top limb, value in (-0.07 p, 2 p); a difference is ONE
+limb-wise subtraction - no spread constant of a multiple of p, no carry pass - whose limbs may be negative, and the
+products take it as it is (v_mad_i64_i32, arithmetic shifts of the column accumulator).  Only P is renormalised
+(its limbs reach 2^30 and it is squared).  The accumulator's y is held as W = sigma Y with sigma = -1 after every
+second step: W' = R^ T' + W PPP with R^ = S2^ - W, S2^ = sigma (+-py) ZZZ, T' = X' - Q gives -sigma Y' without a
+single negation, and sigma is uniform over the wave (a function of the step index), so it costs one s_not_b64 per
+step folded into the lanes' negate mask.  The C++ wrapper (msm.h) converts the four coordinates back to the unsigned
+weakly normalised form of dev_field.h after the loop.
+
 Special cases need no code in the loop: P == 0 (mod p) makes ZZ' == 0 (mod p), and a ZZ that is 0 (mod p) stays
 0 through every later product, so ONE test per task after the loop (the C++ wrapper in msm.h) sends the task to
 the generic kernel for a second pass.
@@ -36,7 +46,6 @@ N, B = 14, 28
 MASK = (1 << B) - 1
 PL = [(P >> (B * j)) & MASK for j in range(N)]
 INV = (-pow(P, -1, 1 << B)) & MASK
-MO, BX, BY = 2, 10, 5            # dev_curve.h XYZZ<Fq28>: a product < MO p, stored X < BX p, Y < BY p
 
 
 class Emitter(g.Emitter):
@@ -84,6 +93,7 @@ class Regs:
         self.sEXEC = "s[54:55]"
         self.sK, self.sK1, self.s112 = 56, 57, 58
         self.sSIGN = "s[60:61]"
+        self.sPAR = "s[62:63]"                       # all ones while the stored W is -Y
         self.clob_s = list(range(36, 64))
 
 
@@ -117,12 +127,11 @@ def _column_tail(e, R, k, out, lo, hi):
     if k < N:
         e.valu_op("v_mul_lo_u32 %s, %s, %s" % (v(R.M[k]), v(lo), s(R.sINV)))
         e.valu_op("v_and_b32_e32 %s, %s, %s" % (v(R.M[k]), s(R.sMASK), v(R.M[k])))
-        e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (vp(lo), R.sDUMMY, v(R.M[k]), s(R.sP[0]), vp(lo)))
+        e.valu_op("v_mad_i64_i32 %s, %s, %s, %s, %s" % (vp(lo), R.sDUMMY, v(R.M[k]), s(R.sP[0]), vp(lo)))
     else:
         e.valu_op("v_and_b32_e32 %s, %s, %s" % (v(out[k - N]), s(R.sMASK), v(lo)))
     if k < 2 * N - 2:
-        e.valu_op("v_alignbit_b32 %s, %s, %s, %d" % (v(lo), v(hi), v(lo), B))
-        e.valu_op("v_lshrrev_b32_e32 %s, %d, %s" % (v(hi), B, v(hi)))
+        e.valu_op("v_ashrrev_i64 %s, %d, %s" % (vp(lo), B, vp(lo)))    # full rate on gfx950 (profiles/r03b_ubench.txt)
     else:
         e.valu_op("v_alignbit_b32 %s, %s, %s, %d" % (v(out[N - 1]), v(hi), v(lo), B))   # the top limb takes the rest
 
@@ -136,7 +145,7 @@ def _columns(e, R, col_prods, out):
     first = True
     for k in range(2 * N - 1):
         for x, y in col_prods(k) + _mprods(R, k):
-            e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (vp(lo), R.sDUMMY, x, y, "0" if first else vp(lo)))
+            e.valu_op("v_mad_i64_i32 %s, %s, %s, %s, %s" % (vp(lo), R.sDUMMY, x, y, "0" if first else vp(lo)))
             first = False
         _column_tail(e, R, k, out, lo, hi)
 
@@ -181,9 +190,10 @@ def mac2(e, R, x0, y0, x1, y1, out):
 
 
 def wnorm(e, R, t, out, tmp):
-    """dev_field.h fq28_wnorm: limbs back to <= 2^28 + 15 (carries are not propagated further than one limb)."""
+    """signed carry pass: digits 0..12 back to [-8, 2^28 + 8], the top limb takes the rest (dev_field.h fq28_wnorm with
+    arithmetic shifts)"""
     for i in range(13):
-        e.valu_op("v_lshrrev_b32_e32 %s, %d, %s" % (v(tmp[i]), B, v(t[i])))
+        e.valu_op("v_ashrrev_i32_e32 %s, %d, %s" % (v(tmp[i]), B, v(t[i])))
     e.valu_op("v_and_b32_e32 %s, %s, %s" % (v(out[0]), s(R.sMASK), v(t[0])))
     for i in range(1, 13):
         e.valu_op("v_and_b32_e32 %s, %s, %s" % (v(out[i]), s(R.sMASK), v(t[i])))
@@ -191,27 +201,17 @@ def wnorm(e, R, t, out, tmp):
     e.valu_op("v_add_u32_e32 %s, %s, %s" % (v(out[13]), v(t[13]), v(tmp[12])))
 
 
-def sub_raw(e, a, b, out, M):
-    """out_i = a_i + spread(M)_i - b_i (no limb goes negative for b_i <= 3 * 2^28 - 3); limbs < 2^30.4."""
-    S = g.spread28(P, M)
+def sub(e, a, b, out):
+    """out_i = a_i - b_i, signed limbs, no carry pass"""
     for i in range(N):
-        e.valu_op("v_add_u32_e32 %s, 0x%08x, %s" % (v(out[i]), S[i], v(a[i])))
-        e.valu_op("v_sub_u32_e32 %s, %s, %s" % (v(out[i]), v(out[i]), v(b[i])))
+        e.valu_op("v_sub_u32_e32 %s, %s, %s" % (v(out[i]), v(a[i]), v(b[i])))
 
 
-def neg_raw(e, b, out, M):
-    S = g.spread28(P, M)
-    for i in range(N):
-        e.valu_op("v_sub_u32_e32 %s, 0x%08x, %s" % (v(out[i]), S[i], v(b[i])))
-
-
-def x3_raw(e, r2, ppp, q, out, M, tmp):
-    """out_i = r2_i + spread(M)_i - ppp_i - 2 q_i   (ppp, q exactly normalised: ppp_i + 2 q_i <= 3 * 2^28 - 3)."""
-    S = g.spread28(P, M)
+def x3(e, r2, ppp, q, out, tmp):
+    """out_i = r2_i - ppp_i - 2 q_i: limbs in (-3 * 2^28, 2^28)"""
     for i in range(N):
         e.valu_op("v_lshl_add_u32 %s, %s, 1, %s" % (v(tmp), v(q[i]), v(ppp[i])))
-        e.valu_op("v_add_u32_e32 %s, 0x%08x, %s" % (v(out[i]), S[i], v(r2[i])))
-        e.valu_op("v_sub_u32_e32 %s, %s, %s" % (v(out[i]), v(out[i]), v(tmp)))
+        e.valu_op("v_sub_u32_e32 %s, %s, %s" % (v(out[i]), v(r2[i]), v(tmp)))
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -251,6 +251,7 @@ def gen_loop():
     e.salu_op("s_movk_i32 %s, 0x70" % s(R.s112))
     e.salu_op("s_mov_b64 %s, exec" % R.sEXEC)
     e.salu_op("s_mov_b32 %s, 1" % s(R.sK))
+    e.salu_op("s_mov_b64 %s, 0" % R.sPAR)
     e.valu_op("v_add_u32_e32 %s, -1, %s" % (v(R.NM1), v(R.NCNT)))
     load_pair(e, R, R.sK)                       # pair word of point 1 (every active lane has n >= 2)
     e.salu_op("s_waitcnt vmcnt(0)")
@@ -265,17 +266,18 @@ def gen_loop():
     e.valu_op("v_cmp_ne_u32_e64 %s, 0, %s" % (R.sSIGN, v(R.TMP)), writes=[R.sSIGN])
     e.salu_op("s_add_u32 %s, %s, 1" % (s(R.sK1), s(R.sK)))
     load_pair(e, R, R.sK1)                      # pair word of point k + 1 (clamped to the last one), lands during the body
-    # step 0: py <- negate ? 3p - py : py   (raw: first operand of ONE product)
-    S3 = g.spread28(P, MO + 1)
+    # the lanes' negate mask, with the sign sigma of the stored W folded in (uniform: it flips every step)
+    e.salu_op("s_xor_b64 %s, %s, %s" % (R.sSIGN, R.sSIGN, R.sPAR))
+    e.salu_op("s_not_b64 %s, %s" % (R.sPAR, R.sPAR))
+    # step 0: py <- (negate ^ sigma) ? -py : py
     for i in range(N):
-        e.valu_op("v_sub_u32_e32 %s, 0x%08x, %s" % (v(R.TMP), S3[i], v(R.L2[i])))
+        e.valu_op("v_sub_u32_e32 %s, 0, %s" % (v(R.TMP), v(R.L2[i])))
         e.valu_op("v_cndmask_b32_e64 %s, %s, %s, %s" % (v(R.L2[i]), v(R.L2[i]), v(R.TMP), R.sSIGN), reads=[R.sSIGN])
     mul(e, R, R.L1, R.ZZ, R.A1)                 # U2 = px ZZ
-    mul(e, R, R.L2, R.ZZZ, R.A2)                # S2 = py ZZZ
-    sub_raw(e, R.A1, R.X, R.A1, BX + 1)         # P = U2 - X                 < (MO + BX + 1) p
+    mul(e, R, R.L2, R.ZZZ, R.A2)                # S2^ = sigma (+-py) ZZZ
+    sub(e, R.A1, R.X, R.A1)                     # P = U2 - X        |limb| < 2^30, |value| < 8 p
     wnorm(e, R, R.A1, R.A1, R.M)
-    sub_raw(e, R.A2, R.Y, R.A2, BY + 1)         # R = S2 - Y                 < (MO + BY + 1) p
-    wnorm(e, R, R.A2, R.A2, R.M)
+    sub(e, R.A2, R.Y, R.A2)                     # R^ = S2^ - W      |limb| < 2^28 + 8
     sqr(e, R, R.A1, R.T1)                       # PP = P^2
     mul(e, R, R.A1, R.T1, R.A1)                 # PPP = P PP   (in place over P)
     mul(e, R, R.ZZ, R.T1, R.ZZ)                 # ZZ' = ZZ PP  (in place)
@@ -284,11 +286,9 @@ def gen_loop():
     # ---- the table entry registers are free from here on: fetch the entry of point k + 1
     e.salu_op("s_waitcnt vmcnt(0)")             # its pair word
     load_point(e, R)
-    x3_raw(e, R.X, R.A1, R.T1, R.X, MO + 2 * MO + 1, R.TMP)   # X' = R^2 - PPP - 2Q   < (4 MO + 2) p = BX p
-    wnorm(e, R, R.X, R.X, R.M)
-    sub_raw(e, R.T1, R.X, R.T1, BX + 1)         # T = Q - X'  (raw: second operand of the fused sum)
-    neg_raw(e, R.Y, R.Y, BY + 1)                # (BY + 1) p - Y  (raw)
-    mac2(e, R, R.A2, R.T1, R.Y, R.A1, R.Y)      # Y' = R T - Y PPP
+    x3(e, R.X, R.A1, R.T1, R.X, R.TMP)          # X' = R^2 - PPP - 2Q      limbs in (-3 * 2^28, 2^28), value in (-6 p, 2 p)
+    sub(e, R.X, R.T1, R.T1)                     # T' = X' - Q
+    mac2(e, R, R.A2, R.T1, R.Y, R.A1, R.Y)      # W' = R^ T' + W PPP = -sigma Y'
     mul(e, R, R.ZZZ, R.A1, R.ZZZ)               # ZZZ' = ZZZ PPP (in place)
     e.salu_op("s_add_u32 %s, %s, 1" % (s(R.sK), s(R.sK)))
     e.salu_op("s_branch 1b")

@@ -632,18 +632,46 @@ k_msm_accumulate_wide(const Affine<F>* __restrict__ table, const uint32_t* __res
 
 // Pass 5, G1: the whole loop as ONE generated assembly body (madd_asm.h, tools/gen_madd_asm.py): every product is
 // emitted in place over the registers its operands live in, the modulus stays in SGPRs, 160 VGPRs = three waves per
-// SIMD (the compiled loop above: 198 VGPRs, two waves, ~390 operand moves per addition).  The loop computes the generic
-// madd-2008-s formula only; a step that meets P == +-acc leaves ZZ == 0 (mod p), which every later step preserves, so
-// ONE test per task after the loop queues the task for k_msm_accumulate_redo (the compiled loop with all special
-// cases).  The first point of a task initialises the accumulator here, the assembly adds points 1 .. n - 1.
+// SIMD (the compiled loop above: 198 VGPRs, two waves, ~390 operand moves per addition), and inside the loop the field
+// is SIGNED and lazily reduced - a difference is one limb-wise subtraction, no multiple of p, no carry pass - with
+// the accumulator's y held as sigma * Y, sigma = -1 after every second step (see the generator).  The loop computes
+// the generic madd-2008-s formula only; a step that meets P == +-acc leaves ZZ == 0 (mod p), which every later step
+// preserves, so ONE test per task after the loop queues the task for k_msm_accumulate_redo (the compiled loop with
+// all special cases).  The first point of a task initialises the accumulator here, the assembly adds points
+// 1 .. n - 1, and the four coordinates return to the unsigned weakly normalised form of dev_field.h below.
 #if !defined(ZK_EMU) && !defined(ZK_NO_MADD_ASM)
 #include "madd_asm.h"
 #define ZK_HAVE_MADD_ASM 1
+// a product of the signed loop: digits exactly normalised, top limb possibly negative, value in (-0.07 p, 2 p) -> [0, 2 p)
+ZK_DI Fq28 fq28_from_signed_product(const u32x16& v) {
+    Fq28 r = fq28_unvec(v);
+    if ((int32_t)r.l[13] < 0) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 13; i++) {
+            const uint32_t t = r.l[i] + Fq28Consts::P[i] + c;
+            r.l[i] = t & FQ28_MASK;
+            c = t >> 28;
+        }
+        r.l[13] += Fq28Consts::P[13] + c;
+    }
+    return r;
+}
+// spread(M) +- a signed lazy value (limbs above -(3 * 2^28 - 3)): the unsigned weakly normalised form, value < (M + 2) p
+template <int M, bool NEGATE>
+ZK_DI Fq28 fq28_from_signed(const u32x16& v) {
+    Fq28 r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = NEGATE ? Fq28Spread<M>::V[i] - v[i] : Fq28Spread<M>::V[i] + v[i];
+    fq28_wnorm(r.l);
+    return r;
+}
 static __global__ void __launch_bounds__(128, 3)
 k_msm_accumulate_g1asm(const Affine<Fq28>* __restrict__ table, const uint32_t* __restrict__ pairs,
                        const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq28>* __restrict__ tsums,
                        uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
     static_assert(ZK_MADD_G1_VGPRS <= 168, "the loop must fit three waves per SIMD");
+    static_assert(XYZZ<Fq28>::BX >= 9 && XYZZ<Fq28>::BY >= 5, "bounds of the values handed back by the loop");
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total[0]) return;
     const uint4 d = sorted[t];
@@ -653,9 +681,14 @@ k_msm_accumulate_g1asm(const Affine<Fq28>* __restrict__ table, const uint32_t* _
         const uint32_t* pp = pairs + d.x;
         const uint32_t pr = pp[0];
         const Affine<Fq28> p = table[pr >> 1];
-        u32x16 X = fq28_vec(p.x), Y = fq28_vec((pr & 1u) ? neg_b<Fq28::MO>(p.y) : p.y);
-        u32x16 ZZ = fq28_vec(Fq28::one()), ZZZ = ZZ;
-        if (n > 1) {
+        if (n == 1) {
+            acc = XYZZ<Fq28>{p.x, (pr & 1u) ? neg_b<Fq28::MO>(p.y) : p.y, Fq28::one(), Fq28::one()};
+        } else {
+            u32x16 X = fq28_vec(p.x), Y = fq28_vec(p.y), ZZ = fq28_vec(Fq28::one()), ZZZ = ZZ;
+            if (pr & 1u) {
+#pragma unroll
+                for (int i = 0; i < 14; i++) Y[i] = 0u - Y[i];   // W = -y as signed limbs (sigma = +1)
+            }
             // the loop state rides in the pad registers of the operand blocks
             const uint64_t pa = (uint64_t)(uintptr_t)pp, ta = (uint64_t)(uintptr_t)table;
             X[14] = (uint32_t)pa;
@@ -667,12 +700,13 @@ k_msm_accumulate_g1asm(const Affine<Fq28>* __restrict__ table, const uint32_t* _
                          : "+{v[0:15]}"(X), "+{v[16:31]}"(Y), "+{v[32:47]}"(ZZ), "+{v[48:63]}"(ZZZ)
                          :
                          : ZK_MADD_G1_ASM_CLOBBERS);
+            acc.x = fq28_from_signed<7, false>(X);                       // X in (-6 p, 2 p)      -> < 9 p
+            acc.y = ((n - 1) & 1u) ? fq28_from_signed<3, true>(Y)        // W = -Y in (-0.07 p, 2 p) -> Y < 3.07 p
+                                   : fq28_from_signed<2, false>(Y);      // W = +Y                -> Y < 4 p
+            acc.zz = fq28_from_signed_product(ZZ);
+            acc.zzz = fq28_from_signed_product(ZZZ);
+            if (acc.zz.is_zero_norm()) redo[atomicAdd(n_redo, 1u)] = t;
         }
-        acc.x = fq28_unvec(X);
-        acc.y = fq28_unvec(Y);
-        acc.zz = fq28_unvec(ZZ);
-        acc.zzz = fq28_unvec(ZZZ);
-        if (n > 1 && acc.zz.is_zero_norm()) redo[atomicAdd(n_redo, 1u)] = t;
     }
     tsums[d.y] = acc;
 }

@@ -244,7 +244,7 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
     memcpy(out, o.data(), o.size());
     // the toxic waste does not outlive the call on the device (the buffers are freed next)
     for (DevBuf* b : {&consts, &tmp2, &d_vk1, &d_vk2, &eh, &ea, &eb, &eext, &lag})
-        if (b->p) (void)hipMemsetAsync(b->p, 0, b->bytes, g_stream);
+        if (b->p) (void)hipMemsetAsync(b->p, 0, b->cap, g_stream);
     (void)hipStreamSynchronize(g_stream);
     return ZK_OK;
 }
