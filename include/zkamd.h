@@ -224,7 +224,10 @@ void zk_pipeline_free(zk_pipeline* pl);
  * rs (n x 64 bytes) the two Fr::rand draws of create_random_proof; scalars 32 bytes little-endian, points in the
  * 32-byte Jubjub encoding.
  * zk_transfer_derive is the host half alone (request -> statement and rsk); zk_spending_key_from_seed is
- * SpendingKey::from_seed (keys.rs:45-58).
+ * SpendingKey::from_seed (keys.rs:45-58).  The points of a REQUEST (recipient key, encrypted balance, g_epoch) pass
+ * through as_prime_order as the reference's typed readers do (keys.rs:269-276, elgamal.rs:117-133): a point outside the
+ * prime-order subgroup is ZK_ERR_INVALID_ARGUMENT.  The points of a STATEMENT (zk_transfer_statement, the circuit
+ * instance itself, whose fields are Point<E, PrimeOrder> by type in the reference) are decoded and curve-checked only.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     uint32_t amount, fee, remaining_balance, reserved;
@@ -238,6 +241,16 @@ typedef struct {   /* ConfidentialXt, confidential.rs:349-361 */
         right_randomness[32], rsk[32], rvk[32], enc_balance[64], nonce[32];
 } zk_confidential_xt;
 zk_status zk_spending_key_from_seed(const uint8_t* seed, size_t len, uint8_t spending_key_out[32]);
+/* The two Jubjub operations every key and ciphertext a wallet hands to gen_proof is made of (so a batch of requests can
+ * be built without the reference's host code):
+ * zk_jubjub_base_mul: scalar * FixedGenerators::NoteCommitmentRandomness, the generator of the reference's keys and
+ *   ciphertexts; with the decryption key this is EncryptionKey::from_decryption_key (no_std_aliases/keys.rs:250-261).
+ *   scalars: n x 32 bytes little-endian canonical Fs; points_out: n x 32 bytes (edwards::Point::write).
+ * zk_elgamal_encrypt: elgamal::Ciphertext::encrypt (no_std_aliases/elgamal.rs:46-63): left = value G + randomness
+ *   enc_key, right = randomness G.  enc_keys pass through as_prime_order as EncryptionKey::read does (keys.rs:269-276). */
+zk_status zk_jubjub_base_mul(const uint8_t* scalars, size_t n, uint8_t* points_out);
+zk_status zk_elgamal_encrypt(const uint32_t* values, const uint8_t* randomness, const uint8_t* enc_keys, size_t n,
+                             uint8_t* left_out, uint8_t* right_out);
 zk_status zk_transfer_derive(const zk_transfer_request* req, size_t n, zk_transfer_statement* statements_out, uint8_t* rsk_out);
 struct zk_vk;
 zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, struct zk_vk* vk, size_t n, const zk_transfer_request* req,

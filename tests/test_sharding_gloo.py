@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: two processes over the gloo backend shard a batch of independent proofs
+"""N > 1 path on CPU: two and four processes over the gloo backend shard a batch of independent proofs
 (zero_chain_amd.prove_sharded), each proves its block, rank 0 gathers 192 B per proof and checks
 every proof against the oracle.  The per-rank prover here is the TEST-ONLY x86 emulation build of
 the kernel sources (tests/emu/); on the GPU box the same front-end runs over libzkamd.so with the
@@ -83,21 +83,23 @@ def test_shard_bounds_partition():
                         assert owner_of(i, n, world) == r
 
 
-@pytest.mark.parametrize("n_total", [5, 2])
-def test_two_ranks_gloo_gather(emu_lib, n_total, tmp_path):
+@pytest.mark.parametrize("world,n_total", [(2, 5), (2, 2), (4, 10)])
+def test_ranks_gloo_gather(emu_lib, world, n_total, tmp_path):
+    """2 ranks (5 and 2 proofs) and 4 ranks over an uneven split (10 proofs: blocks of 3, 2, 3, 2): every rank proves
+    exactly its contiguous block, rank 0 gathers and checks every proof against the oracle."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(n_total)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=300)
+            out, _ = p.communicate(timeout=600)
         except subprocess.TimeoutExpired:
             p.kill()
             out, _ = p.communicate()
@@ -105,3 +107,6 @@ def test_two_ranks_gloo_gather(emu_lib, n_total, tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out)
     assert "GATHER_OK %d" % n_total in outs[0]
+    if world == 4 and n_total == 10:
+        import zero_chain_amd as zk
+        assert [zk.shard_bounds(10, r, 4) for r in range(4)] == [(0, 3), (3, 5), (5, 8), (8, 10)]

@@ -63,6 +63,11 @@ class Emitter(g.Emitter):
         self.slot += 1
         self.vmem += 1
 
+    def lds_op(self, text):
+        self.lines.append(text)
+        self.slot += 1
+        self.lds = getattr(self, "lds", 0) + 1
+
     def label(self, name):
         self.lines.append(name + ":")
 
@@ -298,19 +303,248 @@ def gen_loop():
     return R, e
 
 
-def render(R, e):
-    out = ["// GENERATED by tools/gen_madd_asm.py - do not edit.",
-           "// The bucket-accumulation loop of the G1 multiexp: XYZZ mixed additions in the radix-2^28 field, %d VGPRs."
-           % R.n_vgpr,
+
+# ===============================================================================================================
+# G2: the same loop over Fq2 = Fq[u]/(u^2 + 1), two interleaved column streams per product
+# ===============================================================================================================
+class Regs2:
+    """Register map of the G2 loop: 256 VGPRs = two waves per SIMD (the compiled loop: 468, one wave).  X and ZZ live in
+    registers, W (= sigma Y) and ZZZ in LDS (224 bytes per lane), staged into registers where a product reads them.
+    Blocks of 16 registers (14 limbs + 2 pads carrying the loop state); an Fq2 value is two blocks."""
+    def __init__(self):
+        blk = lambda b: list(range(b, b + 14))
+        f2 = lambda b: (blk(b), blk(b + 16))
+        self.X, self.ZZ = f2(0), f2(32)
+        self.LX, self.LY = f2(64), f2(96)           # the table entry; scratch for temporaries once it is dead
+        self.A1, self.A2, self.T1 = f2(128), f2(160), f2(192)
+        self.M, self.ACC = list(range(224, 238)), (238, 239)
+        self.M2, self.ACC2 = list(range(240, 254)), (254, 255)
+        self.PTR = (14, 15)
+        self.NCNT, self.PR = 30, 31
+        self.TBL = (46, 47)
+        self.ADDR = (62, 63)
+        self.TMP, self.NM1 = 78, 79
+        self.LDSA = 94                               # byte address of this lane's first 16-byte slot in the parking area
+        self.LDSA_IN = 62                            # ... as the C++ wrapper hands it over (pad of the ZZ.c1 operand)
+        self.n_vgpr = 256
+        self.sP = list(range(36, 50))
+        self.sINV, self.sMASK = 50, 51
+        self.sDUMMY = "s[52:53]"
+        self.sEXEC = "s[54:55]"
+        self.sK, self.sK1, self.s224 = 56, 57, 58
+        self.sSIGN = "s[60:61]"
+        self.sPAR = "s[62:63]"
+        self.clob_s = list(range(36, 64))
+
+
+LDS_W, LDS_ZZZ = 0, 2        # element slots of the parking area: W.c0, W.c1, ZZZ.c0, ZZZ.c1 (4 quads of 16 bytes each)
+LDS_QUAD_STRIDE = 128 * 16   # [element * 4 + quad][thread of the 128-thread workgroup] x 16 bytes
+
+
+def _columns2(e, R, prods0, prods1, out0, out1):
+    """two independent column streams (the two components of an Fq2 result), their multiply-adds alternating"""
+    accs = (R.ACC, R.ACC2)
+    Ms = (R.M, R.M2)
+    outs = (out0, out1)
+    first = [True, True]
+    for k in range(2 * N - 1):
+        lists = []
+        for t, pr in enumerate((prods0, prods1)):
+            mp = [(v(Ms[t][i]), s(R.sP[k - i])) for i in range(N) if 0 <= k - i < N and (k >= N or i < k)]
+            lists.append(pr(k) + mp)
+        for j in range(max(len(lists[0]), len(lists[1]))):
+            for t in (0, 1):
+                if j < len(lists[t]):
+                    lo = accs[t][0]
+                    x, y = lists[t][j]
+                    e.valu_op("v_mad_i64_i32 %s, %s, %s, %s, %s" % (vp(lo), R.sDUMMY, x, y, "0" if first[t] else vp(lo)))
+                    first[t] = False
+        if k < N:
+            for t in (0, 1):
+                e.valu_op("v_mul_lo_u32 %s, %s, %s" % (v(Ms[t][k]), v(accs[t][0]), s(R.sINV)))
+            for t in (0, 1):
+                e.valu_op("v_and_b32_e32 %s, %s, %s" % (v(Ms[t][k]), s(R.sMASK), v(Ms[t][k])))
+            for t in (0, 1):
+                e.valu_op("v_mad_i64_i32 %s, %s, %s, %s, %s" % (vp(accs[t][0]), R.sDUMMY, v(Ms[t][k]), s(R.sP[0]), vp(accs[t][0])))
+        else:
+            for t in (0, 1):
+                e.valu_op("v_and_b32_e32 %s, %s, %s" % (v(outs[t][k - N]), s(R.sMASK), v(accs[t][0])))
+        for t in (0, 1):
+            if k < 2 * N - 2:
+                e.valu_op("v_ashrrev_i64 %s, %d, %s" % (vp(accs[t][0]), B, vp(accs[t][0])))
+            else:
+                e.valu_op("v_alignbit_b32 %s, %s, %s, %d" % (v(outs[t][N - 1]), v(accs[t][1]), v(accs[t][0]), B))
+
+
+def _pairs(a, b):
+    return lambda k: [(v(a[i]), v(b[k - i])) for i in range(N) if 0 <= k - i < N]
+
+
+def _cat(*fs):
+    """column products of several limb-product groups, interleaved term by term"""
+    def prods(k):
+        cols = [f(k) for f in fs]
+        out = []
+        for j in range(len(cols[0])):
+            for c in cols:
+                out.append(c[j])
+        return out
+    return prods
+
+
+def fq2_mul(e, R, a, b, out, neg):
+    """out = a b in Fq2: c0 = a0 b0 + (-a1) b1, c1 = a0 b1 + a1 b0; `neg`: 14 free registers for -a1"""
+    (a0, a1), (b0, b1), (o0, o1) = a, b, out
+    _check_inplace(o0, [a0, a1, b0, b1], "fq2_mul c0")
+    _check_inplace(o1, [a0, a1, b0, b1], "fq2_mul c1")
+    assert not set(neg) & (set(a0) | set(a1) | set(b0) | set(b1) | set(o0) | set(o1))
+    for i in range(N):
+        e.valu_op("v_sub_u32_e32 %s, 0, %s" % (v(neg[i]), v(a1[i])))
+    _columns2(e, R, _cat(_pairs(a0, b0), _pairs(neg, b1)), _cat(_pairs(a0, b1), _pairs(a1, b0)), o0, o1)
+
+
+def fq2_sqr(e, R, a, out, tmp):
+    """out = a^2 in Fq2: (a0 + a1)(a0 - a1), (2 a0) a1; tmp: three free 14-register lists"""
+    (a0, a1), (o0, o1) = a, out
+    sm, df, tw = tmp
+    for t_ in tmp:
+        assert not set(t_) & (set(a0) | set(a1) | set(o0) | set(o1))
+    _check_inplace(o0, [a0, a1], "fq2_sqr")
+    _check_inplace(o1, [a0, a1], "fq2_sqr")
+    for i in range(N):
+        e.valu_op("v_add_u32_e32 %s, %s, %s" % (v(sm[i]), v(a0[i]), v(a1[i])))
+        e.valu_op("v_sub_u32_e32 %s, %s, %s" % (v(df[i]), v(a0[i]), v(a1[i])))
+        e.valu_op("v_lshlrev_b32_e32 %s, 1, %s" % (v(tw[i]), v(a0[i])))
+    _columns2(e, R, _pairs(sm, df), _pairs(tw, a1), o0, o1)
+
+
+def fq2_mac(e, R, r, t, w, p, out, negr, negw):
+    """out = r t + w p in Fq2 with two reductions (eight limb-product groups); negr, negw: free registers for -r1, -w1"""
+    (r0, r1), (t0, t1), (w0, w1), (p0, p1), (o0, o1) = r, t, w, p, out
+    ops = [r0, r1, t0, t1, w0, w1, p0, p1]
+    _check_inplace(o0, ops, "fq2_mac c0")
+    _check_inplace(o1, ops, "fq2_mac c1")
+    for i in range(N):
+        e.valu_op("v_sub_u32_e32 %s, 0, %s" % (v(negr[i]), v(r1[i])))
+        e.valu_op("v_sub_u32_e32 %s, 0, %s" % (v(negw[i]), v(w1[i])))
+    _columns2(e, R,
+              _cat(_pairs(r0, t0), _pairs(negr, t1), _pairs(w0, p0), _pairs(negw, p1)),
+              _cat(_pairs(r0, t1), _pairs(r1, t0), _pairs(w0, p1), _pairs(w1, p0)), o0, o1)
+
+
+def lds_read(e, R, slot, blocks):
+    """the parked Fq2 value of element slots `slot`, `slot + 1` -> the two 14-register lists `blocks`"""
+    for c in (0, 1):
+        b = blocks[c][0]
+        for q in range(3):
+            e.lds_op("ds_read_b128 v[%d:%d], %s offset:%d" % (b + 4 * q, b + 4 * q + 3, v(R.LDSA), ((slot + c) * 4 + q) * LDS_QUAD_STRIDE))
+        e.lds_op("ds_read_b64 v[%d:%d], %s offset:%d" % (b + 12, b + 13, v(R.LDSA), ((slot + c) * 4 + 3) * LDS_QUAD_STRIDE))
+
+
+def lds_write(e, R, slot, blocks):
+    for c in (0, 1):
+        b = blocks[c][0]
+        for q in range(3):
+            e.lds_op("ds_write_b128 %s, v[%d:%d] offset:%d" % (v(R.LDSA), b + 4 * q, b + 4 * q + 3, ((slot + c) * 4 + q) * LDS_QUAD_STRIDE))
+        e.lds_op("ds_write_b64 %s, v[%d:%d] offset:%d" % (v(R.LDSA), b + 12, b + 13, ((slot + c) * 4 + 3) * LDS_QUAD_STRIDE))
+
+
+def load_point2(e, R):
+    """the 224-byte G2 table entry (x.c0, x.c1, y.c0, y.c1) of the pair word in R.PR -> LX, LY (16 loads)"""
+    a = vp(R.ADDR[0])
+    e.valu_op("v_lshrrev_b32_e32 %s, 1, %s" % (v(R.TMP), v(R.PR)))
+    e.valu_op("v_mad_u64_u32 %s, %s, %s, %s, %s" % (a, R.sDUMMY, v(R.TMP), s(R.s224), vp(R.TBL[0])))
+    for c, blk in enumerate((R.LX[0], R.LX[1], R.LY[0], R.LY[1])):
+        b, off = blk[0], 56 * c
+        if off % 16 == 0:
+            for q in range(3):
+                e.vmem_op("global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (b + 4 * q, b + 4 * q + 3, a, off + 16 * q))
+            e.vmem_op("global_load_dwordx2 v[%d:%d], %s, off offset:%d" % (b + 12, b + 13, a, off + 48))
+        else:
+            e.vmem_op("global_load_dwordx2 v[%d:%d], %s, off offset:%d" % (b, b + 1, a, off))
+            for q in range(3):
+                e.vmem_op("global_load_dwordx4 v[%d:%d], %s, off offset:%d" % (b + 2 + 4 * q, b + 5 + 4 * q, a, off + 8 + 16 * q))
+
+
+def sub2(e, a, b, out):
+    for c in (0, 1):
+        sub(e, a[c], b[c], out[c])
+
+
+def gen_loop_g2():
+    R = Regs2()
+    e = Emitter()
+    for j in range(N):
+        e.salu_op("s_mov_b32 %s, 0x%08x" % (s(R.sP[j]), PL[j]))
+    e.salu_op("s_mov_b32 %s, 0x%08x" % (s(R.sINV), INV))
+    e.salu_op("s_mov_b32 %s, 0x%08x" % (s(R.sMASK), MASK))
+    e.salu_op("s_movk_i32 %s, 0xe0" % s(R.s224))
+    e.valu_op("v_mov_b32_e32 %s, %s" % (v(R.LDSA), v(R.LDSA_IN)))
+    e.salu_op("s_mov_b64 %s, exec" % R.sEXEC)
+    e.salu_op("s_mov_b32 %s, 1" % s(R.sK))
+    e.salu_op("s_mov_b64 %s, 0" % R.sPAR)
+    e.valu_op("v_add_u32_e32 %s, -1, %s" % (v(R.NM1), v(R.NCNT)))
+    load_pair(e, R, R.sK)
+    e.label("1")
+    e.valu_op("v_cmp_lt_u32_e32 vcc, %s, %s" % (s(R.sK), v(R.NCNT)), writes=["vcc"])
+    e.salu_op("s_and_b64 exec, %s, vcc" % R.sEXEC)
+    e.salu_op("s_cbranch_execz 2f")
+    e.salu_op("s_waitcnt vmcnt(0)")             # the pair word of point k
+    load_point2(e, R)
+    e.valu_op("v_and_b32_e32 %s, 1, %s" % (v(R.TMP), v(R.PR)))
+    e.valu_op("v_cmp_ne_u32_e64 %s, 0, %s" % (R.sSIGN, v(R.TMP)), writes=[R.sSIGN])
+    e.salu_op("s_add_u32 %s, %s, 1" % (s(R.sK1), s(R.sK)))
+    load_pair(e, R, R.sK1)                      # pair word of point k + 1 (clamped), lands during the body
+    e.salu_op("s_xor_b64 %s, %s, %s" % (R.sSIGN, R.sSIGN, R.sPAR))
+    e.salu_op("s_not_b64 %s, %s" % (R.sPAR, R.sPAR))
+    lds_read(e, R, LDS_ZZZ, R.T1)               # ZZZ -> T1 (free until PP)
+    e.salu_op("s_waitcnt vmcnt(1)")             # the table entry (the pair word of the next point stays in flight)
+    for c in (0, 1):                            # py <- (negate ^ sigma) ? -py : py
+        for i in range(N):
+            e.valu_op("v_sub_u32_e32 %s, 0, %s" % (v(R.TMP), v(R.LY[c][i])))
+            e.valu_op("v_cndmask_b32_e64 %s, %s, %s, %s" % (v(R.LY[c][i]), v(R.LY[c][i]), v(R.TMP), R.sSIGN), reads=[R.sSIGN])
+    fq2_mul(e, R, R.LX, R.ZZ, R.A1, R.A2[0])    # U2 = px ZZ              (-px1 in the registers S2 will be written to)
+    e.salu_op("s_waitcnt lgkmcnt(0)")
+    fq2_mul(e, R, R.LY, R.T1, R.A2, R.LX[0])    # S2^ = sigma (+-py) ZZZ
+    lds_read(e, R, LDS_W, R.T1)                 # W -> T1
+    sub2(e, R.A1, R.X, R.A1)                    # P = U2 - X               X is carry-normalised: |limb| < 2^28 + 16
+    e.salu_op("s_waitcnt lgkmcnt(0)")
+    sub2(e, R.A2, R.T1, R.A2)                   # R^ = S2^ - W
+    fq2_sqr(e, R, R.A1, R.T1, (R.LX[0], R.LX[1], R.LY[0]))   # PP = P^2
+    fq2_mul(e, R, R.A1, R.T1, R.A1, R.LX[0])    # PPP = P PP    (in place over P)
+    fq2_mul(e, R, R.ZZ, R.T1, R.ZZ, R.LX[0])    # ZZ' = ZZ PP   (in place)
+    fq2_mul(e, R, R.X, R.T1, R.T1, R.LX[0])     # Q = X PP      (in place over PP); X is dead
+    fq2_sqr(e, R, R.A2, R.X, (R.LX[0], R.LX[1], R.LY[0]))    # R^2 -> X registers
+    for c in (0, 1):
+        x3(e, R.X[c], R.A1[c], R.T1[c], R.X[c], R.TMP)       # X' = R^2 - PPP - 2Q
+        wnorm(e, R, R.X[c], R.X[c], R.M)                     # carry pass: X' feeds P (squared) and T'
+    sub2(e, R.X, R.T1, R.T1)                    # T' = X' - Q
+    lds_read(e, R, LDS_W, R.LX)                 # W -> LX
+    e.salu_op("s_waitcnt lgkmcnt(0)")
+    fq2_mac(e, R, R.A2, R.T1, R.LX, R.A1, R.LX, R.LY[0], R.LY[1])   # W' = R^ T' + W PPP = -sigma Y'   (in place over W)
+    lds_write(e, R, LDS_W, R.LX)
+    lds_read(e, R, LDS_ZZZ, R.A2)               # ZZZ -> A2 (R^ is dead)
+    e.salu_op("s_waitcnt lgkmcnt(0)")
+    fq2_mul(e, R, R.A2, R.A1, R.A2, R.LY[0])    # ZZZ' = ZZZ PPP
+    lds_write(e, R, LDS_ZZZ, R.A2)
+    e.salu_op("s_add_u32 %s, %s, 1" % (s(R.sK), s(R.sK)))
+    e.salu_op("s_branch 1b")
+    e.label("2")
+    e.salu_op("s_mov_b64 exec, %s" % R.sEXEC)
+    e.salu_op("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    return R, e
+
+
+def render(R, e, name, what):
+    out = ["// The bucket-accumulation loop of the %s multiexp: %s, %d VGPRs." % (name, what, R.n_vgpr),
            "// per step: %d VALU + %d SALU + %d VMEM instructions" % (body_counts(e)),
-           "#pragma once", "",
-           "#define ZK_MADD_G1_ASM \\"]
+           "#define ZK_MADD_%s_ASM \\" % name]
     for l in e.lines:
         out.append('    "%s\\n\\t" \\' % l)
     out[-1] = out[-1][:-2]
     clob = ["v%d" % i for i in range(64, R.n_vgpr)] + ["s%d" % i for i in R.clob_s] + ["vcc", "memory"]
-    out.append("#define ZK_MADD_G1_ASM_CLOBBERS %s" % ", ".join('"%s"' % c for c in clob))
-    out.append("#define ZK_MADD_G1_VGPRS %d" % R.n_vgpr)
+    out.append("#define ZK_MADD_%s_ASM_CLOBBERS %s" % (name, ", ".join('"%s"' % c for c in clob)))
+    out.append("#define ZK_MADD_%s_VGPRS %d" % (name, R.n_vgpr))
     return "\n".join(out) + "\n"
 
 
@@ -327,10 +561,18 @@ def body_counts(e):
 
 def main():
     R, e = gen_loop()
+    R2, e2 = gen_loop_g2()
     path = os.path.join(ROOT, "zero-chain_amd", "csrc", "madd_asm.h")
     with open(path, "w") as f:
-        f.write(render(R, e))
-    print("madd loop: %d lines, per step VALU %d SALU %d VMEM %d, hazard wait states %d" % ((len(e.lines),) + body_counts(e) + (e.nops,)))
+        f.write("// GENERATED by tools/gen_madd_asm.py - do not edit.\n#pragma once\n\n")
+        f.write(render(R, e, "G1", "XYZZ mixed additions in the signed lazy radix-2^28 field"))
+        f.write("\n")
+        f.write(render(R2, e2, "G2", "the same over Fq2, W and ZZZ parked in LDS"))
+        f.write("#define ZK_MADD_G2_LDS_QUAD_STRIDE %d\n#define ZK_MADD_G2_LDS_W %d\n#define ZK_MADD_G2_LDS_ZZZ %d\n"
+                % (LDS_QUAD_STRIDE, LDS_W, LDS_ZZZ))
+    for nm, ee in (("G1", e), ("G2", e2)):
+        print("%s madd loop: %d lines, per step VALU %d SALU %d VMEM %d, hazard wait states %d"
+              % ((nm, len(ee.lines)) + body_counts(ee) + (ee.nops,)))
 
 
 if __name__ == "__main__":

@@ -42,6 +42,8 @@ class Lane:
         self.exec = 1
         self.vcc = 0
         self.pending = []         # in-order list of (dest registers, values)
+        self.lds = {}             # byte address -> u32 (this lane's parking slots)
+        self.lgkm = []            # LDS reads in flight
         self.inflight = {}        # register -> number of loads in flight into it
         self.labels = {}
         for i, l in enumerate(lines):
@@ -109,6 +111,14 @@ class Lane:
                 if x is not None:
                     self.v[r] = x
 
+    def retire_lds(self, keep):
+        while len(self.lgkm) > keep:
+            regs, vals = self.lgkm.pop(0)
+            for r, x in zip(regs, vals):
+                self.inflight[r] -= 1
+                if x is not None:
+                    self.v[r] = x
+
     # ---- execution
     def run(self, max_steps=10 ** 8):
         pc = 0
@@ -140,8 +150,12 @@ class Lane:
                 elif op == "s_nop":
                     pass
                 elif op == "s_waitcnt":
-                    m = re.match(r"vmcnt\((\d+)\)", ops[0])
-                    self.retire(int(m.group(1)))
+                    m = re.search(r"vmcnt\((\d+)\)", rest)
+                    if m:
+                        self.retire(int(m.group(1)))
+                    m = re.search(r"lgkmcnt\((\d+)\)", rest)
+                    if m:
+                        self.retire_lds(int(m.group(1)))
                 elif op == "s_branch":
                     pc = self.target(ops[0], pc)
                 elif op == "s_cbranch_execz":
@@ -149,6 +163,31 @@ class Lane:
                         pc = self.target(ops[0], pc)
                 else:
                     raise SimError("unknown op " + ln)
+                continue
+            if op.startswith("ds_"):
+                self.count["lds"] = self.count.get("lds", 0) + 1
+                m = re.search(r"offset:(\d+)", rest)
+                off = int(m.group(1)) if m else 0
+                n = 4 if op.endswith("b128") else 2
+                if op.startswith("ds_read"):
+                    dst = ops[0]
+                    lo = int(dst[2:dst.index(":")])
+                    regs = list(range(lo, lo + n))
+                    addr = self.rd(ops[1].split()[0]) + off
+                    vals = [self.lds[addr + 4 * i] if self.exec else None for i in range(n)]
+                    for r in regs:
+                        if self.inflight.get(r):
+                            raise SimError("two loads in flight into v%d" % r)
+                        self.inflight[r] = self.inflight.get(r, 0) + 1
+                    self.lgkm.append((regs, vals))
+                else:
+                    addr = self.rd(ops[0]) + off
+                    src = ops[1].split()[0]
+                    lo = int(src[2:src.index(":")])
+                    if self.exec:
+                        for i in range(n):
+                            self.lds[addr + 4 * i] = self.rv(lo + i)
+                    self.lgkm.append(([], []))
                 continue
             if op.startswith("global_load"):
                 self.count["vmem"] += 1
@@ -236,7 +275,7 @@ class Lane:
                 self.wr(ops[0], val)
             else:
                 raise SimError("unknown op " + ln)
-        if self.pending:
+        if self.pending or self.lgkm:
             raise SimError("loads still in flight at the end")
         return self.v
 
@@ -381,5 +420,88 @@ def main(cases=12):
           % (total, cases, valu, salu, vmem))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# G2
+# ---------------------------------------------------------------------------------------------------------------
+def run_task_g2(points, signs, rnd):
+    from oracle import bls12_381 as bls
+    R, e = gm.gen_loop_g2()
+    n = len(points)
+    table_base, pairs_base, lds_a = 0x7f5600000000, 0x7f7800002000, 16 * 5
+    mem = {}
+    idxs = [rnd.randrange(1 << 19) for _ in points]
+    mont = lambda c: lim(c * R392 % P + (P if rnd.random() < 0.5 else 0))
+    for ((x0, x1), (y0, y1)), idx in zip(points, idxs):
+        for i, w in enumerate(mont(x0) + mont(x1) + mont(y0) + mont(y1)):
+            mem[table_base + idx * 224 + 4 * i] = w
+    for k in range(n):
+        mem[pairs_base + 4 * k] = (idxs[k] << 1) | signs[k]
+    (x0, x1), (y0, y1) = points[0]
+    one, zero = lim(R392), [0] * 14
+    vregs = {}
+    lds = {}
+
+    def park(slot, limbs):
+        for q in range(4):
+            for j in range(4):
+                i = 4 * q + j
+                lds[lds_a + (slot * 4 + q) * gm.LDS_QUAD_STRIDE + 4 * j] = limbs[i] if i < 14 else 0xdeadbeef
+    neg = (lambda l: [(-t) & M32 for t in l]) if signs[0] else (lambda l: l)
+    for blk, limbs in ((R.X[0], lim(x0 * R392 % P)), (R.X[1], lim(x1 * R392 % P)), (R.ZZ[0], one), (R.ZZ[1], zero)):
+        for i in range(14):
+            vregs[blk[i]] = limbs[i]
+    park(gm.LDS_W, neg(lim(y0 * R392 % P)))
+    park(gm.LDS_W + 1, neg(lim(y1 * R392 % P)))
+    park(gm.LDS_ZZZ, one)
+    park(gm.LDS_ZZZ + 1, zero)
+    vregs[R.PTR[0]], vregs[R.PTR[1]] = pairs_base & M32, pairs_base >> 32
+    vregs[R.NCNT] = n
+    vregs[R.TBL[0]], vregs[R.TBL[1]] = table_base & M32, table_base >> 32
+    vregs[R.LDSA_IN] = lds_a
+    lane = Lane(e.lines, vregs, mem)
+    lane.lds = lds
+    out = lane.run()
+    getv = lambda blk: sval([out[blk[i]] for i in range(14)])
+    getl = lambda slot: sval([lane.lds[lds_a + (slot * 4 + i // 4) * gm.LDS_QUAD_STRIDE + 4 * (i % 4)] for i in range(14)])
+    sigma = -1 if (n - 1) & 1 else 1
+    X = (getv(R.X[0]), getv(R.X[1]))
+    ZZ = (getv(R.ZZ[0]), getv(R.ZZ[1]))
+    W = (sigma * getl(gm.LDS_W), sigma * getl(gm.LDS_W + 1))
+    ZZZ = (getl(gm.LDS_ZZZ), getl(gm.LDS_ZZZ + 1))
+    return X, W, ZZ, ZZZ, lane.count
+
+
+def main_g2(cases=6):
+    from oracle import bls12_381 as bls
+    F, G2 = bls.Fq2Ops, bls.G2
+    rnd = random.Random(950)
+    total = 0
+    red = lambda a: (a[0] % P, a[1] % P)
+    for c in range(cases):
+        n = [2, 3, 6, 2, 11, 4][c % 6]
+        pts = [G2.to_affine(G2.mul(G2.gen, rnd.randrange(1, 1 << 40))) for _ in range(n)]
+        signs = [rnd.randrange(2) for _ in range(n)]
+        X, Y, ZZ, ZZZ, count = run_task_g2(pts, signs, rnd)
+        want = None
+        for pt, sg in zip(pts, signs):
+            want = G2.add(want, G2.to_jac(G2.neg_affine(pt) if sg else pt))
+        want = G2.to_affine(want)
+        # the registers hold Montgomery forms: x = X / ZZ, y = Y / ZZZ (the factors 2^392 cancel)
+        got = (F.mul(red(X), F.inv(red(ZZ))), F.mul(red(Y), F.inv(red(ZZZ))))
+        assert F.eq(got[0], want[0]) and F.eq(got[1], want[1]), "G2 task %d: wrong sum" % c
+        for comp in X + Y + ZZ + ZZZ:
+            assert abs(comp) < 8 * P
+        total += n - 1
+    a = G2.to_affine(G2.mul(G2.gen, 12345))
+    b = G2.to_affine(G2.mul(G2.gen, 777))
+    for pts, signs in (([a, a, b], [0, 0, 1]), ([a, a, b], [0, 1, 0])):
+        X, Y, ZZ, ZZZ, count = run_task_g2(pts, signs, rnd)
+        assert ZZ[0] in (0, P) and ZZ[1] in (0, P), "G2 special case not flagged by ZZ == 0 (mod p)"
+    valu, salu, vmem = gm.body_counts(gm.gen_loop_g2()[1])
+    print("MADD_G2 ok: %d mixed additions in %d tasks (+ the flagged special cases); per step %d VALU, %d SALU, %d VMEM"
+          % (total, cases, valu, salu, vmem))
+
+
 if __name__ == "__main__":
     main()
+    main_g2()

@@ -25,7 +25,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
-           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "transfer_requests", "transfer_derive", "gen_proofs", "gen_proof", "XT_FIELDS",
+           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "gen_proof", "XT_FIELDS",
            "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_prove_batch",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
@@ -549,6 +549,34 @@ def spending_key_from_seed(seed, lib=None):
     out = np.zeros(32, dtype=np.uint8)
     lib.check(lib.zk_spending_key_from_seed(_ptr(buf), buf.size, _ptr(out)))
     return int.from_bytes(out.tobytes(), "little")
+
+
+def jubjub_base_mul(scalars, lib=None):
+    """scalar * FixedGenerators::NoteCommitmentRandomness for a list of Fs scalars (zk_jubjub_base_mul;
+    EncryptionKey::from_decryption_key, keys.rs:250-261).  Returns the 32-byte encodings."""
+    lib = lib or _lib.load()
+    sb = scalars_to_bytes(scalars)
+    out = np.zeros(32 * len(scalars), dtype=np.uint8)
+    lib.check(lib.zk_jubjub_base_mul(_ptr(sb) if sb.size else None, len(scalars), _ptr(out) if out.size else None))
+    ob = out.tobytes()
+    return [ob[i:i + 32] for i in range(0, len(ob), 32)]
+
+
+def elgamal_encrypt(values, randomness, enc_keys, lib=None):
+    """elgamal::Ciphertext::encrypt (elgamal.rs:46-63) for lists of u32 values, Fs randomness and 32-byte encryption
+    keys (zk_elgamal_encrypt).  Returns (left encodings, right encodings)."""
+    lib = lib or _lib.load()
+    n = len(values)
+    if not (len(randomness) == n and len(enc_keys) == n):
+        raise ValueError("values, randomness and enc_keys must have the same length")
+    vb = np.asarray(values, dtype=np.uint32)
+    rb = scalars_to_bytes(randomness)
+    kb = _u8(b"".join(bytes(k) for k in enc_keys), 32 * n)
+    left, right = np.zeros(32 * n, dtype=np.uint8), np.zeros(32 * n, dtype=np.uint8)
+    if n:
+        lib.check(lib.zk_elgamal_encrypt(_ptr(vb), _ptr(rb), _ptr(kb), n, _ptr(left), _ptr(right)))
+    lb, rbb = left.tobytes(), right.tobytes()
+    return [lb[i:i + 32] for i in range(0, 32 * n, 32)], [rbb[i:i + 32] for i in range(0, 32 * n, 32)]
 
 
 def transfer_requests(items):

@@ -120,6 +120,8 @@ _PROTOS = {
     "zk_pipeline_wait": (C.c_int32, [C.c_void_p]),
     "zk_pipeline_free": (None, [C.c_void_p]),
     "zk_spending_key_from_seed": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zk_jubjub_base_mul": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zk_elgamal_encrypt": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zk_transfer_derive": (C.c_int32, [C.POINTER(TransferRequest), C.c_size_t, C.POINTER(TransferStatement), C.c_void_p]),
     "zk_transfer_gen_proof_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TransferRequest), C.c_void_p,
                                                 C.POINTER(ConfidentialXt)]),

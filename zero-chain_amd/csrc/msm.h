@@ -710,6 +710,80 @@ k_msm_accumulate_g1asm(const Affine<Fq28>* __restrict__ table, const uint32_t* _
     }
     tsums[d.y] = acc;
 }
+// Pass 5, G2: the same loop over Fq2 (madd_asm.h ZK_MADD_G2_ASM).  256 VGPRs = two waves per SIMD (the compiled
+// kernel above: 468 registers, one wave): X and ZZ in registers, W = sigma Y and ZZZ parked in LDS (224 bytes per lane,
+// [element quad][thread] x 16 bytes so that a wave's ds_read_b128 sweeps every bank once).
+static __global__ void __launch_bounds__(128, 2)
+k_msm_accumulate_g2asm(const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                       const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq2x>* __restrict__ tsums,
+                       uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+    static_assert(ZK_MADD_G2_VGPRS <= 256, "the loop must fit two waves per SIMD");
+    static_assert(ZK_MADD_G2_LDS_QUAD_STRIDE == 128 * 16, "parking area laid out for 128-thread workgroups");
+    ZK_SHARED uint4 park[16][128];
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total[0]) return;
+    const uint4 d = sorted[t];
+    const uint32_t n = d.z;
+    XYZZ<Fq2x> acc = XYZZ<Fq2x>::inf();
+    if (n) {
+        const uint32_t* pp = pairs + d.x;
+        const uint32_t pr = pp[0];
+        const Affine<Fq2x> p = table[pr >> 1];
+        if (n == 1) {
+            acc = XYZZ<Fq2x>{p.x, (pr & 1u) ? neg_b<Fq2x::MO>(p.y) : p.y, Fq2x::one(), Fq2x::one()};
+        } else {
+            const uint32_t tid = threadIdx.x;
+            auto put = [&](int slot, const Fq28& a, bool negate) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w[j] = 4 * q + j < 14 ? (negate ? 0u - a.l[4 * q + j] : a.l[4 * q + j]) : 0u;
+                    park[slot * 4 + q][tid] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            };
+            auto get = [&](int slot) {
+                u32x16 v;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint4 w = park[slot * 4 + q][tid];
+                    v[4 * q] = w.x;
+                    v[4 * q + 1] = w.y;
+                    v[4 * q + 2] = w.z;
+                    v[4 * q + 3] = w.w;
+                }
+                return v;
+            };
+            const Fq28 one = Fq28::one(), zero = Fq28::zero();
+            put(ZK_MADD_G2_LDS_W, p.y.c0, (pr & 1u) != 0);        // W = +-y as signed limbs (sigma = +1)
+            put(ZK_MADD_G2_LDS_W + 1, p.y.c1, (pr & 1u) != 0);
+            put(ZK_MADD_G2_LDS_ZZZ, one, false);
+            put(ZK_MADD_G2_LDS_ZZZ + 1, zero, false);
+            u32x16 X0 = fq28_vec(p.x.c0), X1 = fq28_vec(p.x.c1), ZZ0 = fq28_vec(one), ZZ1 = fq28_vec(zero);
+            const uint64_t pa = (uint64_t)(uintptr_t)pp, ta = (uint64_t)(uintptr_t)table;
+            X0[14] = (uint32_t)pa;
+            X0[15] = (uint32_t)(pa >> 32);
+            X1[14] = n;
+            ZZ0[14] = (uint32_t)ta;
+            ZZ0[15] = (uint32_t)(ta >> 32);
+            ZZ1[14] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)&park[0][tid];
+            asm volatile(ZK_MADD_G2_ASM
+                         : "+{v[0:15]}"(X0), "+{v[16:31]}"(X1), "+{v[32:47]}"(ZZ0), "+{v[48:63]}"(ZZ1)
+                         :
+                         : ZK_MADD_G2_ASM_CLOBBERS);
+            const bool flip = ((n - 1) & 1u) != 0;
+            // X is carry-normalised inside the loop, value in (-6 p, 2 p)
+            acc.x = Fq2x{fq28_from_signed<7, false>(X0), fq28_from_signed<7, false>(X1)};
+            const u32x16 w0 = get(ZK_MADD_G2_LDS_W), w1 = get(ZK_MADD_G2_LDS_W + 1);
+            acc.y = flip ? Fq2x{fq28_from_signed<3, true>(w0), fq28_from_signed<3, true>(w1)}
+                         : Fq2x{fq28_from_signed<2, false>(w0), fq28_from_signed<2, false>(w1)};
+            acc.zz = Fq2x{fq28_from_signed_product(ZZ0), fq28_from_signed_product(ZZ1)};
+            acc.zzz = Fq2x{fq28_from_signed_product(get(ZK_MADD_G2_LDS_ZZZ)), fq28_from_signed_product(get(ZK_MADD_G2_LDS_ZZZ + 1))};
+            if (acc.zz.is_zero_norm()) redo[atomicAdd(n_redo, 1u)] = t;
+        }
+    }
+    tsums[d.y] = acc;
+}
 #endif
 // second pass for the tasks the assembly loop flagged (equal or opposite points met on the way): the compiled loop
 template <class F>

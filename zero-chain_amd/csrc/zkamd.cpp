@@ -251,27 +251,39 @@ zk_status check_points_host(const std::vector<zkhost::Affine<HF>>& pts, const ch
     return st;
 }
 
-// The G1 accumulation runs the generated assembly loop (msm.h k_msm_accumulate_g1asm) unless ZKAMD_G1_ASM=0 (A/B
-// switch) or the build has none (the x86 emulation build).
+// The accumulation kernels run the generated assembly loops (msm.h k_msm_accumulate_g1asm / _g2asm) unless
+// ZKAMD_G1_ASM=0 / ZKAMD_G2_ASM=0 (A/B switches) or the build has none (the x86 emulation build).
 template <class DF>
-static bool g1_asm_loop() { return false; }
+static bool asm_loop() { return false; }
+template <class DF>
+static void launch_asm_loop(const zkdev::Affine<DF>*, const uint32_t*, const uint4*, const uint32_t*, zkdev::XYZZ<DF>*, uint32_t*,
+                            uint32_t*, unsigned, hipStream_t) {}
 #ifdef ZK_HAVE_MADD_ASM
 template <>
-bool g1_asm_loop<zkdev::Fq28>() {
+bool asm_loop<zkdev::Fq28>() {
     static const bool on = !(getenv("ZKAMD_G1_ASM") && atoi(getenv("ZKAMD_G1_ASM")) == 0);
     return on;
 }
-#endif
-template <class DF>
-static void launch_g1_asm(const zkdev::Affine<DF>*, const uint32_t*, const uint4*, const uint32_t*, zkdev::XYZZ<DF>*, uint32_t*,
-                          uint32_t*, unsigned, hipStream_t) {}
-#ifdef ZK_HAVE_MADD_ASM
 template <>
-void launch_g1_asm<zkdev::Fq28>(const zkdev::Affine<zkdev::Fq28>* table, const uint32_t* pairs, const uint4* sorted,
-                                const uint32_t* d_total, zkdev::XYZZ<zkdev::Fq28>* tsums, uint32_t* d_nredo, uint32_t* redo,
-                                unsigned blocks, hipStream_t st) {
+bool asm_loop<zkdev::Fq2x>() {
+    static const bool on = !(getenv("ZKAMD_G2_ASM") && atoi(getenv("ZKAMD_G2_ASM")) == 0);
+    return on;
+}
+template <>
+void launch_asm_loop<zkdev::Fq28>(const zkdev::Affine<zkdev::Fq28>* table, const uint32_t* pairs, const uint4* sorted,
+                                  const uint32_t* d_total, zkdev::XYZZ<zkdev::Fq28>* tsums, uint32_t* d_nredo, uint32_t* redo,
+                                  unsigned blocks, hipStream_t st) {
     ZK_LAUNCH(zkdev::k_msm_accumulate_g1asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
     ZK_LAUNCH(zkdev::k_msm_accumulate_redo<zkdev::Fq28>, dim3(256), dim3(64), 0, st, table, pairs, sorted,
+              (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
+}
+template <>
+void launch_asm_loop<zkdev::Fq2x>(const zkdev::Affine<zkdev::Fq2x>* table, const uint32_t* pairs, const uint4* sorted,
+                                  const uint32_t* d_total, zkdev::XYZZ<zkdev::Fq2x>* tsums, uint32_t* d_nredo, uint32_t* redo,
+                                  unsigned blocks, hipStream_t st) {
+    ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo,
+                   redo);
+    ZK_LAUNCH(zkdev::k_msm_accumulate_redo<zkdev::Fq2x>, dim3(256), dim3(64), 0, st, table, pairs, sorted,
               (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
 }
 #endif
@@ -482,15 +494,15 @@ struct MsmGroup {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
             // G2: one wave per SIMD with the whole register file unless ZKAMD_G2_ACC_OCC=2 (A/B switch)
             static const bool wide_g2 = !(getenv("ZKAMD_G2_ACC_OCC") && atoi(getenv("ZKAMD_G2_ACC_OCC")) == 2);
-            if (zkdev::HostWords<DF>::N > 12 && wide_g2)
+            if (asm_loop<DF>()) {
+                // the generated assembly loop (msm.h, madd_asm.h), then the compiled loop over the few tasks it flagged
+                ZK_TRY(redo.ensure((size_t)total_tasks * 4));
+                launch_asm_loop(table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>(), d_nredo,
+                                redo.as<uint32_t>(), (unsigned)((total_tasks + 127) / 128), st);
+            } else if (zkdev::HostWords<DF>::N > 12 && wide_g2)
                 ZK_LAUNCH(zkdev::k_msm_accumulate_wide<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
                           table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
-            else if (g1_asm_loop<DF>()) {
-                // G1: the generated assembly loop (msm.h, madd_asm.h), then the compiled loop over the few tasks it flagged
-                ZK_TRY(redo.ensure((size_t)total_tasks * 4));
-                launch_g1_asm(table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>(), d_nredo,
-                              redo.as<uint32_t>(), (unsigned)((total_tasks + 127) / 128), st);
-            } else
+            else
                 ZK_LAUNCH(zkdev::k_msm_accumulate<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
                           table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
         }
@@ -2037,6 +2049,16 @@ void jubjub_encode(const zkhost::Fr& x_mont, const zkhost::Fr& y_mont, uint8_t o
     if (x.l[0] & 1) out[31] |= 0x80;
 }
 
+template <class Fn>
+void run_threads(unsigned nthreads, Fn& work) {
+    if (nthreads <= 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> ths;
+    for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(std::ref(work), t);
+    for (auto& th : ths) th.join();
+}
 // request -> statement (+ rsk): ProofGenerationKey::from_spending_key, into_decryption_key, SpendingKey::into_rsk
 // Point<E, Unknown>::as_prime_order (core/jubjub/src/curve/edwards.rs:319-330): [s]P == O for the order s of the
 // prime-order subgroup.  The reference's typed inputs (EncryptionKey::read keys.rs:269-276, Ciphertext::read
@@ -2143,6 +2165,67 @@ zk_status zk_spending_key_from_seed(const uint8_t* seed, size_t len, uint8_t spe
     uint64_t v[4];
     fs_to_uniform(d, 64, v);
     memcpy(spending_key_out, v, 32);
+    return ZK_OK;
+}
+
+zk_status zk_jubjub_base_mul(const uint8_t* scalars, size_t n, uint8_t* points_out) {
+    if (n && (!scalars || !points_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return ZK_OK;
+    (void)zkwit::tables();
+    const unsigned nthreads = host_threads(n, 64);
+    std::vector<zk_status> sts(nthreads, ZK_OK);
+    std::vector<std::string> msgs(nthreads);
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
+            uint64_t k[4];
+            load_scalar_le(scalars + 32 * i, k);
+            if (!fs_lt_mod(k)) {
+                sts[t] = fail(ZK_ERR_INVALID_ARGUMENT, "scalar " + std::to_string(i) + " is not a canonical Fs scalar");
+                msgs[t] = g_err;
+                return;
+            }
+            const zkwit::JPoint p = jubjub_fixed_mul(k);
+            jubjub_encode(p.x, p.y, points_out + 32 * i);
+        }
+    };
+    run_threads(nthreads, work);
+    for (unsigned t = 0; t < nthreads; t++)
+        if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
+    return ZK_OK;
+}
+
+zk_status zk_elgamal_encrypt(const uint32_t* values, const uint8_t* randomness, const uint8_t* enc_keys, size_t n, uint8_t* left_out,
+                             uint8_t* right_out) {
+    if (n && (!values || !randomness || !enc_keys || !left_out || !right_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return ZK_OK;
+    (void)zkwit::tables();
+    const unsigned nthreads = host_threads(n, 16);
+    std::vector<zk_status> sts(nthreads, ZK_OK);
+    std::vector<std::string> msgs(nthreads);
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
+            uint64_t r[4], v[4] = {values[i], 0, 0, 0};
+            load_scalar_le(randomness + 32 * i, r);
+            zkwit::JPoint key;
+            zk_status rc = fs_lt_mod(r) ? ZK_OK : fail(ZK_ERR_INVALID_ARGUMENT, "randomness " + std::to_string(i) + " is not a canonical Fs scalar");
+            if (rc == ZK_OK) rc = decode_prime_order(enc_keys + 32 * i, &key, "enc_key " + std::to_string(i));
+            if (rc != ZK_OK) {
+                sts[t] = rc;
+                msgs[t] = g_err;
+                return;
+            }
+            // left = v G + r pk, right = r G  (no_std_aliases/elgamal.rs:46-63)
+            zkwit::EPoint proj[2] = {zkwit::ext_add(zkwit::to_ext(jubjub_fixed_mul(v)), jubjub_var_mul(key, r)),
+                                     zkwit::to_ext(jubjub_fixed_mul(r))};
+            zkwit::JPoint aff[2];
+            zkwit::batch_to_affine(proj, aff, 2);
+            jubjub_encode(aff[0].x, aff[0].y, left_out + 32 * i);
+            jubjub_encode(aff[1].x, aff[1].y, right_out + 32 * i);
+        }
+    };
+    run_threads(nthreads, work);
+    for (unsigned t = 0; t < nthreads; t++)
+        if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
     return ZK_OK;
 }
 
