@@ -391,6 +391,7 @@ def main():
     rs_ints = [[(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(B)] for _ in range(K + W)]
     rs_bytes = [zk.scalars_to_bytes([x for pair in step for x in pair]) for step in rs_ints]
     pipe = zk.TransferPipeline(mats, params)
+    lanes_used = pipe.lanes
     gathered = []
 
     def fence():
@@ -398,14 +399,21 @@ def main():
         torch.cuda.synchronize()
         lib.check(lib.zk_synchronize())
 
+    timing = {"prove_s": 0.0, "gather_s": 0.0}
+
     def run_steps(first, count):
+        t_a = time.perf_counter()
         outs = [pipe.submit(sts, rs_bytes[first + k]) for k in range(count)]
         pipe.wait(raw=True)
+        t_b = time.perf_counter()
         if world > 1:
             # every rank proved its contiguous block of the B * world statements of a step; one gather of
             # 192 B per proof and step to rank 0 (RCCL under "nccl"): the only collective of the data path
             for o in outs:
                 gathered.append(zk.gather_proofs(o, B * world, dist=dist, device=gather_dev, dst=0))
+            if not one_gpu:
+                torch.cuda.synchronize()
+        timing["prove_s"], timing["gather_s"] = t_b - t_a, time.perf_counter() - t_b
         return outs
 
     # priming (setup, not a warmup step): the second lane of the pipeline allocates its chunk workspaces the
@@ -428,10 +436,17 @@ def main():
         if cnt:
             kernels[name] = {"launches": cnt, "total_ms": round(ms.value, 3)}
     lib.zk_profile_end()
+    per_rank = [{"rank": 0, "proofs_per_s": round(B * K / timing["prove_s"], 1), "gather_ms_per_step": 0.0}]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's own rate (submit of its K steps -> its last proof) and what the gather cost it
+        mine = torch.tensor([timing["prove_s"], timing["gather_s"]], dtype=torch.float64, device=gather_dev)
+        allr = [torch.zeros(2, dtype=torch.float64, device=gather_dev) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "proofs_per_s": round(B * K / float(x[0]), 1), "gather_ms_per_step": round(float(x[1]) / K * 1e3, 2)}
+                    for r, x in enumerate(allr)]
 
     # ---- parity gates: EVERY step of the timed region (two pipeline lanes alternate the chunks; VERDICT r2: the
     # last step alone looks at one lane)
@@ -494,63 +509,101 @@ def main():
     g1_terms = info["n_h"] + info["n_l"] + a_terms + b_terms
     chunk = int(os.environ.get("ZKAMD_BATCH_CHUNK", "1024"))
     roof = None
+    TRAFFIC = os.path.join("profiles", "r03_traffic.json")     # tools/make_roofline.py over the PMC passes of tools/gpu_session3.sh
+    CLOCK_HZ = 2.4e9                                            # nominal; the issue fractions below are against it
     if "msm_accumulate_g1" in kernels:
         k = kernels["msm_accumulate_g1"]
         avg_ms = k["total_ms"] / k["launches"]
         proofs_per_launch = B * K / k["launches"]
-        alg_bytes = 128.0 * g1_terms * proofs_per_launch     # 96 B base + 32 B scalar per term
+        g2_terms = b_terms
+        c1 = info["window_bits"]
+        c2 = int(os.environ.get("ZKAMD_WINDOW_BITS_G2") or os.environ.get("ZKAMD_WINDOW_BITS") or
+                 min(range(2, 23), key=lambda c: 254.0 / (c + 1) * info["n_b_g2"] + 12.0 * (1 << (c - 2))))   # zkamd.cpp pick_window
+        m_dom = 1 << info["log_domain"]
+        # algorithmic bytes per launch set of ONE chunk: 128 B per G1 term, 224 B per G2 term, 64 B per
+        # element and transform; sort: scalars in (32 B) + (digit, point) pairs out (4 B, 254 / (c + 1) per scalar, an
+        # upper estimate: zero and one scalars recode shorter); reduction: every bucket's partial sum read once
+        alg = {"msm_accumulate_g1": 128.0 * g1_terms, "msm_accumulate_g2": 224.0 * g2_terms,
+               "ntt": 64.0 * m_dom * 7,
+               "msm_sort_lds": 32.0 * (g1_terms + g2_terms) + 4.0 * (g1_terms * 254.0 / (c1 + 1) + g2_terms * 254.0 / (c2 + 1)),
+               "msm_reduce_g1": 224.0 * 2 * (1 << (c1 - 2)), "msm_reduce_g2": 448.0 * (1 << (c2 - 2))}
+        alg = {g: v * proofs_per_launch for g, v in alg.items()}
+        alg_bytes = alg["msm_accumulate_g1"]
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # HBM bytes and VALU instructions of one launch of the same kernel from the committed rocprofv3 PMC
-        # passes (profiles/r02_traffic.json, tools/gpu_session.sh DO_PMC=1): only if taken at this launch size
-        traffic, traffic_src, valu = None, None, None
+        tj = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-            if tj.get("batch") == proofs_per_launch:
-                kk = tj["kernels"]["void zkdev::k_msm_accumulate<zkdev::Fq28>"]
-                traffic = int(kk["fetch_bytes"] + kk["write_bytes"])
-                traffic_src = "profiles/r02_traffic.json (FETCH_SIZE + WRITE_SIZE, separate passes; raw FETCH_SIZE " \
-                              "calibrated against the known gather bytes of this kernel, see DESIGN.md 4.1)"
-                if kk.get("valu_wave_insts"):
-                    # one wave64 integer instruction per 4 cycles per SIMD, 1024 SIMDs at the measured clock
-                    valu = {"wave_insts_per_launch": kk["valu_wave_insts"],
-                            "issue_frac": round(kk["valu_wave_insts"] * 4.0 / 1024 / (avg_ms * 1e-3 * tj.get("clock_hz", 2.4e9)), 4)}
+            tj = json.load(open(os.path.join(ROOT, TRAFFIC)))
+            if tj.get("batch") != proofs_per_launch:
+                tj = None
         except Exception:
             pass
-        roof = {"bound": "hbm", "kernel": "k_msm_accumulate<Fq28> (G1 bucket accumulation)",
+
+        def counters(group, ms):
+            """HBM bytes and VALU instructions of the group's launches of one chunk, from the committed PMC passes"""
+            if not tj or group not in tj["groups"]:
+                return None, None
+            gk = tj["groups"][group]
+            vi = gk.get("valu_wave_insts")
+            return int(gk.get("fetch_bytes", 0) + gk.get("write_bytes", 0)), (
+                {"wave_insts_per_launch": vi, "issue_frac": round(vi * 4.0 / 1024 / (ms * 1e-3 * CLOCK_HZ), 4)} if vi and ms else None)
+        traffic, valu = counters("msm_accumulate_g1", avg_ms)
+        roof = {"bound": "hbm", "kernel": "k_msm_accumulate_g1asm (G1 bucket accumulation)",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
+                "traffic_source": None if traffic is None else TRAFFIC + " (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                 "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "valu": valu,
                 "note": "integer-VALU bound kernel (381-bit modular arithmetic, no dense contraction); see DESIGN.md 4.1"}
         if rank == 0 and B == chunk:
-            # the same launch alone on the GPU: one chunk, one lane, side streams folded into the main one
+            # every launch of a chunk alone on the GPU: one chunk, one lane, side streams folded into the main one
             try:
                 os.environ["ZKAMD_NO_OVERLAP"] = "1"
                 zk.transfer_prove_batch(mats, params, sts, rs_ints[0])
                 lib.zk_profile_begin()
-                for _ in range(3):
+                reps = 3
+                for _ in range(reps):
                     got = zk.transfer_prove_batch(mats, params, sts, rs_ints[W + K - 1])
-                ms = C.c_double(0)
-                cnt = lib.zk_profile_get(b"msm_accumulate_g1", C.byref(ms))
+                alone = {}
+                for name in KERNEL_NAMES:
+                    ms = C.c_double(0)
+                    if lib.zk_profile_get(name.encode(), C.byref(ms)):
+                        alone[name] = ms.value / reps
                 lib.zk_profile_end()
                 if world == 1:
                     assert b"".join(p.write() for p in got) == outs[-1].tobytes(), "serial and pipelined proofs differ"
-                if cnt:
+                if "msm_accumulate_g1" in alone:
                     # the launch alone is the figure the roofline is priced on: inside the timed region two pipeline lanes
                     # keep two launches of this same kernel in flight, and the event interval of one contains the share
-                    # of the GPU the other took (steady state: 1.6 x the duration alone)
-                    alone_ms = ms.value / cnt
+                    # of the GPU the other took
+                    alone_ms = alone["msm_accumulate_g1"]
                     roof["in_region"] = {"avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"],
-                                         "valu_issue_frac": valu["issue_frac"] if valu else None,
                                          "note": "HIP-event interval of a launch inside the timed region (two lanes in flight)"}
                     roof["avg_launch_ms"] = round(alone_ms, 4)
                     roof["achieved"] = round(alg_bytes / (alone_ms * 1e-3) / 1e9, 3)
                     roof["frac"] = round(alg_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)
                     roof["measured"] = "one launch of the timed region's shape (1024 proofs) alone on the GPU, HIP events on its " \
                                        "stream, live in this run after the timed region; rocprofv3 of the same launches: " \
-                                       "profiles/r02final_serial_bench_b1024_kernel_stats.csv"
-                    if valu:
-                        valu["issue_frac"] = round(valu["wave_insts_per_launch"] * 4.0 / 1024 / (alone_ms * 1e-3 * 2.4e9), 4)
+                                       "profiles/r03final_serial_bench_b1024_kernel_stats.csv"
+                    roof["traffic"], roof["valu"] = counters("msm_accumulate_g1", alone_ms)
                     roof["alone"] = {"avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"]}
+                # the other hot kernels of a chunk, each alone on the GPU, priced the same way (VERDICT r2 item 5)
+                alone["ntt"] = alone.get("ntt_pass_dif", 0.0) + alone.get("ntt_pass_dit", 0.0)
+                names = {"msm_accumulate_g2": "k_msm_accumulate_g2asm (G2 bucket accumulation)",
+                         "ntt": "k_ntt_pass (the 7 transforms of 2^15 of the H pipeline, all passes)",
+                         "msm_sort_lds": "k_msm_sort_lds (digit recoding + counting sort of the (digit, point) pairs)",
+                         "msm_reduce_g1": "bucket reduction G1 (k_msm_merge_heavy, k_msm_suffix_buckets, k_msm_segsum, k_msm_suffix)",
+                         "msm_reduce_g2": "bucket reduction G2 (the same over Fq2)"}
+                others = []
+                for grp, label in names.items():
+                    ms = alone.get(grp)
+                    if not ms:
+                        continue
+                    tr, va = counters(grp, ms)
+                    ach = alg[grp] / (ms * 1e-3) / 1e9
+                    others.append({"kernel": label, "group": grp, "ms_alone_per_chunk": round(ms, 3),
+                                   "algorithmic_bytes_per_chunk": int(alg[grp]), "achieved": round(ach, 3), "unit": "GB/s",
+                                   "frac": round(ach / HBM_PEAK_GBPS, 6), "traffic": tr, "valu": va})
+                roof["others"] = others
+                roof["alone_ms_per_chunk"] = {g: round(v, 3) for g, v in alone.items()}
             except Exception as exc:   # a side measurement never costs the bench line
                 roof["alone"] = {"error": repr(exc)[:200]}
             finally:
@@ -574,7 +627,27 @@ def main():
         cp.create_proof(helpers.le(a0.a), helpers.le(a0.b), helpers.le(a0.c), helpers.le(a0.inputs), helpers.le(a0.aux),
                         bytes(dens[0]), bytes(dens[1]), bytes(dens[2]), bls.fr_le(1), bls.fr_le(2), min(cores, 32))
         lat = time.perf_counter() - t1
+        # one proof on ONE thread (SURVEY.md 8d "report single-thread too"): bellman's algorithm with a pool of one
+        t1 = time.perf_counter()
+        one = cp.create_proof(helpers.le(a0.a), helpers.le(a0.b), helpers.le(a0.c), helpers.le(a0.inputs), helpers.le(a0.aux),
+                              bytes(dens[0]), bytes(dens[1]), bytes(dens[2]), bls.fr_le(r0), bls.fr_le(s0), 1)
+        lat1 = time.perf_counter() - t1
+        assert bytes(one) == proofs[:192]
+        # the synthesis the GPU headline includes and create_proof does not: the reference's synthesize under bellman's
+        # ProvingAssignment is single-threaded; the product's native host calculator stands in for it here (an upper
+        # bound on what the reference's would reach), one thread
+        lib.zk_set_host_threads(1)
+        t1 = time.perf_counter()
+        zk.transfer_witness(zk.transfer_statements(items[:8]), lib=lib)
+        syn1 = (time.perf_counter() - t1) / 8
+        lib.zk_set_host_threads(host_threads)
         cpu = {"value": round(n_cpu / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
+               "single_thread": {"value": round(1.0 / lat1, 4), "unit": "proofs/s", "cores": 1, "create_proof_s": round(lat1, 3),
+                                 "witness_s": round(syn1, 4),
+                                 "value_with_witness": round(1.0 / (lat1 + syn1), 4),
+                                 "sample": "one create_proof on one thread (%.1f s); witness_s = the product's native host witness "
+                                           "calculator on one thread (the reference's single-threaded synthesize is not "
+                                           "buildable here)" % lat1},
                "sample": "%d confidential-transfer proofs (create_proof from a finished assignment; synthesis not included), "
                          "one single-threaded create_proof per core, %.1f s wall" % (n_cpu, dt),
                "single_proof_latency_s": round(lat, 3), "single_proof_threads": min(cores, 32)}
@@ -664,7 +737,7 @@ def main():
                    "statement_seeds": "SplitMix64(4 + i), i = rank * %d + k" % B,
                    "window_bits": info["window_bits"], "batch_chunk": chunk, "host_cores": cores, "host_threads_per_rank": host_threads,
                    "parallelism": "dp%d (independent proofs, contiguous blocks, %s gather of 192 B/proof/step)" % (world, "gloo" if one_gpu else "RCCL"),
-                   "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
+                   "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend, "pipeline_lanes": lanes_used, "per_rank": per_rank,
                    "proofs_checked_vs_oracle": checked, "proofs_checked_from_other_ranks": cross_rank,
                    "proofs_verified_by_product_verifier": verified, "verify_ms_per_step": None if verify_ms is None else round(verify_ms, 1), "setup_s": round(setup_s, 2), "statements_s": round(statements_s, 2), "generate_parameters_s": round(keygen_s, 2)},
         "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "secondary": secondary, "micro": micro,

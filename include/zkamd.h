@@ -211,6 +211,9 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out);
 zk_status zk_pipeline_submit(zk_pipeline* pl, size_t n, const zk_transfer_statement* st, const uint8_t* rs,
                              uint8_t* proofs_out);
 zk_status zk_pipeline_wait(zk_pipeline* pl);
+/* chunks proved concurrently (ZKAMD_PIPELINE_LANES, default 2; fewer when the device's free memory does not hold the
+ * workspaces of that many lanes - about 36 MB per proof of a chunk and lane) */
+int zk_pipeline_lanes(const zk_pipeline* pl);
 void zk_pipeline_free(zk_pipeline* pl);
 
 /* ------------------------------------------------------------------------------------------

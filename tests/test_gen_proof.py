@@ -127,3 +127,62 @@ def test_anonymous_derivation_matches_oracle():
         with pytest.raises(zk.ZkError) as e:
             zk.anonymous_derive(zk.anonymous_requests([cases[1][0], bad]), lib=lib)
         assert e.value.variant == "InvalidArgument" and "request 1" in str(e.value) and what in str(e.value)
+
+
+def test_jubjub_entries_match_oracle():
+    """zk_jubjub_base_mul = scalar * NoteCommitmentRandomness generator (EncryptionKey::from_decryption_key, keys.rs:250-261),
+    zk_elgamal_encrypt = Ciphertext::encrypt (no_std_aliases/elgamal.rs:46-63), against the oracle's big-integer Jubjub."""
+    import zero_chain_amd as zk
+    lib = _lib()
+    g = jj.note_commitment_randomness_generator()
+    rng = synth.SplitMix64(77)
+    ks = [0, 1, 2, jj.FS_MOD - 1] + [rng.field(jj.FS_MOD) for _ in range(5)]
+    assert zk.jubjub_base_mul(ks, lib=lib) == [jj.write_point(jj.mul(g, k)) for k in ks]
+    vals = [0, 1, 100, 0xffffffff, 12345]
+    rnd = [rng.field(jj.FS_MOD) for _ in vals]
+    keys = [jj.mul(g, rng.field(jj.FS_MOD)) for _ in vals]
+    left, right = zk.elgamal_encrypt(vals, rnd, [jj.write_point(k) for k in keys], lib=lib)
+    for v, r, k, l, rr in zip(vals, rnd, keys, left, right):
+        want = og.encrypt(v, r, k)
+        assert (l, rr) == (jj.write_point(want[0]), jj.write_point(want[1]))
+    with pytest.raises(zk.ZkError):
+        zk.jubjub_base_mul([jj.FS_MOD], lib=lib)                      # not a canonical Fs scalar
+
+
+def test_points_outside_the_prime_order_subgroup_are_refused():
+    """The reference's typed inputs pass through as_prime_order (EncryptionKey::read keys.rs:269-276, Ciphertext::read
+    elgamal.rs:117-133): P + (0, -1) = (-x, -y) decodes, lies on the curve and has order 2 s - the wallet-level entries
+    refuse it, as the reference's readers do."""
+    import zero_chain_amd as zk
+    lib = _lib()
+    g = jj.note_commitment_randomness_generator()
+    x, y = jj.mul(g, 0x1234567)
+    torsion = jj.write_point(((-x) % jj.R, (-y) % jj.R))
+    good = jj.write_point((x, y))
+    with pytest.raises(zk.ZkError) as e:
+        zk.elgamal_encrypt([1], [5], [torsion], lib=lib)
+    assert "prime-order" in str(e.value)
+    zk.elgamal_encrypt([1], [5], [good], lib=lib)
+    for field in ("enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch"):
+        rq, _ = reference_request(3)
+        zk.transfer_derive(zk.transfer_requests([rq]), lib=lib)       # the untouched request is fine
+        rq[field] = torsion
+        with pytest.raises(zk.ZkError) as e:
+            zk.transfer_derive(zk.transfer_requests([rq]), lib=lib)
+        assert e.value.variant == "InvalidArgument" and field in str(e.value) and "prime-order" in str(e.value)
+
+
+def test_bench_statements_built_natively_equal_the_oracles():
+    """bench.py builds its statements with the product's Jubjub entries; they are the oracle's statements."""
+    import importlib.util, os
+    import zero_chain_amd as zk
+    from oracle import transfer_circuit as tc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("zk_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = bench.make_statements_native(zk, _lib(), 1021, 1027, check=2)
+    for k, i in enumerate(range(1021, 1027)):
+        seed, amount, fee, balance = bench.statement_params(i)
+        assert rows[k] == tc.statement_dict(tc.make_witness(seed, amount=amount, fee=fee, balance=balance))
+    zk.transfer_statements(rows)

@@ -745,6 +745,11 @@ class TransferPipeline:
         self._h = h
         self._pending = []
 
+    @property
+    def lanes(self):
+        """chunks proved concurrently (zk_pipeline_lanes)"""
+        return int(self._lib.zk_pipeline_lanes(self._h))
+
     def submit(self, statements, rs):
         n = len(statements)
         rsb = rs if isinstance(rs, np.ndarray) else scalars_to_bytes([x for pair in rs for x in pair])

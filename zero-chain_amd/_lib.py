@@ -118,6 +118,7 @@ _PROTOS = {
     "zk_pipeline_create": (C.c_int32, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "zk_pipeline_submit": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(TransferStatement), C.c_void_p, C.c_void_p]),
     "zk_pipeline_wait": (C.c_int32, [C.c_void_p]),
+    "zk_pipeline_lanes": (C.c_int, [C.c_void_p]),
     "zk_pipeline_free": (None, [C.c_void_p]),
     "zk_spending_key_from_seed": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "zk_jubjub_base_mul": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -2049,6 +2049,17 @@ void jubjub_encode(const zkhost::Fr& x_mont, const zkhost::Fr& y_mont, uint8_t o
     if (x.l[0] & 1) out[31] |= 0x80;
 }
 
+// k * p for a point of the statement (double-and-add over the complete addition law; k < 2^252)
+zkwit::EPoint jubjub_var_mul(const zkwit::JPoint& p, const uint64_t k[4]) {
+    zkwit::EPoint acc = zkwit::ext_zero();
+    const zkwit::EPoint base = zkwit::to_ext(p);
+    for (int bit = 251; bit >= 0; bit--) {
+        acc = zkwit::ext_add(acc, acc);
+        if ((k[bit >> 6] >> (bit & 63)) & 1) acc = zkwit::ext_add(acc, base);
+    }
+    return acc;
+}
+
 template <class Fn>
 void run_threads(unsigned nthreads, Fn& work) {
     if (nthreads <= 1) {
@@ -2339,17 +2350,6 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
 }  // extern "C"
 
 namespace {
-
-// k * p for a point of the statement (double-and-add over the complete addition law; k < 2^252)
-zkwit::EPoint jubjub_var_mul(const zkwit::JPoint& p, const uint64_t k[4]) {
-    zkwit::EPoint acc = zkwit::ext_zero();
-    const zkwit::EPoint base = zkwit::to_ext(p);
-    for (int bit = 251; bit >= 0; bit--) {
-        acc = zkwit::ext_add(acc, acc);
-        if ((k[bit >> 6] >> (bit & 63)) & 1) acc = zkwit::ext_add(acc, base);
-    }
-    return acc;
-}
 
 struct AnonDerived {
     zkwit::JPoint pub[4 * ZK_ANONYMOUS_SIZE + 4];   // the public points in the order of the circuit's inputs
@@ -2711,6 +2711,25 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
         lanes = 1;   // the test-only emulation runs one launch at a time
 #endif
         if (lanes > zk_pipeline::MAX_LANES) lanes = zk_pipeline::MAX_LANES;
+        // Every lane allocates its chunk workspaces the first time it proves (~36 MB per proof of a chunk: 35 GB at 1024).
+        // Lanes that would not fit the device's free memory are not started (several ranks sharing one GPU,
+        // or a device with other tenants, must degrade to fewer lanes instead of failing in the middle of a batch).
+        {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                size_t per_lane = L->chunk * ((size_t)36 << 20);
+                if (const char* env = getenv("ZKAMD_LANE_BYTES"))
+                    if (atoll(env) > 0) per_lane = (size_t)atoll(env);
+                const size_t reserve = (size_t)2 << 30;
+                const size_t fit = free_b > reserve ? (free_b - reserve) / per_lane : 0;
+                if (fit < 1) {
+                    delete L;
+                    return fail(ZK_ERR_OUT_OF_MEMORY, "device memory: " + std::to_string(free_b >> 20) + " MiB free, one pipeline lane needs about " +
+                                                          std::to_string(per_lane >> 20) + " MiB");
+                }
+                if ((size_t)lanes > fit) lanes = (int)fit;
+            }
+        }
         for (int l = 1; l < lanes; l++) {
             L->Pl[l] = params_clone_for_lane(p);
             L->Rl[l] = r1cs_clone_for_lane(circuit);
@@ -2749,6 +2768,8 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
     *out = L;
     return ZK_OK;
 }
+
+int zk_pipeline_lanes(const zk_pipeline* L) { return L ? L->n_lanes : 0; }
 
 zk_status zk_pipeline_submit(zk_pipeline* L, size_t n, const zk_transfer_statement* st, const uint8_t* rs, uint8_t* proofs_out) {
     if (!L || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
