@@ -94,7 +94,8 @@ ZK_DI void st_tile(uint32_t* tile, uint32_t tile_elems, uint32_t e, const Fr& v)
 // One pass over a batch of polynomials (blockIdx.y = polynomial).  `tw` holds w^e (Montgomery)
 // for e in [0, n/2).  `pre` / `post` (optional, n entries each) are multiplied into every
 // element at load / store, indexed by the element's global position.  `src` (optional) replaces
-// `data` as the load source for the first pass of a chain.
+// `data` as the load source for the first pass of a chain; `minus` (optional, same element order as the store, one
+// array of `minus_stride` elements per polynomial) is subtracted after `post`.
 //
 // Occupancy is what this kernel is sensitive to: the Montgomery product is one long dependent
 // multiply-add chain per lane, so a SIMD needs ~4 waves to keep issuing.  Measured on MI355X (7 x 1024
@@ -104,7 +105,8 @@ ZK_DI void st_tile(uint32_t* tile, uint32_t tile_elems, uint32_t e, const Fr& v)
 // field) measured 22.1 ms at the same occupancy and 26.4 ms at 2 waves/SIMD: rejected.
 static __global__ void __launch_bounds__(NTT_BIG_THREADS, 4)
 k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __restrict__ tw,
-           const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post, NttPass ps, uint32_t* bad = nullptr) {
+           const uint32_t* __restrict__ pre, const uint32_t* __restrict__ post, NttPass ps, uint32_t* bad = nullptr,
+           const uint32_t* __restrict__ minus = nullptr, uint32_t minus_stride = 0) {
     ZK_DYN_SHARED(uint32_t, tile);   // 2 planes x [2^g][CW][4]
     const uint32_t k = ps.log_n, g = ps.g, lcw = ps.log_cw;
     const uint32_t rows = 1u << g, cw = 1u << lcw;
@@ -173,14 +175,22 @@ k_ntt_pass(uint32_t* data, const uint32_t* __restrict__ src, const uint32_t* __r
         uint32_t idx = (hi << (s + g)) | (m << s) | lo;
         Fr v = ld_tile(tile, tile_elems, e);
         if (post) v = mul(v, ld_fr(post + (size_t)idx * 8));
+        // last pass of the H pipeline: the coefficients of c are subtracted on the way out (see prove_chunk)
+        if (minus) v = sub(v, ld_fr(minus + ((size_t)blockIdx.y * minus_stride + idx) * 8));
         st_fr(base + (size_t)idx * 8, v);
     }
 }
 
-// h = (a*b - c) * zinv, element-wise over `count` = batch * m elements (a, b, c Montgomery), written
-// to out[proof * out_stride + e]: the last inverse transform then runs in place inside the
-// per-proof scalar vector of the merged C multiexp.
-// bellman: a.mul_assign(b); a.sub_assign(c); a.divide_by_z_on_coset()  
+// h' = a * b * zinv, element-wise over `count` = batch * m elements (a, b Montgomery, on the coset), written to
+// out[proof * out_stride + e]: the last inverse transform then runs in place inside the per-proof scalar vector of
+// the merged C multiexp.  With `c` given: (a * b - c) * zinv, bellman's literal order
+// (a.mul_assign(b); a.sub_assign(c); a.divide_by_z_on_coset()).
+// The prover passes c = nullptr and never evaluates c on the coset: with ab = lo + x^m hi (both halves of degree < m),
+// the coset interpolation of ab is lo + g^m hi and c itself is a polynomial of degree < m, so
+//     icoset_fft((ab - c) / Z on the coset) = (lo + g^m hi - c) / (g^m - 1) = (icoset_fft(ab on the coset) - c) / (g^m - 1)
+// coefficient by coefficient - for ANY a, b, c, satisfied constraints or not: the same vector as bellman's, one
+// transform of size m less (6 instead of 7).  The coefficients of c come out of its inverse transform scaled by
+// 1 / (m (g^m - 1)) (NttPlan sc_*) and are subtracted in the store of the last pass (k_ntt_pass `minus`).
 static __global__ void __launch_bounds__(256)
 k_h_pointwise(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, const uint32_t* __restrict__ c,
               const uint32_t* __restrict__ zinv, uint32_t* out, uint32_t m, uint32_t out_stride, size_t count) {
@@ -188,7 +198,7 @@ k_h_pointwise(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, co
     if (i >= count) return;
     Fr z = ld_fr(zinv);
     Fr x = mul(ld_fr(a + i * 8), ld_fr(b + i * 8));
-    x = sub(x, ld_fr(c + i * 8));
+    if (c) x = sub(x, ld_fr(c + i * 8));
     size_t proof = i / m, e = i % m;
     st_fr(out + (proof * out_stride + e) * 8, mul(x, z));
 }

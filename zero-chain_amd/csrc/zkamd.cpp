@@ -62,6 +62,7 @@ struct NttPlan {
     size_t n = 0;
     DevBuf tw_fwd, tw_inv;           // w^e, w^-e, e < n/2 (Montgomery)
     DevBuf s1_plain, s1_mont, s2;    // prover tables, bit-reversed order (see prove_chunk)
+    DevBuf sc_plain, sc_mont;        // constant 1 / (n (g^n - 1)): the scaling of c's coefficients (k_h_pointwise)
     DevBuf coset_fwd, coset_inv;     // g^i and g^-i / n, natural order (Montgomery)
     DevBuf consts;                   // [0] = 1/n, [1] = 1/(g^n - 1)   (Montgomery)
     DevBuf scratch;                  // permutation scratch for the stand-alone entry
@@ -142,6 +143,9 @@ struct NttPlan {
         ZK_TRY(pow_table(s1_mont, g, ninv, 1, 0, n));
         // after the last inverse transform: * g^-i / n and drop the Montgomery factor
         ZK_TRY(pow_table(s2, ginv, ninv, 1, 1, n));
+        // c's inverse transform: * 1 / (n (g^n - 1)), result plain (from a plain or a Montgomery input)
+        ZK_TRY(pow_table(sc_plain, Fr::one(), ninv * zinv, 2, 0, n));
+        ZK_TRY(pow_table(sc_mont, Fr::one(), ninv * zinv, 2, 1, n));
         ZK_TRY(pow_table(coset_fwd, g, Fr::one(), 0, 0, n));
         ZK_TRY(pow_table(coset_inv, ginv, ninv, 2, 0, n));
         return ZK_OK;
@@ -150,7 +154,8 @@ struct NttPlan {
     // Run one chain of passes over `batch` polynomials laid out with `stride` elements.
     zk_status chain(uint32_t* data, uint32_t batch, uint32_t stride, bool dif, bool inverse,
                     const uint32_t* pre, const uint32_t* post, const uint32_t* src = nullptr,
-                    uint32_t src_stride = 0, uint32_t src_valid = 0, uint32_t* bad = nullptr) {
+                    uint32_t src_stride = 0, uint32_t src_valid = 0, uint32_t* bad = nullptr,
+                    const uint32_t* sub = nullptr, uint32_t sub_stride = 0) {
         std::vector<NttPass> ps = passes(log_n, dif, stride);
         const uint32_t* tw = inverse ? tw_inv.as<uint32_t>() : tw_fwd.as<uint32_t>();
         for (size_t i = 0; i < ps.size(); i++) {
@@ -180,7 +185,8 @@ struct NttPlan {
 #endif
             ZK_LAUNCH_SYNC(zkdev::k_ntt_pass, grid, dim3(big(log_n) ? zkdev::NTT_BIG_THREADS : zkdev::NTT_THREADS), shmem, g_stream, data, s, tw,
                            i == 0 ? pre : (const uint32_t*)nullptr,
-                           i + 1 == ps.size() ? post : (const uint32_t*)nullptr, p, i == 0 && s ? bad : (uint32_t*)nullptr);
+                           i + 1 == ps.size() ? post : (const uint32_t*)nullptr, p, i == 0 && s ? bad : (uint32_t*)nullptr,
+                           i + 1 == ps.size() ? sub : (const uint32_t*)nullptr, sub_stride);
         }
         if (ps.empty() && (pre || post || src)) return fail(ZK_ERR_INVALID_ARGUMENT, "size-1 transform");
         HIP_TRY(hipGetLastError());
@@ -836,6 +842,8 @@ zk_params* params_clone_for_lane(const zk_params* P) {
     Q->ntt.s1_plain.borrow(P->ntt.s1_plain);
     Q->ntt.s1_mont.borrow(P->ntt.s1_mont);
     Q->ntt.s2.borrow(P->ntt.s2);
+    Q->ntt.sc_plain.borrow(P->ntt.sc_plain);
+    Q->ntt.sc_mont.borrow(P->ntt.sc_mont);
     Q->ntt.coset_fwd.borrow(P->ntt.coset_fwd);
     Q->ntt.coset_inv.borrow(P->ntt.coset_inv);
     Q->ntt.consts.borrow(P->ntt.consts);
@@ -991,19 +999,23 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
                                (const uint32_t*)bt->d_b + first * (size_t)n_rows * 8,
                                (const uint32_t*)bt->d_c + first * (size_t)n_rows * 8};
     uint32_t* dsts[3] = {A, B, C};
-    for (int k = 0; k < 3; k++)   // ifft (natural -> bit-reversed), then * g^i / m  (coset shift)
-        ZK_TRY(P->ntt.chain(dsts[k], (uint32_t)np, (uint32_t)m, true, true, nullptr, s1, srcs[k], n_rows, n_rows, bad));
-    // coset fft (bit-reversed -> natural) of all three at once
-    ZK_TRY(P->ntt.chain(A, (uint32_t)(3 * np), (uint32_t)m, false, false, nullptr, nullptr));
+    // ifft (natural -> bit-reversed) of a and b, then * g^i / m (coset shift); c: * 1 / (m (g^m - 1)), plain - its
+    // coefficients are all the H pipeline needs of c (ntt.h k_h_pointwise: 6 transforms per proof instead of bellman's 7)
+    const uint32_t* sc = mont ? P->ntt.sc_mont.as<uint32_t>() : P->ntt.sc_plain.as<uint32_t>();
+    for (int k = 0; k < 3; k++)
+        ZK_TRY(P->ntt.chain(dsts[k], (uint32_t)np, (uint32_t)m, true, true, nullptr, k < 2 ? s1 : sc, srcs[k], n_rows, n_rows, bad));
+    // coset fft (bit-reversed -> natural) of a and b at once
+    ZK_TRY(P->ntt.chain(A, (uint32_t)(2 * np), (uint32_t)m, false, false, nullptr, nullptr));
     {
         ProfScope ps("h_pointwise");
         size_t count = np * m;
         ZK_LAUNCH(zkdev::k_h_pointwise, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, g_stream, (const uint32_t*)A,
-                  (const uint32_t*)B, (const uint32_t*)C, P->ntt.consts.as<uint32_t>() + 8, cvec, (uint32_t)m, cstride, count);
+                  (const uint32_t*)B, (const uint32_t*)nullptr, P->ntt.consts.as<uint32_t>() + 8, cvec, (uint32_t)m, cstride, count);
     }
-    // icoset fft: ifft (natural -> bit-reversed), * g^-i / m, Montgomery factor dropped; in place
-    // inside the merged scalar vectors
-    ZK_TRY(P->ntt.chain(cvec, (uint32_t)np, cstride, true, true, nullptr, P->ntt.s2.as<uint32_t>()));
+    // icoset fft of a b / (g^m - 1): ifft (natural -> bit-reversed), * g^-i / m, Montgomery factor dropped, minus the
+    // scaled coefficients of c (same bit-reversed order); in place inside the merged scalar vectors
+    ZK_TRY(P->ntt.chain(cvec, (uint32_t)np, cstride, true, true, nullptr, P->ntt.s2.as<uint32_t>(), nullptr, 0, 0, nullptr,
+                        (const uint32_t*)C, (uint32_t)m));
     // job order: all C' jobs, then all A jobs.  Workgroup i of a launch runs on XCD i mod 8 and the
     // sort is one workgroup per job: alternating A, C' (a fifth against four fifths of the scalars)
     // put every large job on the odd XCDs.  Largest first also keeps the tail of the launch short.
@@ -2714,6 +2726,7 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
         // Every lane allocates its chunk workspaces the first time it proves (~36 MB per proof of a chunk: 35 GB at 1024).
         // Lanes that would not fit the device's free memory are not started (several ranks sharing one GPU,
         // or a device with other tenants, must degrade to fewer lanes instead of failing in the middle of a batch).
+#ifndef ZK_EMU
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -2730,6 +2743,7 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
                 if ((size_t)lanes > fit) lanes = (int)fit;
             }
         }
+#endif
         for (int l = 1; l < lanes; l++) {
             L->Pl[l] = params_clone_for_lane(p);
             L->Rl[l] = r1cs_clone_for_lane(circuit);
