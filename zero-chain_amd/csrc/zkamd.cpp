@@ -279,7 +279,11 @@ template <>
 void launch_asm_loop<zkdev::Fq28>(const zkdev::Affine<zkdev::Fq28>* table, const uint32_t* pairs, const uint4* sorted,
                                   const uint32_t* d_total, zkdev::XYZZ<zkdev::Fq28>* tsums, uint32_t* d_nredo, uint32_t* redo,
                                   unsigned blocks, hipStream_t st) {
-    ZK_LAUNCH(zkdev::k_msm_accumulate_g1asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
+    static const bool four = getenv("ZKAMD_G1_ASM") && atoi(getenv("ZKAMD_G1_ASM")) == 4;   // A/B: the four-waves-per-SIMD variant
+    if (four)
+        ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g1asm4, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
+    else
+        ZK_LAUNCH(zkdev::k_msm_accumulate_g1asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
     ZK_LAUNCH(zkdev::k_msm_accumulate_redo<zkdev::Fq28>, dim3(256), dim3(64), 0, st, table, pairs, sorted,
               (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
 }
