@@ -12,7 +12,7 @@ One "step" = one batch of B = 1024 transfer STATEMENTS per GPU, each through the
     the ten private values of a statement                     (host memory, 336 B)
  -> witness: the 19 978 variable values                        (native calculator, host cores)
  -> row evaluations A z, B z, C z                              (GPU, resident constraint matrices)
- -> 7 NTTs of size 2^15, the eight multiexps (three jobs), fold, into_affine   (GPU)
+ -> 6 NTTs of size 2^15, the eight multiexps (three jobs), fold, into_affine   (GPU)
  -> 192-byte proof                                             (host encoding)
 All B * N statements of a step are DISTINCT (keys, amounts, balances, randomness of statement i from
 SplitMix64(4 + i)); every proof has its own (r, s).  Steps are submitted to a zk_pipeline,
@@ -524,7 +524,7 @@ def main():
         # element and transform; sort: scalars in (32 B) + (digit, point) pairs out (4 B, 254 / (c + 1) per scalar, an
         # upper estimate: zero and one scalars recode shorter); reduction: every bucket's partial sum read once
         alg = {"msm_accumulate_g1": 128.0 * g1_terms, "msm_accumulate_g2": 224.0 * g2_terms,
-               "ntt": 64.0 * m_dom * 7,
+               "ntt": 64.0 * m_dom * 6,     # six transforms per proof since round 3 (bellman: seven)
                "msm_sort_lds": 32.0 * (g1_terms + g2_terms) + 4.0 * (g1_terms * 254.0 / (c1 + 1) + g2_terms * 254.0 / (c2 + 1)),
                "msm_reduce_g1": 224.0 * 2 * (1 << (c1 - 2)), "msm_reduce_g2": 448.0 * (1 << (c2 - 2))}
         alg = {g: v * proofs_per_launch for g, v in alg.items()}
@@ -588,7 +588,7 @@ def main():
                 # the other hot kernels of a chunk, each alone on the GPU, priced the same way
                 alone["ntt"] = alone.get("ntt_pass_dif", 0.0) + alone.get("ntt_pass_dit", 0.0)
                 names = {"msm_accumulate_g2": "k_msm_accumulate_g2asm (G2 bucket accumulation)",
-                         "ntt": "k_ntt_pass (the 7 transforms of 2^15 of the H pipeline, all passes)",
+                         "ntt": "k_ntt_pass (the 6 transforms of 2^15 of the H pipeline, all passes)",
                          "msm_sort_lds": "k_msm_sort_lds (digit recoding + counting sort of the (digit, point) pairs)",
                          "msm_reduce_g1": "bucket reduction G1 (k_msm_merge_heavy, k_msm_suffix_buckets, k_msm_segsum, k_msm_suffix)",
                          "msm_reduce_g2": "bucket reduction G2 (the same over Fq2)"}
@@ -730,7 +730,7 @@ def main():
         "dtype": "u32 limbs (Fq 381-bit: 14 x 28-bit; Fr 255-bit: 8 x 32-bit; modular integer arithmetic)",
         "data": "synthetic",
         "config": {"workload": "BASELINE config %d: batch of %d confidential-transfer statements per GPU per step, statement -> "
-                               "192-byte proof (full create_random_proof: witness generation + row evaluations + 7 NTT of 2^15 "
+                               "192-byte proof (full create_random_proof: witness generation + row evaluations + 6 NTT of 2^15 "
                                "+ 4 x MSM (H, L, A, B1 in G1; B2 in G2) + fold + encoding); circuit 19974 constraints / 23 inputs "
                                "/ 19955 aux, cs.hash d23c92fb..1784" % (4 if world == 1 else 5, B),
                    "proofs_per_gpu_per_step": B, "distinct_statements_per_step": B * world,

@@ -26,7 +26,10 @@ def emu_lib():
 
 @pytest.fixture(scope="session")
 def gpu_lib():
-    """The product library on a real GPU; a missing library or device is a hard failure."""
+    """The product library on a real GPU; a missing library or device is a hard failure.  The parity suite sends EVERY
+    multiexp launch through the generated assembly loops and their second pass (equal / opposite / repeated bases, the
+    point at infinity, single proofs), not only the launches large enough to take them by default (ZKAMD_ASM_MIN_PAIRS)."""
+    os.environ.setdefault("ZKAMD_ASM_MIN_PAIRS", "0")
     import zero_chain_amd
     lib = zero_chain_amd.load_library()
     import ctypes

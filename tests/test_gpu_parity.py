@@ -399,6 +399,22 @@ def test_pipeline_two_lanes_full_chunks_every_proof_checked(gpu_lib, monkeypatch
         params.close()
 
 
+def test_lone_proof_takes_the_compiled_loop_by_default(gpu_lib, monkeypatch):
+    """Launches below ZKAMD_ASM_MIN_PAIRS (a proof made alone) keep the compiled accumulation loop; the suite forces
+    the assembly loops everywhere else (conftest.py).  Same bytes either way."""
+    import zero_chain_amd as zk
+    r1, asg, P, pk = helpers.small_case(1, 3, 40, 44)
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    try:
+        want = helpers.expected_proof_trapdoor(P, asg, 77, 99)
+        monkeypatch.delenv("ZKAMD_ASM_MIN_PAIRS", raising=False)
+        assert zk.create_proof(helpers.to_assignment(zk, asg), params, 77, 99).write() == want
+        monkeypatch.setenv("ZKAMD_ASM_MIN_PAIRS", "0")
+        assert zk.create_proof(helpers.to_assignment(zk, asg), params, 77, 99).write() == want
+    finally:
+        params.close()
+
+
 def test_witness_gpu_matches_host(gpu_lib):
     pc.witness_gpu_matches_host(gpu_lib, n_extra=6)
 

@@ -284,8 +284,8 @@ void launch_asm_loop<zkdev::Fq28>(const zkdev::Affine<zkdev::Fq28>* table, const
         ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g1asm4, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
     else
         ZK_LAUNCH(zkdev::k_msm_accumulate_g1asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
-    ZK_LAUNCH(zkdev::k_msm_accumulate_redo<zkdev::Fq28>, dim3(256), dim3(64), 0, st, table, pairs, sorted,
-              (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
+    ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_redo<zkdev::Fq28>, dim3(1024), dim3(64), 0, st, table, pairs, sorted,
+                   (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
 }
 template <>
 void launch_asm_loop<zkdev::Fq2x>(const zkdev::Affine<zkdev::Fq2x>* table, const uint32_t* pairs, const uint4* sorted,
@@ -293,8 +293,8 @@ void launch_asm_loop<zkdev::Fq2x>(const zkdev::Affine<zkdev::Fq2x>* table, const
                                   unsigned blocks, hipStream_t st) {
     ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo,
                    redo);
-    ZK_LAUNCH(zkdev::k_msm_accumulate_redo<zkdev::Fq2x>, dim3(256), dim3(64), 0, st, table, pairs, sorted,
-              (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
+    ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_redo<zkdev::Fq2x>, dim3(1024), dim3(64), 0, st, table, pairs, sorted,
+                   (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
 }
 #endif
 
@@ -504,11 +504,37 @@ struct MsmGroup {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
             // G2: one wave per SIMD with the whole register file unless ZKAMD_G2_ACC_OCC=2 (A/B switch)
             static const bool wide_g2 = !(getenv("ZKAMD_G2_ACC_OCC") && atoi(getenv("ZKAMD_G2_ACC_OCC")) == 2);
-            if (asm_loop<DF>()) {
+            // the assembly loops are built for launches that fill the machine; a proof made alone (one or two jobs, 16- or
+            // 32-point tasks: `total` below the short-task threshold above) keeps the compiled kernel and saves the second launch
+            const char* min_env = getenv("ZKAMD_ASM_MIN_PAIRS");   // tests set 0: every launch, however small, through the assembly loop
+            if (asm_loop<DF>() && total >= (min_env ? (uint64_t)atoll(min_env) : 4000000ull)) {
                 // the generated assembly loop (msm.h, madd_asm.h), then the compiled loop over the few tasks it flagged
                 ZK_TRY(redo.ensure((size_t)total_tasks * 4));
                 launch_asm_loop(table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>(), d_nredo,
                                 redo.as<uint32_t>(), (unsigned)((total_tasks + 127) / 128), st);
+                if (getenv("ZKAMD_DEBUG_REDO")) {   // diagnostics: how many tasks went to the second pass, and what they look like
+                    (void)hipStreamSynchronize(st);
+                    uint32_t nr = 0, tot = 0;
+                    (void)hipMemcpy(&nr, d_nredo, 4, hipMemcpyDeviceToHost);
+                    (void)hipMemcpy(&tot, d_total, 4, hipMemcpyDeviceToHost);
+                    fprintf(stderr, "[redo] group %s: %u of %u tasks flagged\n", is_g2 ? "G2" : "G1", nr, tot);
+                    for (uint32_t q = 0; q < nr && q < 6; q++) {
+                        uint32_t ti = 0;
+                        uint4 dsc;
+                        (void)hipMemcpy(&ti, redo.as<uint32_t>() + q, 4, hipMemcpyDeviceToHost);
+                        (void)hipMemcpy(&dsc, sorted.as<uint4>() + ti, 16, hipMemcpyDeviceToHost);
+                        std::vector<uint32_t> pw(dsc.z);
+                        (void)hipMemcpy(pw.data(), pairs.as<uint32_t>() + dsc.x, dsc.z * 4, hipMemcpyDeviceToHost);
+                        std::sort(pw.begin(), pw.end());
+                        uint32_t dup = 0, opp = 0;
+                        for (size_t u = 1; u < pw.size(); u++) {
+                            dup += pw[u] == pw[u - 1];
+                            opp += (pw[u] ^ pw[u - 1]) == 1u;
+                        }
+                        fprintf(stderr, "[redo]   task %u: n = %u, equal pair words %u, opposite pair words %u, first %u %u %u\n", ti, dsc.z, dup, opp,
+                                pw.size() > 0 ? pw[0] : 0, pw.size() > 1 ? pw[1] : 0, pw.size() > 2 ? pw[2] : 0);
+                    }
+                }
             } else if (zkdev::HostWords<DF>::N > 12 && wide_g2)
                 ZK_LAUNCH(zkdev::k_msm_accumulate_wide<DF>, dim3((unsigned)((total_tasks + 127) / 128)), dim3(128), 0, st,
                           table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>());
@@ -2076,6 +2102,15 @@ zkwit::EPoint jubjub_var_mul(const zkwit::JPoint& p, const uint64_t k[4]) {
     return acc;
 }
 
+// secrets (spending keys, decryption keys, rsk, the statements that carry them) do not outlive the call that held
+// them: wiped on every exit path
+struct WipeOnExit {
+    void* p;
+    size_t n;
+    ~WipeOnExit() {
+        if (p && n) explicit_bzero(p, n);
+    }
+};
 template <class Fn>
 void run_threads(unsigned nthreads, Fn& work) {
     if (nthreads <= 1) {
@@ -2147,6 +2182,8 @@ zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_tr
     uint64_t r[4];
     fs_add(sk, alpha, r);   // PrivateKey(sk).randomize(alpha)
     memcpy(rsk, r, 32);
+    explicit_bzero(sk, sizeof(sk));
+    explicit_bzero(r, sizeof(r));
     return ZK_OK;
 }
 zk_status transfer_derive(const zk_transfer_request* rq, size_t n, zk_transfer_statement* st, uint8_t* rsk) {
@@ -2307,6 +2344,7 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
         return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
     std::vector<zk_transfer_statement> st(n);
     std::vector<uint8_t> rsk(n * 32), proofs(n * 192), ok(n);
+    WipeOnExit wipe_st{st.data(), n * sizeof(zk_transfer_statement)}, wipe_rsk{rsk.data(), rsk.size()};
     ZK_TRY(transfer_derive(req, n, st.data(), rsk.data()));
     const size_t chunk = batch_chunk(), nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX, n_pub = ZK_TRANSFER_N_INPUTS - 1;
     PinBuf pin_in;
@@ -2502,6 +2540,7 @@ zk_status zk_anonymous_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk
     std::vector<zk_anonymous_statement> st(n);
     std::vector<AnonDerived> der(n);
     std::vector<uint8_t> rsk(n * 32), proofs(n * 192), ok(n), inputs(n * n_pub * 32);
+    WipeOnExit wipe_st{st.data(), n * sizeof(zk_anonymous_statement)}, wipe_rsk{rsk.data(), rsk.size()};
     ZK_TRY(anonymous_derive(req, n, st.data(), rsk.data(), der.data()));
     ZK_TRY(zk_anonymous_prove_batch(p, circuit, n, st.data(), rs, proofs.data()));
     for (size_t i = 0; i < n; i++) {
