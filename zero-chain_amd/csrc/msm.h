@@ -666,14 +666,11 @@ ZK_DI Fq28 fq28_from_signed(const u32x16& v) {
     fq28_wnorm(r.l);
     return r;
 }
-static __global__ void __launch_bounds__(128, 3)
-k_msm_accumulate_g1asm(const Affine<Fq28>* __restrict__ table, const uint32_t* __restrict__ pairs,
-                       const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq28>* __restrict__ tsums,
-                       uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+ZK_DI void g1asm_task(uint32_t t, const Affine<Fq28>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                       const uint4* __restrict__ sorted, XYZZ<Fq28>* __restrict__ tsums, uint32_t* __restrict__ n_redo,
+                       uint32_t* __restrict__ redo) {
     static_assert(ZK_MADD_G1_VGPRS <= 168, "the loop must fit three waves per SIMD");
     static_assert(XYZZ<Fq28>::BX >= 9 && XYZZ<Fq28>::BY >= 5, "bounds of the values handed back by the loop");
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total[0]) return;
     const uint4 d = sorted[t];
     const uint32_t n = d.z;
     XYZZ<Fq28> acc = XYZZ<Fq28>::inf();
@@ -709,6 +706,32 @@ k_msm_accumulate_g1asm(const Affine<Fq28>* __restrict__ table, const uint32_t* _
         }
     }
     tsums[d.y] = acc;
+}
+static __global__ void __launch_bounds__(128, 3)
+k_msm_accumulate_g1asm(const Affine<Fq28>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                       const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq28>* __restrict__ tsums,
+                       uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total[0]) g1asm_task(t, table, pairs, sorted, tsums, n_redo, redo);
+}
+// The same as a PERSISTENT launch (ZKAMD_G1_PERSIST = workgroups per CU): a fixed number of workgroups, every wave
+// fetching blocks of 64 consecutive tasks from a counter.  With 4 workgroups per CU the launch holds two of the three
+// wave slots its registers allow, so the short kernels of the other pipeline lane (NTT passes, sort, witness levels,
+// reduction tails: up to 184 registers) find room on every SIMD while it runs instead of waiting for its workgroups
+// to retire (r03final2 trace: a 3 ms pass of the other lane stretched to 114 ms beside a full-occupancy launch).
+static __global__ void __launch_bounds__(128, 3)
+k_msm_accumulate_g1asm_persistent(const Affine<Fq28>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                                  const uint4* __restrict__ sorted, const uint32_t* __restrict__ total,
+                                  XYZZ<Fq28>* __restrict__ tsums, uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo,
+                                  uint32_t* __restrict__ next) {
+    const uint32_t ntask = total[0], lane = threadIdx.x & 63u;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= ntask) break;
+        if (base + lane < ntask) g1asm_task(base + lane, table, pairs, sorted, tsums, n_redo, redo);
+    }
 }
 // The same loop at FOUR waves per SIMD (ZKAMD_G1_ASM=4, an A/B variant): 128 VGPRs, W and ZZZ parked in LDS as in the
 // G2 loop below, the table entry fetched at the top of a step instead of one step ahead.
@@ -776,15 +799,11 @@ k_msm_accumulate_g1asm4(const Affine<Fq28>* __restrict__ table, const uint32_t* 
 // Pass 5, G2: the same loop over Fq2 (madd_asm.h ZK_MADD_G2_ASM).  256 VGPRs = two waves per SIMD (the compiled
 // kernel above: 468 registers, one wave): X and ZZ in registers, W = sigma Y and ZZZ parked in LDS (224 bytes per lane,
 // [element quad][thread] x 16 bytes so that a wave's ds_read_b128 sweeps every bank once).
-static __global__ void __launch_bounds__(128, 2)
-k_msm_accumulate_g2asm(const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
-                       const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq2x>* __restrict__ tsums,
-                       uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+ZK_DI void g2asm_task(uint32_t t, uint4 (*park)[128], const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                       const uint4* __restrict__ sorted, XYZZ<Fq2x>* __restrict__ tsums, uint32_t* __restrict__ n_redo,
+                       uint32_t* __restrict__ redo) {
     static_assert(ZK_MADD_G2_VGPRS <= 256, "the loop must fit two waves per SIMD");
     static_assert(ZK_MADD_G2_LDS_QUAD_STRIDE == 128 * 16, "parking area laid out for 128-thread workgroups");
-    ZK_SHARED uint4 park[16][128];
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total[0]) return;
     const uint4 d = sorted[t];
     const uint32_t n = d.z;
     XYZZ<Fq2x> acc = XYZZ<Fq2x>::inf();
@@ -846,6 +865,30 @@ k_msm_accumulate_g2asm(const Affine<Fq2x>* __restrict__ table, const uint32_t* _
         }
     }
     tsums[d.y] = acc;
+}
+static __global__ void __launch_bounds__(128, 2)
+k_msm_accumulate_g2asm(const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                       const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq2x>* __restrict__ tsums,
+                       uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+    ZK_SHARED uint4 park[16][128];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total[0]) g2asm_task(t, park, table, pairs, sorted, tsums, n_redo, redo);
+}
+// persistent form (see k_msm_accumulate_g1asm_persistent): a lane's LDS slots are its own, no barrier between tasks
+static __global__ void __launch_bounds__(128, 2)
+k_msm_accumulate_g2asm_persistent(const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                                  const uint4* __restrict__ sorted, const uint32_t* __restrict__ total,
+                                  XYZZ<Fq2x>* __restrict__ tsums, uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo,
+                                  uint32_t* __restrict__ next) {
+    ZK_SHARED uint4 park[16][128];
+    const uint32_t ntask = total[0], lane = threadIdx.x & 63u;
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= ntask) break;
+        if (base + lane < ntask) g2asm_task(base + lane, park, table, pairs, sorted, tsums, n_redo, redo);
+    }
 }
 #endif
 // Second pass for the tasks the assembly loop flagged: the compiled addition with every special case.  A circuit's

@@ -265,6 +265,12 @@ template <class DF>
 static void launch_asm_loop(const zkdev::Affine<DF>*, const uint32_t*, const uint4*, const uint32_t*, zkdev::XYZZ<DF>*, uint32_t*,
                             uint32_t*, unsigned, hipStream_t) {}
 #ifdef ZK_HAVE_MADD_ASM
+// workgroups per CU of the persistent form of the G1 loop (0 = one workgroup per 128 tasks, the plain launch)
+static int persist_wgs(int group = 1) {
+    static const int v1 = getenv("ZKAMD_G1_PERSIST") ? atoi(getenv("ZKAMD_G1_PERSIST")) : 6;
+    static const int v2 = getenv("ZKAMD_G2_PERSIST") ? atoi(getenv("ZKAMD_G2_PERSIST")) : 4;
+    return group == 2 ? v2 : v1;
+}
 template <>
 bool asm_loop<zkdev::Fq28>() {
     static const bool on = !(getenv("ZKAMD_G1_ASM") && atoi(getenv("ZKAMD_G1_ASM")) == 0);
@@ -282,6 +288,9 @@ void launch_asm_loop<zkdev::Fq28>(const zkdev::Affine<zkdev::Fq28>* table, const
     static const bool four = getenv("ZKAMD_G1_ASM") && atoi(getenv("ZKAMD_G1_ASM")) == 4;   // A/B: the four-waves-per-SIMD variant
     if (four)
         ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g1asm4, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
+    else if (persist_wgs() > 0 && blocks > 256u * (unsigned)persist_wgs())
+        ZK_LAUNCH(zkdev::k_msm_accumulate_g1asm_persistent, dim3(256u * (unsigned)persist_wgs()), dim3(128), 0, st, table, pairs, sorted,
+                  d_total, tsums, d_nredo, redo, d_nredo + 1);
     else
         ZK_LAUNCH(zkdev::k_msm_accumulate_g1asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
     ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_redo<zkdev::Fq28>, dim3(1024), dim3(64), 0, st, table, pairs, sorted,
@@ -291,8 +300,12 @@ template <>
 void launch_asm_loop<zkdev::Fq2x>(const zkdev::Affine<zkdev::Fq2x>* table, const uint32_t* pairs, const uint4* sorted,
                                   const uint32_t* d_total, zkdev::XYZZ<zkdev::Fq2x>* tsums, uint32_t* d_nredo, uint32_t* redo,
                                   unsigned blocks, hipStream_t st) {
-    ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo,
-                   redo);
+    if (persist_wgs(2) > 0 && blocks > 256u * (unsigned)persist_wgs(2))
+        ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm_persistent, dim3(256u * (unsigned)persist_wgs(2)), dim3(128), 0, st, table, pairs,
+                       sorted, d_total, tsums, d_nredo, redo, d_nredo + 1);
+    else
+        ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo,
+                       redo);
     ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_redo<zkdev::Fq2x>, dim3(1024), dim3(64), 0, st, table, pairs, sorted,
                    (const uint32_t*)d_nredo, (const uint32_t*)redo, tsums);
 }
@@ -407,7 +420,7 @@ struct MsmGroup {
         ZK_TRY(toff.ensure(n_buckets * 4));
         ZK_TRY(ntasks.ensure(nj * 4));
         ZK_TRY(tbase.ensure(nj * 4));
-        ZK_TRY(hist.ensure((2 * n_class + 3) * 4));     // [length histogram | placement cursors | total | #heavy | #redo]
+        ZK_TRY(hist.ensure((2 * n_class + 4) * 4));     // [length histogram | placement cursors | total | #heavy | #redo | next task block]
         const bool few = nj <= MSM_FEW_JOBS;   // latency-optimised bucket reduction (msm.h, passes 5c and 6)
         const uint32_t merge_inline = nj >= 64 || few ? 8u : 2u;
         const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
@@ -435,7 +448,7 @@ struct MsmGroup {
         memcpy((uint8_t*)pin_jobs.p + nj * sizeof(MsmJob), tbase_h.data(), nj * 4);
         HIP_TRY(hipMemcpyAsync(jobs_d.p, pin_jobs.p, nj * sizeof(MsmJob), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(tbase.p, (const uint8_t*)pin_jobs.p + nj * sizeof(MsmJob), nj * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 3) * 4, st));
+        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 4) * 4, st));
         uint32_t* lenhist = hist.as<uint32_t>();
         uint32_t* cursor = lenhist + n_class;
         uint32_t* d_total = cursor + n_class;
