@@ -341,6 +341,11 @@ def main():
     # ZK_BENCH_ONE_GPU=1 (check of the N > 1 code path on a 1-GPU box): every rank uses cuda:0 and the
     # gather goes over gloo, since RCCL refuses two ranks on one device
     one_gpu = os.environ.get("ZK_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        # two processes on one device: the persistent forms of the accumulation loops hold every wave slot for the whole
+        # launch and would starve the other process's short kernels; the plain launches interleave workgroup by workgroup
+        os.environ.setdefault("ZKAMD_G1_PERSIST", "0")
+        os.environ.setdefault("ZKAMD_G2_PERSIST", "0")
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
