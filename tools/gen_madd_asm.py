@@ -7,7 +7,8 @@ Why: hipcc needs 198 VGPRs for the mixed addition built from
 (two waves per SIMD) and spends ~390 of its ~770 non-product instructions per addition on operand moves into the
 routines' fixed registers.  Here every product is generated in place over the registers its operands already live
 in (a result limb is written over an operand limb that died one column earlier), the modulus lives in SGPRs for
-the whole loop, and the body needs 160 VGPRs: three waves per SIMD.
+the whole loop, and the body needs 160 VGPRs: three waves per SIMD (G2: 256 VGPRs, two waves, half the accumulator
+parked in LDS).
 
 The group law is the one dev_curve.h `madd` computes (EFD madd-2008-s on extended Jacobian XYZZ coordinates; the
 reference's Jacobian law for the same group elements: core/pairing/src/bls12_381/ec.rs:356-444), on the lazily
@@ -156,14 +157,17 @@ def _columns(e, R, col_prods, out):
 
 
 def mul(e, R, a, b, out):
-    """out = a b 2^-392 (exactly normalised, < 2p).  a: limbs < 2^30.4 allowed; b: limbs <= 2^28 + 8."""
+    """out = a b 2^-392: digits 0..12 in [0, 2^28), top limb signed, value in (-|a||b| / 2^11.3, |a||b| / 2^11.3 + 1) p.
+    Signed limbs; one operand may have limbs up to 2^30 in magnitude if the other's stay below 2^28 + 16 (14 products of
+    2^58 and the reduction's 14 of 2^56 stay below 2^63)."""
     _check_inplace(out, [a, b], "mul")
     assert not (set(R.M) | set(R.ACC)) & (set(a) | set(b) | set(out))
     _columns(e, R, lambda k: [(v(a[i]), v(b[k - i])) for i in range(N) if 0 <= k - i < N], out)
 
 
 def sqr(e, R, a, out):
-    """out = a^2 2^-392; a weakly normalised.  The cross products are taken once against doubled limbs (R.D)."""
+    """out = a^2 2^-392; |limbs of a| < 2^29 (carry-normalised, or a difference of two normalised values).  The cross
+    products are taken once against doubled limbs (R.D)."""
     _check_inplace(out, [a], "sqr")
     d = [None] + R.D
     assert not set(R.D) & (set(a) | set(out) | set(R.M) | set(R.ACC))
@@ -181,7 +185,7 @@ def sqr(e, R, a, out):
 
 
 def mac2(e, R, x0, y0, x1, y1, out):
-    """out = (x0 y0 + x1 y1) 2^-392 with one reduction.  x0, y1: limbs <= 2^28 + 8; y0: < 2^30.4; x1: < 2^30."""
+    """out = (x0 y0 + x1 y1) 2^-392 with one reduction (signed limbs: |x0|, |x1|, |y1| < 2^28 + 16, |y0| < 2^30)."""
     _check_inplace(out, [x0, y0, x1, y1], "mac2")
 
     def prods(k):

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Single-lane interpreter for what tools/gen_madd_asm.py emits (the G1 bucket-accumulation loop): control flow,
-EXEC masking of the one lane, global loads that deliver their data only when an s_waitcnt retires them (a register
-read or overwritten while its load is in flight is an error), 64-bit column accumulators that must not overflow,
-limb-wise subtractions that must not go negative.  The result of a task is compared, as a group element, with the
-sum of the points computed by the big-integer curve arithmetic of oracle/bls12_381.py."""
+"""Single-lane interpreter for what tools/gen_madd_asm.py emits (the G1 and G2 bucket-accumulation loops and the
+four-waves variant of the G1 loop): control flow, EXEC masking of the one lane, global and LDS loads that deliver
+their data only when an s_waitcnt retires them (a register read or overwritten while its load is in flight is an
+error), SIGNED 64-bit column accumulators and signed 32-bit limbs that must not overflow.  The result of a task is
+compared, as a group element, with the sum of the points computed by big-integer curve arithmetic (G2: the Jacobian
+law of oracle/bls12_381.py); tasks that meet equal or opposite points must come out flagged (ZZ == 0 mod p)."""
 import os
 import random
 import re
