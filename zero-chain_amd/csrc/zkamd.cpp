@@ -57,6 +57,24 @@ Fr fr_const(const uint64_t (&v)[4]) {
     return x;
 }
 
+// work(t) for t = 0 .. nthreads - 1 on host threads
+template <class Fn>
+void run_threads(unsigned nthreads, Fn& work) {
+    if (nthreads <= 1) {
+        work(0);
+        return;
+    }
+    // a thread that cannot be started (std::system_error must not cross the C ABI) leaves its share to this thread
+    std::vector<std::thread> ths;
+    unsigned started = 0;
+    try {
+        for (; started < nthreads; started++) ths.emplace_back(std::ref(work), started);
+    } catch (const std::system_error&) {
+    }
+    for (unsigned t = started; t < nthreads; t++) work(t);
+    for (auto& th : ths) th.join();
+}
+
 struct NttPlan {
     uint32_t log_n = 0;
     size_t n = 0;
@@ -1111,13 +1129,8 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
             zkhost::g1_to_compressed(zkhost::to_affine(P->pin_g1.as<HG1>()[p]), out + 144);
         }
     };
-    if (nthreads <= 1) {
-        work(0, np);
-    } else {
-        std::vector<std::thread> ths;
-        for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, np * t / nthreads, np * (t + 1) / nthreads);
-        for (auto& th : ths) th.join();
-    }
+    auto part = [&](unsigned t) { work(np * t / nthreads, np * (t + 1) / nthreads); };
+    run_threads(nthreads, part);
     if (trace_host) {
         const auto t_end = std::chrono::steady_clock::now();
         fprintf(stderr, "[zkamd] chunk of %zu: enqueue %.2f ms, wait for the GPU %.2f ms, host encoding %.2f ms\n", np,
@@ -1449,13 +1462,7 @@ zk_status witness_batch(size_t n, size_t n_inputs, size_t n_aux, uint32_t flags,
                 }
         }
     };
-    if (nthreads <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> ths;
-        for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, t);
-        for (auto& th : ths) th.join();
-    }
+    run_threads(nthreads, work);
     for (unsigned t = 0; t < nthreads; t++)
         if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
     return ZK_OK;
@@ -2124,16 +2131,6 @@ struct WipeOnExit {
         if (p && n) explicit_bzero(p, n);
     }
 };
-template <class Fn>
-void run_threads(unsigned nthreads, Fn& work) {
-    if (nthreads <= 1) {
-        work(0);
-        return;
-    }
-    std::vector<std::thread> ths;
-    for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(std::ref(work), t);
-    for (auto& th : ths) th.join();
-}
 // request -> statement (+ rsk): ProofGenerationKey::from_spending_key, into_decryption_key, SpendingKey::into_rsk
 // Point<E, Unknown>::as_prime_order (core/jubjub/src/curve/edwards.rs:319-330): [s]P == O for the order s of the
 // prime-order subgroup.  The reference's typed inputs (EncryptionKey::read keys.rs:269-276, Ciphertext::read
@@ -2215,13 +2212,7 @@ zk_status transfer_derive(const zk_transfer_request* rq, size_t n, zk_transfer_s
             }
         }
     };
-    if (nthreads <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> ths;
-        for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, t);
-        for (auto& th : ths) th.join();
-    }
+    run_threads(nthreads, work);
     for (unsigned t = 0; t < nthreads; t++)
         if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
     return ZK_OK;
@@ -2524,13 +2515,7 @@ zk_status anonymous_derive(const zk_anonymous_request* rq, size_t n, zk_anonymou
             }
         }
     };
-    if (nthreads <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> ths;
-        for (unsigned t = 0; t < nthreads; t++) ths.emplace_back(work, t);
-        for (auto& th : ths) th.join();
-    }
+    run_threads(nthreads, work);
     for (unsigned t = 0; t < nthreads; t++)
         if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
     return ZK_OK;
