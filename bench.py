@@ -795,7 +795,10 @@ def run_micro(lib, zk, dev):
                           "bases": "resident table of all 255 doublings of every base (fixed-base setting: a CRS), "
                                    "built once in table_build_s",
                           "gbps_algorithmic": round(128.0 * n / dt / 1e9, 3),
-                          "accumulate_kernel_ms": round(acc_ms, 3), "table_build_s": round(table_s, 2),
+                          "frac_of_hbm_peak": round(128.0 * n / dt / 1e9 / HBM_PEAK_GBPS, 5),
+                          "accumulate_kernel_ms": round(acc_ms, 3),
+                          "accumulate_kernel_gbps_algorithmic": round(128.0 * n / (acc_ms * 1e-3) / 1e9, 3) if acc_ms else None,
+                          "table_build_s": round(table_s, 2),
                           "kernel_ms": kern}
     # variable-base figures (no table of doublings: Pippenger over the bases themselves)
     try:
@@ -813,6 +816,7 @@ def run_micro(lib, zk, dev):
         vctx.close()
         out["msm_g1_2p20_variable_base"] = {
             "mscalar_per_s": round(nv / dtr / 1e6, 3), "ms": round(dtr * 1e3, 3),
+            "gbps_algorithmic": round(128.0 * nv / dtr / 1e9, 3), "frac_of_hbm_peak": round(128.0 * nv / dtr / 1e9 / HBM_PEAK_GBPS, 5),
             "one_shot_mscalar_per_s": round(nv / dtv / 1e6, 3), "one_shot_ms": round(dtv * 1e3, 3),
             "note": "zk_msm_create_variable: signed-digit Pippenger, one bucket pass per digit position, host Horner fold; "
                     "'ms' = bases resident (decoded once), scalars in HBM; 'one_shot' = decode + upload of 2^20 fresh "
