@@ -42,10 +42,12 @@ def gather_proofs(local_proofs, n_total, dist=None, device=None, dst=0):
             raise ValueError("empty batch but %d local bytes" % local.size)
         rank0 = dist is None or not dist.is_initialized() or dist.get_rank() == dst
         return b"" if rank0 else None
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         if local.size != n_total * PROOF_SIZE:
             raise ValueError("single-rank gather: expected the whole batch")
         return local.tobytes()
+    # (a process group of ONE rank still goes through the collective below: that is how the RCCL path is exercised on
+    #  a one-GPU box, tests/test_rccl_single_rank.py)
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     lo, hi = shard_bounds(n_total, rank, world)
