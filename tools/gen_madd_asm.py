@@ -309,115 +309,6 @@ def gen_loop():
 
 
 # ===============================================================================================================
-# G1 at FOUR waves per SIMD (an experiment, ZKAMD_G1_ASM=4): 128 VGPRs, W and ZZZ parked in LDS, no prefetch
-# ===============================================================================================================
-class Regs4:
-    def __init__(self):
-        blk = lambda b: list(range(b, b + 14))
-        self.X, self.ZZ = blk(0), blk(16)
-        self.L1, self.L2 = blk(32), blk(48)
-        self.A1, self.A2, self.T1 = blk(64), blk(80), blk(96)
-        self.M = list(range(112, 126))
-        self.ACC = (126, 127)
-        self.D = self.L1[1:]
-        self.PTR = (14, 15)
-        self.NCNT, self.PR = 30, 31
-        self.LDSA_IN = 31                            # handed over in the pad that becomes the pair word
-        self.TBL = (46, 47)
-        self.ADDR = (62, 63)
-        self.TMP, self.NM1 = 78, 79
-        self.LDSA = 94
-        self.n_vgpr = 128
-        self.sP = list(range(36, 50))
-        self.sINV, self.sMASK = 50, 51
-        self.sDUMMY = "s[52:53]"
-        self.sEXEC = "s[54:55]"
-        self.sK, self.sK1, self.s112 = 56, 57, 58
-        self.sSIGN = "s[60:61]"
-        self.sPAR = "s[62:63]"
-        self.clob_s = list(range(36, 64))
-
-
-LDS4_W, LDS4_ZZZ = 0, 1
-
-
-def lds_read1(e, R, slot, blk):
-    b = blk[0]
-    for q in range(3):
-        e.lds_op("ds_read_b128 v[%d:%d], %s offset:%d" % (b + 4 * q, b + 4 * q + 3, v(R.LDSA), (slot * 4 + q) * LDS_QUAD_STRIDE))
-    e.lds_op("ds_read_b64 v[%d:%d], %s offset:%d" % (b + 12, b + 13, v(R.LDSA), (slot * 4 + 3) * LDS_QUAD_STRIDE))
-
-
-def lds_write1(e, R, slot, blk):
-    b = blk[0]
-    for q in range(3):
-        e.lds_op("ds_write_b128 %s, v[%d:%d] offset:%d" % (v(R.LDSA), b + 4 * q, b + 4 * q + 3, (slot * 4 + q) * LDS_QUAD_STRIDE))
-    e.lds_op("ds_write_b64 %s, v[%d:%d] offset:%d" % (v(R.LDSA), b + 12, b + 13, (slot * 4 + 3) * LDS_QUAD_STRIDE))
-
-
-def gen_loop4():
-    R = Regs4()
-    e = Emitter()
-    for j in range(N):
-        e.salu_op("s_mov_b32 %s, 0x%08x" % (s(R.sP[j]), PL[j]))
-    e.salu_op("s_mov_b32 %s, 0x%08x" % (s(R.sINV), INV))
-    e.salu_op("s_mov_b32 %s, 0x%08x" % (s(R.sMASK), MASK))
-    e.salu_op("s_movk_i32 %s, 0x70" % s(R.s112))
-    e.valu_op("v_mov_b32_e32 %s, %s" % (v(R.LDSA), v(R.LDSA_IN)))
-    e.salu_op("s_mov_b64 %s, exec" % R.sEXEC)
-    e.salu_op("s_mov_b32 %s, 1" % s(R.sK))
-    e.salu_op("s_mov_b64 %s, 0" % R.sPAR)
-    e.valu_op("v_add_u32_e32 %s, -1, %s" % (v(R.NM1), v(R.NCNT)))
-    load_pair(e, R, R.sK)
-    e.label("1")
-    e.valu_op("v_cmp_lt_u32_e32 vcc, %s, %s" % (s(R.sK), v(R.NCNT)), writes=["vcc"])
-    e.salu_op("s_and_b64 exec, %s, vcc" % R.sEXEC)
-    e.salu_op("s_cbranch_execz 2f")
-    e.salu_op("s_waitcnt vmcnt(0)")
-    load_point(e, R)
-    e.valu_op("v_and_b32_e32 %s, 1, %s" % (v(R.TMP), v(R.PR)))
-    e.valu_op("v_cmp_ne_u32_e64 %s, 0, %s" % (R.sSIGN, v(R.TMP)), writes=[R.sSIGN])
-    e.salu_op("s_add_u32 %s, %s, 1" % (s(R.sK1), s(R.sK)))
-    load_pair(e, R, R.sK1)
-    e.salu_op("s_xor_b64 %s, %s, %s" % (R.sSIGN, R.sSIGN, R.sPAR))
-    e.salu_op("s_not_b64 %s, %s" % (R.sPAR, R.sPAR))
-    lds_read1(e, R, LDS4_ZZZ, R.T1)
-    e.salu_op("s_waitcnt vmcnt(1)")
-    for i in range(N):
-        e.valu_op("v_sub_u32_e32 %s, 0, %s" % (v(R.TMP), v(R.L2[i])))
-        e.valu_op("v_cndmask_b32_e64 %s, %s, %s, %s" % (v(R.L2[i]), v(R.L2[i]), v(R.TMP), R.sSIGN), reads=[R.sSIGN])
-    mul(e, R, R.L1, R.ZZ, R.A1)
-    e.salu_op("s_waitcnt lgkmcnt(0)")
-    mul(e, R, R.L2, R.T1, R.A2)
-    lds_read1(e, R, LDS4_W, R.T1)
-    sub(e, R.A1, R.X, R.A1)
-    wnorm(e, R, R.A1, R.A1, R.M)
-    e.salu_op("s_waitcnt lgkmcnt(0)")
-    sub(e, R.A2, R.T1, R.A2)
-    sqr(e, R, R.A1, R.T1)
-    mul(e, R, R.A1, R.T1, R.A1)
-    mul(e, R, R.ZZ, R.T1, R.ZZ)
-    mul(e, R, R.X, R.T1, R.T1)
-    sqr(e, R, R.A2, R.X)
-    x3(e, R.X, R.A1, R.T1, R.X, R.TMP)
-    sub(e, R.X, R.T1, R.T1)
-    lds_read1(e, R, LDS4_W, R.L1)
-    e.salu_op("s_waitcnt lgkmcnt(0)")
-    mac2(e, R, R.A2, R.T1, R.L1, R.A1, R.L1)
-    lds_write1(e, R, LDS4_W, R.L1)
-    lds_read1(e, R, LDS4_ZZZ, R.L2)
-    e.salu_op("s_waitcnt lgkmcnt(0)")
-    mul(e, R, R.L2, R.A1, R.L2)
-    lds_write1(e, R, LDS4_ZZZ, R.L2)
-    e.salu_op("s_add_u32 %s, %s, 1" % (s(R.sK), s(R.sK)))
-    e.salu_op("s_branch 1b")
-    e.label("2")
-    e.salu_op("s_mov_b64 exec, %s" % R.sEXEC)
-    e.salu_op("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    return R, e
-
-
-# ===============================================================================================================
 # G2: the same loop over Fq2 = Fq[u]/(u^2 + 1), two interleaved column streams per product
 # ===============================================================================================================
 class Regs2:
@@ -681,9 +572,6 @@ def main():
         f.write(render(R, e, "G1", "XYZZ mixed additions in the signed lazy radix-2^28 field"))
         f.write("\n")
         f.write(render(R2, e2, "G2", "the same over Fq2, W and ZZZ parked in LDS"))
-        f.write("\n")
-        R4, e4 = gen_loop4()
-        f.write(render(R4, e4, "G1X4", "the G1 loop at four waves per SIMD: W and ZZZ parked in LDS, no prefetch (experiment)", first_clobber=48))
         f.write("#define ZK_MADD_G2_LDS_QUAD_STRIDE %d\n#define ZK_MADD_G2_LDS_W %d\n#define ZK_MADD_G2_LDS_ZZZ %d\n"
                 % (LDS_QUAD_STRIDE, LDS_W, LDS_ZZZ))
     for nm, ee in (("G1", e), ("G2", e2)):

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Single-lane interpreter for what tools/gen_madd_asm.py emits (the G1 and G2 bucket-accumulation loops and the
-four-waves variant of the G1 loop): control flow, EXEC masking of the one lane, global and LDS loads that deliver
+"""Single-lane interpreter for what tools/gen_madd_asm.py emits (the G1 and G2 bucket-accumulation loops): control flow, EXEC masking of the one lane, global and LDS loads that deliver
 their data only when an s_waitcnt retires them (a register read or overwritten while its load is in flight is an
 error), SIGNED 64-bit column accumulators and signed 32-bit limbs that must not overflow.  The result of a task is
 compared, as a group element, with the sum of the points computed by big-integer curve arithmetic (G2: the Jacobian
@@ -421,64 +420,6 @@ def main(cases=12):
           % (total, cases, valu, salu, vmem))
 
 
-def run_task4(points, signs, rnd):
-    """the four-waves-per-SIMD variant of the G1 loop: W and ZZZ live in the lane's LDS slots"""
-    R, e = gm.gen_loop4()
-    n = len(points)
-    table_base, pairs_base, lds_a = 0x7f1200000000, 0x7f3400001000, 16 * 9
-    mem, lds = {}, {}
-    idxs = [rnd.randrange(1 << 20) for _ in points]
-    for (x, y), idx in zip(points, idxs):
-        xm, ym = x * R392 % P + (P if rnd.random() < 0.5 else 0), y * R392 % P + (P if rnd.random() < 0.5 else 0)
-        for i, w in enumerate(lim(xm) + lim(ym)):
-            mem[table_base + idx * 112 + 4 * i] = w
-    for k in range(n):
-        mem[pairs_base + 4 * k] = (idxs[k] << 1) | signs[k]
-
-    def park(slot, limbs):
-        for i in range(16):
-            lds[lds_a + (slot * 4 + i // 4) * gm.LDS_QUAD_STRIDE + 4 * (i % 4)] = limbs[i] if i < 14 else 0xdeadbeef
-    x0, y0 = points[0]
-    ym = lim(y0 * R392 % P)
-    park(gm.LDS4_W, [(-t) & M32 for t in ym] if signs[0] else ym)
-    park(gm.LDS4_ZZZ, lim(R392))
-    vregs = {}
-    for base, limbs in ((R.X[0], lim(x0 * R392 % P)), (R.ZZ[0], lim(R392))):
-        for i in range(14):
-            vregs[base + i] = limbs[i]
-    vregs[R.PTR[0]], vregs[R.PTR[1]] = pairs_base & M32, pairs_base >> 32
-    vregs[R.NCNT] = n
-    vregs[R.LDSA_IN] = lds_a
-    vregs[R.TBL[0]], vregs[R.TBL[1]] = table_base & M32, table_base >> 32
-    lane = Lane(e.lines, vregs, mem)
-    lane.lds = lds
-    out = lane.run()
-    getv = lambda blk: sval([out[blk[i]] for i in range(14)])
-    getl = lambda slot: sval([lane.lds[lds_a + (slot * 4 + i // 4) * gm.LDS_QUAD_STRIDE + 4 * (i % 4)] for i in range(14)])
-    sigma = -1 if (n - 1) & 1 else 1
-    return getv(R.X), sigma * getl(gm.LDS4_W), getv(R.ZZ), getl(gm.LDS4_ZZZ), lane.count
-
-
-def main4(cases=8):
-    rnd = random.Random(404)
-    total = 0
-    for c in range(cases):
-        n = [2, 3, 5, 9, 2, 17, 4, 6][c % 8]
-        pts = [aff_mul(rnd.randrange(1, 1 << 64), G1) for _ in range(n)]
-        signs = [rnd.randrange(2) for _ in range(n)]
-        X, Y, ZZ, ZZZ, count = run_task4(pts, signs, rnd)
-        want = None
-        for pt, sg in zip(pts, signs):
-            want = aff_add(want, (pt[0], (-pt[1]) % P) if sg else pt)
-        assert to_affine(X, Y, ZZ, ZZZ) == want, "task %d: wrong sum" % c
-        total += n - 1
-    a = aff_mul(99, G1)
-    X, Y, ZZ, ZZZ, count = run_task4([a, a, aff_mul(7, G1)], [0, 1, 0], rnd)
-    assert ZZ in (0, P)
-    valu, salu, vmem = gm.body_counts(gm.gen_loop4()[1])
-    print("MADD_G1X4 ok: %d mixed additions in %d tasks; per step %d VALU, %d SALU, %d VMEM" % (total, cases, valu, salu, vmem))
-
-
 # ---------------------------------------------------------------------------------------------------------------
 # G2
 # ---------------------------------------------------------------------------------------------------------------
@@ -563,5 +504,4 @@ def main_g2(cases=6):
 
 if __name__ == "__main__":
     main()
-    main4()
     main_g2()

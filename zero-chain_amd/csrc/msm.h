@@ -733,69 +733,6 @@ k_msm_accumulate_g1asm_persistent(const Affine<Fq28>* __restrict__ table, const 
         if (base + lane < ntask) g1asm_task(base + lane, table, pairs, sorted, tsums, n_redo, redo);
     }
 }
-// The same loop at FOUR waves per SIMD (ZKAMD_G1_ASM=4, an A/B variant): 128 VGPRs, W and ZZZ parked in LDS as in the
-// G2 loop below, the table entry fetched at the top of a step instead of one step ahead.
-static __global__ void __launch_bounds__(128, 4)
-k_msm_accumulate_g1asm4(const Affine<Fq28>* __restrict__ table, const uint32_t* __restrict__ pairs,
-                        const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq28>* __restrict__ tsums,
-                        uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
-    static_assert(ZK_MADD_G1X4_VGPRS <= 128, "the loop must fit four waves per SIMD");
-    ZK_SHARED uint4 park[8][128];
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total[0]) return;
-    const uint4 d = sorted[t];
-    const uint32_t n = d.z;
-    XYZZ<Fq28> acc = XYZZ<Fq28>::inf();
-    if (n) {
-        const uint32_t* pp = pairs + d.x;
-        const uint32_t pr = pp[0];
-        const Affine<Fq28> p = table[pr >> 1];
-        if (n == 1) {
-            acc = XYZZ<Fq28>{p.x, (pr & 1u) ? neg_b<Fq28::MO>(p.y) : p.y, Fq28::one(), Fq28::one()};
-        } else {
-            const uint32_t tid = threadIdx.x;
-            auto put = [&](int slot, const Fq28& a, bool negate) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    uint32_t w[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) w[j] = 4 * q + j < 14 ? (negate ? 0u - a.l[4 * q + j] : a.l[4 * q + j]) : 0u;
-                    park[slot * 4 + q][tid] = make_uint4(w[0], w[1], w[2], w[3]);
-                }
-            };
-            auto get = [&](int slot) {
-                u32x16 v;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint4 w = park[slot * 4 + q][tid];
-                    v[4 * q] = w.x;
-                    v[4 * q + 1] = w.y;
-                    v[4 * q + 2] = w.z;
-                    v[4 * q + 3] = w.w;
-                }
-                return v;
-            };
-            put(0, p.y, (pr & 1u) != 0);
-            put(1, Fq28::one(), false);
-            u32x16 X = fq28_vec(p.x), ZZ = fq28_vec(Fq28::one()), T = ZZ;
-            const uint64_t pa = (uint64_t)(uintptr_t)pp, ta = (uint64_t)(uintptr_t)table;
-            X[14] = (uint32_t)pa;
-            X[15] = (uint32_t)(pa >> 32);
-            ZZ[14] = n;
-            ZZ[15] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)&park[0][tid];
-            T[14] = (uint32_t)ta;
-            T[15] = (uint32_t)(ta >> 32);
-            asm volatile(ZK_MADD_G1X4_ASM : "+{v[0:15]}"(X), "+{v[16:31]}"(ZZ), "+{v[32:47]}"(T) : : ZK_MADD_G1X4_ASM_CLOBBERS);
-            acc.x = fq28_from_signed<7, false>(X);
-            acc.y = ((n - 1) & 1u) ? fq28_from_signed<3, true>(get(0)) : fq28_from_signed<2, false>(get(0));
-            acc.zz = fq28_from_signed_product(ZZ);
-            acc.zzz = fq28_from_signed_product(get(1));
-            if (acc.zz.is_zero_norm()) redo[atomicAdd(n_redo, 1u)] = t;
-        }
-    }
-    tsums[d.y] = acc;
-}
-
 // Pass 5, G2: the same loop over Fq2 (madd_asm.h ZK_MADD_G2_ASM).  256 VGPRs = two waves per SIMD (the compiled
 // kernel above: 468 registers, one wave): X and ZZ in registers, W = sigma Y and ZZZ parked in LDS (224 bytes per lane,
 // [element quad][thread] x 16 bytes so that a wave's ds_read_b128 sweeps every bank once).

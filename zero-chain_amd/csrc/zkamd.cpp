@@ -303,10 +303,7 @@ template <>
 void launch_asm_loop<zkdev::Fq28>(const zkdev::Affine<zkdev::Fq28>* table, const uint32_t* pairs, const uint4* sorted,
                                   const uint32_t* d_total, zkdev::XYZZ<zkdev::Fq28>* tsums, uint32_t* d_nredo, uint32_t* redo,
                                   unsigned blocks, hipStream_t st) {
-    static const bool four = getenv("ZKAMD_G1_ASM") && atoi(getenv("ZKAMD_G1_ASM")) == 4;   // A/B: the four-waves-per-SIMD variant
-    if (four)
-        ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g1asm4, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo, redo);
-    else if (persist_wgs() > 0 && blocks > 256u * (unsigned)persist_wgs())
+    if (persist_wgs() > 0 && blocks > 256u * (unsigned)persist_wgs())
         ZK_LAUNCH(zkdev::k_msm_accumulate_g1asm_persistent, dim3(256u * (unsigned)persist_wgs()), dim3(128), 0, st, table, pairs, sorted,
                   d_total, tsums, d_nredo, redo, d_nredo + 1);
     else
