@@ -426,6 +426,13 @@ def main():
     for _ in range(2):
         pipe.submit(sts, rs_bytes[0])
     pipe.wait(raw=True)
+    if world > 1:
+        # ... and the gather's point-to-point channels are connected lazily by both backends: the first three or four
+        # gathers of a process group cost 90-250 ms each on the test box under gloo (profiles/r03_experiments.txt,
+        # tools/gloo_gather_probe.py), 2 ms afterwards
+        blank = np.zeros(B * 192, dtype=np.uint8)
+        for _ in range(4):
+            zk.gather_proofs(blank, B * world, dist=dist, device=gather_dev, dst=0)
     run_steps(0, W)
     gathered.clear()
     fence()
