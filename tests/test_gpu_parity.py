@@ -493,6 +493,15 @@ def test_gen_proof_confidential_xt(gpu_lib, monkeypatch):
         with pytest.raises(zk.ZkError) as e:
             zk.gen_proofs(params, mats, pvk, zk.transfer_requests([items[1], bad]), rs[:2])
         assert e.value.variant == "Unsatisfiable" and "request 1" in str(e.value)
+        # the typed inputs pass through as_prime_order (keys.rs:269-276, elgamal.rs:117-133, g_epoch.rs:75): in gen_proof
+        # the witness kernels of the chunk run it; P + (0, -1) = (-x, -y) lies on the curve and has order 2 s
+        x, y = jj.mul(jj.note_commitment_randomness_generator(), 0x1234567)
+        torsion = jj.write_point(((-x) % jj.R, (-y) % jj.R))
+        for field in ("enc_key_recipient", "enc_balance_left", "enc_balance_right", "g_epoch"):
+            with pytest.raises(zk.ZkError) as e:
+                zk.gen_proofs(params, mats, pvk, zk.transfer_requests([items[1], dict(items[0], **{field: torsion})]), rs[:2])
+            assert e.value.variant == "InvalidArgument" and field in str(e.value) and "prime-order" in str(e.value)
+            assert "statement 1" in str(e.value)
         # several chunks: check_proof of chunk k runs on its own lane while chunk k + 1 is proved
         monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "2")
         again = zk.gen_proofs(params, mats, pvk, zk.transfer_requests(items + items[:2]), rs + rs[:2])

@@ -25,7 +25,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
-           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "gen_proof", "XT_FIELDS",
+           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "xt_fields", "gen_proof", "XT_FIELDS",
            "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_prove_batch",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
@@ -602,15 +602,20 @@ def transfer_derive(requests, lib=None):
     return st, [rsk[32 * i:32 * i + 32].tobytes() for i in range(n)]
 
 
-def gen_proofs(params, matrices, pvk, requests, rs):
+def gen_proofs(params, matrices, pvk, requests, rs, raw=False):
     """zk_transfer_gen_proof_batch: one ConfidentialXt (dict of byte strings, XT_FIELDS) per request; raises ZkError
-    Unsatisfiable when a proof fails the self-check, as the reference's gen_proof."""
+    Unsatisfiable when a proof fails the self-check, as the reference's gen_proof.  raw=True: the array of
+    ConfidentialXt structures as the library filled it (xt_fields() turns one into the dict)."""
     lib = params._lib
     n = len(requests)
     rsb = rs if isinstance(rs, np.ndarray) else scalars_to_bytes([x for pair in rs for x in pair])
     out = (_lib.ConfidentialXt * n)()
     lib.check(lib.zk_transfer_gen_proof_batch(params._h, matrices._h, pvk._h, n, requests, _ptr(rsb), out))
-    return [{f: bytes(getattr(x, f)) for f in XT_FIELDS} for x in out]
+    return out if raw else [xt_fields(x) for x in out]
+
+
+def xt_fields(x):
+    return {f: bytes(getattr(x, f)) for f in XT_FIELDS}
 
 
 def gen_proof(params, matrices, pvk, amount, fee, remaining_balance, spending_key, enc_key_recipient, encrypted_balance, g_epoch, rng):

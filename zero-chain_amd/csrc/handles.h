@@ -48,5 +48,14 @@ struct zk_r1cs {
 
 // GPU witness generator of the transfer circuit (witness.cpp): np statements -> R->z[slot], enqueued on `stream`;
 // finish() waits for it and reports a malformed statement with its absolute index
-zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_t np, int slot, hipStream_t stream);
+// typed_inputs: also run the reference's as_prime_order on the four points a wallet-level request brings in
+zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_t np, int slot, hipStream_t stream,
+                              bool typed_inputs = false);
 zk_status witness_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base);
+
+// Groth16 verification of a batch (verify.cpp; zk_verify_batch is this with own_proofs = false).  own_proofs: the
+// proofs are this library's own fresh results (gen_proof's self-check) - decoded without the r-torsion test.
+namespace zkrt {
+zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,
+                       bool own_proofs);
+}

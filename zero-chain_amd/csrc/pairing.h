@@ -219,6 +219,31 @@ ZK_NOINLINE void f12_sqr(F12& r, const F12& a) {
     f6_sub(r.c0, s, t);
     f6_add(r.c1, ab, ab);
 }
+// a^2 for a in the cyclotomic subgroup (a^(q^4 - q^2 + 1) = 1: everything after the easy part of the final
+// exponentiation).  Granger-Scott, eprint 2009/565 section 3.2: over Fq4 = Fq2[s]/(s^2 - xi) the element is three
+// Fq4 values (z0, z1), (z2, z3), (z4, z5) and its square needs only their three Fq4 squares - 9 Fq2 squarings
+// instead of the 12 Fq2 products of f12_sqr.  Same field element as f12_sqr(a) there (tests: final exponentiation
+// against the reference's vectors); NOT a square outside the subgroup.
+ZK_DI void f4_sqr(F2& c0, F2& c1, const F2& a, const F2& b) {   // (a + b s)^2
+    const F2 t0 = f2_sqr(a), t1 = f2_sqr(b);
+    c0 = add(f2_mul_xi(t1), t0);
+    c1 = sub(sub(f2_sqr(add(a, b)), t0), t1);
+}
+ZK_NOINLINE void f12_cyc_sqr(F12& r, const F12& a) {
+    // in the basis of the tower: z0 = c0.c0, z4 = c0.c1, z3 = c0.c2, z2 = c1.c0, z1 = c1.c1, z5 = c1.c2
+    F2 t0, t1, t2, t3, u0, u1;
+    f4_sqr(t0, t1, a.c0.c0, a.c1.c1);
+    f4_sqr(t2, t3, a.c1.c0, a.c0.c2);
+    f4_sqr(u0, u1, a.c0.c1, a.c1.c2);
+    const F2 z0 = a.c0.c0, z1 = a.c1.c1, z2 = a.c1.c0, z3 = a.c0.c2, z4 = a.c0.c1, z5 = a.c1.c2;
+    r.c0.c0 = add(f2_dbl(sub(t0, z0)), t0);        // 3 t0 - 2 z0
+    r.c1.c1 = add(f2_dbl(add(t1, z1)), t1);        // 3 t1 + 2 z1
+    r.c0.c1 = add(f2_dbl(sub(t2, z4)), t2);
+    r.c1.c2 = add(f2_dbl(add(t3, z5)), t3);
+    const F2 x = f2_mul_xi(u1);
+    r.c1.c0 = add(f2_dbl(add(x, z2)), x);
+    r.c0.c2 = add(f2_dbl(sub(u0, z3)), u0);
+}
 // f * (c0 + c1 v + c4 v w): the line evaluations of the Miller loop (13 Fq2 products instead of 18)
 ZK_NOINLINE void f12_mul_014(F12& f, const F2& c0, const F2& c1, const F2& c4) {
     F6 aa, bb, s, t;
@@ -346,79 +371,76 @@ k_g2_prepare(const uint32_t* __restrict__ q, uint32_t* __restrict__ out, uint32_
     coef_st(o + idx * 72, l);
 }
 
-// One proof's (or any three pairs') Miller loop.  Per item i:
+// The Miller loops of one proof (or of any three pairs).  Per item i:
 //   pair 0: (P0, Q0) with Q0 a variable G2 point - its line coefficients are computed on the fly
 //   pairs 1, 2: (P1, prepared1), (P2, prepared2) with fixed G2 points - coefficient tables shared by all items
 // p0 / p1 / p2: [n][24] words (x, y); q0: [n][48] words; skip: [n] bit k set = pair k is left out (a point at
-// infinity: mod.rs:50-54); f_out: [n] F12.
+// infinity: mod.rs:50-54).
+// The reference runs the three pairs through ONE loop (one squaring of f per bit, three line products); a batch of
+// proofs is a batch of serial chains with a few waves on the whole GPU, so the chain is what costs: here every
+// pair has its own thread (blockIdx.y = pair, a wave runs ONE kind of pair) and its own accumulator,
+// f_out[pair * n + i] = the Miller function of that pair alone, and k_final_exp multiplies the three - the same
+// field element, since (f0 f1 f2)^2 l0 l1 l2 = (f0^2 l0)(f1^2 l1)(f2^2 l2).  Chain per bit: one squaring + ONE line
+// (+ the G2 step for pair 0) instead of one squaring + three lines + the G2 step.
 static __global__ void __launch_bounds__(64, 1)
 k_miller_loop(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ q0, const uint32_t* __restrict__ p1,
               const uint32_t* __restrict__ prep1, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ prep2,
               const uint32_t* __restrict__ skip, F12* __restrict__ f_out, uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, pair = blockIdx.y;
     if (i >= n) return;
     const uint32_t sk = skip[i];
-    const bool on0 = !(sk & 1u), on1 = !(sk & 2u) && p1 && prep1, on2 = !(sk & 4u) && p2 && prep2;
-    Fq32 x0, y0, x1, y1, x2, y2;
-    F2 qx, qy, X, Y, Z;
-    if (on0) {
-        x0 = fq_ld(p0 + (size_t)i * 24);
-        y0 = fq_ld(p0 + (size_t)i * 24 + 12);
-        qx = f2_ld(q0 + (size_t)i * 48);
-        qy = f2_ld(q0 + (size_t)i * 48 + 24);
-        X = qx;
-        Y = qy;
-        Z = F2::one();
-    }
-    if (on1) {
-        x1 = fq_ld(p1 + (size_t)i * 24);
-        y1 = fq_ld(p1 + (size_t)i * 24 + 12);
-    }
-    if (on2) {
-        x2 = fq_ld(p2 + (size_t)i * 24);
-        y2 = fq_ld(p2 + (size_t)i * 24 + 12);
-    }
+    const uint32_t* pp = pair == 0 ? p0 : pair == 1 ? p1 : p2;
+    const uint32_t* prep = pair == 1 ? prep1 : prep2;
+    const bool on = !(sk & (1u << pair)) && pp && (pair == 0 ? q0 != nullptr : prep != nullptr);
     F12 f;
     f12_one(f);
+    if (!on) {
+        f_out[(size_t)pair * n + i] = f;
+        return;
+    }
+    const Fq32 px = fq_ld(pp + (size_t)i * 24), py = fq_ld(pp + (size_t)i * 24 + 12);
     LineCoef l;
-    int idx = 0;
-    for (int b = 61; b >= -1; b--) {
-        // doubling lines of the three pairs (b == -1: the last one, after the loop in mod.rs:93-95)
-        if (on0) {
+    if (pair == 0) {
+        const F2 qx = f2_ld(q0 + (size_t)i * 48), qy = f2_ld(q0 + (size_t)i * 48 + 24);
+        F2 X = qx, Y = qy, Z = F2::one();
+        for (int b = 61; b >= -1; b--) {
+            // b == -1: the last doubling line, after the loop in mod.rs:93-95
             g2_double_step(X, Y, Z, l);
-            ell(f, l, x0, y0);
-        }
-        if (on1) ell(f, coef_ld(prep1 + idx * 72), x1, y1);
-        if (on2) ell(f, coef_ld(prep2 + idx * 72), x2, y2);
-        idx++;
-        if (b < 0) break;
-        if ((PAIRING_LOOP >> b) & 1ull) {
-            if (on0) {
+            ell(f, l, px, py);
+            if (b < 0) break;
+            if ((PAIRING_LOOP >> b) & 1ull) {
                 g2_add_step(X, Y, Z, qx, qy, l);
-                ell(f, l, x0, y0);
+                ell(f, l, px, py);
             }
-            if (on1) ell(f, coef_ld(prep1 + idx * 72), x1, y1);
-            if (on2) ell(f, coef_ld(prep2 + idx * 72), x2, y2);
-            idx++;
+            f12_sqr(f, f);
         }
-        f12_sqr(f, f);
+    } else {
+        int idx = 0;
+        for (int b = 61; b >= -1; b--) {
+            ell(f, coef_ld(prep + (idx++) * 72), px, py);
+            if (b < 0) break;
+            if ((PAIRING_LOOP >> b) & 1ull) ell(f, coef_ld(prep + (idx++) * 72), px, py);
+            f12_sqr(f, f);
+        }
     }
     f12_conj(f, f);   // the curve parameter is negative
-    f_out[i] = f;
+    f_out[(size_t)pair * n + i] = f;
 }
 
 // f^|x| by square and multiply (|x| = 0xd201000000010000: 63 squarings, 5 products), then the conjugate:
-// inside the cyclotomic subgroup (after the easy part) the inverse is the conjugate and x is negative.
+// inside the cyclotomic subgroup (after the easy part) the inverse is the conjugate, x is negative, and the
+// squarings are the cheap ones.
 ZK_NOINLINE void f12_exp_x(F12& r, const F12& a) {
     F12 t = a;
     for (int b = 62; b >= 0; b--) {
-        f12_sqr(t, t);
+        f12_cyc_sqr(t, t);
         if ((ZK_BLS_X_ABS >> b) & 1ull) f12_mul(t, t, a);
     }
     f12_conj(r, t);
 }
 
-// Final exponentiation f^(3 (q^12 - 1) / r) and the comparison with e(alpha, beta).  One thread per item.
+// Final exponentiation f^(3 (q^12 - 1) / r) of f = f_in[i] * f_in[n + i] * f_in[2 n + i] (the three Miller functions
+// of k_miller_loop) and the comparison with e(alpha, beta).  One thread per item.
 // want: one F12 (nullptr: no comparison); ok: [n] result of the comparison, AND-ed with valid[i] (0 = the item
 // failed an earlier stage); value_out: optional [n] F12.
 static __global__ void __launch_bounds__(64, 1)
@@ -431,6 +453,10 @@ k_final_exp(const F12* __restrict__ f_in, const uint32_t* __restrict__ gam, cons
         return;
     }
     F12 f = f_in[i], t, u;
+    t = f_in[(size_t)n + i];
+    f12_mul(f, f, t);
+    t = f_in[(size_t)2 * n + i];
+    f12_mul(f, f, t);
     // easy part: f^((q^6 - 1)(q^2 + 1))
     f12_conj(t, f);
     f12_inv(u, f);
@@ -470,7 +496,7 @@ k_final_exp(const F12* __restrict__ f_in, const uint32_t* __restrict__ gam, cons
 // ---------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(64, 1)
 k_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out,
-            uint32_t* __restrict__ st, uint32_t n) {
+            uint32_t* __restrict__ st, uint32_t n, uint32_t check_subgroup) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (flags[i] & 1u) {
@@ -486,18 +512,20 @@ k_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags,
         return;
     }
     if (fq_lex_largest(y) != ((flags[i] & 2u) != 0)) y = neg(y);
-    // r * P == infinity (ec.rs:142-144)
-    const uint32_t r[8] = ZK_FR_P_32;
-    const Affine<Fq32> p{x, y};
-    XYZZ<Fq32> acc = XYZZ<Fq32>::inf();
-    for (int w = 7; w >= 0; w--)
-        for (int b = 31; b >= 0; b--) {
-            acc = xdbl(acc);
-            if ((r[w] >> b) & 1u) madd(acc, p, false);
+    // r * P == infinity (ec.rs:142-144); check_subgroup == 0: the point is one of this library's own results
+    if (check_subgroup) {
+        const uint32_t r[8] = ZK_FR_P_32;
+        const Affine<Fq32> p{x, y};
+        XYZZ<Fq32> acc = XYZZ<Fq32>::inf();
+        for (int w = 7; w >= 0; w--)
+            for (int b = 31; b >= 0; b--) {
+                acc = xdbl(acc);
+                if ((r[w] >> b) & 1u) madd(acc, p, false);
+            }
+        if (!acc.is_inf()) {
+            st[i] = 2;
+            return;
         }
-    if (!acc.is_inf()) {
-        st[i] = 2;
-        return;
     }
     fq_st(out + (size_t)i * 24, x);
     fq_st(out + (size_t)i * 24 + 12, y);
@@ -528,7 +556,7 @@ ZK_DI bool f2_sqrt(const F2& a, F2* out) {
 
 static __global__ void __launch_bounds__(64, 1)
 k_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out,
-            uint32_t* __restrict__ st, uint32_t n) {
+            uint32_t* __restrict__ st, uint32_t n, uint32_t check_subgroup) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (flags[i] & 1u) {
@@ -543,17 +571,19 @@ k_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags,
         return;
     }
     if (f2_lex_largest(y) != ((flags[i] & 2u) != 0)) y = neg(y);
-    const uint32_t r[8] = ZK_FR_P_32;
-    const Affine<F2> p{x, y};
-    XYZZ<F2> acc = XYZZ<F2>::inf();
-    for (int w = 7; w >= 0; w--)
-        for (int b = 31; b >= 0; b--) {
-            acc = xdbl(acc);
-            if ((r[w] >> b) & 1u) madd(acc, p, false);
+    if (check_subgroup) {
+        const uint32_t r[8] = ZK_FR_P_32;
+        const Affine<F2> p{x, y};
+        XYZZ<F2> acc = XYZZ<F2>::inf();
+        for (int w = 7; w >= 0; w--)
+            for (int b = 31; b >= 0; b--) {
+                acc = xdbl(acc);
+                if ((r[w] >> b) & 1u) madd(acc, p, false);
+            }
+        if (!acc.is_inf()) {
+            st[i] = 2;
+            return;
         }
-    if (!acc.is_inf()) {
-        st[i] = 2;
-        return;
     }
     f2_st(out + (size_t)i * 48, x);
     f2_st(out + (size_t)i * 48 + 24, y);

@@ -253,9 +253,9 @@ zk_status vk_prepare(const uint8_t* bytes, size_t len, int device, zk_vk** out) 
         ZK_TRY(upload(p0, &alpha_g1, sizeof(alpha_g1)));
         ZK_TRY(upload(q0, &beta_g2, sizeof(beta_g2)));
         ZK_TRY(upload(sk, &skip, 4));
-        ZK_TRY(f.ensure(sizeof(F12)));
+        ZK_TRY(f.ensure(3 * sizeof(F12)));
         ZK_TRY(val.ensure(sizeof(F12)));
-        ZK_LAUNCH(zkdev::k_miller_loop, dim3(1), dim3(64), 0, g_stream, (const uint32_t*)p0.as<uint32_t>(),
+        ZK_LAUNCH(zkdev::k_miller_loop, dim3(1, 3), dim3(64), 0, g_stream, (const uint32_t*)p0.as<uint32_t>(),
                   (const uint32_t*)q0.as<uint32_t>(), (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                   (const uint32_t*)nullptr, (const uint32_t*)sk.as<uint32_t>(), f.as<F12>(), 1u);
         ZK_LAUNCH(zkdev::k_final_exp, dim3(1), dim3(64), 0, g_stream, (const F12*)f.as<F12>(), (const uint32_t*)V->gam.as<uint32_t>(),
@@ -359,7 +359,10 @@ bool parse_g2_compressed(const uint8_t* b, uint32_t* x, uint32_t* flags) {
     return fq_words_from_be(b, x + 12, 0x1f) && fq_words_from_be(b + 48, x, 0xff);   // c1 first on the wire
 }
 
-zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t* inputs, uint8_t* ok_out) {
+// own_proofs: A, B, C were computed by this library's prover a moment ago (the self-check of gen_proof): group elements
+// by construction, as the in-memory Proof the reference hands to verify_proof in check_proof (confidential.rs:208-278,
+// no deserialisation there) - the decoders then skip the r-torsion test, which only a foreign byte string needs.
+zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t* inputs, uint8_t* ok_out, bool own_proofs) {
     const uint32_t ni = V->n_ic - 1;
     std::vector<uint32_t> g1((size_t)2 * n * 12), g2((size_t)n * 24), f1(2 * n), f2(n), bad(n, 0), sc((size_t)n * ni * 8);
     static const uint64_t RMOD[4] = ZK_FR_P_64;
@@ -407,16 +410,17 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     ZK_TRY(V->acc_inf.ensure(n * 4));
     ZK_TRY(V->skip.ensure(n * 4));
     ZK_TRY(V->valid.ensure(n * 4));
-    ZK_TRY(V->f.ensure(n * sizeof(F12)));
+    ZK_TRY(V->f.ensure(3 * n * sizeof(F12)));   // one Miller function per pair
     ZK_TRY(V->ok.ensure(n * 4));
     const unsigned b64 = (unsigned)((n + 63) / 64);
     {
         ProfScope ps("verify_decode");
         ZK_LAUNCH(zkdev::k_decode_g2, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->in_g2.as<uint32_t>(),
-                  (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n);
+                  (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n,
+                  own_proofs ? 0u : 1u);
         ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, g_stream,
                   (const uint32_t*)V->in_g1.as<uint32_t>(), (const uint32_t*)V->fl_g1.as<uint32_t>(), V->aff_g1.as<uint32_t>(),
-                  V->st_g1.as<uint32_t>(), (uint32_t)(2 * n));
+                  V->st_g1.as<uint32_t>(), (uint32_t)(2 * n), own_proofs ? 0u : 1u);
     }
     {
         ProfScope ps("verify_inputs");
@@ -432,7 +436,7 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
               (const uint32_t*)V->host_bad.as<uint32_t>(), V->skip.as<uint32_t>(), V->valid.as<uint32_t>(), (uint32_t)n);
     {
         ProfScope ps("verify_miller");
-        ZK_LAUNCH(zkdev::k_miller_loop, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g1.as<uint32_t>(),
+        ZK_LAUNCH(zkdev::k_miller_loop, dim3(b64, 3), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g1.as<uint32_t>(),
                   (const uint32_t*)V->aff_g2.as<uint32_t>(), (const uint32_t*)V->acc.as<uint32_t>(),
                   V->gamma_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[0].as<uint32_t>(),
                   (const uint32_t*)(V->aff_g1.as<uint32_t>() + n * 24),
@@ -454,6 +458,21 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
 }
 
 }  // namespace
+
+namespace zkrt {
+zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,
+                       bool own_proofs) {
+    if (!vk || (n && (!proofs || !ok_out)) || (n && n_inputs && !public_inputs)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    // verifier.rs:38-40
+    if (n_inputs + 1 != vk->ic.size()) return fail(ZK_ERR_MALFORMED_VERIFYING_KEY, "number of public inputs + 1 differs from ic");
+    ZK_TRY(use_device(vk->device));
+    for (size_t first = 0; first < n; first += VERIFY_CHUNK) {
+        const size_t np = std::min(VERIFY_CHUNK, n - first);
+        ZK_TRY(verify_chunk(vk, np, proofs + first * 192, public_inputs + first * n_inputs * 32, ok_out + first, own_proofs));
+    }
+    return ZK_OK;
+}
+}  // namespace zkrt
 
 extern "C" {
 
@@ -507,15 +526,7 @@ void zk_vk_free(zk_vk* vk) { delete vk; }
 
 zk_status zk_verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
                           uint8_t* ok_out) {
-    if (!vk || (n && (!proofs || !ok_out)) || (n && n_inputs && !public_inputs)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
-    // verifier.rs:38-40
-    if (n_inputs + 1 != vk->ic.size()) return fail(ZK_ERR_MALFORMED_VERIFYING_KEY, "number of public inputs + 1 differs from ic");
-    ZK_TRY(use_device(vk->device));
-    for (size_t first = 0; first < n; first += VERIFY_CHUNK) {
-        const size_t np = std::min(VERIFY_CHUNK, n - first);
-        ZK_TRY(verify_chunk(vk, np, proofs + first * 192, public_inputs + first * n_inputs * 32, ok_out + first));
-    }
-    return ZK_OK;
+    return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false);
 }
 zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* public_inputs, size_t n_inputs, int* ok) {
     if (!ok) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");

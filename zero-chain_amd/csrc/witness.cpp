@@ -22,7 +22,7 @@ static zk_status witness_gpu_init(zk_r1cs* R) {
     R->wit_ready = true;
     return ZK_OK;
 }
-zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_t np, int slot, hipStream_t stream) {
+zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_t np, int slot, hipStream_t stream, bool typed_inputs) {
     ZK_TRY(witness_gpu_init(R));
     const size_t nv = zkwitdev::NV;
     ZK_TRY(R->z[slot].ensure(np * nv * 32));
@@ -48,7 +48,7 @@ zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_
     {
         ProfScope ps("witness_gpu", stream);
         ZK_LAUNCH(zkwitdev::k_wit_decode, dim3((unsigned)((np * 5 + 63) / 64)), dim3(64), 0, stream, c);
-        ZK_LAUNCH(zkwitdev::k_wit_level1, dim3(b64, zkwitdev::L1_ROLES), dim3(64), 0, stream, c);
+        ZK_LAUNCH(zkwitdev::k_wit_level1, dim3(b64, zkwitdev::L1_ROLES + (typed_inputs ? zkwitdev::L1_TYPED_ROLES : 0u)), dim3(64), 0, stream, c);
         ZK_LAUNCH(zkwitdev::k_wit_level2, dim3(b64, zkwitdev::L2_ROLES), dim3(64), 0, stream, c);
         ZK_LAUNCH(zkwitdev::k_wit_level3, dim3(b64), dim3(64), 0, stream, c);
     }
@@ -71,6 +71,9 @@ zk_status witness_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base)
             if (bad[i] & (1u << (8 + k))) return fail(ZK_ERR_INVALID_ARGUMENT, who + scalars[k] + " is not a canonical Fs scalar");
         for (int k = 0; k < 5; k++)
             if (bad[i] & (2u << k)) return fail(ZK_ERR_INVALID_ARGUMENT, who + points[k] + " is not a Jubjub point");
+        for (int k = 0; k < 5; k++)
+            if (bad[i] & (1u << (zkwitdev::BAD_NOT_PRIME_ORDER + k)))
+                return fail(ZK_ERR_INVALID_ARGUMENT, who + points[k] + " is not in the prime-order subgroup");
         return fail(ZK_ERR_INVALID_ARGUMENT, who + "malformed");
     }
     return ZK_OK;

@@ -449,8 +449,27 @@ k_wit_decode(Ctx c) {
 }
 
 constexpr uint32_t L1_ROLES = 10, L2_ROLES = 3;
+// roles L1_ROLES .. L1_ROLES + 3 of level 1, launched only for the wallet-level entries (gen_proof): the typed inputs of
+// the reference pass through Point::as_prime_order when they are read (EncryptionKey::read keys.rs:269-276,
+// Ciphertext::read elgamal.rs:117-133, g_epoch.rs:75; core/jubjub/src/curve/edwards.rs:319-330): [s]P == O for
+// enc_key_recipient, enc_balance_left, enc_balance_right, g_epoch.  A 252-step chain like the gadgets beside it -
+// on the host it was 1.1 ms of a core per request, most of gen_proof's serial head.
+constexpr uint32_t L1_TYPED_ROLES = 4;
+constexpr uint32_t BAD_NOT_PRIME_ORDER = 16;   // flag bit 16 + k: point k (P_RECIP ..) has a torsion component
 ZK_DI Scratch scratch_of(const Ctx& c, uint32_t role, uint32_t p) {
     return Scratch{c.scratch + ((size_t)role * SCRATCH_SLOTS * c.n + p) * 8, c.n};
+}
+ZK_DI bool is_prime_order(const Ctx& c, const JP& pt) {
+    const uint64_t FS64[4] = ZK_JUBJUB_FS_MODULUS_64;
+    const Fr d2 = ld_fr(c.consts + 8);
+    const EP base = to_ext(pt);
+    EP acc = to_ext(neutral());
+#pragma unroll 1
+    for (int bit = 251; bit >= 0; bit--) {
+        acc = ext_add(acc, acc, d2);
+        if ((FS64[bit >> 6] >> (bit & 63)) & 1ull) acc = ext_add(acc, base, d2);
+    }
+    return acc.X.is_zero() && acc.Y == acc.Z;
 }
 
 // level 1: everything that needs only the statement.  blockIdx.y = gadget
@@ -461,9 +480,14 @@ k_wit_level1(Ctx c) {
     const Stmt& s = c.st[p];
     uint32_t* z = c.z + (size_t)p * NV * 8;
     uint32_t* aux = z + (size_t)N_IN * 8;
-    const Scratch sc = scratch_of(c, role, p);
+    const Scratch sc = scratch_of(c, role < L1_ROLES ? role : 0, p);
     auto A = [&](uint32_t off) { return aux + (size_t)off * 8; };
     switch (role) {
+        default: {   // L1_ROLES + k: as_prime_order of typed input k
+            const uint32_t k = P_RECIP + (role - L1_ROLES);
+            if (!is_prime_order(c, pt_ld(c, p, k))) zkdev::raise_flag(c.bad + p, 1u << (BAD_NOT_PRIME_ORDER + k));
+            break;
+        }
         case 0: {   // bits, witnessed points, small-order checks
             st_fr(z, Fr::one());
             u32_into_bit_vec_le(A(LAYOUT.amount_bits), s.amount);

@@ -2155,7 +2155,10 @@ zk_status decode_prime_order(const uint8_t b[32], zkwit::JPoint* out, const std:
     return ZK_OK;
 }
 
-zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_transfer_statement* st, uint8_t rsk[32]) {
+// check_points: decode the four typed inputs and run as_prime_order on them HERE (zk_transfer_derive, a host-only
+// entry); gen_proof leaves both to the witness kernels of the chunk (witness_gpu_enqueue typed_inputs: same refusals,
+// reported by witness_gpu_finish before the chunk is proved).
+zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_transfer_statement* st, uint8_t rsk[32], bool check_points) {
     uint64_t sk[4], alpha[4], rnd[4];
     load_scalar_le(rq.spending_key, sk);
     load_scalar_le(rq.alpha, alpha);
@@ -2178,10 +2181,12 @@ zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_tr
     h.update(st->proof_generation_key, 32);
     h.finish(st->dec_key_sender);
     st->dec_key_sender[31] &= 0x07;
-    ZK_TRY(decode_prime_order(rq.enc_key_recipient, nullptr, who + "enc_key_recipient"));
-    ZK_TRY(decode_prime_order(rq.enc_balance_left, nullptr, who + "enc_balance_left"));
-    ZK_TRY(decode_prime_order(rq.enc_balance_right, nullptr, who + "enc_balance_right"));
-    ZK_TRY(decode_prime_order(rq.g_epoch, nullptr, who + "g_epoch"));
+    if (check_points) {
+        ZK_TRY(decode_prime_order(rq.enc_key_recipient, nullptr, who + "enc_key_recipient"));
+        ZK_TRY(decode_prime_order(rq.enc_balance_left, nullptr, who + "enc_balance_left"));
+        ZK_TRY(decode_prime_order(rq.enc_balance_right, nullptr, who + "enc_balance_right"));
+        ZK_TRY(decode_prime_order(rq.g_epoch, nullptr, who + "g_epoch"));
+    }
     memcpy(st->enc_key_recipient, rq.enc_key_recipient, 32);
     memcpy(st->enc_balance_left, rq.enc_balance_left, 32);
     memcpy(st->enc_balance_right, rq.enc_balance_right, 32);
@@ -2193,7 +2198,7 @@ zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_tr
     explicit_bzero(r, sizeof(r));
     return ZK_OK;
 }
-zk_status transfer_derive(const zk_transfer_request* rq, size_t n, zk_transfer_statement* st, uint8_t* rsk) {
+zk_status transfer_derive(const zk_transfer_request* rq, size_t n, zk_transfer_statement* st, uint8_t* rsk, bool check_points) {
     if (n == 0) return ZK_OK;
     (void)zkwit::tables();
     const unsigned nthreads = host_threads(n, 64);
@@ -2201,7 +2206,7 @@ zk_status transfer_derive(const zk_transfer_request* rq, size_t n, zk_transfer_s
     std::vector<std::string> msgs(nthreads);
     auto work = [&](unsigned t) {
         for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
-            zk_status rc = transfer_derive_one(rq[i], i, &st[i], rsk + i * 32);
+            zk_status rc = transfer_derive_one(rq[i], i, &st[i], rsk + i * 32, check_points);
             if (rc != ZK_OK) {
                 sts[t] = rc;
                 msgs[t] = g_err;
@@ -2296,41 +2301,10 @@ zk_status zk_elgamal_encrypt(const uint32_t* values, const uint8_t* randomness, 
 
 zk_status zk_transfer_derive(const zk_transfer_request* req, size_t n, zk_transfer_statement* statements_out, uint8_t* rsk_out) {
     if (n && (!req || !statements_out || !rsk_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
-    return transfer_derive(req, n, statements_out, rsk_out);
+    return transfer_derive(req, n, statements_out, rsk_out, true);
 }
 
 }  // extern "C"
-namespace {
-// One verification at a time on a helper thread with its own lane: check_proof of chunk k overlaps the proving of
-// chunk k + 1 (the pairing chains are latency-bound and take a few per cent of the GPU).
-struct AsyncVerifier {
-    std::thread th;
-    zk_status rc = ZK_OK;
-    std::string err;
-    zk_status join() {
-        if (th.joinable()) th.join();
-        if (rc != ZK_OK) return fail(rc, err);
-        return ZK_OK;
-    }
-    ~AsyncVerifier() {
-        if (th.joinable()) th.join();
-    }
-};
-zk_status verify_chunk_async(AsyncVerifier& v, zk_vk* vk, size_t first, size_t end, const uint8_t* proofs, const uint8_t* inputs,
-                             size_t n_pub, uint8_t* ok) {
-    ZK_TRY(v.join());
-    try {
-        v.th = std::thread([&v, vk, first, end, proofs, inputs, n_pub, ok] {
-            g_lane = 5;   // not one of the pipeline's lanes (0 .. 3)
-            v.rc = zk_verify_batch(vk, end - first, proofs + first * 192, inputs + first * n_pub * 32, n_pub, ok + first);
-            if (v.rc != ZK_OK) v.err = g_err;
-        });
-    } catch (const std::system_error& e) {
-        return fail(ZK_ERR_OUT_OF_MEMORY, std::string("cannot start the verification worker: ") + e.what());
-    }
-    return ZK_OK;
-}
-}  // namespace
 extern "C" {
 
 zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk, size_t n, const zk_transfer_request* req,
@@ -2346,23 +2320,29 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
     std::vector<zk_transfer_statement> st(n);
     std::vector<uint8_t> rsk(n * 32), proofs(n * 192), ok(n);
     WipeOnExit wipe_st{st.data(), n * sizeof(zk_transfer_statement)}, wipe_rsk{rsk.data(), rsk.size()};
-    ZK_TRY(transfer_derive(req, n, st.data(), rsk.data()));
+    // ZKAMD_DEBUG_TIMING=1: where the wall time of the call goes (stderr)
+    const bool timing = getenv("ZKAMD_DEBUG_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    ZK_TRY(transfer_derive(req, n, st.data(), rsk.data(), false));   // the typed inputs are checked by the witness kernels
+    if (timing) fprintf(stderr, "[gen_proof] derive done %.1f ms\n", since());
     const size_t chunk = batch_chunk(), nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX, n_pub = ZK_TRANSFER_N_INPUTS - 1;
     PinBuf pin_in;
     ZK_TRY(pin_in.ensure(std::min(chunk, n) * ZK_TRANSFER_N_INPUTS * 32));
     std::vector<uint8_t> inputs(n * n_pub * 32);
-    AsyncVerifier ver;
     int slot = 0;
-    ZK_TRY(witness_gpu_enqueue(circuit, st.data(), std::min(chunk, n), slot, g_copy_stream));
+    ZK_TRY(witness_gpu_enqueue(circuit, st.data(), std::min(chunk, n), slot, g_copy_stream, true));
     for (size_t first = 0; first < n; first += chunk) {
         const size_t np = std::min(chunk, n - first), next = first + chunk;
         ZK_TRY(witness_gpu_finish(circuit, np, slot, first));
-        if (next < n) ZK_TRY(witness_gpu_enqueue(circuit, st.data() + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream));
+        if (next < n) ZK_TRY(witness_gpu_enqueue(circuit, st.data() + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream, true));
         // the 23 public inputs of every statement (the head of its assignment), for check_proof and the packing
         HIP_TRY(hipMemcpy2DAsync(pin_in.p, ZK_TRANSFER_N_INPUTS * 32, circuit->z[slot].p, nv * 32, ZK_TRANSFER_N_INPUTS * 32, np,
                                  hipMemcpyDeviceToHost, g_stream));
+        if (timing) fprintf(stderr, "[gen_proof] chunk %zu witness ready %.1f ms\n", first / chunk, since());
         ZK_TRY(prove_from_z(p, circuit, np, slot, rs + first * 64, proofs.data() + first * 192));
         HIP_TRY(hipStreamSynchronize(g_stream));
+        if (timing) fprintf(stderr, "[gen_proof] chunk %zu proved %.1f ms\n", first / chunk, since());
         for (size_t i = 0; i < np; i++) {
             const zkhost::Fr* z = reinterpret_cast<const zkhost::Fr*>(pin_in.as<uint8_t>() + i * ZK_TRANSFER_N_INPUTS * 32);
             zk_confidential_xt& x = out[first + i];
@@ -2384,13 +2364,17 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
             jubjub_encode(z[21], z[22], x.nonce);
             memcpy(x.rsk, rsk.data() + (first + i) * 32, 32);
         }
-        // check_proof of this chunk runs on its own lane (streams) while the next chunk is proved
-        if (next < n) ZK_TRY(verify_chunk_async(ver, vk, first, first + np, proofs.data(), inputs.data(), n_pub, ok.data()));
         slot ^= 1;
     }
-    // check_proof of the last chunk, then the verdicts of all of them
-    ZK_TRY(verify_chunk_async(ver, vk, n > chunk ? (n - 1) / chunk * chunk : 0, n, proofs.data(), inputs.data(), n_pub, ok.data()));
-    ZK_TRY(ver.join());
+    // check_proof of every proof of the call, in ONE set of launches at the end: a verification is a bundle of serial
+    // chains (a few dozen waves on the whole GPU) whose duration hardly depends on how many proofs it holds - 45 ms for
+    // 1024, about the same for 8192.  Run beside the proving of the next chunk, as rounds 2 and 3 first did, it is
+    // starved by the persistent accumulation launches (its one-wave-per-SIMD kernels wait for a whole SIMD's
+    // registers): chunk 0's check was still running 335 ms later and the call waited 40 ms for it
+    // (profiles/r03_experiments.txt r03q).
+    if (timing) fprintf(stderr, "[gen_proof] packed %.1f ms\n", since());
+    ZK_TRY(verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data(), true));
+    if (timing) fprintf(stderr, "[gen_proof] done %.1f ms\n", since());
     for (size_t i = 0; i < n; i++)
         if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
     return ZK_OK;
@@ -2556,7 +2540,7 @@ zk_status zk_anonymous_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk
         memcpy(x.rsk, &rsk[i * 32], 32);
     }
     // check_proof (anonymous.rs:200-262)
-    ZK_TRY(zk_verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data()));
+    ZK_TRY(verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data(), true));
     for (size_t i = 0; i < n; i++)
         if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
     return ZK_OK;
