@@ -357,6 +357,13 @@ void zk_vk_free(zk_vk* vk);
 zk_status zk_verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
                           uint8_t* ok_out);
 zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* public_inputs, size_t n_inputs, int* ok);
+/* Proof::read (core/bellman-verifier/src/lib.rs:67-110) for n proofs of 192 bytes, without the pairing: is every
+ * point a well-formed compressed encoding (ec.rs:785-837, :1438-1518) of a curve point in the r-torsion subgroup that
+ * is not the point at infinity?  status_out[i] = 0 when Proof::read would succeed, else
+ * (which point: 1 = A, 2 = B, 3 = C) | (reason << 2) for the first point that fails.  vk supplies the device and
+ * the workspaces; its key material is not used. */
+enum { ZK_PROOF_BAD_ENCODING = 1, ZK_PROOF_NOT_ON_CURVE = 2, ZK_PROOF_NOT_IN_SUBGROUP = 3, ZK_PROOF_INFINITY = 4 };
+zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_t* status_out);
 
 /* ------------------------------------------------------------------------------------------
  * Stand-alone kernels (micro-benchmark / test entries)

@@ -619,6 +619,121 @@ def verifier_golden_multiples(lib):
         pvk.close()
 
 
+def _g2_order():
+    """#E'(Fq2) of the twist that carries G2 (the one of the six twists whose order r divides)."""
+    import math
+    x, q, r = -bls.BLS_X, bls.Q_MOD, bls.R_MOD
+    t = x + 1
+    t2 = t * t - 2 * q
+    f = math.isqrt((4 * q * q - t2 * t2) // 3)
+    for n in (q * q + 1 - (t2 + 3 * f) // 2, q * q + 1 - (t2 - 3 * f) // 2, q * q + 1 + (t2 + 3 * f) // 2, q * q + 1 + (t2 - 3 * f) // 2):
+        if n % r == 0 and bls.G2.to_affine(bls.G2.mul(bls.G2_GEN, n)) is None:
+            return n
+    raise AssertionError("no twist order")
+
+
+def proof_reader(lib):
+    """zk_proof_read_batch = Proof::read (core/bellman-verifier/src/lib.rs:67-110) without the pairing.  The decoders
+    test the r-torsion with the curve's endomorphisms (pairing.h: phi(P) = -[x^2] P on G1, psi(Q) = [x] Q on G2)
+    where the reference multiplies by r (ec.rs:142-144): every verdict is compared with the oracle's r * P on
+    points inside the subgroup, outside it, in the cofactor subgroups, of order 3, and on the malformed encodings of
+    ec.rs:785-837 / :1438-1518."""
+    g1c, g2c = helpers.golden_points("g1_compressed"), helpers.golden_points("g2_compressed")
+    g1u = helpers.golden_points("g1_uncompressed")
+    one2 = bls.g2_uncompressed(bls.G2_GEN)
+    vk = g1u[1] + g1u[1] + one2 + one2 + g1u[1] + one2 + (1).to_bytes(4, "big") + g1u[3]
+    pvk = zk.prepare_verifying_key(vk, lib=lib)
+    q, r = bls.Q_MOD, bls.R_MOD
+    F2 = bls.Fq2Ops
+    h1 = (bls.BLS_X + 1) ** 2 // 3
+    n2 = _g2_order()
+    h2 = n2 // r
+    try:
+        cases, want = [], []
+
+        def add(a, b, c, verdict):
+            cases.append(a + b + c)
+            want.append(verdict)
+        good_a, good_b, good_c = g1c[5], g2c[7], g1c[31]
+        for k in (1, 2, 200, 255):
+            add(g1c[k], g2c[256 - k], g1c[k], None)
+        # --- G1 points on the curve, the oracle decides by r * P
+        found_out = 0
+        for x in range(1, 400):
+            y2 = (x ** 3 + 4) % q
+            y = pow(y2, (q + 1) // 4, q)
+            if y * y % q != y2:
+                if x < 40:
+                    xb = bytearray(x.to_bytes(48, "big"))
+                    xb[0] |= 0x80
+                    add(bytes(xb), good_b, good_c, ("A", "not on the curve"))
+                    add(good_a, good_b, bytes(xb), ("C", "not on the curve"))
+                continue
+            inside = bls.G1.in_subgroup((x, y))
+            assert not inside                      # a small x in the subgroup would be a miracle
+            if found_out < 6:
+                found_out += 1
+                add(bls.g1_compressed((x, y)), good_b, good_c, ("A", "not in the subgroup"))
+                add(good_a, good_b, bls.g1_compressed((x, q - y)), ("C", "not in the subgroup"))
+                cleared = bls.G1.to_affine(bls.G1.mul((x, y), h1))      # h1 * P lies in G1
+                assert bls.G1.in_subgroup(cleared)
+                add(bls.g1_compressed(cleared), good_b, good_c, None)
+                torsion = bls.G1.to_affine(bls.G1.mul((x, y), r))       # r * P: in the cofactor subgroup
+                if torsion is not None:
+                    add(bls.g1_compressed(torsion), good_b, good_c, ("A", "not in the subgroup"))
+                    mixed = bls.G1.to_affine(bls.G1.add(bls.G1.to_jac(torsion), bls.G1.to_jac(cleared)))
+                    add(bls.g1_compressed(mixed), good_b, good_c, ("A", "not in the subgroup"))
+        assert found_out == 6
+        add(bls.g1_compressed((0, 2)), good_b, good_c, ("A", "not in the subgroup"))           # order 3: phi(P) = P
+        add(good_a, good_b, bls.g1_compressed((0, q - 2)), ("C", "not in the subgroup"))
+        # --- G2
+        found = 0
+        for a in range(1, 60):
+            x = (a, 1)
+            rhs = F2.add(F2.mul(F2.sqr(x), x), (4, 4))
+            y = F2.sqrt(rhs)
+            if y is None or not F2.eq(F2.sqr(y), rhs):
+                xb = bytearray((1).to_bytes(48, "big") + a.to_bytes(48, "big"))   # c1 first on the wire
+                xb[0] |= 0x80
+                if found < 3:
+                    add(good_a, bytes(xb), good_c, ("B", "not on the curve"))
+                continue
+            if found >= 4:
+                continue
+            found += 1
+            assert not bls.G2.in_subgroup((x, y))
+            add(good_a, bls.g2_compressed((x, y)), good_c, ("B", "not in the subgroup"))
+            cleared = bls.G2.to_affine(bls.G2.mul((x, y), h2))
+            assert cleared is not None and bls.G2.in_subgroup(cleared)
+            add(good_a, bls.g2_compressed(cleared), good_c, None)
+            torsion = bls.G2.to_affine(bls.G2.mul((x, y), r))
+            assert torsion is not None
+            add(good_a, bls.g2_compressed(torsion), good_c, ("B", "not in the subgroup"))
+            mixed = bls.G2.to_affine(bls.G2.add(bls.G2.to_jac(torsion), bls.G2.to_jac(cleared)))
+            add(good_a, bls.g2_compressed(mixed), good_c, ("B", "not in the subgroup"))
+        assert found == 4
+        # --- encodings
+        inf1 = bytes([0xc0]) + bytes(47)
+        inf2 = bytes([0xc0]) + bytes(95)
+        add(inf1, good_b, good_c, ("A", "point at infinity"))
+        add(good_a, inf2, good_c, ("B", "point at infinity"))
+        add(good_a, good_b, inf1, ("C", "point at infinity"))
+        add(bytes([good_a[0] & 0x7f]) + good_a[1:], good_b, good_c, ("A", "bad encoding"))     # the uncompressed form's flag
+        add(good_a, bytes([good_b[0] & 0x7f]) + good_b[1:], good_c, ("B", "bad encoding"))
+        add(good_a, good_b, bytes([0xc1]) + bytes(47), ("C", "bad encoding"))                    # infinity with coordinate bits
+        big = bytearray(q.to_bytes(48, "big"))
+        big[0] |= 0x80
+        add(bytes(big), good_b, good_c, ("A", "bad encoding"))                                  # x = q: not a field element
+        add(bytes(big), inf2, inf1, ("A", "bad encoding"))                                      # the first failure is reported
+        assert zk.read_proofs(pvk, cases) == want
+        assert zk.read_proofs(pvk, []) == []
+        # the verdict of the verifier follows the reader's
+        oks = zk.verify_proofs(pvk, cases, [[]] * len(cases))
+        assert all(not ok for ok, w in zip(oks, want) if w is not None)
+    finally:
+        pvk.close()
+
+
 def verifier_reference_vectors(lib):
     """The reference's literal proofs through the decoder: core/primitives/src/proof.rs:89 and the byte_cast proof
     (core/bellman-verifier/src/lib.rs:392-414) are well-formed (every point decodes and lies in the subgroup: they

@@ -147,3 +147,7 @@ def test_setup_matches_oracle(emu_lib):
 
 def test_msm_variable_base(emu_lib):
     pc.msm_variable_base(emu_lib, windows=(9,), n=60, g2_n=24, auto_n=40, g2_w=9, one_w=6)
+
+
+def test_proof_reader_subgroup_tests(emu_lib):
+    pc.proof_reader(emu_lib)

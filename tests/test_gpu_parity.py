@@ -559,6 +559,10 @@ def test_gen_proof_anonymous_xt(gpu_lib):
         mats.close()
 
 
+def test_proof_reader_subgroup_tests(gpu_lib):
+    pc.proof_reader(gpu_lib)
+
+
 def test_msm_variable_base(gpu_lib):
     pc.msm_variable_base(gpu_lib)
 

@@ -143,3 +143,31 @@ def test_xorshift_fr_rand_is_reduced_and_deterministic():
     a, b = bls.fr_rand(rng), bls.fr_rand(rng)
     rng2 = bls.XorShiftRng([0x5dbe6259, 0x8d313d76, 0x3237db17, 0xe5bc0654])
     assert (a, b) == (bls.fr_rand(rng2), bls.fr_rand(rng2)) and a != b and a < bls.R_MOD
+
+
+def test_endomorphism_subgroup_tests_are_exact():
+    """The arithmetic behind the r-torsion tests of the point decoders (csrc/pairing.h: phi(P) = -[x^2] P on G1,
+    psi(Q) = [x] Q on G2, instead of the reference's r * P, ec.rs:142-144):
+      * r = x^4 - x^2 + 1, so lambda = -x^2 has lambda^2 + lambda + 1 = r as integers: phi(P) = [lambda] P forces
+        [r] P = (phi^2 + phi + 1) P = O on all of E(Fq);
+      * q = x (mod r) and psi^2 - t psi + q = 0: psi(Q) = [x] Q forces [q - x] Q = O, and gcd(q - x, #E'(Fq2)) = r;
+      * beta, cx, cy of tools/gen_constants.py realise phi and psi with exactly these eigenvalues on the subgroups."""
+    import math
+    import parity_cases as pc
+    x, q, r = -bls.BLS_X, bls.Q_MOD, bls.R_MOD
+    assert r == x ** 4 - x ** 2 + 1 and q == (x - 1) ** 2 * r // 3 + x and (q - x) % r == 0
+    lam = -x * x
+    assert lam * lam + lam + 1 == r
+    n2 = pc._g2_order()
+    assert math.gcd(q - x, n2) == r
+    F2 = bls.Fq2Ops
+    beta = 0x5f19672fdf76ce51ba69c6076a0f77eaddb3a93be6f89688de17d813620a00022e01fffffffefffe
+    cx = F2.inv(bls.fq2_pow((1, 1), (q - 1) // 3))
+    cy = F2.inv(bls.fq2_pow((1, 1), (q - 1) // 2))
+    assert beta != 1 and pow(beta, 3, q) == 1 and cx[0] == 0
+    conj = lambda a: (a[0], (-a[1]) % q)
+    for k in (1, 7, 0x123456789abcdef):
+        P = bls.G1.to_affine(bls.G1.mul(bls.G1_GEN, k))
+        assert bls.G1.to_affine(bls.G1.mul(P, lam % r)) == (beta * P[0] % q, P[1])
+        Q = bls.G2.to_affine(bls.G2.mul(bls.G2_GEN, k))
+        assert bls.G2.to_affine(bls.G2.mul(Q, x % r)) == (F2.mul(cx, conj(Q[0])), F2.mul(cy, conj(Q[1])))

@@ -23,7 +23,7 @@ from ._shard import shard_bounds, gather_proofs, prove_sharded
 from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSET, ZK_NTT_IN_BITREV,
                    ZK_NTT_OUT_BITREV)
 
-__all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs",
+__all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs", "read_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "xt_fields", "gen_proof", "XT_FIELDS",
            "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_prove_batch",
@@ -325,6 +325,25 @@ def verify_proofs(pvk, proofs, public_inputs):
 def verify_proof(pvk, proof, public_inputs):
     """verifier.rs:32-63 for one proof."""
     return verify_proofs(pvk, [proof], [list(public_inputs)])[0]
+
+
+PROOF_READ_REASONS = {1: "bad encoding", 2: "not on the curve", 3: "not in the subgroup", 4: "point at infinity"}
+
+
+def read_proofs(pvk, proofs):
+    """zk_proof_read_batch = Proof::read (core/bellman-verifier/src/lib.rs:67-110) without the pairing: per proof None
+    when every point decodes, lies in the r-torsion subgroup and is not the point at infinity, else the pair
+    (point "A" | "B" | "C", reason) of the first point that fails."""
+    if isinstance(proofs, np.ndarray):
+        pb = _u8(proofs)
+    else:
+        pb = _u8(b"".join(p.write() if isinstance(p, Proof) else bytes(p) for p in proofs))
+    if pb.size % PROOF_SIZE:
+        raise ValueError("proofs: %d bytes is not a whole number of %d-byte proofs" % (pb.size, PROOF_SIZE))
+    n = pb.size // PROOF_SIZE
+    st = np.zeros(n, dtype=np.uint8)
+    pvk._lib.check(pvk._lib.zk_proof_read_batch(pvk._h, n, _ptr(pb), _ptr(st)))
+    return [None if not v else ("ABC"[(int(v) & 3) - 1], PROOF_READ_REASONS[int(v) >> 2]) for v in st]
 
 
 def verify_transfer_batch(pvk, statements, proofs, lib=None):

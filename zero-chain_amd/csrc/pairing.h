@@ -494,6 +494,59 @@ k_final_exp(const F12* __restrict__ f_in, const uint32_t* __restrict__ gam, cons
 // out: affine (x, y) Montgomery; st: 0 = ok, 1 = not on the curve, 2 = not in the subgroup, 3 = infinity (a legal
 // encoding of a point that Proof::read then refuses).
 // ---------------------------------------------------------------------------------------------
+// ---- r-torsion tests.  The reference computes r * P (ec.rs:142-144: 255 doublings, 127 additions); the decoders
+// here use the curve's endomorphisms, whose tests accept EXACTLY the same points (tests/test_oracle.py holds the
+// arithmetic of the argument; M. Scott, eprint 2021/1130):
+//   G1: phi(x, y) = (beta x, y) satisfies phi^2 + phi + 1 = 0 on E(Fq) (three points with the same y are collinear).
+//       On the r-torsion phi acts as lambda = -x^2 (beta is the cube root of unity that goes with this eigenvalue), and
+//       lambda^2 + lambda + 1 = x^4 - x^2 + 1 = r as INTEGERS: phi(P) = [-x^2] P  =>  [r] P = (phi^2 + phi + 1) P = O.
+//   G2: psi = twist o Frobenius o untwist satisfies psi^2 - t psi + q = 0 on E'(Fq2) and acts as q = x (mod r) on
+//       the r-torsion; psi(Q) = [x] Q  =>  [x^2 - t x + q] Q = [q - x] Q = O, and gcd(q - x, #E'(Fq2)) = r.
+// Two (G1) / one (G2) multiplications by the 64-bit |x| = 0xd201000000010000 of weight 6 instead of one by the
+// 255-bit r of weight 128.
+template <class F>
+ZK_DI XYZZ<F> mul_x_abs(const Affine<F>& p) {   // [|x|] p, p affine and not infinity
+    XYZZ<F> acc = XYZZ<F>::from_affine(p);
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        acc = xdbl(acc);
+        if ((ZK_BLS_X_ABS >> b) & 1ull) madd(acc, p, false);
+    }
+    return acc;
+}
+template <class F>
+ZK_DI XYZZ<F> mul_x_abs(const XYZZ<F>& p) {
+    XYZZ<F> acc = p;
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        acc = xdbl(acc);
+        if ((ZK_BLS_X_ABS >> b) & 1ull) acc = xadd(acc, p);
+    }
+    return acc;
+}
+ZK_DI Fq32 fq32_const(const uint32_t (&v)[12]) {
+    Fq32 r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = v[i];
+    return r;
+}
+// phi(P) == -[x^2] P
+ZK_DI bool g1_in_subgroup(const Affine<Fq32>& p) {
+    const uint32_t beta[12] = ZK_G1_BETA_MONT_32;
+    const XYZZ<Fq32> t = mul_x_abs(mul_x_abs(p));
+    if (t.is_inf()) return false;
+    return t.x == mul(mul(fq32_const(beta), p.x), t.zz) && t.y == neg(mul(p.y, t.zzz));
+}
+// psi(Q) == [x] Q = -[|x|] Q
+ZK_DI bool g2_in_subgroup(const Affine<F2>& q) {
+    const uint32_t cx1[12] = ZK_G2_PSI_CX1_MONT_32, cy0[12] = ZK_G2_PSI_CY0_MONT_32, cy1[12] = ZK_G2_PSI_CY1_MONT_32;
+    const XYZZ<F2> t = mul_x_abs(q);
+    if (t.is_inf()) return false;
+    const F2 px = f2_mul(F2{Fq32::zero(), fq32_const(cx1)}, f2_conj(q.x));
+    const F2 py = f2_mul(F2{fq32_const(cy0), fq32_const(cy1)}, f2_conj(q.y));
+    return t.x == f2_mul(px, t.zz) && t.y == neg(f2_mul(py, t.zzz));
+}
+
 static __global__ void __launch_bounds__(64, 1)
 k_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out,
             uint32_t* __restrict__ st, uint32_t n, uint32_t check_subgroup) {
@@ -513,19 +566,9 @@ k_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags,
     }
     if (fq_lex_largest(y) != ((flags[i] & 2u) != 0)) y = neg(y);
     // r * P == infinity (ec.rs:142-144); check_subgroup == 0: the point is one of this library's own results
-    if (check_subgroup) {
-        const uint32_t r[8] = ZK_FR_P_32;
-        const Affine<Fq32> p{x, y};
-        XYZZ<Fq32> acc = XYZZ<Fq32>::inf();
-        for (int w = 7; w >= 0; w--)
-            for (int b = 31; b >= 0; b--) {
-                acc = xdbl(acc);
-                if ((r[w] >> b) & 1u) madd(acc, p, false);
-            }
-        if (!acc.is_inf()) {
-            st[i] = 2;
-            return;
-        }
+    if (check_subgroup && !g1_in_subgroup(Affine<Fq32>{x, y})) {
+        st[i] = 2;
+        return;
     }
     fq_st(out + (size_t)i * 24, x);
     fq_st(out + (size_t)i * 24 + 12, y);
@@ -571,19 +614,9 @@ k_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags,
         return;
     }
     if (f2_lex_largest(y) != ((flags[i] & 2u) != 0)) y = neg(y);
-    if (check_subgroup) {
-        const uint32_t r[8] = ZK_FR_P_32;
-        const Affine<F2> p{x, y};
-        XYZZ<F2> acc = XYZZ<F2>::inf();
-        for (int w = 7; w >= 0; w--)
-            for (int b = 31; b >= 0; b--) {
-                acc = xdbl(acc);
-                if ((r[w] >> b) & 1u) madd(acc, p, false);
-            }
-        if (!acc.is_inf()) {
-            st[i] = 2;
-            return;
-        }
+    if (check_subgroup && !g2_in_subgroup(Affine<F2>{x, y})) {
+        st[i] = 2;
+        return;
     }
     f2_st(out + (size_t)i * 48, x);
     f2_st(out + (size_t)i * 48 + 24, y);

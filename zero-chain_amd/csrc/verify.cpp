@@ -118,6 +118,12 @@ struct zk_vk {
     DevBuf ic_table, prep[2], gam, alpha_beta;
     // per-batch workspaces
     DevBuf in_g1, in_g2, fl_g1, fl_g2, aff_g1, aff_g2, st_g1, st_g2, scal, part, acc, acc_inf, host_bad, skip, valid, f, ok;
+    // the G1 decoder and the input accumulator run beside the G2 decoder on the lane's side streams
+    hipEvent_t ev_join[2] = {nullptr, nullptr};
+    ~zk_vk() {
+        for (int k = 0; k < 2; k++)
+            if (ev_join[k]) (void)hipEventDestroy(ev_join[k]);
+    }
 };
 
 namespace {
@@ -413,24 +419,38 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     ZK_TRY(V->f.ensure(3 * n * sizeof(F12)));   // one Miller function per pair
     ZK_TRY(V->ok.ensure(n * 4));
     const unsigned b64 = (unsigned)((n + 63) / 64);
+    // three independent bundles of serial chains - the G2 decoder, the G1 decoder, the input accumulator - side by side
+    // on the lane's three streams (each is a few dozen waves; one after the other they were 60 % of a verification)
+    for (int k = 0; k < 2; k++)
+        if (!V->ev_join[k]) HIP_TRY(hipEventCreate(&V->ev_join[k]));
+    HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
+    HIP_TRY(hipStreamWaitEvent(g_stream2, g_ev_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(g_copy_stream, g_ev_fork, 0));
     {
         ProfScope ps("verify_decode");
         ZK_LAUNCH(zkdev::k_decode_g2, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->in_g2.as<uint32_t>(),
                   (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n,
                   own_proofs ? 0u : 1u);
-        ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, g_stream,
+    }
+    {
+        ProfScope ps("verify_decode_g1", g_stream2);
+        ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, g_stream2,
                   (const uint32_t*)V->in_g1.as<uint32_t>(), (const uint32_t*)V->fl_g1.as<uint32_t>(), V->aff_g1.as<uint32_t>(),
                   V->st_g1.as<uint32_t>(), (uint32_t)(2 * n), own_proofs ? 0u : 1u);
     }
+    HIP_TRY(hipEventRecord(V->ev_join[0], g_stream2));
     {
-        ProfScope ps("verify_inputs");
+        ProfScope ps("verify_inputs", g_copy_stream);
         if (ni)
-            ZK_LAUNCH(zkdev::k_inputs_mul, dim3((unsigned)((n * ni + 63) / 64)), dim3(64), 0, g_stream,
+            ZK_LAUNCH(zkdev::k_inputs_mul, dim3((unsigned)((n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
                       (const DG1A*)V->ic_table.as<DG1A>(), (const uint32_t*)V->scal.as<uint32_t>(), V->part.as<DG1>(), V->n_ic,
                       (uint32_t)n);
-        ZK_LAUNCH(zkdev::k_inputs_sum, dim3(b64), dim3(64), 0, g_stream, (const DG1A*)V->ic_table.as<DG1A>(),
+        ZK_LAUNCH(zkdev::k_inputs_sum, dim3(b64), dim3(64), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
                   (const DG1*)V->part.as<DG1>(), V->acc.as<uint32_t>(), V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n);
     }
+    HIP_TRY(hipEventRecord(V->ev_join[1], g_copy_stream));
+    HIP_TRY(hipStreamWaitEvent(g_stream, V->ev_join[0], 0));
+    HIP_TRY(hipStreamWaitEvent(g_stream, V->ev_join[1], 0));
     ZK_LAUNCH(zkdev::k_verify_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, (const uint32_t*)V->st_g1.as<uint32_t>(),
               (const uint32_t*)V->st_g2.as<uint32_t>(), (const uint32_t*)V->acc_inf.as<uint32_t>(),
               (const uint32_t*)V->host_bad.as<uint32_t>(), V->skip.as<uint32_t>(), V->valid.as<uint32_t>(), (uint32_t)n);
@@ -527,6 +547,60 @@ void zk_vk_free(zk_vk* vk) { delete vk; }
 zk_status zk_verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
                           uint8_t* ok_out) {
     return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false);
+}
+zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_t* status_out) {
+    if (!vk || (n && (!proofs || !status_out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    ZK_TRY(use_device(vk->device));
+    for (size_t first = 0; first < n; first += VERIFY_CHUNK) {
+        const size_t np = std::min(VERIFY_CHUNK, n - first);
+        const uint8_t* pr = proofs + first * 192;
+        std::vector<uint32_t> g1((size_t)2 * np * 12), g2((size_t)np * 24), f1(2 * np), f2(np);
+        std::vector<uint8_t> enc(np, 0);   // first point whose ENCODING is refused on the host (1 = A, 2 = B, 3 = C)
+        for (size_t i = 0; i < np; i++) {
+            const uint8_t* p = pr + i * 192;
+            if (!parse_g1_compressed(p, &g1[i * 12], &f1[i])) enc[i] = 1;
+            else if (!parse_g2_compressed(p + 48, &g2[i * 24], &f2[i])) enc[i] = 2;
+            else if (!parse_g1_compressed(p + 144, &g1[(np + i) * 12], &f1[np + i])) enc[i] = 3;
+            if (enc[i]) {
+                f1[i] = f1[np + i] = f2[i] = 1;   // decode nothing
+                memset(&g1[i * 12], 0, 48);
+                memset(&g1[(np + i) * 12], 0, 48);
+                memset(&g2[i * 24], 0, 96);
+            }
+        }
+        ZK_TRY(upload(vk->in_g1, g1.data(), g1.size() * 4));
+        ZK_TRY(upload(vk->in_g2, g2.data(), g2.size() * 4));
+        ZK_TRY(upload(vk->fl_g1, f1.data(), f1.size() * 4));
+        ZK_TRY(upload(vk->fl_g2, f2.data(), f2.size() * 4));
+        ZK_TRY(vk->aff_g1.ensure((size_t)2 * np * 96));
+        ZK_TRY(vk->aff_g2.ensure(np * 192));
+        ZK_TRY(vk->st_g1.ensure(2 * np * 4));
+        ZK_TRY(vk->st_g2.ensure(np * 4));
+        ZK_LAUNCH(zkdev::k_decode_g2, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, (const uint32_t*)vk->in_g2.as<uint32_t>(),
+                  (const uint32_t*)vk->fl_g2.as<uint32_t>(), vk->aff_g2.as<uint32_t>(), vk->st_g2.as<uint32_t>(), (uint32_t)np, 1u);
+        ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * np + 63) / 64)), dim3(64), 0, g_stream,
+                  (const uint32_t*)vk->in_g1.as<uint32_t>(), (const uint32_t*)vk->fl_g1.as<uint32_t>(), vk->aff_g1.as<uint32_t>(),
+                  vk->st_g1.as<uint32_t>(), (uint32_t)(2 * np), 1u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        std::vector<uint32_t> s1(2 * np), s2(np);
+        HIP_TRY(hipMemcpy(s1.data(), vk->st_g1.p, 2 * np * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(s2.data(), vk->st_g2.p, np * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < np; i++) {
+            uint8_t st = 0;
+            if (enc[i]) {
+                st = (uint8_t)(enc[i] | (ZK_PROOF_BAD_ENCODING << 2));
+            } else {
+                // the order Proof::read meets them in: A, B, C (core/bellman-verifier/src/lib.rs:67-110)
+                const uint32_t d[3] = {s1[i], s2[i], s1[np + i]};
+                for (int k = 0; k < 3 && !st; k++)
+                    if (d[k])   // decoder states 1 / 2 / 3 = not on the curve / not in the subgroup / infinity
+                        st = (uint8_t)((k + 1) | ((d[k] == 1 ? ZK_PROOF_NOT_ON_CURVE : d[k] == 2 ? ZK_PROOF_NOT_IN_SUBGROUP : ZK_PROOF_INFINITY) << 2));
+            }
+            status_out[first + i] = st;
+        }
+    }
+    return ZK_OK;
 }
 zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* public_inputs, size_t n_inputs, int* ok) {
     if (!ok) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
