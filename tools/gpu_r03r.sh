@@ -1,5 +1,6 @@
 #!/bin/bash
 # staged scatter of the LDS sort: parity subset, then the bench with 16 / 8 / 0 (direct) slots per bucket on one box
+# (kept as the record of experiment r03r: the ZKAMD_SORT_STAGE switch it drives was removed with the staged scatter)
 set -u
 OUT=gpurun_out/r03r; mkdir -p $OUT; export TMPDIR=/tmp
 true
