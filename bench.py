@@ -730,7 +730,7 @@ def main():
                 okv = zk.verify_proofs(pvk3, pr, pi)
                 dt = time.perf_counter() - t0
                 stages = {}
-                for name in ("verify_decode", "verify_decode_g1", "verify_inputs", "verify_miller", "verify_final"):
+                for name in ("verify_decode", "verify_decode_g1", "verify_inputs", "verify_prepare", "verify_miller", "verify_final"):
                     ms = C.c_double(0)
                     if lib.zk_profile_get(name.encode(), C.byref(ms)):
                         stages[name] = round(ms.value, 2)

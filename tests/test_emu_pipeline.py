@@ -151,3 +151,12 @@ def test_msm_variable_base(emu_lib):
 
 def test_proof_reader_subgroup_tests(emu_lib):
     pc.proof_reader(emu_lib)
+
+
+def test_verifier_one_thread_per_pair_kernels(emu_lib, monkeypatch):
+    """ZKAMD_VERIFY_WIDE=0: the Miller loop with one thread per pair and the final exponentiation with one thread per
+    proof (the kernels the key's e(alpha, beta) always takes) give the verdicts of the six-lanes-per-element kernels."""
+    monkeypatch.setenv("ZKAMD_VERIFY_WIDE", "0")
+    pc.verifier_golden_multiples(emu_lib)
+    pc.verifier_small_circuit(emu_lib)
+    pc.proof_reader(emu_lib)            # B's r-torsion test inside the decoder instead of at the end of the line preparation

@@ -559,6 +559,13 @@ def test_gen_proof_anonymous_xt(gpu_lib):
         mats.close()
 
 
+def test_verifier_one_thread_per_pair_kernels(gpu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_VERIFY_WIDE", "0")
+    pc.verifier_golden_multiples(gpu_lib)
+    pc.verifier_small_circuit(gpu_lib)
+    pc.proof_reader(gpu_lib)            # B's r-torsion test inside the decoder instead of at the end of the line preparation
+
+
 def test_proof_reader_subgroup_tests(gpu_lib):
     pc.proof_reader(gpu_lib)
 

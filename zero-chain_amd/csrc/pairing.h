@@ -348,12 +348,23 @@ ZK_DI void coef_st(uint32_t* p, const LineCoef& l) {
     f2_st(p + 48, l.c);
 }
 
+ZK_DI Fq32 fq32_const(const uint32_t (&v)[12]) {
+    Fq32 r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = v[i];
+    return r;
+}
 // G2Prepared::from_affine (mod.rs:335-359): the 68 coefficient triples of a fixed G2 point, one thread per
 // point.  q: [n][48] words (x.c0, x.c1, y.c0, y.c1; Montgomery), out: [n][68][72] words.
+// With `st` (the states k_decode_g2 left: 0 = decoded) the chain also settles the r-torsion test of the point: its last
+// running point IS [|x|] Q, so psi(Q) == [x] Q = -[|x|] Q (g2_in_subgroup) costs two products more - st[i] = 2 when it
+// fails.  The incomplete formulas are safe for that: a special case (R = +-Q at an addition, a 2-torsion R at a
+// doubling) can only occur for a point outside the subgroup and leaves Z = 0 for good.
 static __global__ void __launch_bounds__(64, 1)
-k_g2_prepare(const uint32_t* __restrict__ q, uint32_t* __restrict__ out, uint32_t n) {
+k_g2_prepare(const uint32_t* __restrict__ q, uint32_t* __restrict__ out, uint32_t n, uint32_t* st = nullptr) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (st && st[i] != 0) return;   // nothing was decoded
     const F2 qx = f2_ld(q + (size_t)i * 48), qy = f2_ld(q + (size_t)i * 48 + 24);
     F2 X = qx, Y = qy, Z = F2::one();
     uint32_t* o = out + (size_t)i * PAIRING_NCOEF * 72;
@@ -369,6 +380,14 @@ k_g2_prepare(const uint32_t* __restrict__ q, uint32_t* __restrict__ out, uint32_
     }
     g2_double_step(X, Y, Z, l);
     coef_st(o + idx * 72, l);
+    if (st) {
+        const uint32_t cx1[12] = ZK_G2_PSI_CX1_MONT_32, cy0[12] = ZK_G2_PSI_CY0_MONT_32, cy1[12] = ZK_G2_PSI_CY1_MONT_32;
+        const F2 px = f2_mul(F2{Fq32::zero(), fq32_const(cx1)}, f2_conj(qx));
+        const F2 py = f2_mul(F2{fq32_const(cy0), fq32_const(cy1)}, f2_conj(qy));
+        const F2 zz = f2_sqr(Z);
+        const bool in = !Z.is_zero() && X == f2_mul(px, zz) && Y == neg(f2_mul(py, f2_mul(zz, Z)));
+        if (!in) st[i] = 2;
+    }
 }
 
 // The Miller loops of one proof (or of any three pairs).  Per item i:
@@ -488,6 +507,217 @@ k_final_exp(const F12* __restrict__ f_in, const uint32_t* __restrict__ gam, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Lane-parallel Fq12 (r3).  The kernels above give a proof (or a pair) ONE thread: a verification is then a bundle
+// of serial chains, and what it costs is the length of the chain.  Here SIX lanes share an Fq12 element: in the
+// basis 1, w, ..., w^5 over Fq2 (w^6 = xi; the tower's c0.cj sits at w^(2j), c1.cj at w^(2j+1)) lane i holds the
+// coefficient of w^i, operands meet in LDS, and every lane computes ITS coefficient of the result:
+//     product        c_k = sum_(i+j = k) a_i b_j + xi sum_(i+j = k+6) a_i b_j              6 Fq2 products per lane (serial: 18)
+//     square         the same with a_i a_j = a_j a_i folded                               4                     (12)
+//     line product   f (l0 + l1 w^2 + l4 w^3)                                             3                     (13)
+//     cyclotomic square   lanes i, i + 3 share one Fq4 square (a + b s)^2 = (a^2 + xi b^2, 2 a b)     2         (9 squarings)
+// Same instructions on every lane (operands and weights come from small tables indexed by the lane), so a wave runs
+// ten elements at once without divergence; Frobenius and conjugation touch each coefficient alone; the one inversion
+// of a final exponentiation is done redundantly by all six lanes.  All 64 threads of a block take every barrier: the
+// four spare lanes and the groups past the end of the batch work on a slot of their own and store nothing.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t WIDE_LANES = 6, WIDE_GROUPS = 10, WIDE_THREADS = 64, WIDE_SLOTS = 11;
+struct WideLds {
+    F2 xa[WIDE_SLOTS][WIDE_LANES];
+    F2 xb[WIDE_SLOTS][WIDE_LANES];
+    uint32_t flag[WIDE_SLOTS];
+};
+struct Wide {
+    F2* xa;          // this element's six exchange slots (operand a / the element itself)
+    F2* xb;          // operand b / intermediate values
+    uint32_t* flag;
+    uint32_t i;      // the coefficient this lane owns
+};
+ZK_DI Wide wide_of(WideLds& l, uint32_t tid) {
+    const uint32_t g = tid / WIDE_LANES;
+    return Wide{l.xa[g], l.xb[g], &l.flag[g], tid % WIDE_LANES};
+}
+ZK_DI F2 f2_sel(bool c, const F2& a, const F2& b) {
+    F2 r;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        r.c0.l[k] = c ? a.c0.l[k] : b.c0.l[k];
+        r.c1.l[k] = c ? a.c1.l[k] : b.c1.l[k];
+    }
+    return r;
+}
+// a * b
+ZK_DI F2 wide_mul(const Wide& w, const F2& a, const F2& b) {
+    w.xa[w.i] = a;
+    w.xb[w.i] = b;
+    __syncthreads();
+    F2 lo = F2::zero(), hi = F2::zero();
+#pragma unroll 1
+    for (uint32_t j = 0; j < WIDE_LANES; j++) {
+        const bool wrap = j > w.i;
+        const F2 t = f2_mul(w.xa[j], w.xb[wrap ? w.i + WIDE_LANES - j : w.i - j]);
+        lo = f2_sel(wrap, lo, add(lo, t));
+        hi = f2_sel(wrap, add(hi, t), hi);
+    }
+    __syncthreads();
+    return add(lo, f2_mul_xi(hi));
+}
+// a^2: the unordered pairs (j, j') with j + j' = k (mod 6); code = j | j' << 3 | doubled << 6 | wrapped << 7 | used << 8
+ZK_DI F2 wide_sqr(const Wide& w, const F2& a) {
+    constexpr uint16_t T[6][4] = {
+        {0x100 | 0 | 0 << 3, 0x1c0 | 1 | 5 << 3, 0x1c0 | 2 | 4 << 3, 0x180 | 3 | 3 << 3},
+        {0x140 | 0 | 1 << 3, 0x1c0 | 2 | 5 << 3, 0x1c0 | 3 | 4 << 3, 0},
+        {0x140 | 0 | 2 << 3, 0x100 | 1 | 1 << 3, 0x1c0 | 3 | 5 << 3, 0x180 | 4 | 4 << 3},
+        {0x140 | 0 | 3 << 3, 0x140 | 1 | 2 << 3, 0x1c0 | 4 | 5 << 3, 0},
+        {0x140 | 0 | 4 << 3, 0x140 | 1 | 3 << 3, 0x100 | 2 | 2 << 3, 0x180 | 5 | 5 << 3},
+        {0x140 | 0 | 5 << 3, 0x140 | 1 | 4 << 3, 0x140 | 2 | 3 << 3, 0},
+    };
+    w.xa[w.i] = a;
+    __syncthreads();
+    F2 lo = F2::zero(), hi = F2::zero();
+#pragma unroll 1
+    for (uint32_t s = 0; s < 4; s++) {
+        const uint32_t code = T[w.i][s];
+        F2 t = f2_mul(w.xa[code & 7u], w.xa[(code >> 3) & 7u]);
+        t = f2_sel((code & 0x40u) != 0, f2_dbl(t), t);
+        const bool used = (code & 0x100u) != 0, wrap = (code & 0x80u) != 0;
+        lo = f2_sel(used && !wrap, add(lo, t), lo);
+        hi = f2_sel(used && wrap, add(hi, t), hi);
+    }
+    __syncthreads();
+    return add(lo, f2_mul_xi(hi));
+}
+// f * (l0 + l1 w^2 + l4 w^3): the line of the Miller loop (constant term at 1, b x_P at v = w^2, a y_P at v w = w^3)
+ZK_DI F2 wide_mul_line(const Wide& w, const F2& f, const F2& l0, const F2& l1, const F2& l4) {
+    w.xa[w.i] = f;
+    __syncthreads();
+    const uint32_t i = w.i;
+    F2 r = f2_mul(f, l0);
+    const F2 t1 = f2_mul(w.xa[i >= 2 ? i - 2 : i + 4], l1), t4 = f2_mul(w.xa[i >= 3 ? i - 3 : i + 3], l4);
+    r = add(r, f2_sel(i >= 2, t1, f2_mul_xi(t1)));
+    r = add(r, f2_sel(i >= 3, t4, f2_mul_xi(t4)));
+    __syncthreads();
+    return r;
+}
+// a^2 in the cyclotomic subgroup (f12_cyc_sqr): the Fq4 pairs are (w^i, w^(i+3)); lane i < 3 computes t0 = a^2 + xi b^2 of
+// its pair, lane i + 3 computes t1 = 2 a b, and the new coefficients are 3 t -+ 2 z with the pairs cross-wired as there
+ZK_DI F2 wide_cyc_sqr(const Wide& w, const F2& z) {
+    const uint32_t i = w.i;
+    const bool low = i < 3;
+    w.xa[i] = z;
+    __syncthreads();
+    const F2 a = w.xa[low ? i : i - 3], b = w.xa[low ? i + 3 : i];
+    const F2 m1 = f2_mul(a, low ? a : b), m2 = f2_mul(b, b);
+    w.xb[i] = f2_sel(low, add(m1, f2_mul_xi(m2)), f2_dbl(m1));
+    __syncthreads();
+    constexpr uint32_t SRC[6] = {0, 5, 1, 3, 2, 4};
+    F2 t = w.xb[SRC[i]];
+    t = f2_sel(i == 1, f2_mul_xi(t), t);
+    const F2 d = f2_sel((i & 1u) != 0, add(t, z), sub(t, z));
+    __syncthreads();
+    return add(f2_dbl(d), t);                                      // 3 t +- 2 z = 2 (t +- z) + t
+}
+ZK_DI F2 wide_conj(const Wide& w, const F2& a) { return f2_sel((w.i & 1u) != 0, neg(a), a); }   // a^(q^6): w -> -w
+ZK_DI F2 wide_frob(const Wide& w, const F2& a, int k, const uint32_t* __restrict__ gam) {       // a^(q^k), k = 1, 2
+    const F2 x = (k & 1) ? f2_conj(a) : a;
+    const F2 y = f2_mul(x, f2_ld(gam + ((size_t)(k - 1) * 6 + w.i) * 24));
+    return f2_sel(w.i == 0, x, y);
+}
+// tower element <-> lanes: the coefficient of w^i is F12's (i & 1 ? c1 : c0).c(i >> 1)
+ZK_DI const F2* f12_coef(const F12* f, uint32_t i) { return reinterpret_cast<const F2*>(f) + (i & 1u) * 3 + (i >> 1); }
+ZK_DI F2* f12_coef(F12* f, uint32_t i) { return reinterpret_cast<F2*>(f) + (i & 1u) * 3 + (i >> 1); }
+// 1 / a: every lane gathers the element and inverts it (the chain is the Fq inversion inside; six copies cost no time)
+ZK_DI F2 wide_inv(const Wide& w, const F2& a) {
+    w.xa[w.i] = a;
+    __syncthreads();
+    F12 t, r;
+    for (uint32_t j = 0; j < WIDE_LANES; j++) *f12_coef(&t, j) = w.xa[j];
+    __syncthreads();
+    f12_inv(r, t);
+    return *f12_coef(&r, w.i);
+}
+ZK_DI F2 wide_exp_x(const Wide& w, const F2& a) {   // f12_exp_x
+    F2 t = a;
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        t = wide_cyc_sqr(w, t);
+        if ((ZK_BLS_X_ABS >> b) & 1ull) t = wide_mul(w, t, a);
+    }
+    return wide_conj(w, t);
+}
+
+// k_miller_loop with six lanes per (item, pair).  Every pair reads PREPARED line coefficients: prep0 [n][68][72] words =
+// the triples of the items' own G2 points (k_g2_prepare over the decoded B of the batch), prep1 / prep2 the key's.
+// Grid (ceil(n / 10), 3 pairs), 64 threads.  f_out[pair * n + i] as k_miller_loop.
+static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+k_miller_loop_wide(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ prep0, const uint32_t* __restrict__ p1,
+                   const uint32_t* __restrict__ prep1, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ prep2,
+                   const uint32_t* __restrict__ skip, F12* __restrict__ f_out, uint32_t n) {
+    ZK_SHARED WideLds lds;
+    const uint32_t tid = threadIdx.x, pair = blockIdx.y;
+    const Wide w = wide_of(lds, tid);
+    const uint32_t item = blockIdx.x * WIDE_GROUPS + tid / WIDE_LANES;
+    const bool real = tid < WIDE_GROUPS * WIDE_LANES && item < n;
+    const uint32_t it = real ? item : 0;
+    const uint32_t* pp = pair == 0 ? p0 : pair == 1 ? p1 : p2;
+    const uint32_t* prep = pair == 0 ? (prep0 ? prep0 + (size_t)it * PAIRING_NCOEF * 72 : nullptr) : pair == 1 ? prep1 : prep2;
+    const bool on = !(skip[it] & (1u << pair)) && pp && prep;   // uniform per block except across items: every lane runs the loop
+    const uint32_t* coef = prep ? prep : (pair == 0 ? prep1 : prep0);   // something readable for a pair that is left out
+    if (!coef) coef = prep2;
+    const uint32_t* pq = pp ? pp : (p0 ? p0 : p1);
+    const Fq32 px = fq_ld(pq + (size_t)it * 24), py = fq_ld(pq + (size_t)it * 24 + 12);
+    F2 f = f2_sel(w.i == 0, F2::one(), F2::zero());
+    int idx = 0;
+#pragma unroll 1
+    for (int b = 61; b >= -1; b--) {
+        {
+            const LineCoef l = coef_ld(coef + (idx++) * 72);
+            f = wide_mul_line(w, f, l.c, f2_mul_fq(l.b, px), f2_mul_fq(l.a, py));
+        }
+        if (b < 0) break;
+        if ((PAIRING_LOOP >> b) & 1ull) {
+            const LineCoef l = coef_ld(coef + (idx++) * 72);
+            f = wide_mul_line(w, f, l.c, f2_mul_fq(l.b, px), f2_mul_fq(l.a, py));
+        }
+        f = wide_sqr(w, f);
+    }
+    f = wide_conj(w, f);   // the curve parameter is negative
+    if (!on) f = f2_sel(w.i == 0, F2::one(), F2::zero());
+    if (real) *f12_coef(&f_out[(size_t)pair * n + item], w.i) = f;
+}
+
+// k_final_exp with six lanes per item; same arguments, grid ceil(n / 10), 64 threads
+static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+k_final_exp_wide(const F12* __restrict__ f_in, const uint32_t* __restrict__ gam, const F12* __restrict__ want,
+                 const uint32_t* __restrict__ valid, uint32_t* __restrict__ ok, F12* value_out, uint32_t n) {
+    ZK_SHARED WideLds lds;
+    const uint32_t tid = threadIdx.x;
+    const Wide w = wide_of(lds, tid);
+    const uint32_t item = blockIdx.x * WIDE_GROUPS + tid / WIDE_LANES;
+    const bool real = tid < WIDE_GROUPS * WIDE_LANES && item < n;
+    const uint32_t it = real ? item : 0;
+    F2 f = *f12_coef(&f_in[it], w.i);
+    f = wide_mul(w, f, *f12_coef(&f_in[(size_t)n + it], w.i));
+    f = wide_mul(w, f, *f12_coef(&f_in[(size_t)2 * n + it], w.i));
+    // easy part: f^((q^6 - 1)(q^2 + 1))
+    F2 t = wide_mul(w, wide_conj(w, f), wide_inv(w, f));
+    f = wide_mul(w, wide_frob(w, t, 2, gam), t);
+    // hard part (k_final_exp): a = f^((x-1)^2), b = a^(x+q), c = b^(x^2+q^2-1), c * f^3
+    F2 a = wide_mul(w, wide_exp_x(w, f), wide_conj(w, f));
+    a = wide_mul(w, wide_exp_x(w, a), wide_conj(w, a));
+    const F2 b = wide_mul(w, wide_exp_x(w, a), wide_frob(w, a, 1, gam));
+    F2 c = wide_mul(w, wide_exp_x(w, wide_exp_x(w, b)), wide_frob(w, b, 2, gam));
+    c = wide_mul(w, c, wide_conj(w, b));
+    c = wide_mul(w, c, wide_mul(w, wide_sqr(w, f), f));
+    if (real && value_out) *f12_coef(&value_out[item], w.i) = c;
+    // the comparison: every lane looks at its coefficient
+    if (w.i == 0) *w.flag = 1u;
+    __syncthreads();
+    if (want && !(c == *f12_coef(want, w.i))) *w.flag = 0u;
+    __syncthreads();
+    if (real && ok && w.i == 0) ok[item] = (valid && !valid[item]) ? 0u : *w.flag;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Proof decoding: compressed G1 / G2 -> affine, with the checks of into_affine() (ec.rs:776-868,
 // :1429-1548): x < q (host), a square root exists, the point lies in the r-torsion subgroup.
 // in: [n][12 | 24] words, PLAIN little-endian x (G2: c0 then c1); flags: bit 0 = infinity, bit 1 = the larger y.
@@ -523,12 +753,6 @@ ZK_DI XYZZ<F> mul_x_abs(const XYZZ<F>& p) {
         if ((ZK_BLS_X_ABS >> b) & 1ull) acc = xadd(acc, p);
     }
     return acc;
-}
-ZK_DI Fq32 fq32_const(const uint32_t (&v)[12]) {
-    Fq32 r;
-#pragma unroll
-    for (int i = 0; i < 12; i++) r.l[i] = v[i];
-    return r;
 }
 // phi(P) == -[x^2] P
 ZK_DI bool g1_in_subgroup(const Affine<Fq32>& p) {

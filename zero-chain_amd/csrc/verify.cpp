@@ -118,6 +118,7 @@ struct zk_vk {
     DevBuf ic_table, prep[2], gam, alpha_beta;
     // per-batch workspaces
     DevBuf in_g1, in_g2, fl_g1, fl_g2, aff_g1, aff_g2, st_g1, st_g2, scal, part, acc, acc_inf, host_bad, skip, valid, f, ok;
+    DevBuf prep_b;   // line coefficients of the batch's own B points (the lane-parallel Miller loop reads every pair prepared)
     // the G1 decoder and the input accumulator run beside the G2 decoder on the lane's side streams
     hipEvent_t ev_join[2] = {nullptr, nullptr};
     ~zk_vk() {
@@ -426,11 +427,23 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
     HIP_TRY(hipStreamWaitEvent(g_stream2, g_ev_fork, 0));
     HIP_TRY(hipStreamWaitEvent(g_copy_stream, g_ev_fork, 0));
+    // six lanes per (proof, pair) and per final exponentiation (pairing.h "Lane-parallel Fq12"): the chains are 3-4x
+    // shorter; ZKAMD_VERIFY_WIDE=0 keeps one thread per pair / per proof (A/B; the key's e(alpha, beta) always takes it)
+    const char* wide_env = getenv("ZKAMD_VERIFY_WIDE");
+    const bool wide = !(wide_env && atoi(wide_env) == 0);
     {
+        // the lane-parallel Miller loop reads the lines of B prepared, and the preparation's last point settles B's r-torsion
+        // test (k_g2_prepare): the decoder leaves it out there
         ProfScope ps("verify_decode");
         ZK_LAUNCH(zkdev::k_decode_g2, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->in_g2.as<uint32_t>(),
                   (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n,
-                  own_proofs ? 0u : 1u);
+                  (own_proofs || wide) ? 0u : 1u);
+    }
+    if (wide) {
+        ZK_TRY(V->prep_b.ensure(n * COEF_WORDS * 4));
+        ProfScope ps("verify_prepare");
+        ZK_LAUNCH(zkdev::k_g2_prepare, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g2.as<uint32_t>(),
+                  V->prep_b.as<uint32_t>(), (uint32_t)n, own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>());
     }
     {
         ProfScope ps("verify_decode_g1", g_stream2);
@@ -454,20 +467,37 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     ZK_LAUNCH(zkdev::k_verify_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, (const uint32_t*)V->st_g1.as<uint32_t>(),
               (const uint32_t*)V->st_g2.as<uint32_t>(), (const uint32_t*)V->acc_inf.as<uint32_t>(),
               (const uint32_t*)V->host_bad.as<uint32_t>(), V->skip.as<uint32_t>(), V->valid.as<uint32_t>(), (uint32_t)n);
-    {
-        ProfScope ps("verify_miller");
-        ZK_LAUNCH(zkdev::k_miller_loop, dim3(b64, 3), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g1.as<uint32_t>(),
-                  (const uint32_t*)V->aff_g2.as<uint32_t>(), (const uint32_t*)V->acc.as<uint32_t>(),
-                  V->gamma_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[0].as<uint32_t>(),
-                  (const uint32_t*)(V->aff_g1.as<uint32_t>() + n * 24),
-                  V->delta_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[1].as<uint32_t>(),
-                  (const uint32_t*)V->skip.as<uint32_t>(), V->f.as<F12>(), (uint32_t)n);
-    }
-    {
-        ProfScope ps("verify_final");
-        ZK_LAUNCH(zkdev::k_final_exp, dim3(b64), dim3(64), 0, g_stream, (const F12*)V->f.as<F12>(), (const uint32_t*)V->gam.as<uint32_t>(),
-                  (const F12*)V->alpha_beta.as<F12>(), (const uint32_t*)V->valid.as<uint32_t>(), V->ok.as<uint32_t>(), (F12*)nullptr,
-                  (uint32_t)n);
+    const uint32_t* prep_gamma = V->gamma_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[0].as<uint32_t>();
+    const uint32_t* prep_delta = V->delta_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[1].as<uint32_t>();
+    if (wide) {
+        const unsigned bw = (unsigned)((n + zkdev::WIDE_GROUPS - 1) / zkdev::WIDE_GROUPS);
+        {
+            ProfScope ps("verify_miller");
+            ZK_LAUNCH_SYNC(zkdev::k_miller_loop_wide, dim3(bw, 3), dim3(zkdev::WIDE_THREADS), 0, g_stream,
+                           (const uint32_t*)V->aff_g1.as<uint32_t>(), (const uint32_t*)V->prep_b.as<uint32_t>(),
+                           (const uint32_t*)V->acc.as<uint32_t>(), prep_gamma, (const uint32_t*)(V->aff_g1.as<uint32_t>() + n * 24),
+                           prep_delta, (const uint32_t*)V->skip.as<uint32_t>(), V->f.as<F12>(), (uint32_t)n);
+        }
+        {
+            ProfScope ps("verify_final");
+            ZK_LAUNCH_SYNC(zkdev::k_final_exp_wide, dim3(bw), dim3(zkdev::WIDE_THREADS), 0, g_stream, (const F12*)V->f.as<F12>(),
+                           (const uint32_t*)V->gam.as<uint32_t>(), (const F12*)V->alpha_beta.as<F12>(),
+                           (const uint32_t*)V->valid.as<uint32_t>(), V->ok.as<uint32_t>(), (F12*)nullptr, (uint32_t)n);
+        }
+    } else {
+        {
+            ProfScope ps("verify_miller");
+            ZK_LAUNCH(zkdev::k_miller_loop, dim3(b64, 3), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g1.as<uint32_t>(),
+                      (const uint32_t*)V->aff_g2.as<uint32_t>(), (const uint32_t*)V->acc.as<uint32_t>(), prep_gamma,
+                      (const uint32_t*)(V->aff_g1.as<uint32_t>() + n * 24), prep_delta, (const uint32_t*)V->skip.as<uint32_t>(),
+                      V->f.as<F12>(), (uint32_t)n);
+        }
+        {
+            ProfScope ps("verify_final");
+            ZK_LAUNCH(zkdev::k_final_exp, dim3(b64), dim3(64), 0, g_stream, (const F12*)V->f.as<F12>(), (const uint32_t*)V->gam.as<uint32_t>(),
+                      (const F12*)V->alpha_beta.as<F12>(), (const uint32_t*)V->valid.as<uint32_t>(), V->ok.as<uint32_t>(), (F12*)nullptr,
+                      (uint32_t)n);
+        }
     }
     HIP_TRY(hipGetLastError());
     std::vector<uint32_t> okv(n);
@@ -576,8 +606,18 @@ zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_
         ZK_TRY(vk->aff_g2.ensure(np * 192));
         ZK_TRY(vk->st_g1.ensure(2 * np * 4));
         ZK_TRY(vk->st_g2.ensure(np * 4));
+        // B as zk_verify_batch treats it: decoded, then the r-torsion test either inside the decoder or at the end of the
+        // line preparation (ZKAMD_VERIFY_WIDE, verify_chunk) - the reader reports what the verifier would act on
+        const char* wide_env = getenv("ZKAMD_VERIFY_WIDE");
+        const bool wide = !(wide_env && atoi(wide_env) == 0);
         ZK_LAUNCH(zkdev::k_decode_g2, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, (const uint32_t*)vk->in_g2.as<uint32_t>(),
-                  (const uint32_t*)vk->fl_g2.as<uint32_t>(), vk->aff_g2.as<uint32_t>(), vk->st_g2.as<uint32_t>(), (uint32_t)np, 1u);
+                  (const uint32_t*)vk->fl_g2.as<uint32_t>(), vk->aff_g2.as<uint32_t>(), vk->st_g2.as<uint32_t>(), (uint32_t)np,
+                  wide ? 0u : 1u);
+        if (wide) {
+            ZK_TRY(vk->prep_b.ensure(np * COEF_WORDS * 4));
+            ZK_LAUNCH(zkdev::k_g2_prepare, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, (const uint32_t*)vk->aff_g2.as<uint32_t>(),
+                      vk->prep_b.as<uint32_t>(), (uint32_t)np, vk->st_g2.as<uint32_t>());
+        }
         ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * np + 63) / 64)), dim3(64), 0, g_stream,
                   (const uint32_t*)vk->in_g1.as<uint32_t>(), (const uint32_t*)vk->fl_g1.as<uint32_t>(), vk->aff_g1.as<uint32_t>(),
                   vk->st_g1.as<uint32_t>(), (uint32_t)(2 * np), 1u);
