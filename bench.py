@@ -743,7 +743,7 @@ def main():
             assert not okv[5] and sum(okv) == B - 1, "the verifier accepted a damaged proof"
             pvk3.close()
             vb["note"] = "zk_verify_batch on the last step's proofs (x1, x8): parse, decode + r-torsion tests, input accumulator, " \
-                         "three Miller loops on three threads, final exponentiation; a damaged proof is refused"
+                         "line preparation, three Miller loops and the final exponentiation on six lanes each; a damaged proof is refused"
             secondary["verify_batch"] = vb
         except Exception as exc:
             secondary["verify_batch"] = {"error": repr(exc)[:200]}
