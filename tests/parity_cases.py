@@ -655,8 +655,8 @@ def proof_reader(lib):
             cases.append(a + b + c)
             want.append(verdict)
         good_a, good_b, good_c = g1c[5], g2c[7], g1c[31]
-        for k in (1, 2, 200, 255):
-            add(g1c[k], g2c[256 - k], g1c[k], None)
+        for k in range(1, 256):          # every golden multiple through both decoders (square roots, sign flags, tests)
+            add(g1c[k], g2c[256 - k], g1c[256 - k], None)
         # --- G1 points on the curve, the oracle decides by r * P
         found_out = 0
         for x in range(1, 400):
