@@ -734,6 +734,32 @@ def proof_reader(lib):
         pvk.close()
 
 
+def verifier_skipped_pairs(lib):
+    """Pairs that drop out of the Miller loop (core/pairing/src/bls12_381/mod.rs:50-54: a pair with a point at infinity is
+    left out): an input accumulator at infinity for SOME proofs of a batch, gamma or delta at infinity in the key.  Keys
+    over the golden multiples: alpha = G1, beta = G2, gamma / delta = G2 or infinity, ic = [G1, G1], one public input x,
+    acc = (1 + x) G1:   e(a G1, b G2) e(acc, -gamma) e(c G1, -delta) == e(G1, G2)  <=>  a b - [gamma](1 + x) - [delta] c == 1."""
+    g1c, g2c = helpers.golden_points("g1_compressed"), helpers.golden_points("g2_compressed")
+    G1, G2 = bls.G1_GEN, bls.G2_GEN
+    r = bls.R_MOD
+    for gamma, delta in ((G2, G2), (None, G2), (G2, None), (None, None)):
+        pvk = zk.prepare_verifying_key(_vk_bytes(G1, G1, G2, gamma, G1, delta, [G1, G1]), lib=lib)
+        try:
+            cases, inputs, want = [], [], []
+            for a, b, x in ((2, 3, r - 1), (2, 3, 0), (3, 5, 2), (7, 9, r - 1), (1, 2, 0), (4, 4, 5), (4, 4, r - 1), (6, 6, 1),
+                            (5, 5, r - 1), (5, 5, 3), (1, 1, r - 1), (1, 1, 0), (2, 2, 2)):
+                acc = (1 + x) % r                      # 0 for x = r - 1: the accumulator is the point at infinity
+                rest = a * b - (acc if gamma is not None else 0) - 1
+                for c in sorted({rest if 0 < rest < 256 else 7, rest + 1 if 0 < rest + 1 < 256 else 9}):
+                    cases.append(g1c[a] + g2c[b] + g1c[c])
+                    inputs.append([x])
+                    want.append((rest - (c if delta is not None else 0)) % r == 0)
+            assert any(want) and not all(want)
+            assert zk.verify_proofs(pvk, cases, inputs) == want, (gamma is None, delta is None)
+        finally:
+            pvk.close()
+
+
 def verifier_reference_vectors(lib):
     """The reference's literal proofs through the decoder: core/primitives/src/proof.rs:89 and the byte_cast proof
     (core/bellman-verifier/src/lib.rs:392-414) are well-formed (every point decodes and lies in the subgroup: they

@@ -160,3 +160,8 @@ def test_verifier_one_thread_per_pair_kernels(emu_lib, monkeypatch):
     pc.verifier_golden_multiples(emu_lib)
     pc.verifier_small_circuit(emu_lib)
     pc.proof_reader(emu_lib)            # B's r-torsion test inside the decoder instead of at the end of the line preparation
+    pc.verifier_skipped_pairs(emu_lib)
+
+
+def test_verifier_skipped_pairs(emu_lib):
+    pc.verifier_skipped_pairs(emu_lib)

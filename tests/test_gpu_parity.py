@@ -564,6 +564,11 @@ def test_verifier_one_thread_per_pair_kernels(gpu_lib, monkeypatch):
     pc.verifier_golden_multiples(gpu_lib)
     pc.verifier_small_circuit(gpu_lib)
     pc.proof_reader(gpu_lib)            # B's r-torsion test inside the decoder instead of at the end of the line preparation
+    pc.verifier_skipped_pairs(gpu_lib)
+
+
+def test_verifier_skipped_pairs(gpu_lib):
+    pc.verifier_skipped_pairs(gpu_lib)
 
 
 def test_proof_reader_subgroup_tests(gpu_lib):
