@@ -793,30 +793,60 @@ def main():
     print(json.dumps(line), flush=True)
 
 
+def splitmix_fields(seed, n, modulus):
+    """n values of oracle/synth.py SplitMix64(seed).field(modulus) - four 64-bit outputs per value, most significant
+    first, reduced mod `modulus` - with the generator vectorised in numpy.  Returns Python ints."""
+    import numpy as np
+    idx = np.arange(1, 4 * n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    raw = z.reshape(n, 4)[:, ::-1].copy().tobytes()     # little-endian 256-bit words: the FIRST output is the top limb
+    return [int.from_bytes(raw[32 * i:32 * i + 32], "little") % modulus for i in range(n)]
+
+
+def fields_to_u8(values):
+    import numpy as np
+    return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in values), dtype=np.uint8)
+
+
 def run_micro(lib, zk, dev):
-    """BASELINE configs 2 and 3 on one GPU: 2^20 G1 multiexp and the 2^20 NTT + coset-iFFT pair."""
+    """BASELINE configs 2 and 3 on one GPU, on exactly the inputs BASELINE.md section 3 states: 2^20 G1 bases k_i G with
+    k_i = SplitMix64(seed 1), scalars uniform in [0, r) from SplitMix64(seed 2); the 2^20 NTT + coset-iFFT pair on
+    SplitMix64(seed 3).  Plus the witness-like scalar distribution of SURVEY.md section 8(d) (12 % of the scalars 0 / 1)."""
     import numpy as np
     import torch
     from oracle import bls12_381 as bls
     from oracle import cport
+    from oracle import synth
     import helpers
     out = {}
     n = 1 << 20
-    rng = np.random.default_rng(1)
-    ks = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
-    ks[:, 3] >>= 2   # < 2^252 < r
-    bases = cport.fixed_base_mul(1, ks.tobytes(), min(64, usable_cores()))
+    ks = splitmix_fields(1, n, bls.R_MOD)
+    assert ks[:2] == [synth.SplitMix64(1).field(bls.R_MOD), (lambda g: (g.field(bls.R_MOD), g.field(bls.R_MOD))[1])(synth.SplitMix64(1))]
+    bases = cport.fixed_base_mul(1, fields_to_u8(ks).tobytes(), min(64, usable_cores()))
     t0 = time.time()
     ctx = zk.MultiexpContext(1, bases, lib=lib)
     table_s = time.time() - t0
-    sc = np.random.default_rng(2).integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
-    sc[:, 3] >>= 2
-    d_sc = torch.from_numpy(sc.view(np.uint8).reshape(-1).copy()).to(dev)
+    scv = splitmix_fields(2, n, bls.R_MOD)
+    sc = fields_to_u8(scv)
+    d_sc = torch.from_numpy(sc.copy()).to(dev)
     res = ctx.run_dev(d_sc.data_ptr())
     # identity check: sum s_i (k_i G) == (sum s_i k_i) G
-    to_int = lambda row: sum(int(row[j]) << (64 * j) for j in range(4))
-    tot = sum(to_int(a) * to_int(b) for a, b in zip(ks, sc)) % bls.R_MOD
+    tot = sum(a * b for a, b in zip(ks, scv)) % bls.R_MOD
     assert res == helpers.g1_of(tot), "2^20 multiexp identity failed"
+    # witness-like scalars: 12 % of them 0 or 1 (the boolean wires of a circuit), the rest uniform (seed 2 again)
+    pick = synth.SplitMix64(12)
+    wl = list(scv)
+    for i in range(n):
+        u = pick.next()
+        if u % 100 < 12:
+            wl[i] = (u >> 32) & 1
+    d_wl = torch.from_numpy(fields_to_u8(wl).copy()).to(dev)
+    res_wl = ctx.run_dev(d_wl.data_ptr())
+    assert res_wl == helpers.g1_of(sum(a * b for a, b in zip(ks, wl)) % bls.R_MOD), "2^20 witness-like multiexp identity failed"
     lib.zk_profile_begin()
     reps = 5
     t0 = time.perf_counter()
@@ -832,43 +862,69 @@ def run_micro(lib, zk, dev):
         if k:
             kern[name] = round(ms.value / reps, 3)
     lib.zk_profile_end()
-    out["msm_g1_2p20"] = {"mscalar_per_s": round(n / dt / 1e6, 3), "ms": round(dt * 1e3, 3),
-                          "bases": "resident table of all 255 doublings of every base (fixed-base setting: a CRS), "
-                                   "built once in table_build_s",
-                          "gbps_algorithmic": round(128.0 * n / dt / 1e9, 3),
-                          "frac_of_hbm_peak": round(128.0 * n / dt / 1e9 / HBM_PEAK_GBPS, 5),
-                          "accumulate_kernel_ms": round(acc_ms, 3),
-                          "accumulate_kernel_gbps_algorithmic": round(128.0 * n / (acc_ms * 1e-3) / 1e9, 3) if acc_ms else None,
-                          "table_build_s": round(table_s, 2),
-                          "kernel_ms": kern}
-    # variable-base figures (no table of doublings: Pippenger over the bases themselves)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.run_dev(d_wl.data_ptr())
+    dt_wl = (time.perf_counter() - t0) / reps
+    inputs_note = "bases k_i G, k_i = SplitMix64(1).field(r); scalars SplitMix64(2).field(r), uniform in [0, r) (BASELINE.md section 3)"
+    fixed = {"mscalar_per_s": round(n / dt / 1e6, 3), "ms": round(dt * 1e3, 3),
+             "bases": "FIXED-BASE figure: resident table of all 255 doublings of every base (a CRS), built once in "
+                      "table_build_s outside the clock; the like-for-like Pippenger figure is msm_g1_2p20_variable_base",
+             "inputs": inputs_note,
+             "gbps_algorithmic": round(128.0 * n / dt / 1e9, 3),
+             "frac_of_hbm_peak": round(128.0 * n / dt / 1e9 / HBM_PEAK_GBPS, 5),
+             "accumulate_kernel_ms": round(acc_ms, 3),
+             "accumulate_kernel_gbps_algorithmic": round(128.0 * n / (acc_ms * 1e-3) / 1e9, 3) if acc_ms else None,
+             "table_build_s": round(table_s, 2),
+             "kernel_ms": kern}
+    witness_like = {"fixed_base": {"mscalar_per_s": round(n / dt_wl / 1e6, 3), "ms": round(dt_wl * 1e3, 3)},
+                    "inputs": "the same bases; 12 % of the scalars 0 or 1 (SplitMix64(12) picks them), the rest as above "
+                              "(SURVEY.md section 8(d) secondary point); identity checked"}
+    # variable-base figures (no table of doublings: Pippenger over the bases themselves) - the like-for-like
+    # "2^20-point Pippenger MSM" of BASELINE config 2, reported FIRST
     try:
         nv = 1 << 20
         t0 = time.perf_counter()
         vctx = zk.MultiexpContext(1, bases[:96 * nv], lib=lib, variable_base=True)
         one = vctx.run_dev(d_sc.data_ptr())
         dtv = time.perf_counter() - t0
-        assert one == res
+        assert one == res, "variable-base 2^20 multiexp differs from the table form"
         vctx.run_dev(d_sc.data_ptr())
         t0 = time.perf_counter()
         for _ in range(reps):
             vctx.run_dev(d_sc.data_ptr())
         dtr = (time.perf_counter() - t0) / reps
+        assert vctx.run_dev(d_wl.data_ptr()) == res_wl, "variable-base witness-like multiexp differs from the table form"
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            vctx.run_dev(d_wl.data_ptr())
+        dtr_wl = (time.perf_counter() - t0) / reps
         vctx.close()
         out["msm_g1_2p20_variable_base"] = {
             "mscalar_per_s": round(nv / dtr / 1e6, 3), "ms": round(dtr * 1e3, 3),
             "gbps_algorithmic": round(128.0 * nv / dtr / 1e9, 3), "frac_of_hbm_peak": round(128.0 * nv / dtr / 1e9 / HBM_PEAK_GBPS, 5),
             "one_shot_mscalar_per_s": round(nv / dtv / 1e6, 3), "one_shot_ms": round(dtv * 1e3, 3),
-            "note": "zk_msm_create_variable: signed-digit Pippenger, one bucket pass per digit position, host Horner fold; "
-                    "'ms' = bases resident (decoded once), scalars in HBM; 'one_shot' = decode + upload of 2^20 fresh "
-                    "bases + the multiexp"}
+            "inputs": inputs_note,
+            "note": "BASELINE config 2, like for like: zk_msm_create_variable = signed-digit Pippenger over the bases "
+                    "themselves, one bucket pass per digit position, host Horner fold; 'ms' = bases resident (decoded "
+                    "once), scalars in HBM; 'one_shot' = decode + upload of 2^20 fresh bases + the multiexp; identity "
+                    "sum s_i (k_i G) == (sum s_i k_i) G checked through the table form, which this result equals"}
+        witness_like["variable_base"] = {"mscalar_per_s": round(nv / dtr_wl / 1e6, 3), "ms": round(dtr_wl * 1e3, 3)}
     except Exception as exc:
         out["msm_g1_2p20_variable_base"] = {"error": repr(exc)[:200]}
+    out["msm_g1_2p20"] = fixed
+    out["msm_g1_2p20_witness_like"] = witness_like
     ctx.close()
-    # NTT pair, Montgomery data resident in HBM
+    # NTT pair (BASELINE config 3), SplitMix64(seed 3) field elements resident in HBM
     t = C.c_void_p()
     lib.check(lib.zk_ntt_create(20, dev.index or 0, C.byref(t)))
-    data = torch.from_numpy(sc.view(np.uint8).reshape(-1).copy()).to(dev)
+    ntt_in = fields_to_u8(splitmix_fields(3, n, bls.R_MOD))
+    data = torch.from_numpy(ntt_in.copy()).to(dev)
+    # round trip: forward + inverse on the same domain returns the input (size-independent property at the full size)
+    lib.check(lib.zk_ntt_run_dev(t, data.data_ptr(), 1, zk.ZK_NTT_OUT_BITREV))
+    lib.check(lib.zk_ntt_run_dev(t, data.data_ptr(), 1, zk.ZK_NTT_INVERSE | zk.ZK_NTT_IN_BITREV))
+    lib.check(lib.zk_synchronize())
+    assert bytes(data.cpu().numpy().tobytes()) == ntt_in.tobytes(), "2^20 NTT round trip failed"
     lib.check(lib.zk_ntt_run_dev(t, data.data_ptr(), 1, zk.ZK_NTT_OUT_BITREV))
     lib.check(lib.zk_synchronize())
     reps = 20
@@ -879,7 +935,8 @@ def run_micro(lib, zk, dev):
     lib.check(lib.zk_synchronize())
     dt = (time.perf_counter() - t0) / reps
     out["ntt_pair_2p20"] = {"ms": round(dt * 1e3, 3), "gbps_algorithmic": round(2 * 64.0 * n / dt / 1e9, 3),
-                            "frac_of_hbm_peak": round(2 * 64.0 * n / dt / 1e9 / HBM_PEAK_GBPS, 5)}
+                            "frac_of_hbm_peak": round(2 * 64.0 * n / dt / 1e9 / HBM_PEAK_GBPS, 5),
+                            "inputs": "SplitMix64(3).field(r), 2^20 elements (BASELINE.md section 3); forward + inverse round trip checked"}
     lib.zk_ntt_free(t)
     return out
 

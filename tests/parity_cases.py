@@ -434,6 +434,94 @@ def prover_errors(lib):
         params.close()
 
 
+def _pk_offsets(pk):
+    """byte offsets of the first entry of every query of a bellman Parameters file: vk (alpha_g1, beta_g1, beta_g2,
+    gamma_g2, delta_g1, delta_g2 = 864 bytes) | ic | h | l | a | b_g1 | b_g2, each vector behind a big-endian u32 count"""
+    off, out = 864, {}
+    for name, size in (("ic", 96), ("h", 96), ("l", 96), ("a", 96), ("b_g1", 96), ("b_g2", 192)):
+        n = int.from_bytes(pk[off:off + 4], "big")
+        out[name] = (off + 4, n, size)
+        off += 4 + n * size
+    assert off == len(pk)
+    return out
+
+
+def _cofactor_points():
+    """(G1 point, G2 point): on the curve, outside the r-torsion (the smallest x that has a y; the oracle's r * P decides)"""
+    q = bls.Q_MOD
+    F2 = bls.Fq2Ops
+    p1 = p2 = None
+    for x in range(1, 400):
+        y2 = (x ** 3 + 4) % q
+        y = pow(y2, (q + 1) // 4, q)
+        if y * y % q == y2:
+            p1 = (x, y)
+            break
+    for a in range(1, 60):
+        x = (a, 1)
+        rhs = F2.add(F2.mul(F2.sqr(x), x), (4, 4))
+        y = F2.sqrt(rhs)
+        if y is not None and F2.eq(F2.sqr(y), rhs):
+            p2 = (x, y)
+            break
+    assert p1 and p2 and not bls.G1.in_subgroup(p1) and not bls.G2.in_subgroup(p2)
+    return p1, p2
+
+
+def params_subgroup_refusal(lib):
+    """Parameters::read(checked = true) runs into_affine() on every query point: on the curve AND in the r-torsion
+    (core/pairing/src/bls12_381/ec.rs:675-688, is_in_correct_subgroup_assuming_on_curve at :142-144).  A key whose h[0],
+    l[0], a[1], b_g1[0] (G1) or b_g2[0] (G2) is an on-curve point of the cofactor part must be refused as "not in the
+    correct subgroup"; checked = false (into_affine_unchecked) loads it.  The same for zk_msm_create(checked)."""
+    r1, asg, P, pk = helpers.small_case(2, 2, 6, 7)
+    offs = _pk_offsets(pk)
+    p1, p2 = _cofactor_points()
+    torsion1 = bls.G1.to_affine(bls.G1.mul(p1, bls.R_MOD))          # r * P: a point of the cofactor subgroup itself
+    assert torsion1 is not None and not bls.G1.in_subgroup(torsion1)
+    enc = {96: bls.g1_uncompressed(p1), 192: bls.g2_uncompressed(p2)}
+    for name, index in (("h", 0), ("l", 0), ("a", 1), ("b_g1", 0), ("b_g2", 0)):
+        first, n, size = offs[name]
+        assert index < n
+        bad = bytearray(pk)
+        bad[first + index * size:first + (index + 1) * size] = enc[size]
+        with pytest.raises(zk.ZkError) as e:
+            zk.Parameters.read(bytes(bad), checked=True, lib=lib)
+        assert e.value.variant == "IoError" and "subgroup" in str(e.value), name
+        zk.Parameters.read(bytes(bad), checked=False, lib=lib).close()      # into_affine_unchecked: accepted
+    # a point of the cofactor subgroup proper (r * P) in the LAST entry of a query
+    first, n, size = offs["l"]
+    bad = bytearray(pk)
+    bad[first + (n - 1) * size:first + n * size] = bls.g1_uncompressed(torsion1)
+    with pytest.raises(zk.ZkError) as e:
+        zk.Parameters.read(bytes(bad), checked=True, lib=lib)
+    assert e.value.variant == "IoError" and "subgroup" in str(e.value)
+    # the verifying key is read checked in BOTH modes (VerifyingKey::read): a cofactor point in vk.ic / vk.delta_g2
+    first, n, size = offs["ic"]
+    bad = bytearray(pk)
+    bad[first:first + 96] = enc[96]
+    for checked in (True, False):
+        with pytest.raises(zk.ZkError) as e:
+            zk.Parameters.read(bytes(bad), checked=checked, lib=lib)
+        assert e.value.variant == "IoError" and "subgroup" in str(e.value)
+    bad = bytearray(pk)
+    bad[96 * 3 + 192 * 2:96 * 3 + 192 * 3] = enc[192]                 # delta_g2
+    with pytest.raises(zk.ZkError) as e:
+        zk.Parameters.read(bytes(bad), checked=False, lib=lib)
+    assert e.value.variant == "IoError" and "subgroup" in str(e.value)
+    # the untouched key still loads checked
+    zk.Parameters.read(pk, checked=True, lib=lib).close()
+    # zk_msm_create / zk_msm_create_variable (checked = 1), both groups
+    g1u, g2u = helpers.golden_points("g1_uncompressed"), helpers.golden_points("g2_uncompressed")
+    for group, good, badpt in ((1, g1u, enc[96]), (2, g2u, enc[192])):
+        for variable in (False, True):
+            bases = good[1] + good[2] + badpt + good[3]
+            with pytest.raises(zk.ZkError) as e:
+                zk.MultiexpContext(group, bases, window_bits=4, checked=True, lib=lib, variable_base=variable)
+            assert e.value.variant == "IoError" and "subgroup" in str(e.value), (group, variable)
+            zk.MultiexpContext(group, bases, window_bits=4, checked=False, lib=lib, variable_base=variable).close()
+            zk.MultiexpContext(group, good[1] + good[2] + good[3], window_bits=4, checked=True, lib=lib, variable_base=variable).close()
+
+
 # ------------------------------------------------------------------------------------------------
 # verification (zk_vk_*, zk_verify_*): pairing.h / verify.cpp against the oracle and the reference's fixtures
 # ------------------------------------------------------------------------------------------------

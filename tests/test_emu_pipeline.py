@@ -76,6 +76,11 @@ def test_prover_errors(emu_lib, monkeypatch):
     pc.prover_errors(emu_lib)
 
 
+def test_params_subgroup_refusal(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "4")
+    pc.params_subgroup_refusal(emu_lib)
+
+
 def test_msm_recoding_all_widths(emu_lib):
     pc.msm_recoding_stress(emu_lib, windows=(2, 3, 5, 8, 12, 14))   # every width 2..22: GPU suite (the emulation is thread-per-GPU-thread)
 

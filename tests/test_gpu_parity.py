@@ -232,6 +232,11 @@ def test_prover_errors(gpu_lib):
     pc.prover_errors(gpu_lib)
 
 
+def test_params_subgroup_refusal(gpu_lib):
+    """Parameters::read(checked) / zk_msm_create(checked) refuse on-curve points outside the r-torsion (ec.rs:675-688)"""
+    pc.params_subgroup_refusal(gpu_lib)
+
+
 def test_transfer_circuit_proof_bit_exact(gpu_lib):
     """The reference's confidential-transfer circuit itself (19 974 constraints, 23 inputs, cs.hash
     d23c92fb...1784: core/proofs/src/circuit/confidential_transfer.rs:383-386, restated in
