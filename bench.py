@@ -349,6 +349,16 @@ def main():
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    import zero_chain_amd as zk
+    lib = zk.load_library()
+    # one process per GPU: this thread - and every worker the library starts from it - stays on the NUMA node the GPU
+    # hangs off (zk_bind_host_to_device: hipDeviceGetPCIBusId -> sysfs numa_node -> sched_setaffinity); -1 = the platform
+    # reports no node, the mask is left alone
+    numa_node, numa_cpus = C.c_int(-1), C.c_int(0)
+    if os.environ.get("ZK_BENCH_NO_BIND") != "1":
+        lib.check(lib.zk_bind_host_to_device(dev_index, C.byref(numa_node), C.byref(numa_cpus)))
+        if numa_node.value >= 0:
+            host_threads = max(1, min(host_threads, numa_cpus.value))
     dist = None
     backend = None
     if world > 1:
@@ -365,11 +375,9 @@ def main():
         if world > 1:
             dist.barrier()
 
-    import zero_chain_amd as zk
     import helpers
     from oracle import bls12_381 as bls
     from oracle import synth
-    lib = zk.load_library()
     # every rank takes its share of the host cores (encoding, the optional host witness calculator), not all of them
     lib.zk_set_host_threads(host_threads)
     t_st = time.time()
@@ -379,7 +387,11 @@ def main():
 
     B, K, W = args.batch, args.steps, args.warmup
     t0 = t_setup0
-    r1cs, P = build_circuit(host_threads)
+    # the oracle's restatement of the circuit and the discrete logs of the CRS (5 s of Python) only on the rank that compares
+    # proofs with the oracle byte for byte: rank 0 (its own block, and one proof out of every other rank's gathered block).
+    # Every rank's proofs of the timed region are all verified by the product's verifier below.
+    oracle_checks = max(1, args.oracle_checks) if rank == 0 else 0
+    r1cs, P = build_circuit(host_threads) if oracle_checks > 0 else (None, None)
     mats = zk.ConstraintMatrices.transfer_circuit(device=dev_index, lib=lib)   # emitted natively (transfer_r1cs.h)
     digest, _, _, _ = zk.transfer_r1cs_fingerprint(lib)
     assert digest == "d23c92fb60ee547d45118e160679929cfa186957280673af62f09fa12d401784"   # confidential_transfer.rs:384
@@ -448,16 +460,21 @@ def main():
         if cnt:
             kernels[name] = {"launches": cnt, "total_ms": round(ms.value, 3)}
     lib.zk_profile_end()
-    per_rank = [{"rank": 0, "proofs_per_s": round(B * K / timing["prove_s"], 1), "gather_ms_per_step": 0.0}]
+    per_rank = [{"rank": 0, "proofs_per_s": round(B * K / timing["prove_s"], 1), "gather_ms_per_step": 0.0,
+                 "numa_node": numa_node.value, "cpus": len(os.sched_getaffinity(0)), "host_threads": host_threads,
+                 "setup_s": round(setup_s, 2)}]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank's own rate (submit of its K steps -> its last proof) and what the gather cost it
-        mine = torch.tensor([timing["prove_s"], timing["gather_s"]], dtype=torch.float64, device=gather_dev)
-        allr = [torch.zeros(2, dtype=torch.float64, device=gather_dev) for _ in range(world)]
+        mine = torch.tensor([timing["prove_s"], timing["gather_s"], float(numa_node.value), float(len(os.sched_getaffinity(0))),
+                             float(host_threads), setup_s, float(lanes_used)], dtype=torch.float64, device=gather_dev)
+        allr = [torch.zeros(7, dtype=torch.float64, device=gather_dev) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "proofs_per_s": round(B * K / float(x[0]), 1), "gather_ms_per_step": round(float(x[1]) / K * 1e3, 2)}
+        per_rank = [{"rank": r, "proofs_per_s": round(B * K / float(x[0]), 1), "gather_ms_per_step": round(float(x[1]) / K * 1e3, 2),
+                     "numa_node": int(x[2]), "cpus": int(x[3]), "host_threads": int(x[4]), "setup_s": round(float(x[5]), 2),
+                     "pipeline_lanes": int(x[6])}
                     for r, x in enumerate(allr)]
 
     # ---- parity gates: EVERY step of the timed region (two pipeline lanes alternate the chunks; VERDICT r2: the
@@ -465,14 +482,14 @@ def main():
     last = outs[-1]
     last_rs = rs_ints[W + K - 1]
     checked, asg0 = 0, None
-    picks = sorted(set([0, B - 1] + [(7919 * k + 13) % B for k in range(max(0, args.oracle_checks - 2))]))[:max(1, args.oracle_checks)]
+    picks = sorted(set([0, B - 1] + [(7919 * k + 13) % B for k in range(max(0, oracle_checks - 2))]))[:oracle_checks]
     for i in picks:
         want, asg = oracle_proof(P, r1cs, lo + i, *last_rs[i])
         assert last[192 * i:192 * (i + 1)].tobytes() == want, "rank %d: proof %d differs from the oracle" % (rank, i)
         asg0 = asg0 or asg
         checked += 1
     # ... and two proofs of every other step byte-for-byte against the oracle's discrete-log proof
-    per_step = 0 if args.oracle_checks <= 1 else 2
+    per_step = 0 if oracle_checks <= 1 else 2
     for k in range(K - 1):
         for i in sorted(set([(131 * k + 7) % B, (B - 1 - 17 * k) % B]))[:per_step]:
             want, _ = oracle_proof(P, r1cs, lo + i, *rs_ints[W + k][i])
@@ -521,50 +538,62 @@ def main():
     g1_terms = info["n_h"] + info["n_l"] + a_terms + b_terms
     chunk = int(os.environ.get("ZKAMD_BATCH_CHUNK", "1024"))
     roof = None
-    TRAFFIC = os.path.join("profiles", "r03_traffic.json")     # tools/make_roofline.py over the PMC passes of tools/gpu_session3.sh
+    # newest committed counter summary (tools/make_roofline.py over the rocprofv3 --pmc passes of a GPU session); it names
+    # the kernel trace it belongs to itself
+    import glob
+    cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_traffic.json")))
+    TRAFFIC = os.path.relpath(cand[-1], ROOT) if cand else None
     CLOCK_HZ = 2.4e9                                            # nominal; the issue fractions below are against it
     if "msm_accumulate_g1" in kernels:
         k = kernels["msm_accumulate_g1"]
+        n_chunks = max(1, (B + chunk - 1) // chunk) * K             # chunks proved in the timed region
+        lpc = k["launches"] / n_chunks                               # launches of the dominant kernel per chunk (2: the C' set and the A set)
         avg_ms = k["total_ms"] / k["launches"]
-        proofs_per_launch = B * K / k["launches"]
+        proofs_per_chunk = B * K / n_chunks
         g2_terms = b_terms
-        c1 = info["window_bits"]
-        c2 = int(os.environ.get("ZKAMD_WINDOW_BITS_G2") or os.environ.get("ZKAMD_WINDOW_BITS") or
-                 min(range(2, 23), key=lambda c: 254.0 / (c + 1) * info["n_b_g2"] + 12.0 * (1 << (c - 2))))   # zkamd.cpp pick_window
+        wins = (C.c_uint32 * 4)()
+        lib.check(lib.zk_params_get_windows(params._h, wins))
+        c_c, c_a, _, c2 = (int(x) for x in wins)
+        c_terms, a_only = info["n_h"] + info["n_l"] + b_terms, a_terms
         m_dom = 1 << info["log_domain"]
-        # algorithmic bytes per launch set of ONE chunk: 128 B per G1 term, 224 B per G2 term, 64 B per
+        # algorithmic bytes of the launches of ONE chunk: 128 B per G1 term, 224 B per G2 term, 64 B per
         # element and transform; sort: scalars in (32 B) + (digit, point) pairs out (4 B, 254 / (c + 1) per scalar, an
         # upper estimate: zero and one scalars recode shorter); reduction: every bucket's partial sum read once
         alg = {"msm_accumulate_g1": 128.0 * g1_terms, "msm_accumulate_g2": 224.0 * g2_terms,
                "ntt": 64.0 * m_dom * 6,     # six transforms per proof since round 3 (bellman: seven)
-               "msm_sort_lds": 32.0 * (g1_terms + g2_terms) + 4.0 * (g1_terms * 254.0 / (c1 + 1) + g2_terms * 254.0 / (c2 + 1)),
-               "msm_reduce_g1": 224.0 * 2 * (1 << (c1 - 2)), "msm_reduce_g2": 448.0 * (1 << (c2 - 2))}
-        alg = {g: v * proofs_per_launch for g, v in alg.items()}
-        alg_bytes = alg["msm_accumulate_g1"]
+               "msm_sort_lds": 32.0 * (g1_terms + g2_terms) + 4.0 * (c_terms * 254.0 / (c_c + 1) + a_only * 254.0 / (c_a + 1) +
+                                                                       g2_terms * 254.0 / (c2 + 1)),
+               "msm_reduce_g1": 224.0 * ((1 << (c_c - 2)) + (1 << (c_a - 2))), "msm_reduce_g2": 448.0 * (1 << (c2 - 2))}
+        alg = {g: v * proofs_per_chunk for g, v in alg.items()}
+        alg_bytes = alg["msm_accumulate_g1"] / lpc                   # per launch: the contract's unit for the dominant kernel
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         tj = None
         try:
             tj = json.load(open(os.path.join(ROOT, TRAFFIC)))
-            if tj.get("batch") != proofs_per_launch:
+            if tj.get("batch") != proofs_per_chunk:
                 tj = None
         except Exception:
             pass
 
-        def counters(group, ms):
-            """HBM bytes and VALU instructions of the group's launches of one chunk, from the committed PMC passes"""
+        def counters(group, ms, per=1.0):
+            """HBM bytes and VALU instructions of the group's launches of one chunk (divided by `per` launches), from the
+            committed PMC passes; ms = the duration the issue fraction is priced on"""
             if not tj or group not in tj["groups"]:
                 return None, None
             gk = tj["groups"][group]
             vi = gk.get("valu_wave_insts")
-            return int(gk.get("fetch_bytes", 0) + gk.get("write_bytes", 0)), (
-                {"wave_insts_per_launch": vi, "issue_frac": round(vi * 4.0 / 1024 / (ms * 1e-3 * CLOCK_HZ), 4)} if vi and ms else None)
-        traffic, valu = counters("msm_accumulate_g1", avg_ms)
+            return int((gk.get("fetch_bytes", 0) + gk.get("write_bytes", 0)) / per), (
+                {"wave_insts_per_launch": vi / per, "issue_frac": round(vi / per * 4.0 / 1024 / (ms * 1e-3 * CLOCK_HZ), 4)} if vi and ms else None)
+        traffic, valu = counters("msm_accumulate_g1", avg_ms, lpc)
         roof = {"bound": "hbm", "kernel": "k_msm_accumulate_g1asm (G1 bucket accumulation)",
                 "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
                 "traffic_source": None if traffic is None else TRAFFIC + " (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
-                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "valu": valu,
-                "note": "integer-VALU bound kernel (381-bit modular arithmetic, no dense contraction); see DESIGN.md 4.1"}
+                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes), "launches_per_chunk": round(lpc, 3),
+                "valu": valu,
+                "note": "integer-VALU bound kernel (381-bit modular arithmetic, no dense contraction); two launches per 1024-proof "
+                        "chunk (the C' jobs, c = %d, and the A jobs, c = %d): bytes and duration are the average over both; see "
+                        "DESIGN.md 4.1" % (c_c, c_a)}
         if rank == 0 and B == chunk:
             # every launch of a chunk alone on the GPU: one chunk, one lane, side streams folded into the main one
             try:
@@ -574,36 +603,43 @@ def main():
                 reps = 3
                 for _ in range(reps):
                     got = zk.transfer_prove_batch(mats, params, sts, rs_ints[W + K - 1])
-                alone = {}
+                alone, alone_n = {}, {}
                 for name in KERNEL_NAMES:
                     ms = C.c_double(0)
-                    if lib.zk_profile_get(name.encode(), C.byref(ms)):
-                        alone[name] = ms.value / reps
+                    cnt = lib.zk_profile_get(name.encode(), C.byref(ms))
+                    if cnt:
+                        alone[name] = ms.value / reps            # per chunk
+                        alone_n[name] = cnt / reps
                 lib.zk_profile_end()
                 if world == 1:
                     assert b"".join(p.write() for p in got) == outs[-1].tobytes(), "serial and pipelined proofs differ"
                 if "msm_accumulate_g1" in alone:
                     # the launch alone is the figure the roofline is priced on: inside the timed region two pipeline lanes
-                    # keep two launches of this same kernel in flight, and the event interval of one contains the share
-                    # of the GPU the other took
-                    alone_ms = alone["msm_accumulate_g1"]
+                    # keep launches of this same kernel in flight, and the event interval of one contains the share
+                    # of the GPU the others took
+                    alone_ms = alone["msm_accumulate_g1"] / alone_n["msm_accumulate_g1"]
                     roof["in_region"] = {"avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"],
                                          "note": "HIP-event interval of a launch inside the timed region (two lanes in flight)"}
                     roof["avg_launch_ms"] = round(alone_ms, 4)
                     roof["achieved"] = round(alg_bytes / (alone_ms * 1e-3) / 1e9, 3)
                     roof["frac"] = round(alg_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6)
-                    roof["measured"] = "one launch of the timed region's shape (1024 proofs) alone on the GPU, HIP events on its " \
-                                       "stream, live in this run after the timed region; rocprofv3 of the same launches: " \
-                                       "profiles/r03final_serial_bench_b1024_kernel_stats.csv"
-                    roof["traffic"], roof["valu"] = counters("msm_accumulate_g1", alone_ms)
+                    roof["measured"] = "launches of the timed region's shape (1024 proofs per chunk) alone on the GPU, HIP events on " \
+                                       "their stream, live in this run after the timed region; rocprofv3 of the same launches: " + \
+                                       str((tj or {}).get("kernel_stats", "profiles/ (newest *_serial_*kernel_stats.csv)"))
+                    roof["traffic"], roof["valu"] = counters("msm_accumulate_g1", alone_ms, lpc)
                     roof["alone"] = {"avg_launch_ms": roof["avg_launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"]}
+                    # flat copies of the nested figures (a consumer that keeps only the scalars of `roofline` keeps these)
+                    if roof["valu"]:
+                        roof["valu_issue_frac"] = roof["valu"]["issue_frac"]
+                        roof["valu_wave_insts_per_launch"] = roof["valu"]["wave_insts_per_launch"]
+                    roof["ms_alone_per_chunk"] = round(alone["msm_accumulate_g1"], 3)
                 # the other hot kernels of a chunk, each alone on the GPU, priced the same way
                 alone["ntt"] = alone.get("ntt_pass_dif", 0.0) + alone.get("ntt_pass_dit", 0.0)
                 names = {"msm_accumulate_g2": "k_msm_accumulate_g2asm (G2 bucket accumulation)",
                          "ntt": "k_ntt_pass (the 6 transforms of 2^15 of the H pipeline, all passes)",
                          "msm_sort_lds": "k_msm_sort_lds (digit recoding + counting sort of the (digit, point) pairs)",
-                         "msm_reduce_g1": "bucket reduction G1 (k_msm_merge_heavy, k_msm_suffix_buckets, k_msm_segsum, k_msm_suffix)",
-                         "msm_reduce_g2": "bucket reduction G2 (the same over Fq2)"}
+                         "msm_reduce_g1": "bucket reduction G1 (k_msm_merge_heavy, k_msm_reduce1_g1asm, k_msm_level2_acc, k_msm_suffix, k_msm_segsum)",
+                         "msm_reduce_g2": "bucket reduction G2 (k_msm_merge_heavy, k_msm_suffix_buckets, k_msm_segsum, k_msm_suffix over Fq2)"}
                 others = []
                 for grp, label in names.items():
                     ms = alone.get(grp)
@@ -614,6 +650,12 @@ def main():
                     others.append({"kernel": label, "group": grp, "ms_alone_per_chunk": round(ms, 3),
                                    "algorithmic_bytes_per_chunk": int(alg[grp]), "achieved": round(ach, 3), "unit": "GB/s",
                                    "frac": round(ach / HBM_PEAK_GBPS, 6), "traffic": tr, "valu": va})
+                    short = {"msm_accumulate_g2": "g2", "ntt": "ntt", "msm_sort_lds": "sort", "msm_reduce_g1": "reduce_g1",
+                             "msm_reduce_g2": "reduce_g2"}[grp]
+                    roof[short + "_frac"] = round(ach / HBM_PEAK_GBPS, 6)
+                    roof[short + "_ms_alone_per_chunk"] = round(ms, 3)
+                    if va:
+                        roof[short + "_valu_issue_frac"] = va["issue_frac"]
                 roof["others"] = others
                 roof["alone_ms_per_chunk"] = {g: round(v, 3) for g, v in alone.items()}
             except Exception as exc:   # a side measurement never costs the bench line
@@ -654,6 +696,7 @@ def main():
         syn1 = (time.perf_counter() - t1) / 8
         lib.zk_set_host_threads(host_threads)
         cpu = {"value": round(n_cpu / dt, 3), "unit": "proofs/s", "cores": cores, "kind": "port",
+               "single_thread_value": round(1.0 / lat1, 4), "single_thread_value_with_witness": round(1.0 / (lat1 + syn1), 4),
                "single_thread": {"value": round(1.0 / lat1, 4), "unit": "proofs/s", "cores": 1, "create_proof_s": round(lat1, 3),
                                  "witness_s": round(syn1, 4),
                                  "value_with_witness": round(1.0 / (lat1 + syn1), 4),
@@ -781,7 +824,7 @@ def main():
                                "/ 19955 aux, cs.hash d23c92fb..1784" % (4 if world == 1 else 5, B),
                    "proofs_per_gpu_per_step": B, "distinct_statements_per_step": B * world,
                    "statement_seeds": "SplitMix64(4 + i), i = rank * %d + k" % B,
-                   "window_bits": info["window_bits"], "batch_chunk": chunk, "host_cores": cores, "host_threads_per_rank": host_threads,
+                   "window_bits": info["window_bits"], "window_bits_all": window_bits_all(lib, params), "batch_chunk": chunk, "host_cores": cores, "host_threads_per_rank": host_threads,
                    "parallelism": "dp%d (independent proofs, contiguous blocks, %s gather of 192 B/proof/step)" % (world, "gloo" if one_gpu else "RCCL"),
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend, "pipeline_lanes": lanes_used, "per_rank": per_rank,
                    "proofs_checked_vs_oracle": checked, "proofs_checked_from_other_ranks": cross_rank,
@@ -810,6 +853,12 @@ def splitmix_fields(seed, n, modulus):
 def fields_to_u8(values):
     import numpy as np
     return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in values), dtype=np.uint8)
+
+
+def window_bits_all(lib, params):
+    w = (C.c_uint32 * 4)()
+    lib.check(lib.zk_params_get_windows(params._h, w))
+    return {"g1_c_prime": int(w[0]), "g1_a": int(w[1]), "g1_few_proofs": int(w[2]), "g2": int(w[3])}
 
 
 def run_micro(lib, zk, dev):

@@ -68,6 +68,15 @@ zk_status zk_device_count(int* count);
  * One process per GPU on a multi-GPU node should pass cores / ranks. */
 void zk_set_host_threads(int n);
 
+/* One process per GPU: restrict the CALLING thread - and every thread it starts afterwards, the
+ * library's workers included - to the CPUs of the NUMA node the GPU hangs off (hipDeviceGetPCIBusId ->
+ * /sys/bus/pci/devices/<id>/numa_node -> /sys/devices/system/node/node<N>/cpulist, intersected with the mask the
+ * process was given).  Call it first, before zk_params_load / zk_pipeline_create.  *numa_node_out = the node, or -1
+ * when the platform reports none or its CPUs are not ours (the mask is then left as it was); *n_cpus_out = CPUs the
+ * thread may run on afterwards.  No reference counterpart: the reference proves on the CPU in one process
+ * (core/proofs/src/confidential.rs:149). */
+zk_status zk_bind_host_to_device(int device, int* numa_node_out, int* n_cpus_out);
+
 /* ------------------------------------------------------------------------------------------
  * Parameters  (bellman groth16::Parameters<Bls12>)
  * replaces: Parameters::read(reader, checked)   reference call: confidential.rs:99
@@ -91,6 +100,9 @@ typedef struct {
 
 zk_status zk_params_load(const uint8_t* pk_bytes, size_t len, int checked, int device, zk_params** out);
 zk_status zk_params_get_info(const zk_params* p, zk_params_info* info);
+/* The recoding widths in use: out[0] = the C' jobs (H + L + r B1) of a batch, out[1] = its A jobs, out[2] = both G1 jobs
+ * of a few proofs made alone (one launch set), out[3] = the G2 job (B2).  zk_params_info.window_bits is out[0]. */
+zk_status zk_params_get_windows(const zk_params* p, uint32_t out[4]);
 void zk_params_free(zk_params* p);
 
 /* ------------------------------------------------------------------------------------------

@@ -30,6 +30,7 @@ def gpu_lib():
     multiexp launch through the generated assembly loops and their second pass (equal / opposite / repeated bases, the
     point at infinity, single proofs), not only the launches large enough to take them by default (ZKAMD_ASM_MIN_PAIRS)."""
     os.environ.setdefault("ZKAMD_ASM_MIN_PAIRS", "0")
+    os.environ.setdefault("ZKAMD_SPLIT_MIN", "2")    # ... and every batch of two or more proofs through the split G1 launch sets
     import zero_chain_amd
     lib = zero_chain_amd.load_library()
     import ctypes

@@ -65,3 +65,40 @@ void emu_launch(emu_dim3 grid, emu_dim3 block, size_t shmem, bool needs_sync, co
     }
     emu_dyn_shared = nullptr;
 }
+
+// TEST-ONLY diagnostics: ZKAMD_EMU_BACKTRACE=1 prints the native stack of a crash inside the emulation build
+// (llvm-symbolizer -e tests/emu/libzkamd_emu.so <offset> names the frames).
+#include <cstring>
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+void emu_crash_handler(int sig) {
+    void* bt[64];
+    const int n = backtrace(bt, 64);
+    const char msg[] = "[emu] fatal signal, native stack:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(bt, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct EmuCrashInstall {
+    EmuCrashInstall() {
+        if (getenv("ZKAMD_EMU_BACKTRACE")) {
+            static char alt[1 << 16];          // a stack overflow must still reach the handler (main thread only)
+            stack_t ss;
+            ss.ss_sp = alt;
+            ss.ss_size = sizeof(alt);
+            ss.ss_flags = 0;
+            sigaltstack(&ss, nullptr);
+            struct sigaction sa;
+            memset(&sa, 0, sizeof(sa));
+            sa.sa_handler = emu_crash_handler;
+            sa.sa_flags = SA_ONSTACK;
+            sigaction(SIGSEGV, &sa, nullptr);
+            sigaction(SIGBUS, &sa, nullptr);
+            sigaction(SIGABRT, &sa, nullptr);
+        }
+    }
+} g_emu_crash_install;
+}  // namespace

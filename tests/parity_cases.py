@@ -813,6 +813,16 @@ def proof_reader(lib):
         big[0] |= 0x80
         add(bytes(big), good_b, good_c, ("A", "bad encoding"))                                  # x = q: not a field element
         add(bytes(big), inf2, inf1, ("A", "bad encoding"))                                      # the first failure is reported
+        # Proof::read finishes A before it touches B (lib.rs:67-110): a decoded-but-refused A wins over a malformed B / C
+        bad_b = bytes([good_b[0] & 0x7f]) + good_b[1:]
+        add(inf1, bad_b, good_c, ("A", "point at infinity"))
+        x_off = next(x for x in range(1, 40) if pow((x ** 3 + 4) % q, (q - 1) // 2, q) != 1)
+        xb = bytearray(x_off.to_bytes(48, "big"))
+        xb[0] |= 0x80
+        add(bytes(xb), bad_b, bytes([0xc1]) + bytes(47), ("A", "not on the curve"))
+        add(bls.g1_compressed((0, 2)), bad_b, good_c, ("A", "not in the subgroup"))
+        add(good_a, inf2, bytes([0xc1]) + bytes(47), ("B", "point at infinity"))
+        add(good_a, bad_b, inf1, ("B", "bad encoding"))
         assert zk.read_proofs(pvk, cases) == want
         assert zk.read_proofs(pvk, []) == []
         # the verdict of the verifier follows the reader's

@@ -63,3 +63,22 @@ def test_madd_loop_in_the_single_lane_interpreter(capsys):
     s.main_g2(cases=5)        # the G2 loop: Fq2 products on two interleaved column streams, W and ZZZ parked in LDS
     out = capsys.readouterr().out
     assert "MADD_G1 ok" in out and "MADD_G2 ok" in out
+
+
+def test_reduction_loop_header_is_the_generators_output(tmp_path, monkeypatch):
+    g = _load("gen_red_asm")
+    monkeypatch.setattr(g, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "zero-chain_amd" / "csrc")
+    g.main()
+    fresh = open(tmp_path / "zero-chain_amd" / "csrc" / "red_asm.h").read()
+    assert fresh == open(os.path.join(ROOT, "zero-chain_amd", "csrc", "red_asm.h")).read()
+
+
+def test_reduction_loop_in_the_single_lane_interpreter(capsys):
+    """The generated level-1 loop of the G1 bucket reduction (red_asm.h): whole nodes for one lane - empty buckets in every
+    position, the copy / add selection through EXEC, the flags - against the affine group law
+    (core/pairing/src/bls12_381/ec.rs:356-444 computes the same sums in Jacobian coordinates); nodes that meet equal or
+    opposite operands must come out flagged (ZZ == 0 mod p) for the compiled recomputation."""
+    s = _load("sim_red_asm")
+    s.main()
+    assert "RED_G1 ok" in capsys.readouterr().out

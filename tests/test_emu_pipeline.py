@@ -71,6 +71,17 @@ def test_prover_batch(emu_lib, monkeypatch):
     pc.prover_batch(emu_lib, 5, 3, 12, 3)       # one device chunk staged in three blocks
 
 
+def test_prover_batch_split_g1_launch_sets(emu_lib, monkeypatch):
+    """the A jobs and the C' jobs of a batch as two launch sets with their own recoding widths (zkamd.cpp prove_chunk)"""
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS_G1", "6")
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS_G1A", "4")
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS_G2", "5")
+    monkeypatch.setenv("ZKAMD_SPLIT_MIN", "1")
+    pc.prover_batch(emu_lib, 6, 3, 12, 3)
+    monkeypatch.setenv("ZKAMD_G1A_STREAM", "main")
+    pc.prover_batch(emu_lib, 8, 3, 12, 2)
+
+
 def test_prover_errors(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "4")
     pc.prover_errors(emu_lib)

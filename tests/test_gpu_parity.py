@@ -404,6 +404,39 @@ def test_pipeline_two_lanes_full_chunks_every_proof_checked(gpu_lib, monkeypatch
         params.close()
 
 
+def test_pipeline_lane_retires_when_its_workspaces_do_not_fit(gpu_lib, monkeypatch):
+    """the free-memory estimate of zk_pipeline_create is only a hint.  A lane beyond the first whose
+    allocation fails (injected here) hands its jobs back and retires; the stream of proofs is the one a single call
+    makes, nothing is lost or duplicated, and the pipeline reports the lanes that are left."""
+    import zero_chain_amd as zk
+    from oracle import transfer_circuit as tc
+    monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "8")
+    monkeypatch.setenv("ZKAMD_PIPELINE_LANES", "3")
+    monkeypatch.setenv("ZKAMD_INJECT_LANE_OOM", "1")
+    monkeypatch.setenv("ZKAMD_LANE_BYTES", "1048576")       # the hint lets all three lanes start
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    n = 40                                                   # five chunks of 8
+    ws = [tc.make_witness(2100 + i, amount=5 + i, fee=i % 3, balance=500 + i) for i in range(4)]
+    sts = zk.transfer_statements([tc.statement_dict(ws[i % 4]) for i in range(n)])
+    rng = synth.SplitMix64(4242)
+    rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
+    pipe = zk.TransferPipeline(mats, params)
+    try:
+        assert pipe.lanes == 3
+        out = pipe.submit(sts, zk.scalars_to_bytes([x for pair in rs for x in pair]))
+        pipe.wait(raw=True)
+        assert pipe.lanes == 1
+        monkeypatch.delenv("ZKAMD_INJECT_LANE_OOM")
+        serial = zk.transfer_prove_batch(mats, params, sts, rs)
+        assert b"".join(p.write() for p in serial) == out.tobytes()
+    finally:
+        pipe.close()
+        mats.close()
+        params.close()
+
+
 def test_lone_proof_takes_the_compiled_loop_by_default(gpu_lib, monkeypatch):
     """Launches below ZKAMD_ASM_MIN_PAIRS (a proof made alone) keep the compiled accumulation loop; the suite forces
     the assembly loops everywhere else (conftest.py).  Same bytes either way."""

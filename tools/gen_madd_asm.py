@@ -546,7 +546,7 @@ def render(R, e, name, what, first_clobber=64):
     for l in e.lines:
         out.append('    "%s\\n\\t" \\' % l)
     out[-1] = out[-1][:-2]
-    clob = ["v%d" % i for i in range(first_clobber, R.n_vgpr)] + ["s%d" % i for i in R.clob_s] + ["vcc", "memory"]
+    clob = ["v%d" % i for i in range(first_clobber, R.n_vgpr)] + ["s%d" % i for i in R.clob_s] + ["vcc", "scc", "memory"]
     out.append("#define ZK_MADD_%s_ASM_CLOBBERS %s" % (name, ", ".join('"%s"' % c for c in clob)))
     out.append("#define ZK_MADD_%s_VGPRS %d" % (name, R.n_vgpr))
     return "\n".join(out) + "\n"

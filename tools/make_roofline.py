@@ -29,6 +29,8 @@ GROUPS = [   # substring of the rocprofv3 kernel name -> bench.py group
     ("k_ntt_pass", "ntt"), ("k_msm_sort_lds", "msm_sort_lds"),
     ("k_msm_task_hist", "msm_task_sort"), ("k_msm_task_base", "msm_task_sort"), ("k_msm_task_place", "msm_task_sort"),
     ("k_msm_merge_heavy<zkdev::Fq28>", "msm_reduce_g1"), ("k_msm_suffix_buckets<zkdev::Fq28>", "msm_reduce_g1"),
+    ("k_msm_reduce1_g1asm", "msm_reduce_g1"), ("k_msm_level2_acc<zkdev::Fq28>", "msm_reduce_g1"),
+    ("k_msm_level2_acc<zkdev::Fq2x>", "msm_reduce_g2"),
     ("k_msm_segsum<zkdev::Fq28>", "msm_reduce_g1"), ("k_msm_suffix<zkdev::Fq28>", "msm_reduce_g1"),
     ("k_msm_merge_heavy<zkdev::Fq2x>", "msm_reduce_g2"), ("k_msm_suffix_buckets<zkdev::Fq2x>", "msm_reduce_g2"),
     ("k_msm_segsum<zkdev::Fq2x>", "msm_reduce_g2"), ("k_msm_suffix<zkdev::Fq2x>", "msm_reduce_g2"),
@@ -65,11 +67,13 @@ def main():
     busy = pmc(os.path.join(sess, "pmc_SQ_WAVES"), "SQ_BUSY_CYCLES")
     mean = lambda v: sum(v) / len(v) if v else 0.0
     names = sorted(set(fetch) | set(write) | set(valu))
-    # launches per chunk: relative to the G1 accumulation kernel, launched once per chunk
-    ref = [n for n in names if "k_msm_accumulate_g1asm" in n or "k_msm_accumulate<zkdev::Fq28>" in n]
+    # launches per chunk: relative to a kernel launched exactly once per chunk (the scalar builder; round 4 launches the G1
+    # accumulation loop twice per chunk: the C' jobs and the A jobs)
+    ONCE = "k_build_scalars"
+    ref = [n for n in names if ONCE in n] or [n for n in names if "k_msm_accumulate_g1asm" in n or "k_msm_accumulate<zkdev::Fq28>" in n]
     chunks = {"FETCH": len(fetch.get(ref[0], [])) if ref else 1, "WRITE": len(write.get(ref[0], [])) if ref else 1,
               "SQ": len(valu.get(ref[0], [])) if ref else 1}
-    ref_stat = [n for n in stats if "k_msm_accumulate_g1asm" in n or "k_msm_accumulate<zkdev::Fq28>" in n]
+    ref_stat = [n for n in stats if ONCE in n] or [n for n in stats if "k_msm_accumulate_g1asm" in n or "k_msm_accumulate<zkdev::Fq28>" in n]
     stat_chunks = stats[ref_stat[0]][0] if ref_stat else 1
     kernels, groups = {}, collections.defaultdict(lambda: collections.defaultdict(float))
     for n in names:
@@ -88,7 +92,9 @@ def main():
             groups[g]["valu_wave_insts"] += sum(valu.get(n, [])) / max(chunks["SQ"], 1)
             if n in stats:
                 groups[g]["ms_alone"] += stats[n][0] * stats[n][1] / stat_chunks
+    ks = sorted(glob.glob(os.path.join(sess, "prof_serial", "**", "*kernel_stats.csv"), recursive=True))
     out = {"batch": batch, "chunks_profiled": chunks,
+           "kernel_stats": "profiles/%s_serial_bench_b%d_kernel_stats.csv" % (os.path.basename(os.path.normpath(sess)), batch) if ks else None,
            "note": "per launch (kernels) / per 1024-proof chunk (groups); FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc "
                    "passes, KiB -> bytes; valu_wave_insts = SQ_INSTS_VALU; ms_alone from rocprofv3 --kernel-trace --stats of the "
                    "serial run (ZKAMD_PIPELINE_LANES=1 ZKAMD_NO_OVERLAP=1)",

@@ -50,6 +50,7 @@ class Lane:
             if l.endswith(":"):
                 self.labels[l[:-1]] = i
         self.count = {"valu": 0, "salu": 0, "vmem": 0}
+        self.scc = 0
 
     # ---- operands
     def rd(self, tok, wide=False):
@@ -147,6 +148,17 @@ class Lane:
                     self.wr(ops[0], (~self.rd(ops[1])) & 1)
                 elif op == "s_add_u32":
                     self.wr(ops[0], (self.rd(ops[1]) + self.rd(ops[2])) & M32)
+                elif op == "s_sub_u32":
+                    self.wr(ops[0], (self.rd(ops[1]) - self.rd(ops[2])) & M32)
+                elif op == "s_andn2_b64":
+                    self.wr(ops[0], self.rd(ops[1]) & ~self.rd(ops[2]) & 1)       # one lane: bit 0 is the lane's bit
+                elif op == "s_or_b64":
+                    self.wr(ops[0], (self.rd(ops[1]) | self.rd(ops[2])) & 1)
+                elif op == "s_cmp_eq_u32":
+                    self.scc = 1 if self.rd(ops[0]) == self.rd(ops[1]) else 0
+                elif op == "s_cbranch_scc1":
+                    if self.scc:
+                        pc = self.target(ops[0], pc)
                 elif op == "s_nop":
                     pass
                 elif op == "s_waitcnt":
@@ -235,6 +247,10 @@ class Lane:
                 self.wr(ops[0], (self.rd(ops[1]) * self.rd(ops[2])) & M32)
             elif op == "v_mov_b32_e32":
                 self.wr(ops[0], self.rd(ops[1]))
+            elif op == "v_readfirstlane_b32":
+                self.s[int(ops[0][1:])] = self.rd(ops[1])      # (the one lane is the first active lane)
+            elif op == "v_or_b32_e32":
+                self.wr(ops[0], self.rd(ops[1]) | self.rd(ops[2]))
             elif op == "v_and_b32_e32":
                 self.wr(ops[0], self.rd(ops[1]) & self.rd(ops[2]))
             elif op == "v_alignbit_b32":

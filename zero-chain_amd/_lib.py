@@ -96,6 +96,8 @@ _PROTOS = {
     "zk_set_host_threads": (None, [C.c_int]),
     "zk_params_load": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_params_get_info": (C.c_int32, [C.c_void_p, C.POINTER(ParamsInfo)]),
+    "zk_params_get_windows": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    "zk_bind_host_to_device": (C.c_int32, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "zk_params_free": (None, [C.c_void_p]),
     "zk_prove": (C.c_int32, [C.c_void_p, C.POINTER(Assignment), C.c_void_p, C.c_void_p, C.c_void_p]),
     "zk_prove_batch": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(Assignment), C.c_void_p, C.c_void_p]),

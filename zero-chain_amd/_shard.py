@@ -46,27 +46,64 @@ def gather_proofs(local_proofs, n_total, dist=None, device=None, dst=0):
         if local.size != n_total * PROOF_SIZE:
             raise ValueError("single-rank gather: expected the whole batch")
         return local.tobytes()
-    # (a process group of ONE rank still goes through the collective below: that is how the RCCL path is exercised on
-    #  a one-GPU box, tests/test_rccl_single_rank.py)
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1 and device is None:
+        # one rank and no device asked for: there is nobody to exchange with, whatever `dst` says (as before round 3).
+        # With an explicit `device` a process group of ONE rank still goes through the collective below: that is how the
+        # RCCL path is exercised on a one-GPU box (tests/test_rccl_single_rank.py, bench.py).
+        if local.size != n_total * PROOF_SIZE:
+            raise ValueError("single-rank gather: expected the whole batch")
+        return local.tobytes()
     lo, hi = shard_bounds(n_total, rank, world)
     if local.size != (hi - lo) * PROOF_SIZE:
         raise ValueError("rank %d: expected %d proofs, got %d bytes" % (rank, hi - lo, local.size))
     cap = max(shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)) * PROOF_SIZE
-    dev = device if device is not None else torch.device("cpu")
-    send = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if device is not None:
+        dev = device
+    elif dist.get_backend() == "nccl":     # RCCL moves device memory only: default to this rank's current GPU
+        dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
+    # The exchange buffers of a (world, block size, device) are made once and reused by every later gather: a step's gather
+    # is then one copy of the rank's block into a page-locked staging tensor, one asynchronous copy to the device, the
+    # collective, and one copy of the gathered blocks back - no allocation, no pageable-memory copy that would serialise
+    # against the prover's streams.
+    key = (world, cap, str(dev), rank == dst)
+    bufs = _GATHER_BUFS.get(key)
+    if bufs is None:
+        on_gpu = dev.type == "cuda"
+        stage = torch.zeros(cap, dtype=torch.uint8, pin_memory=on_gpu)
+        send = torch.zeros(cap, dtype=torch.uint8, device=dev) if on_gpu else stage
+        recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+        back = torch.empty(world * cap, dtype=torch.uint8, pin_memory=on_gpu) if rank == dst else None
+        bufs = _GATHER_BUFS[key] = (stage, send, recv, back)
+        if len(_GATHER_BUFS) > 8:          # a handful of shapes at most; never grow without bound
+            _GATHER_BUFS.pop(next(iter(_GATHER_BUFS)))
+    stage, send, recv, back = bufs
     if local.size:
-        send[:local.size] = torch.from_numpy(local.copy()).to(dev)
-    recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
+        stage[:local.size] = torch.from_numpy(np.ascontiguousarray(local))
+    if send is not stage:
+        send.copy_(stage, non_blocking=True)
     dist.gather(send, recv, dst=dst)
     if rank != dst:
         return None
+    if recv[0].is_cuda:
+        for r in range(world):
+            back[r * cap:(r + 1) * cap].copy_(recv[r], non_blocking=True)
+        torch.cuda.current_stream(recv[0].device).synchronize()
+        host = back.numpy()
+    else:
+        host = None
     out = bytearray()
     for r in range(world):
         l, h = shard_bounds(n_total, r, world)
-        out += recv[r][:(h - l) * PROOF_SIZE].cpu().numpy().tobytes()
+        blk = host[r * cap:r * cap + (h - l) * PROOF_SIZE] if host is not None else recv[r][:(h - l) * PROOF_SIZE].numpy()
+        out += blk.tobytes()
     return bytes(out)
+
+
+_GATHER_BUFS = {}
 
 
 def prove_sharded(params, assignments, rs, dist=None, device=None, dst=0, create_proofs=None):

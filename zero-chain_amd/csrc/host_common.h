@@ -29,6 +29,7 @@ struct DevCtx {
     hipStream_t stream2 = nullptr;   // side stream: the G2 multiexp of a chunk runs beside the G1 work
     hipStream_t copy = nullptr;      // staging copies of the next block of a host batch
     hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join = nullptr;    // the side stream's G1 launch set (the A jobs of a chunk) is done
 };
 inline std::mutex g_ctx_mu;
 inline std::map<int, DevCtx*> g_ctxs;   // key: device * 16 + lane
@@ -40,6 +41,7 @@ inline thread_local hipStream_t g_stream = nullptr;
 inline thread_local hipStream_t g_stream2 = nullptr;
 inline thread_local hipStream_t g_copy_stream = nullptr;
 inline thread_local hipEvent_t g_ev_fork = nullptr;
+inline thread_local hipEvent_t g_ev_join = nullptr;
 inline thread_local int g_device = -1;
 
 inline zk_status fail(zk_status st, const std::string& msg) {
@@ -70,7 +72,7 @@ inline zk_status use_device(int device) {
         DevCtx* fresh = new DevCtx();
         if (hipStreamCreate(&fresh->stream) != hipSuccess || hipStreamCreate(&fresh->stream2) != hipSuccess ||
             hipStreamCreateWithFlags(&fresh->copy, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&fresh->ev_fork) != hipSuccess) {
+            hipEventCreate(&fresh->ev_fork) != hipSuccess || hipEventCreate(&fresh->ev_join) != hipSuccess) {
             delete fresh;
             g_ctxs.erase(device * 16 + g_lane);
             return fail(ZK_ERR_DEVICE, "cannot create the streams of device " + std::to_string(device));
@@ -81,6 +83,7 @@ inline zk_status use_device(int device) {
     g_stream2 = c->stream2;
     g_copy_stream = c->copy;
     g_ev_fork = c->ev_fork;
+    g_ev_join = c->ev_join;
     g_device = device;
     return ZK_OK;
 }

@@ -828,6 +828,87 @@ k_msm_accumulate_g2asm_persistent(const Affine<Fq2x>* __restrict__ table, const 
     }
 }
 #endif
+// Pass 6, level 1, G1: the generated assembly loop of red_asm.h (tools/gen_red_asm.py).  One thread per node of L
+// buckets walks them from the top down with BOTH accumulators in registers (run = the suffix sum R_k, acc = sum of R_k
+// over k >= 1) and writes S = R_0 and A = acc: nothing but the bucket sums is read, no suffix array goes through HBM
+// (k_msm_suffix_buckets + k_msm_segsum: 224 B read, 224 B written and 224 B read again per bucket), and the XYZZ full
+// addition is ~6 100 in-place instructions against the compiled one's ~9 000 through the out-of-line product routines.
+// Every bucket must hold ONE partial: the launch runs behind k_msm_merge_heavy with all multi-task buckets merged.
+// The level above forms W = 2 A + S (k_msm_level2_acc).  Equal / opposite operands and buckets that are the point at
+// infinity leave ZZ == 0 (mod p) in the result they entered; such a node is recomputed here by the compiled addition.
+#if !defined(ZK_EMU) && !defined(ZK_NO_MADD_ASM)
+#include "red_asm.h"
+#define ZK_HAVE_RED_ASM 1
+ZK_DI XYZZ<Fq28> red_asm_point(const u32x16& x, const u32x16& y, const u32x16& zz, const u32x16& zzz, bool is_inf, bool raw) {
+    if (is_inf) return XYZZ<Fq28>::inf();
+    if (raw) return XYZZ<Fq28>{fq28_unvec(x), fq28_unvec(y), fq28_unvec(zz), fq28_unvec(zzz)};   // copied as it was loaded
+    return XYZZ<Fq28>{fq28_from_signed<7, false>(x),       // X in (-6 p, 2 p)                 -> < 9 p
+                      fq28_from_signed<2, false>(y),       // Y: one reduction of two products, (-0.1 p, 1.1 p) -> < 4 p
+                      fq28_from_signed_product(zz), fq28_from_signed_product(zzz)};
+}
+static __global__ void __launch_bounds__(64, 2)
+k_msm_reduce1_g1asm(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
+                    const uint32_t* __restrict__ task_base, XYZZ<Fq28>* __restrict__ S, XYZZ<Fq28>* __restrict__ A, uint32_t nb,
+                    uint32_t L) {
+    static_assert(ZK_RED_G1_VGPRS <= 256, "the loop must fit two waves per SIMD");
+    static_assert(sizeof(XYZZ<Fq28>) == 224, "the loop loads 224-byte partial sums");
+    const uint32_t T = nb / L;
+    const uint32_t bx = (blockIdx.x + blockIdx.y) % gridDim.x;   // XCD rotation, as in k_msm_suffix_buckets
+    const uint32_t t = bx * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t job = blockIdx.y;
+    const size_t b0 = (size_t)job * nb + (size_t)t * L;
+    const XYZZ<Fq28>* ts = tsums + task_base[job];
+    u32x16 X = {}, Y = {}, ZZ = {}, ZZZ = {}, AX, AY, AZZ, AZZZ;
+    const uint64_t pc = (uint64_t)(uintptr_t)(cnt + b0), pt = (uint64_t)(uintptr_t)(toff + b0), pp = (uint64_t)(uintptr_t)ts;
+    X[14] = (uint32_t)pc;
+    X[15] = (uint32_t)(pc >> 32);
+    Y[14] = (uint32_t)pt;
+    Y[15] = (uint32_t)(pt >> 32);
+    ZZ[14] = (uint32_t)pp;
+    ZZ[15] = (uint32_t)(pp >> 32);
+    ZZZ[14] = L;
+    asm volatile(ZK_RED_G1_ASM
+                 : "+{v[0:15]}"(X), "+{v[16:31]}"(Y), "+{v[32:47]}"(ZZ), "+{v[48:63]}"(ZZZ), "={v[64:79]}"(AX), "={v[80:95]}"(AY),
+                   "={v[96:111]}"(AZZ), "={v[112:127]}"(AZZZ)
+                 :
+                 : ZK_RED_G1_ASM_CLOBBERS);
+    const uint32_t flags = ZZZ[15];
+    XYZZ<Fq28> run = red_asm_point(X, Y, ZZ, ZZZ, (flags & ZK_RED_FLAG_RUN_INF) != 0, (flags & ZK_RED_FLAG_RUN_RAW) != 0);
+    XYZZ<Fq28> acc = red_asm_point(AX, AY, AZZ, AZZZ, (flags & ZK_RED_FLAG_ACC_INF) != 0, (flags & ZK_RED_FLAG_ACC_RAW) != 0);
+    if ((!(flags & ZK_RED_FLAG_RUN_INF) && run.zz.is_zero_norm()) || (!(flags & ZK_RED_FLAG_ACC_INF) && acc.zz.is_zero_norm())) {
+        // a special case somewhere in the node (or a bucket whose points cancelled): the compiled addition knows them all
+        run = XYZZ<Fq28>::inf();
+        acc = XYZZ<Fq28>::inf();
+        for (int k = (int)L - 1; k >= 0; k--) {
+            if (cnt[b0 + k]) run = xadd(run, ts[toff[b0 + k]]);
+            if (k >= 1) acc = xadd(acc, run);
+        }
+    }
+    S[(size_t)job * T + t] = run;
+    A[(size_t)job * T + t] = acc;
+}
+#endif
+// The level above the assembly loop: children k of a parent carry S_k (suffix sums R'_k already formed by k_msm_suffix)
+// and A_k with W_k = 2 A_k + S_k, so  W(parent) = Tred + sum_k W_k = Tred + 2 sum_k A_k + R'_0  with
+// Tred = 2M sum_{k >= 1} R'_k from k_msm_segsum: one doubling per PARENT instead of one per child.
+template <class F>
+static __global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_level2_acc(const XYZZ<F>* __restrict__ A, const XYZZ<F>* __restrict__ Rp, const XYZZ<F>* __restrict__ Tred,
+                 XYZZ<F>* __restrict__ out, uint32_t n, uint32_t seg) {
+    const uint32_t ns = (n + seg - 1) / seg;
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= ns) return;
+    const XYZZ<F>* a = A + (size_t)blockIdx.y * n;
+    const uint32_t c0 = u * seg, c1 = c0 + seg < n ? c0 + seg : n;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t k = c0; k < c1; k++) acc = xadd(acc, a[k]);
+    acc = xdbl(acc);
+    acc = xadd(acc, Tred[(size_t)blockIdx.y * ns + u]);
+    acc = xadd(acc, Rp[(size_t)blockIdx.y * n + c0]);
+    out[(size_t)blockIdx.y * ns + u] = acc;
+}
+
 // Second pass for the tasks the assembly loop flagged: the compiled addition with every special case.  A circuit's
 // CRS holds EQUAL points (variables with identical QAP polynomials: ~100-170 flagged tasks per 1024-proof launch of
 // the transfer circuit, each time a task starts with two of them), so this pass is on the hot path: one WAVE per

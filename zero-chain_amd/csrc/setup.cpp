@@ -86,7 +86,16 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
         return fail(ZK_ERR_INVALID_ARGUMENT, "g1 is not a valid generator encoding");
     if (zkhost::g2_from_uncompressed(g2_bytes, &g2) != zkhost::DEC_OK || g2.is_inf() || !zkhost::on_curve(g2))
         return fail(ZK_ERR_INVALID_ARGUMENT, "g2 is not a valid generator encoding");
-    Fr alpha, beta, gamma, delta, tau;
+    Fr alpha, beta, gamma, delta, tau, tm, zt, ginv, dinv;
+    Fr bs[2], bs3[2], cs[4], vk1[3], vk2[3];   // every host copy of a trapdoor value lives here: wiped on EVERY exit path
+    struct HostWipe {
+        std::vector<std::pair<void*, size_t>> v;
+        ~HostWipe() {
+            for (auto& e : v) explicit_bzero(e.first, e.second);
+        }
+    } host_wipe{{{&alpha, sizeof(Fr)}, {&beta, sizeof(Fr)}, {&gamma, sizeof(Fr)}, {&delta, sizeof(Fr)}, {&tau, sizeof(Fr)},
+                 {&tm, sizeof(Fr)}, {&zt, sizeof(Fr)}, {&ginv, sizeof(Fr)}, {&dinv, sizeof(Fr)}, {bs, sizeof(bs)},
+                 {bs3, sizeof(bs3)}, {cs, sizeof(cs)}, {vk1, sizeof(vk1)}, {vk2, sizeof(vk2)}}};
     if (!load_fr(alpha_b, &alpha) || !load_fr(beta_b, &beta) || !load_fr(gamma_b, &gamma) || !load_fr(delta_b, &delta) ||
         !load_fr(tau_b, &tau))
         return fail(ZK_ERR_INVALID_ARGUMENT, "a trapdoor scalar is not a canonical field element (>= r)");
@@ -129,11 +138,22 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
     }
 
     // ---- L_j(tau): powers of tau, inverse transform (generator.rs: powers_of_tau.ifft())
-    DevBuf lag, tmp2;
+    // Device buffers that hold toxic waste (or values it can be recovered from), declared BEFORE their guard so that the
+    // guard runs first on every exit path - success, UnconstrainedVariable, buffer too small, any failed launch
+    DevBuf lag, tmp2, t3, eh, ea, eb, eext, consts, d_vk1, d_vk2;
+    struct DevWipe {
+        std::vector<DevBuf*> v;
+        ~DevWipe() {
+            for (DevBuf* b : v)
+                if (b->p) (void)hipMemsetAsync(b->p, 0, b->cap, g_stream);
+            (void)hipStreamSynchronize(g_stream);
+        }
+    } dev_wipe{{&lag, &tmp2, &t3, &eh, &ea, &eb, &eext, &consts, &d_vk1, &d_vk2}};
     ZK_TRY(lag.ensure(m * 32));
     const Fr one = Fr::one();
     {
-        const Fr bs[2] = {tau, one};
+        bs[0] = tau;
+        bs[1] = one;
         ZK_TRY(upload(tmp2, bs, sizeof(bs)));
         ZK_LAUNCH(zkdev::k_fr_pow_table, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, g_stream, lag.as<uint32_t>(),
                   (const uint32_t*)tmp2.as<uint32_t>(), (const uint32_t*)tmp2.as<uint32_t>() + 8, log_m, 0u, 0u, (uint32_t)m);
@@ -150,24 +170,24 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
         }
     }
     // ---- exponents: h_i = tau^i (tau^m - 1) / delta, and per variable A_i(tau), B_i(tau), ext_i
-    Fr tm = tau;
+    tm = tau;
     for (uint32_t i = 0; i < log_m; i++) tm = tm.sqr();
-    const Fr zt = tm - one;
-    const Fr ginv = zkhost::fr_inv(gamma), dinv = zkhost::fr_inv(delta);
-    DevBuf eh, ea, eb, eext, consts, evk;
+    zt = tm - one;
+    ginv = zkhost::fr_inv(gamma);
+    dinv = zkhost::fr_inv(delta);
     const size_t n_h = m - 1;
     ZK_TRY(eh.ensure((n_h ? n_h : 1) * 32));
     ZK_TRY(ea.ensure((size_t)nv * 32));
     ZK_TRY(eb.ensure((size_t)nv * 32));
     ZK_TRY(eext.ensure((size_t)nv * 32));
     {
-        const Fr bs[2] = {tau, zt * dinv};
-        DevBuf t3;
-        ZK_TRY(upload(t3, bs, sizeof(bs)));
+        bs3[0] = tau;
+        bs3[1] = zt * dinv;
+        ZK_TRY(upload(t3, bs3, sizeof(bs3)));
         if (n_h)
             ZK_LAUNCH(zkdev::k_fr_pow_table, dim3((unsigned)((n_h + 255) / 256)), dim3(256), 0, g_stream, eh.as<uint32_t>(),
                       (const uint32_t*)t3.as<uint32_t>(), (const uint32_t*)t3.as<uint32_t>() + 8, log_m, 2u, 1u, (uint32_t)n_h);
-        const Fr cs[4] = {alpha, beta, ginv, dinv};
+        cs[0] = alpha; cs[1] = beta; cs[2] = ginv; cs[3] = dinv;
         ZK_TRY(upload(consts, cs, sizeof(cs)));
         ZK_LAUNCH(zkdev::k_setup_qap, dim3((nv + 255) / 256), dim3(256), 0, g_stream, csc[0], csc[1], csc[2],
                   (const uint32_t*)lag.as<uint32_t>(), (const uint32_t*)consts.as<uint32_t>(), n_in, nv, n_con, ea.as<uint32_t>(),
@@ -176,9 +196,8 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
         HIP_TRY(hipStreamSynchronize(g_stream));
     }
     // vk scalars: alpha, beta, delta in G1; beta, gamma, delta in G2
-    const Fr vk1[3] = {alpha.from_mont(), beta.from_mont(), delta.from_mont()};
-    const Fr vk2[3] = {beta.from_mont(), gamma.from_mont(), delta.from_mont()};
-    DevBuf d_vk1, d_vk2;
+    vk1[0] = alpha.from_mont(); vk1[1] = beta.from_mont(); vk1[2] = delta.from_mont();
+    vk2[0] = beta.from_mont(); vk2[1] = gamma.from_mont(); vk2[2] = delta.from_mont();
     ZK_TRY(upload(d_vk1, vk1, sizeof(vk1)));
     ZK_TRY(upload(d_vk2, vk2, sizeof(vk2)));
 
@@ -242,9 +261,5 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
     *len = o.size();
     if (cap < o.size()) return fail(ZK_ERR_INVALID_ARGUMENT, "output buffer too small");
     memcpy(out, o.data(), o.size());
-    // the toxic waste does not outlive the call on the device (the buffers are freed next)
-    for (DevBuf* b : {&consts, &tmp2, &d_vk1, &d_vk2, &eh, &ea, &eb, &eext, &lag})
-        if (b->p) (void)hipMemsetAsync(b->p, 0, b->cap, g_stream);
-    (void)hipStreamSynchronize(g_stream);
-    return ZK_OK;
+    return ZK_OK;   // dev_wipe / host_wipe: the toxic waste does not outlive the call, on the device or on the host
 }

@@ -585,17 +585,25 @@ zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_
         const size_t np = std::min(VERIFY_CHUNK, n - first);
         const uint8_t* pr = proofs + first * 192;
         std::vector<uint32_t> g1((size_t)2 * np * 12), g2((size_t)np * 24), f1(2 * np), f2(np);
-        std::vector<uint8_t> enc(np, 0);   // first point whose ENCODING is refused on the host (1 = A, 2 = B, 3 = C)
+        std::vector<uint8_t> enc(np, 0);   // bit k: the ENCODING of point k (0 = A, 1 = B, 2 = C) is refused on the host
         for (size_t i = 0; i < np; i++) {
             const uint8_t* p = pr + i * 192;
-            if (!parse_g1_compressed(p, &g1[i * 12], &f1[i])) enc[i] = 1;
-            else if (!parse_g2_compressed(p + 48, &g2[i * 24], &f2[i])) enc[i] = 2;
-            else if (!parse_g1_compressed(p + 144, &g1[(np + i) * 12], &f1[np + i])) enc[i] = 3;
-            if (enc[i]) {
-                f1[i] = f1[np + i] = f2[i] = 1;   // decode nothing
+            // every point is parsed on its own: Proof::read finishes A (decode, curve, subgroup, infinity) before it
+            // touches B, so a device-side failure of A must win over a malformed B
+            if (!parse_g1_compressed(p, &g1[i * 12], &f1[i])) {
+                enc[i] |= 1;
+                f1[i] = 1;   // decode nothing
                 memset(&g1[i * 12], 0, 48);
-                memset(&g1[(np + i) * 12], 0, 48);
+            }
+            if (!parse_g2_compressed(p + 48, &g2[i * 24], &f2[i])) {
+                enc[i] |= 2;
+                f2[i] = 1;
                 memset(&g2[i * 24], 0, 96);
+            }
+            if (!parse_g1_compressed(p + 144, &g1[(np + i) * 12], &f1[np + i])) {
+                enc[i] |= 4;
+                f1[np + i] = 1;
+                memset(&g1[(np + i) * 12], 0, 48);
             }
         }
         ZK_TRY(upload(vk->in_g1, g1.data(), g1.size() * 4));
@@ -628,14 +636,14 @@ zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_
         HIP_TRY(hipMemcpy(s2.data(), vk->st_g2.p, np * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < np; i++) {
             uint8_t st = 0;
-            if (enc[i]) {
-                st = (uint8_t)(enc[i] | (ZK_PROOF_BAD_ENCODING << 2));
-            } else {
-                // the order Proof::read meets them in: A, B, C (core/bellman-verifier/src/lib.rs:67-110)
-                const uint32_t d[3] = {s1[i], s2[i], s1[np + i]};
-                for (int k = 0; k < 3 && !st; k++)
-                    if (d[k])   // decoder states 1 / 2 / 3 = not on the curve / not in the subgroup / infinity
-                        st = (uint8_t)((k + 1) | ((d[k] == 1 ? ZK_PROOF_NOT_ON_CURVE : d[k] == 2 ? ZK_PROOF_NOT_IN_SUBGROUP : ZK_PROOF_INFINITY) << 2));
+            // the order Proof::read meets them in: A, B, C, each point completely before the next
+            // (core/bellman-verifier/src/lib.rs:67-110): bad encoding, then the decoder's verdict on that point
+            const uint32_t d[3] = {s1[i], s2[i], s1[np + i]};
+            for (int k = 0; k < 3 && !st; k++) {
+                if (enc[i] & (1u << k))
+                    st = (uint8_t)((k + 1) | (ZK_PROOF_BAD_ENCODING << 2));
+                else if (d[k])   // decoder states 1 / 2 / 3 = not on the curve / not in the subgroup / infinity
+                    st = (uint8_t)((k + 1) | ((d[k] == 1 ? ZK_PROOF_NOT_ON_CURVE : d[k] == 2 ? ZK_PROOF_NOT_IN_SUBGROUP : ZK_PROOF_INFINITY) << 2));
             }
             status_out[first + i] = st;
         }

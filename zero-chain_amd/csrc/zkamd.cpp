@@ -224,11 +224,13 @@ constexpr uint32_t MSM_RED_FAN = 16;   // buckets per level-1 node and children 
 // (G1: 2-3 full additions of 14 products against a mixed addition of 10, plus the tree above;
 // G2: the same in Fq2, where the full addition no longer fits the register file).  `group` 1 / 2.
 uint32_t pick_window(size_t n, int group) {
-    const char* env = getenv(group == 2 ? "ZKAMD_WINDOW_BITS_G2" : "ZKAMD_WINDOW_BITS_G1");
+    const char* env = getenv(group == 2 ? "ZKAMD_WINDOW_BITS_G2" : group == 3 ? "ZKAMD_WINDOW_BITS_G1A" : "ZKAMD_WINDOW_BITS_G1");
     if (!env) env = getenv("ZKAMD_WINDOW_BITS");
     if (env && atoi(env) >= 2 && atoi(env) <= 22) return (uint32_t)atoi(env);
     const char* benv = getenv(group == 2 ? "ZKAMD_BUCKET_COST_G2" : "ZKAMD_BUCKET_COST_G1");
-    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 12.0 : 6.0);
+    // G1: 2.2 full additions of ~6 100 instructions per bucket in the assembly loop of level 1 plus the compiled levels
+    // above it, against 4 324 per mixed addition (round 3, compiled level 1: 6)
+    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 12.0 : 4.0);
     uint32_t best = 2;
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 22; c++) {
@@ -282,6 +284,26 @@ static bool asm_loop() { return false; }
 template <class DF>
 static void launch_asm_loop(const zkdev::Affine<DF>*, const uint32_t*, const uint4*, const uint32_t*, zkdev::XYZZ<DF>*, uint32_t*,
                             uint32_t*, unsigned, hipStream_t) {}
+// Level 1 of the bucket reduction as the generated assembly loop (msm.h k_msm_reduce1_g1asm): G1 only, unless
+// ZKAMD_G1_RED_ASM=0 (A/B switch) or the build has none (the x86 emulation build).
+template <class DF>
+static bool asm_reduce() { return false; }
+template <class DF>
+static void launch_red_asm(const zkdev::XYZZ<DF>*, const uint32_t*, const uint32_t*, const uint32_t*, zkdev::XYZZ<DF>*, zkdev::XYZZ<DF>*,
+                           uint32_t, uint32_t, dim3, hipStream_t) {}
+#ifdef ZK_HAVE_RED_ASM
+template <>
+bool asm_reduce<zkdev::Fq28>() {
+    static const bool on = !(getenv("ZKAMD_G1_RED_ASM") && atoi(getenv("ZKAMD_G1_RED_ASM")) == 0);
+    return on;
+}
+template <>
+void launch_red_asm<zkdev::Fq28>(const zkdev::XYZZ<zkdev::Fq28>* tsums, const uint32_t* cnt, const uint32_t* toff, const uint32_t* tbase,
+                                 zkdev::XYZZ<zkdev::Fq28>* S, zkdev::XYZZ<zkdev::Fq28>* A, uint32_t nb, uint32_t L, dim3 grid,
+                                 hipStream_t st) {
+    ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm, grid, dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L);
+}
+#endif
 #ifdef ZK_HAVE_MADD_ASM
 // workgroups per CU of the persistent form of the G1 loop (0 = one workgroup per 128 tasks, the plain launch)
 static int persist_wgs(int group = 1) {
@@ -451,7 +473,16 @@ struct MsmGroup {
             while (f > 4 && items / f < 32768) f >>= 1;
             return f;
         };
+        // launches large enough for the assembly loops (accumulation and level 1 of the reduction); tests set 0: every
+        // launch, however small, goes through them
+        const char* min_env = getenv("ZKAMD_ASM_MIN_PAIRS");
+        const bool big_launch = total >= (min_env ? (uint64_t)atoll(min_env) : 4000000ull);
+        // level 1 of the reduction in assembly: many-jobs launches only (the few-jobs tail folds level 1 differently)
+        const bool red_asm = asm_reduce<DF>() && big_launch && nj > MSM_FEW_JOBS;
         uint32_t L = pick_fan((uint64_t)nj * nb);
+        if (red_asm)
+            if (const char* env = getenv("ZKAMD_RED_NODE"))   // buckets per node of the assembly loop (a power of two)
+                if (atoi(env) >= 2 && atoi(env) <= 256 && !(atoi(env) & (atoi(env) - 1))) L = (uint32_t)atoi(env);
         if (L > nb) L = nb;
         const uint32_t T = nb / L;
         ZK_TRY(red_r.ensure(nj * ((size_t)nb + 2 * (size_t)T) * sizeof(DPoint)));   // suffix sums: level 1 | two upper-level areas
@@ -534,8 +565,7 @@ struct MsmGroup {
             static const bool wide_g2 = !(getenv("ZKAMD_G2_ACC_OCC") && atoi(getenv("ZKAMD_G2_ACC_OCC")) == 2);
             // the assembly loops are built for launches that fill the machine; a proof made alone (one or two jobs, 16- or
             // 32-point tasks: `total` below the short-task threshold above) keeps the compiled kernel and saves the second launch
-            const char* min_env = getenv("ZKAMD_ASM_MIN_PAIRS");   // tests set 0: every launch, however small, through the assembly loop
-            if (asm_loop<DF>() && total >= (min_env ? (uint64_t)atoll(min_env) : 4000000ull)) {
+            if (asm_loop<DF>() && big_launch) {
                 // the generated assembly loop (msm.h, madd_asm.h), then the compiled loop over the few tasks it flagged
                 ZK_TRY(redo.ensure((size_t)total_tasks * 4));
                 launch_asm_loop(table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>(), d_nredo,
@@ -578,22 +608,45 @@ struct MsmGroup {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_reduce_g2" : "msm_reduce_g1", st);
             auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
             const uint32_t heavy_blocks = (uint32_t)std::min<size_t>(heavy_cap, few ? 512 : 4096);
-            const uint32_t light_buckets = few ? (uint32_t)n_buckets : 0u;
+            // (the assembly loop of level 1 takes ONE partial per bucket: every multi-task bucket is merged here first)
+            const uint32_t light_buckets = few || red_asm ? (uint32_t)n_buckets : 0u;
             ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>,
                            dim3(heavy_blocks + (light_buckets + zkdev::MSM_MERGE_THREADS - 1) / zkdev::MSM_MERGE_THREADS),
                            dim3(zkdev::MSM_MERGE_THREADS), 0, st, (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy,
                            (const uint32_t*)cnt.as<uint32_t>(), (const uint32_t*)toff.as<uint32_t>(),
                            (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg, heavy_blocks, light_buckets,
                            merge_inline);
-            // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
-            ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
-                      toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, few ? 0u : merge_inline, seg);
-            ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
-                      1u, 1u, 1u);
             uint32_t n = T, m = L, stride = L;   // n nodes per job of m buckets each; S(node k) = R[k * stride]
             DPoint* Rcur = R;
             DPoint* Rnext = R + nj * (size_t)nb;       // upper levels ping-pong between two areas behind level 1
             DPoint* Rspare = Rnext + nj * (size_t)T;
+            if (red_asm) {
+                // level 1 in assembly: S = R_0 (compact, one per node) and A = sum_{k>=1} R_k; then the first level above
+                // it, which forms W(parent) = 2M sum_{k>=1} R'_k + 2 sum_k A_k + R'_0 (msm.h k_msm_level2_acc) - run even
+                // for a single node per job, where it is just W = 2 A + S
+                launch_red_asm<DF>(tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(), R, Wa, nb, L,
+                                   grid(T), st);
+                const uint32_t fan = pick_fan((uint64_t)nj * n), n_out = (n + fan - 1) / fan;
+                uint32_t log2_2m = 1;
+                while ((1u << (log2_2m - 1)) < m) log2_2m++;
+                ZK_LAUNCH(zkdev::k_msm_suffix<DF>, grid(n_out), dim3(64), 0, st, (const DPoint*)R, Rnext, n, fan, 1u);
+                ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(n_out), dim3(64), 0, st, (const DPoint*)Rnext, (const DPoint*)nullptr,
+                          red_t.as<DPoint>(), n, fan, 1u, log2_2m, 0u);
+                ZK_LAUNCH(zkdev::k_msm_level2_acc<DF>, grid(n_out), dim3(64), 0, st, (const DPoint*)Wa, (const DPoint*)Rnext,
+                          (const DPoint*)red_t.as<DPoint>(), Wb, n, fan);
+                in = Wb;
+                Rcur = Rnext;
+                std::swap(Rnext, Rspare);
+                stride = fan;
+                m *= fan;
+                n = n_out;
+            } else {
+                // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
+                ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
+                          toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, few ? 0u : merge_inline, seg);
+                ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
+                          1u, 1u, 1u);
+            }
             if (few && T >= 2 && !getenv("ZKAMD_NO_BITSUM")) {
                 // few large jobs: fold the T nodes of level 1 at once (msm.h, k_msm_bitsum)
                 uint32_t nbits = 0, log2_2l = 1;
@@ -765,6 +818,12 @@ struct zk_params {
     // offsets of each query inside the G1 group table (window slice 0)
     uint32_t off_h = 0, off_l = 0, off_a = 0, off_b1 = 0;
     MsmG1 g1;
+    // The two G1 jobs of a proof differ fourfold in size (A: ~15.6 k terms, C' = H + L + r B1: ~65 k for the transfer
+    // circuit), so a batch runs them as TWO launch sets over the same doubling table, each with the recoding width of its
+    // own size (one width for both held the large job at c = 15).  g1 = the C' set; g1a = the A set;
+    // g1_lone = both jobs in one set under the width of their average, for a few proofs made alone (fewer launches).
+    MsmG1 g1a, g1_lone;
+    bool split_g1 = true;
     MsmG2 g2;
     // the G2 group again over the SAME table with a narrower recoding, for a proof made alone: its side stream is the
     // critical path and the depth of the bucket reduction (bit planes, doublings) is what it waits for - 256 buckets
@@ -785,8 +844,8 @@ struct zk_params {
     // vk points bellman accepts at infinity (VerifyingKey::read does not reject them)
     bool alpha_g1_inf = false, beta_g1_inf = false, beta_g2_inf = false, delta_g1_inf = false, delta_g2_inf = false;
     std::vector<uint8_t> vk_bytes;   // VerifyingKey::write of the key (the head of the parameter file)
-    std::vector<MsmJob> jobs1, jobs2;
-    std::vector<HG1> res1;
+    std::vector<MsmJob> jobs1, jobs1a, jobs2;
+    std::vector<HG1> res1, res1a;
     std::vector<HG2> res2;
 };
 
@@ -865,11 +924,14 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
         ZK_TRY((check_points_host<zkhost::Fq, zkdev::Fq>(vk1, "vk (G1: ic | alpha | beta | delta)")));
         ZK_TRY((check_points_host<zkhost::Fq2, DevFq2>(std::vector<HG2A>{beta_g2, gamma_g2, delta_g2}, "vk (G2: beta | gamma | delta)")));
     }
-    // one width per group: the G1 jobs of a proof (H, L, A, B1) average a quarter of the G1 terms
-    // two G1 jobs per proof: A, and the merged C' = H + L + r * B1
-    const uint32_t c1 = pick_window(((size_t)P->n_h + P->n_l + P->n_a + P->n_b1) / 2, 1);
+    // two G1 jobs per proof: A, and the merged C' = H + L + r * B1 - each with the width of its own size
+    const uint32_t c_avg = pick_window(((size_t)P->n_h + P->n_l + P->n_a + P->n_b1) / 2, 1);
+    P->split_g1 = !(getenv("ZKAMD_SPLIT_G1") && atoi(getenv("ZKAMD_SPLIT_G1")) == 0);
+    const uint32_t c1 = P->split_g1 ? pick_window((size_t)P->n_h + P->n_l + P->n_b1, 1) : c_avg;
     const uint32_t c2 = pick_window(P->n_b2, 2);
     ZK_TRY(P->g1.build(pts1, c1, checked != 0, "parameters (G1)"));
+    P->g1a.alias(P->g1, pick_window(P->n_a, 3));
+    P->g1_lone.alias(P->g1, c_avg);
     ZK_TRY(P->g2.build(pts2, c2, checked != 0, "parameters (G2)"));
     P->g2_lone.alias(P->g2, getenv("ZKAMD_WINDOW_BITS_G2") || c2 <= 10 ? c2 : 10u);
     ZK_TRY(P->ntt.init(P->log_m));
@@ -888,8 +950,10 @@ zk_params* params_clone_for_lane(const zk_params* P) {
     Q->log_m = P->log_m;
     Q->m = P->m;
     Q->off_h = P->off_h; Q->off_l = P->off_l; Q->off_a = P->off_a; Q->off_b1 = P->off_b1;
-    Q->g1.c = P->g1.c; Q->g1.maxd = P->g1.maxd; Q->g1.nb = P->g1.nb; Q->g1.n_points = P->g1.n_points;
-    Q->g1.table.borrow(P->g1.table);
+    Q->g1.alias(P->g1, P->g1.c);
+    Q->g1a.alias(P->g1, P->g1a.c);
+    Q->g1_lone.alias(P->g1, P->g1_lone.c);
+    Q->split_g1 = P->split_g1;
     Q->g2.c = P->g2.c; Q->g2.maxd = P->g2.maxd; Q->g2.nb = P->g2.nb; Q->g2.n_points = P->g2.n_points;
     Q->g2.table.borrow(P->g2.table);
     Q->g2_lone.alias(P->g2, P->g2_lone.c);
@@ -1074,37 +1138,58 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     // scaled coefficients of c (same bit-reversed order); in place inside the merged scalar vectors
     ZK_TRY(P->ntt.chain(cvec, (uint32_t)np, cstride, true, true, nullptr, P->ntt.s2.as<uint32_t>(), nullptr, 0, 0, nullptr,
                         (const uint32_t*)C, (uint32_t)m));
-    // job order: all C' jobs, then all A jobs.  Workgroup i of a launch runs on XCD i mod 8 and the
-    // sort is one workgroup per job: alternating A, C' (a fifth against four fifths of the scalars)
-    // put every large job on the odd XCDs.  Largest first also keeps the tail of the launch short.
+    // A batch runs the two G1 jobs of its proofs as two launch sets, each under the recoding width of its own size: the
+    // C' jobs (65 k terms) here on the main stream behind the H pipeline, the A jobs (15.6 k terms, witness scalars only)
+    // on the side stream behind the G2 set (ZKAMD_G1A_STREAM=main: behind the C' set).  A few proofs made alone keep
+    // ONE set (fewer launches on their critical path): all C' jobs, then all A jobs - workgroup i of a launch runs on XCD
+    // i mod 8 and the sort is one workgroup per job, so alternating A, C' would put every large job on the odd XCDs.
+    const size_t split_min = getenv("ZKAMD_SPLIT_MIN") ? (size_t)atoll(getenv("ZKAMD_SPLIT_MIN")) : 64;   // tests: 1
+    const bool split = P->split_g1 && np >= split_min;
+    MsmG1& G1C = split ? P->g1 : P->g1_lone;
     for (size_t p = 0; p < np; p++) {
         MsmJob jc = {cvec + p * (size_t)cstride * 8, P->map_c.as<int32_t>(), cstride, 0, npts1, 0, 0, 0};
         P->jobs1.push_back(jc);
     }
+    P->jobs1a.clear();
     for (size_t p = 0; p < np; p++) {
         const uint32_t* w = wit + p * wstride * 8;
         MsmJob ja = {w, P->map_a.as<int32_t>(), nv + 3, P->off_a, npts1, 0, 0, 0};
-        P->jobs1.push_back(ja);
+        (split ? P->jobs1a : P->jobs1).push_back(ja);
     }
-    ZK_TRY(P->g1.enqueue(P->jobs1, P->res1, g_stream, false));
+    typedef zkdev::XYZZ<zkdev::Fq> DP1;
+    const DP1* a_dev = nullptr;
+    if (split) {
+        const bool a_on_main = getenv("ZKAMD_G1A_STREAM") && !strcmp(getenv("ZKAMD_G1A_STREAM"), "main");
+        const hipStream_t sa = a_on_main ? g_stream : side;
+        if (a_on_main) ZK_TRY(G1C.enqueue(P->jobs1, P->res1, g_stream, false));
+        ZK_TRY(P->g1a.enqueue(P->jobs1a, P->res1a, sa, false));
+        a_dev = P->g1a.res_dev;
+        if (!a_on_main) {
+            HIP_TRY(hipEventRecord(g_ev_join, sa));
+            ZK_TRY(G1C.enqueue(P->jobs1, P->res1, g_stream, false));
+            HIP_TRY(hipStreamWaitEvent(g_stream, g_ev_join, 0));   // (a no-op when ZKAMD_NO_OVERLAP made the side stream the main one)
+        }
+    } else {
+        ZK_TRY(G1C.enqueue(P->jobs1, P->res1, g_stream, false));
+        a_dev = G1C.res_dev + np;
+    }
     // ---- final fold on the GPU: C = s * A + C' (k_xyzz_scale_add), A and C to affine form; the host
     // only encodes.  (On the host the fold was 0.47 ms per proof with the GPU idle: 8 % of the step.)
     {
-        typedef zkdev::XYZZ<zkdev::Fq> DP1;
         ProfScope ps("proof_fold", g_stream);
         ZK_TRY(P->fold_tbl.ensure(np * 15 * sizeof(DP1)));
         ZK_TRY(P->fold_c.ensure(np * sizeof(DP1)));
-        const DP1* cprime = P->g1.res_dev;
-        const DP1* a = P->g1.res_dev + np;
+        const DP1* cprime = G1C.res_dev;
+        const DP1* a = a_dev;
         ZK_LAUNCH(zkdev::k_xyzz_scale_add<zkdev::Fq>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, a, cprime,
                   (const uint32_t*)P->tail.as<uint32_t>() + 16, 24u, P->fold_tbl.as<DP1>(), P->fold_c.as<DP1>(), (uint32_t)np);
-        ZK_TRY(P->g1.normalize2_to_host(a, P->fold_c.as<DP1>(), np, P->pin_g1.as<HG1>() + np, P->pin_g1.as<HG1>(), P->fold_a1, P->fold_c1,
-                                        g_stream));
+        ZK_TRY(G1C.normalize2_to_host(a, P->fold_c.as<DP1>(), np, P->pin_g1.as<HG1>() + np, P->pin_g1.as<HG1>(), P->fold_a1, P->fold_c1,
+                                      g_stream));
     }
     HIP_TRY(hipMemcpyAsync(P->pin_bad.p, bad, 8, hipMemcpyDeviceToHost, g_stream));
     const bool trace_host = getenv("ZKAMD_TRACE_HOST") != nullptr;
     const auto t_wait = std::chrono::steady_clock::now();
-    ZK_TRY(P->g1.collect(g_stream));
+    ZK_TRY(G1C.collect(g_stream));
     ZK_TRY(G2.collect(side));
     {
         // the reference cannot even represent these assignments (FrRepr -> Fr fails for values >= r,
@@ -1809,6 +1894,14 @@ zk_status zk_params_get_info(const zk_params* p, zk_params_info* info) {
     info->device_bytes = p->g1.bytes + p->g2.bytes + p->ntt.bytes;
     return ZK_OK;
 }
+zk_status zk_params_get_windows(const zk_params* p, uint32_t out[4]) {
+    if (!p || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    out[0] = p->g1.c;
+    out[1] = p->split_g1 ? p->g1a.c : p->g1.c;
+    out[2] = p->g1_lone.c;
+    out[3] = p->g2.c;
+    return ZK_OK;
+}
 void zk_params_free(zk_params* p) { delete p; }
 zk_status zk_params_write_vk(const zk_params* p, uint8_t* out, size_t cap, size_t* len) {
     if (!p || !len) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
@@ -2159,7 +2252,8 @@ zk_status decode_prime_order(const uint8_t b[32], zkwit::JPoint* out, const std:
 // entry); gen_proof leaves both to the witness kernels of the chunk (witness_gpu_enqueue typed_inputs: same refusals,
 // reported by witness_gpu_finish before the chunk is proved).
 zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_transfer_statement* st, uint8_t rsk[32], bool check_points) {
-    uint64_t sk[4], alpha[4], rnd[4];
+    uint64_t sk[4], alpha[4], rnd[4], r[4] = {0, 0, 0, 0};
+    WipeOnExit wipe_sk{sk, sizeof(sk)}, wipe_alpha{alpha, sizeof(alpha)}, wipe_rnd{rnd, sizeof(rnd)}, wipe_r{r, sizeof(r)};   // every exit path
     load_scalar_le(rq.spending_key, sk);
     load_scalar_le(rq.alpha, alpha);
     load_scalar_le(rq.randomness, rnd);
@@ -2191,11 +2285,8 @@ zk_status transfer_derive_one(const zk_transfer_request& rq, size_t index, zk_tr
     memcpy(st->enc_balance_left, rq.enc_balance_left, 32);
     memcpy(st->enc_balance_right, rq.enc_balance_right, 32);
     memcpy(st->g_epoch, rq.g_epoch, 32);
-    uint64_t r[4];
     fs_add(sk, alpha, r);   // PrivateKey(sk).randomize(alpha)
     memcpy(rsk, r, 32);
-    explicit_bzero(sk, sizeof(sk));
-    explicit_bzero(r, sizeof(r));
     return ZK_OK;
 }
 zk_status transfer_derive(const zk_transfer_request* rq, size_t n, zk_transfer_statement* st, uint8_t* rsk, bool check_points) {
@@ -2572,7 +2663,8 @@ struct zk_pipeline {
     zk_params* Pl[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     zk_r1cs* Rl[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     std::thread t_lane[MAX_LANES];
-    int n_lanes = 1;
+    int n_lanes = 1;      // lanes started at create
+    int live_lanes = 1;   // ... minus the ones that retired when their workspaces did not fit (mu held)
     size_t chunk = 1024, nv = 0;
     PinBuf buf[2];
     std::mutex mu;
@@ -2654,12 +2746,14 @@ struct zk_pipeline {
                 lk.unlock();
                 cur.slot = slot;
                 if (!skip) rc = start(cur, slot);
+                // test hook: a lane beyond the first behaves as if its workspaces did not fit (tests/test_gpu_parity.py)
+                if (!skip && lane > 0 && getenv("ZKAMD_INJECT_LANE_OOM")) rc = fail(ZK_ERR_OUT_OF_MEMORY, "injected: lane workspaces do not fit");
             }
             bool have_nxt = false;
             {
                 // (with several lanes a job is only taken ahead of time if the other lanes still find one each)
                 std::lock_guard<std::mutex> lk(mu);
-                if (q_wit.size() >= (size_t)n_lanes) {
+                if (q_wit.size() >= (size_t)live_lanes) {
                     nxt = q_wit.front();
                     q_wit.pop_front();
                     have_nxt = true;
@@ -2676,6 +2770,26 @@ struct zk_pipeline {
             if (!skip && rc == ZK_OK) rc = prove_from_z(P, R, cur.n, cur.slot, cur.rs, cur.out);
             // nothing of a failed job stays in flight when wait() returns: drain the device BEFORE the job is counted done
             if (rc != ZK_OK || rc_next != ZK_OK) (void)hipDeviceSynchronize();
+            if (lane > 0 && (rc == ZK_ERR_OUT_OF_MEMORY || rc_next == ZK_ERR_OUT_OF_MEMORY)) {
+                // The workspaces of a lane are allocated when it proves its first chunk; the free-memory estimate at
+                // create is only a hint (two ranks on one GPU see the same free bytes - ADVICE r3).  A lane beyond the
+                // first that does not get its memory hands its jobs back, releases what it holds and retires: the
+                // pipeline degrades to fewer lanes instead of failing in the middle of a batch.
+                std::unique_lock<std::mutex> lk(mu);
+                if (have_nxt) q_wit.push_front(nxt);
+                q_wit.push_front(cur);
+                live_lanes--;
+                zk_params* mine = Pl[lane];
+                zk_r1cs* mine_r = Rl[lane];
+                Pl[lane] = nullptr;
+                Rl[lane] = nullptr;
+                lk.unlock();
+                delete mine;      // borrowed tables stay with the original, the lane's own buffers are freed
+                delete mine_r;
+                std::lock_guard<std::mutex> lk2(mu);
+                cv.notify_all();
+                return;
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 if (rc != ZK_OK) fail_with(rc, g_err);
@@ -2745,9 +2859,11 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
         lanes = 1;   // the test-only emulation runs one launch at a time
 #endif
         if (lanes > zk_pipeline::MAX_LANES) lanes = zk_pipeline::MAX_LANES;
-        // Every lane allocates its chunk workspaces the first time it proves (~36 MB per proof of a chunk: 35 GB at 1024).
-        // Lanes that would not fit the device's free memory are not started (several ranks sharing one GPU,
-        // or a device with other tenants, must degrade to fewer lanes instead of failing in the middle of a batch).
+        // Every lane allocates its chunk workspaces the first time it proves (~36 MB per proof of a transfer-circuit chunk:
+        // 35 GB at 1024).  The free memory seen here only caps the number of lanes STARTED (a hint: it is check-then-
+        // allocate, and another process may take the memory in between); it never refuses the pipeline - lane 0 lets the
+        // real allocation report OutOfMemory, and a further lane whose allocation fails later hands its jobs back and
+        // retires (run_gpu_witness).  A zk_params that has proved before already holds lane 0's workspaces.
 #ifndef ZK_EMU
         {
             size_t free_b = 0, total_b = 0;
@@ -2756,16 +2872,14 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
                 if (const char* env = getenv("ZKAMD_LANE_BYTES"))
                     if (atoll(env) > 0) per_lane = (size_t)atoll(env);
                 const size_t reserve = (size_t)2 << 30;
-                const size_t fit = free_b > reserve ? (free_b - reserve) / per_lane : 0;
-                if (fit < 1) {
-                    delete L;
-                    return fail(ZK_ERR_OUT_OF_MEMORY, "device memory: " + std::to_string(free_b >> 20) + " MiB free, one pipeline lane needs about " +
-                                                          std::to_string(per_lane >> 20) + " MiB");
-                }
+                const size_t avail = free_b > reserve ? free_b - reserve : 0;
+                const size_t lane0 = p->abc.p ? 0 : per_lane;       // nothing more to allocate once it has proved a chunk
+                const size_t fit = 1 + (avail > lane0 ? (avail - lane0) / per_lane : 0);
                 if ((size_t)lanes > fit) lanes = (int)fit;
             }
         }
 #endif
+        if (lanes < 1) lanes = 1;
         for (int l = 1; l < lanes; l++) {
             L->Pl[l] = params_clone_for_lane(p);
             L->Rl[l] = r1cs_clone_for_lane(circuit);
@@ -2778,6 +2892,7 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
             }
             L->n_lanes = l + 1;
         }
+        L->live_lanes = L->n_lanes;
         try {
             L->t_gpu = std::thread([L] { L->run_gpu_witness(0); });
             for (int l = 1; l < L->n_lanes; l++) L->t_lane[l] = std::thread([L, l] { L->run_gpu_witness(l); });
@@ -2805,7 +2920,11 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
     return ZK_OK;
 }
 
-int zk_pipeline_lanes(const zk_pipeline* L) { return L ? L->n_lanes : 0; }
+int zk_pipeline_lanes(const zk_pipeline* L) {
+    if (!L) return 0;
+    std::lock_guard<std::mutex> lk(const_cast<zk_pipeline*>(L)->mu);
+    return L->live_lanes;
+}
 
 zk_status zk_pipeline_submit(zk_pipeline* L, size_t n, const zk_transfer_statement* st, const uint8_t* rs, uint8_t* proofs_out) {
     if (!L || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
