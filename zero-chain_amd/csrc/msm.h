@@ -541,7 +541,7 @@ static __global__ void __launch_bounds__(256)
 k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff,
                  const uint32_t* __restrict__ task_base, const uint32_t* __restrict__ base, uint32_t* cursor,
                  uint4* sorted, uint32_t* n_heavy, uint32_t* heavy, uint32_t nb, uint32_t nj, uint32_t merge_inline,
-                 uint32_t seg) {
+                 uint32_t seg, uint32_t* n_light, uint32_t* light) {
     ZK_SHARED uint32_t h[MSM_SEG_MAX];
     ZK_SHARED uint32_t start[MSM_SEG_MAX];
     const uint32_t tid = threadIdx.x, job = blockIdx.y;
@@ -562,6 +562,7 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
     }
     __syncthreads();
     if (tc.n_long + tc.n_short > merge_inline) heavy[atomicAdd(n_heavy, 1u)] = job * nb + b;
+    else if (light && tc.n_long + tc.n_short > 1) light[atomicAdd(n_light, 1u)] = job * nb + b;   // 2 .. merge_inline partials
     if (tc.n_long + tc.n_short) {
         const uint32_t o = off[(size_t)job * nb + b], ti = task_base[job] + toff[(size_t)job * nb + b];
         if (tc.n_long) {
@@ -849,7 +850,7 @@ ZK_DI XYZZ<Fq28> red_asm_point(const u32x16& x, const u32x16& y, const u32x16& z
 static __global__ void __launch_bounds__(64, 2)
 k_msm_reduce1_g1asm(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
                     const uint32_t* __restrict__ task_base, XYZZ<Fq28>* __restrict__ S, XYZZ<Fq28>* __restrict__ A, uint32_t nb,
-                    uint32_t L) {
+                    uint32_t L, uint32_t* __restrict__ n_fallback) {
     static_assert(ZK_RED_G1_VGPRS <= 256, "the loop must fit two waves per SIMD");
     static_assert(sizeof(XYZZ<Fq28>) == 224, "the loop loads 224-byte partial sums");
     const uint32_t T = nb / L;
@@ -878,6 +879,7 @@ k_msm_reduce1_g1asm(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __rest
     XYZZ<Fq28> acc = red_asm_point(AX, AY, AZZ, AZZZ, (flags & ZK_RED_FLAG_ACC_INF) != 0, (flags & ZK_RED_FLAG_ACC_RAW) != 0);
     if ((!(flags & ZK_RED_FLAG_RUN_INF) && run.zz.is_zero_norm()) || (!(flags & ZK_RED_FLAG_ACC_INF) && acc.zz.is_zero_norm())) {
         // a special case somewhere in the node (or a bucket whose points cancelled): the compiled addition knows them all
+        atomicAdd(n_fallback, 1u);   // diagnostics (ZKAMD_DEBUG_REDO)
         run = XYZZ<Fq28>::inf();
         acc = XYZZ<Fq28>::inf();
         for (int k = (int)L - 1; k >= 0; k--) {
@@ -986,6 +988,25 @@ k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict
     }
 }
 
+
+// Pass 5c for the many-jobs launches: the buckets with 2 .. merge_inline partials (the small magnitudes that collect the
+// top digits of the recoding: ~30 of a job's 8 192 buckets, ~60 000 per launch set) are LISTED by k_msm_task_place and
+// merged here, one thread per listed bucket, every lane busy.  Left to the level-1 threads of the reduction they cost a
+// serial chain of additions in one lane of a wave while its 63 neighbours wait (k_msm_suffix_buckets: 10.9 ms per launch
+// set, the same again when every bucket's thread only looked whether it had something to merge: profiles/r04d).
+template <class F>
+static __global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_merge_light(const uint32_t* __restrict__ light, const uint32_t* __restrict__ n_light, const uint32_t* __restrict__ cnt,
+                  const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb, uint32_t seg) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_light[0]; i += gridDim.x * blockDim.x) {
+        const uint32_t gb = light[i];
+        const uint32_t nt_b = (cnt[gb] + seg - 1) / seg;
+        XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
+        XYZZ<F> acc = ts[0];
+        for (uint32_t u = 1; u < nt_b; u++) acc = xadd(acc, ts[u]);
+        ts[0] = acc;
+    }
+}
 
 // Pass 5c (few jobs only, the trailing workgroups of k_msm_merge_heavy): one thread per bucket sums the
 // 2 .. merge_inline partials of a bucket into its first partial, so that the level-1 threads of the

@@ -230,7 +230,9 @@ uint32_t pick_window(size_t n, int group) {
     const char* benv = getenv(group == 2 ? "ZKAMD_BUCKET_COST_G2" : "ZKAMD_BUCKET_COST_G1");
     // G1: 2.2 full additions of ~6 100 instructions per bucket in the assembly loop of level 1 plus the compiled levels
     // above it, against 4 324 per mixed addition (round 3, compiled level 1: 6)
-    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 12.0 : 4.0);
+    // (group 3, the small A jobs of a split batch: their reduction is half latency - the levels above the assembly loop -
+    //  so a bucket weighs more; 14 and 15 measured the same, profiles/r04_experiments.txt r04g: the narrower one it is)
+    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 12.0 : group == 3 ? 6.0 : 4.0);
     uint32_t best = 2;
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 22; c++) {
@@ -290,7 +292,7 @@ template <class DF>
 static bool asm_reduce() { return false; }
 template <class DF>
 static void launch_red_asm(const zkdev::XYZZ<DF>*, const uint32_t*, const uint32_t*, const uint32_t*, zkdev::XYZZ<DF>*, zkdev::XYZZ<DF>*,
-                           uint32_t, uint32_t, dim3, hipStream_t) {}
+                           uint32_t, uint32_t, dim3, hipStream_t, uint32_t*) {}
 #ifdef ZK_HAVE_RED_ASM
 template <>
 bool asm_reduce<zkdev::Fq28>() {
@@ -300,8 +302,8 @@ bool asm_reduce<zkdev::Fq28>() {
 template <>
 void launch_red_asm<zkdev::Fq28>(const zkdev::XYZZ<zkdev::Fq28>* tsums, const uint32_t* cnt, const uint32_t* toff, const uint32_t* tbase,
                                  zkdev::XYZZ<zkdev::Fq28>* S, zkdev::XYZZ<zkdev::Fq28>* A, uint32_t nb, uint32_t L, dim3 grid,
-                                 hipStream_t st) {
-    ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm, grid, dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L);
+                                 hipStream_t st, uint32_t* n_fallback) {
+    ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm, grid, dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L, n_fallback);
 }
 #endif
 #ifdef ZK_HAVE_MADD_ASM
@@ -362,7 +364,7 @@ struct MsmGroup {
     uint32_t c = 0, maxd = 0, nb = 0;
     size_t n_points = 0;
     DevBuf table;
-    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, blockbase, coarse, tbase, rank, pairs, tsums, red_r, red_w, red_t, result, redo;
+    DevBuf jobs_d, cnt, off, toff, ntasks, hist, tclass, sorted, heavy, light, blockbase, coarse, tbase, rank, pairs, tsums, red_r, red_w, red_t, result, redo;
     DPoint* res_dev = nullptr;
     PinBuf pin_jobs;
     std::vector<uint32_t> tbase_h;
@@ -457,11 +459,15 @@ struct MsmGroup {
         ZK_TRY(toff.ensure(n_buckets * 4));
         ZK_TRY(ntasks.ensure(nj * 4));
         ZK_TRY(tbase.ensure(nj * 4));
-        ZK_TRY(hist.ensure((2 * n_class + 4) * 4));     // [length histogram | placement cursors | total | #heavy | #redo | next task block]
+        ZK_TRY(hist.ensure((2 * n_class + 6) * 4));     // [length histogram | placement cursors | total | #heavy | #redo | next task block | #light | #level-1 nodes recomputed]
         const bool few = nj <= MSM_FEW_JOBS;   // latency-optimised bucket reduction (msm.h, passes 5c and 6)
         const uint32_t merge_inline = nj >= 64 || few ? 8u : 2u;
         const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
         ZK_TRY(heavy.ensure(heavy_cap * 4));
+        // buckets with 2 .. merge_inline task partials (each holds more than seg pairs): listed for k_msm_merge_light
+        const bool use_light = !few;
+        const size_t light_cap = (size_t)(total / seg) + 1;
+        if (use_light) ZK_TRY(light.ensure(light_cap * 4));
         ZK_TRY(tclass.ensure(n_class * 4));
         ZK_TRY(sorted.ensure((size_t)total_tasks * sizeof(uint4)));
         ZK_TRY(tsums.ensure((size_t)total_tasks * sizeof(DPoint)));
@@ -480,9 +486,13 @@ struct MsmGroup {
         // level 1 of the reduction in assembly: many-jobs launches only (the few-jobs tail folds level 1 differently)
         const bool red_asm = asm_reduce<DF>() && big_launch && nj > MSM_FEW_JOBS;
         uint32_t L = pick_fan((uint64_t)nj * nb);
-        if (red_asm)
-            if (const char* env = getenv("ZKAMD_RED_NODE"))   // buckets per node of the assembly loop (a power of two)
+        if (red_asm) {
+            // buckets per node of the assembly loop (a power of two): 32 - half the nodes for the compiled levels above
+            // it, still eight generations of waves per launch (16 / 32 / 64 measured within noise, r04g)
+            L = 32;
+            if (const char* env = getenv("ZKAMD_RED_NODE"))
                 if (atoi(env) >= 2 && atoi(env) <= 256 && !(atoi(env) & (atoi(env) - 1))) L = (uint32_t)atoi(env);
+        }
         if (L > nb) L = nb;
         const uint32_t T = nb / L;
         ZK_TRY(red_r.ensure(nj * ((size_t)nb + 2 * (size_t)T) * sizeof(DPoint)));   // suffix sums: level 1 | two upper-level areas
@@ -494,12 +504,14 @@ struct MsmGroup {
         memcpy((uint8_t*)pin_jobs.p + nj * sizeof(MsmJob), tbase_h.data(), nj * 4);
         HIP_TRY(hipMemcpyAsync(jobs_d.p, pin_jobs.p, nj * sizeof(MsmJob), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(tbase.p, (const uint8_t*)pin_jobs.p + nj * sizeof(MsmJob), nj * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 4) * 4, st));
+        HIP_TRY(hipMemsetAsync(hist.p, 0, (2 * n_class + 6) * 4, st));
         uint32_t* lenhist = hist.as<uint32_t>();
         uint32_t* cursor = lenhist + n_class;
         uint32_t* d_total = cursor + n_class;
         uint32_t* d_nheavy = d_total + 1;
         uint32_t* d_nredo = d_total + 2;
+        uint32_t* d_nlight = d_total + 4;
+        uint32_t* d_nfallback = d_total + 5;
         const MsmJob* dj = jobs_d.as<MsmJob>();
         dim3 gridn((max_n + 255) / 256, (unsigned)nj);
         dim3 gridb((nb + 255) / 256, (unsigned)nj);
@@ -557,7 +569,8 @@ struct MsmGroup {
                            (uint32_t)nj, seg);
             ZK_LAUNCH_SYNC(zkdev::k_msm_task_place, gridb, dim3(256), 0, st, cnt.as<uint32_t>(), off.as<uint32_t>(),
                            toff.as<uint32_t>(), tbase.as<uint32_t>(), tclass.as<uint32_t>(), cursor, sorted.as<uint4>(), d_nheavy,
-                           heavy.as<uint32_t>(), nb, (uint32_t)nj, merge_inline, seg);
+                           heavy.as<uint32_t>(), nb, (uint32_t)nj, merge_inline, seg, d_nlight,
+                           use_light ? light.as<uint32_t>() : (uint32_t*)nullptr);
         }
         {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_accumulate_g2" : "msm_accumulate_g1", st);
@@ -608,14 +621,19 @@ struct MsmGroup {
             ProfScope ps(zkdev::HostWords<DF>::N > 12 ? "msm_reduce_g2" : "msm_reduce_g1", st);
             auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
             const uint32_t heavy_blocks = (uint32_t)std::min<size_t>(heavy_cap, few ? 512 : 4096);
-            // (the assembly loop of level 1 takes ONE partial per bucket: every multi-task bucket is merged here first)
-            const uint32_t light_buckets = few || red_asm ? (uint32_t)n_buckets : 0u;
+            const uint32_t light_buckets = few ? (uint32_t)n_buckets : 0u;
             ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>,
                            dim3(heavy_blocks + (light_buckets + zkdev::MSM_MERGE_THREADS - 1) / zkdev::MSM_MERGE_THREADS),
                            dim3(zkdev::MSM_MERGE_THREADS), 0, st, (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy,
                            (const uint32_t*)cnt.as<uint32_t>(), (const uint32_t*)toff.as<uint32_t>(),
                            (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg, heavy_blocks, light_buckets,
                            merge_inline);
+            // the listed buckets with 2 .. merge_inline partials, one thread each (the heavier ones above): level 1 then
+            // meets ONE partial per bucket
+            if (use_light)
+                ZK_LAUNCH_SYNC(zkdev::k_msm_merge_light<DF>, dim3((unsigned)std::min<size_t>((light_cap + 63) / 64, 2048)), dim3(64), 0, st,
+                               (const uint32_t*)light.as<uint32_t>(), (const uint32_t*)d_nlight, (const uint32_t*)cnt.as<uint32_t>(),
+                               (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg);
             uint32_t n = T, m = L, stride = L;   // n nodes per job of m buckets each; S(node k) = R[k * stride]
             DPoint* Rcur = R;
             DPoint* Rnext = R + nj * (size_t)nb;       // upper levels ping-pong between two areas behind level 1
@@ -625,7 +643,14 @@ struct MsmGroup {
                 // it, which forms W(parent) = 2M sum_{k>=1} R'_k + 2 sum_k A_k + R'_0 (msm.h k_msm_level2_acc) - run even
                 // for a single node per job, where it is just W = 2 A + S
                 launch_red_asm<DF>(tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(), R, Wa, nb, L,
-                                   grid(T), st);
+                                   grid(T), st, d_nfallback);
+                if (getenv("ZKAMD_DEBUG_REDO")) {   // diagnostics: nodes of level 1 the assembly loop handed to the compiled addition
+                    (void)hipStreamSynchronize(st);
+                    uint32_t v[2] = {0, 0};
+                    (void)hipMemcpy(v, d_nlight, 8, hipMemcpyDeviceToHost);
+                    fprintf(stderr, "[redo] reduction G1: %u buckets with 2..%u partials merged, %u of %zu level-1 nodes recomputed\n", v[0],
+                            merge_inline, v[1], (size_t)nj * T);
+                }
                 const uint32_t fan = pick_fan((uint64_t)nj * n), n_out = (n + fan - 1) / fan;
                 uint32_t log2_2m = 1;
                 while ((1u << (log2_2m - 1)) < m) log2_2m++;
@@ -643,7 +668,7 @@ struct MsmGroup {
             } else {
                 // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
                 ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
-                          toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, few ? 0u : merge_inline, seg);
+                          toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, few ? 0u : 1u /* merged by now */, seg);
                 ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
                           1u, 1u, 1u);
             }
