@@ -289,9 +289,11 @@ typedef struct {
 } zk_anonymous_statement;
 /* witness_out: n x (105 + 50429) x 32 bytes; plain little-endian, or Montgomery limbs with ZK_FR_MONTGOMERY */
 zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out);
+/* The same vectors from the GPU witness generator (csrc/witness_anon_gpu.h; tests compare the two element by element) */
+zk_status zk_anonymous_witness_gpu(zk_r1cs* circuit, const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out);
 /* statement -> proof for that circuit (create_random_proof of AnonymousTransfer, core/proofs/src/anonymous.rs:165):
- * the host witness calculator on the host cores, overlapped chunk by chunk with row evaluations + create_proof on
- * the GPU, over the matrices loaded with zk_r1cs_load. */
+ * witness generation on the GPU (round 4; ZKAMD_WITNESS=host: the host calculator on the host cores), the kernels of
+ * chunk k + 1 beside row evaluations + create_proof of chunk k, over the matrices loaded with zk_anonymous_r1cs_load. */
 zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_anonymous_statement* st,
                                    const uint8_t* rs, uint8_t* proofs_out);
 /* The constraint system of that circuit, emitted natively (the structure half of AnonymousTransfer::synthesize):

@@ -19,7 +19,8 @@ def emu_lib():
     spec = importlib.util.spec_from_file_location("zk_build_emu", os.path.join(ROOT, "tests", "emu", "build_emu.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    path = mod.build_emu()
+    # ZKAMD_EMU_SANITIZED=1 (tests/emu/run_sanitized.sh): the same sources under AddressSanitizer + UBSan
+    path = mod.build_emu(sanitize=os.environ.get("ZKAMD_EMU_SANITIZED") == "1")
     from zero_chain_amd._lib import ZkLib
     return ZkLib(path)
 

@@ -4,6 +4,7 @@ Never loaded by the product."""
 import os
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -49,10 +50,11 @@ def build_emu(force=False, sanitize=False):
             continue
         cmd = [cxx] + flags + ["-std=c++17", "-fPIC", "-DZK_EMU=1", "-Wno-psabi", "-x", "c++", "-c", src, "-o", obj]
         print("+", " ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        procs.append((cmd, subprocess.Popen(cmd), obj, time.time()))
+    for cmd, p, obj, t0 in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        os.utime(obj, (t0, t0))   # an edit made WHILE the unit compiled must make it stale again
     if not procs and os.path.exists(lib) and all(os.path.getmtime(o) <= os.path.getmtime(lib) for o in objs):
         return lib
     cmd = [cxx, "-rdynamic", "-shared", "-fPIC"] + (["-fsanitize=address,undefined", "-shared-libsan"] if sanitize else []) + objs + ["-o", lib, "-lpthread"]

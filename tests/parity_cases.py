@@ -926,6 +926,49 @@ def witness_gpu_matches_host(lib, n_extra=3):
         mats.close()
 
 
+def anonymous_witness_gpu_matches_host(lib, n=3):
+    """The GPU witness generator of the anonymous circuit (witness_anon_gpu.h, zk_anonymous_witness_gpu) against the host
+    calculator (zk_anonymous_witness, compared with the oracle's circuit in test_anonymous_circuit.py): every one of the
+    50 534 values of every statement - sender / recipient in different positions of the set, equal positions included -
+    plain and Montgomery; malformed statements are reported in the host calculator's words with the statement's index."""
+    from oracle import anonymous_circuit as ac
+    from oracle import jubjub as jj
+    ws = [ac.make_witness(300 + s, amount=5 + 7 * s, balance=900 + 31 * s) for s in range(n)]
+    items = [ac.statement_dict(w) for w in ws]
+    # move the sender / recipient around the set (the statement stays well-formed for the VALUE computation: the
+    # calculators evaluate every gadget whatever the indices say)
+    items[1 % n] = dict(items[1 % n], s_index=11, t_index=0)
+    if n > 2:
+        items[2] = dict(items[2], s_index=4, t_index=4)
+    mats = zk.ConstraintMatrices.anonymous_circuit(lib=lib)
+    try:
+        sts = zk.anonymous_statements(items)
+        nv = zk.ANONYMOUS_N_INPUTS + zk.ANONYMOUS_N_AUX
+        for mont in (False, True):
+            host = zk.anonymous_witness(sts, montgomery=mont, lib=lib).reshape(n, nv, 32)
+            dev = zk.anonymous_witness_gpu(mats, sts, montgomery=mont).reshape(n, nv, 32)
+            diff = np.argwhere((host != dev).any(axis=2))
+            assert len(diff) == 0, "statement %d, variable %d differs (%d in all)" % (diff[0][0], diff[0][1], len(diff))
+        d = items[0]
+        y = 2
+        while jj.get_for_y(y, False) is not None:
+            y += 1
+        bad_pt = y.to_bytes(32, "little")
+        keys = list(d["enc_keys"])
+        keys[7] = bad_pt
+        lefts = list(d["enc_balances_left"])
+        lefts[0] = bad_pt
+        for bad, what in ((dict(d, g_epoch=bytes([0xff] * 32)), "g_epoch"), (dict(d, randomness=jj.FS_MOD), "randomness"),
+                          (dict(d, enc_keys=keys), "enc_keys[7]"), (dict(d, enc_balances_left=lefts, enc_keys=keys), "enc_balances_left[0]"),
+                          (dict(d, dec_key=jj.FS_MOD + 5, alpha=jj.FS_MOD), "alpha"), (dict(d, s_index=12), "member index")):
+            for run in (lambda s: zk.anonymous_witness(s, lib=lib), lambda s: zk.anonymous_witness_gpu(mats, s)):
+                with pytest.raises(zk.ZkError) as e:
+                    run(zk.anonymous_statements([items[1 % n], bad]))
+                assert e.value.variant == "InvalidArgument" and "statement 1" in str(e.value) and what in str(e.value), str(e.value)
+    finally:
+        mats.close()
+
+
 def setup_matches_oracle(lib, seed=21, n_in=3, n_aux=17, n_con=20):
     """zk_generate_parameters against the oracle's restatement of bellman's generator
     (oracle.groth16.generate_parameters + Parameters::write): byte-identical parameter files for explicit toxic

@@ -60,3 +60,15 @@ def test_product_sources_never_touch_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle|#include\s+\".*oracle|libzkoracle|libzkamd_emu", text, re.M):
                         bad.append(os.path.join(base, f))
     assert not bad, "product code references the oracle / emulation: %s" % bad
+
+
+def test_c_program_binds_the_boundary(tmp_path, emu_lib):
+    """include/zkamd.h as strict C99, the struct layouts the Rust / ctypes mirrors assume (compile-time assertions in
+    tests/abi_smoke.c), and a C program that dlopens a build of the library (the x86 emulation build here: no GPU runtime
+    needed to LOAD it), resolves every declared entry point and calls zk_strerror."""
+    import subprocess
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_smoke.c"), "-ldl", "-o", exe])
+    out = subprocess.check_output([exe, emu_lib.path] + declared_symbols()).decode()
+    assert "abi ok: %d symbols resolved" % len(declared_symbols()) in out

@@ -181,3 +181,7 @@ def test_verifier_one_thread_per_pair_kernels(emu_lib, monkeypatch):
 
 def test_verifier_skipped_pairs(emu_lib):
     pc.verifier_skipped_pairs(emu_lib)
+
+
+def test_anonymous_witness_gpu_matches_host(emu_lib):
+    pc.anonymous_witness_gpu_matches_host(emu_lib, n=2)

@@ -457,6 +457,10 @@ def test_witness_gpu_matches_host(gpu_lib):
     pc.witness_gpu_matches_host(gpu_lib, n_extra=6)
 
 
+def test_anonymous_witness_gpu_matches_host(gpu_lib):
+    pc.anonymous_witness_gpu_matches_host(gpu_lib, n=5)
+
+
 def test_setup_matches_oracle(gpu_lib):
     pc.setup_matches_oracle(gpu_lib)
 

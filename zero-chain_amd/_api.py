@@ -26,7 +26,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs", "read_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "xt_fields", "gen_proof", "XT_FIELDS",
-           "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_prove_batch",
+           "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_witness_gpu", "anonymous_prove_batch",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
            "ZK_NTT_COSET", "ZK_NTT_IN_BITREV", "ZK_NTT_OUT_BITREV", "shard_bounds", "gather_proofs", "prove_sharded"]
@@ -685,6 +685,15 @@ def anonymous_witness(statements, montgomery=False, lib=None):
     n = len(statements)
     out = np.zeros(n * (ANONYMOUS_N_INPUTS + ANONYMOUS_N_AUX) * 32, dtype=np.uint8)
     lib.check(lib.zk_anonymous_witness(statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
+    return out
+
+
+def anonymous_witness_gpu(matrices, statements, montgomery=False):
+    """zk_anonymous_witness_gpu: the assignments the GPU witness generator produces (same format as anonymous_witness)."""
+    lib = matrices._lib
+    n = len(statements)
+    out = np.zeros(n * (ANONYMOUS_N_INPUTS + ANONYMOUS_N_AUX) * 32, dtype=np.uint8)
+    lib.check(lib.zk_anonymous_witness_gpu(matrices._h, statements, n, ZK_FR_MONTGOMERY if montgomery else 0, _ptr(out)))
     return out
 
 

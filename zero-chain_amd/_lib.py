@@ -129,6 +129,7 @@ _PROTOS = {
     "zk_transfer_gen_proof_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TransferRequest), C.c_void_p,
                                                 C.POINTER(ConfidentialXt)]),
     "zk_anonymous_witness": (C.c_int32, [C.POINTER(AnonymousStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
+    "zk_anonymous_witness_gpu": (C.c_int32, [C.c_void_p, C.POINTER(AnonymousStatement), C.c_size_t, C.c_uint32, C.c_void_p]),
     "zk_generate_parameters": (C.c_int32, [C.c_void_p] + [C.c_void_p] * 7 + [C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zk_params_write_vk": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "zk_vk_prepare": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),

@@ -6,6 +6,7 @@
 import os
 import subprocess
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -67,10 +68,11 @@ def build_lib(force=False):
         cmd = [HIPCC] + extra + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-x", "hip",
                                  os.path.join(CSRC, tu), "-o", obj]
         print("+", " ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        procs.append((cmd, subprocess.Popen(cmd), obj, time.time()))
+    for cmd, p, obj, t0 in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
+        os.utime(obj, (t0, t0))   # an edit made WHILE the unit compiled must make it stale again
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-lpthread"])
     return LIB
 

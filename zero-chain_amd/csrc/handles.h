@@ -52,6 +52,10 @@ struct zk_r1cs {
 zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_t np, int slot, hipStream_t stream,
                               bool typed_inputs = false);
 zk_status witness_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base);
+// ... and of the anonymous-transfer circuit (witness_anon_gpu.h)
+zk_status witness_anon_gpu_enqueue(zk_r1cs* R, const zk_anonymous_statement* st, size_t np, int slot, hipStream_t stream,
+                                   size_t index_base = 0);
+zk_status witness_anon_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base);
 
 // Groth16 verification of a batch (verify.cpp; zk_verify_batch is this with own_proofs = false).  own_proofs: the
 // proofs are this library's own fresh results (gen_proof's self-check) - decoded without the r-torsion test.

@@ -3,6 +3,7 @@
 #include "handles.h"
 #include "transfer_witness.h"
 #include "witness_gpu.h"
+#include "witness_anon_gpu.h"
 
 using namespace zkrt;
 
@@ -79,3 +80,67 @@ zk_status witness_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base)
     return ZK_OK;
 }
 
+
+// ---- the anonymous-transfer circuit (witness_anon_gpu.h): np statements -> R->z[slot], enqueued on `stream`.  The
+// handle's witness buffers are shared with the transfer generator (a zk_r1cs holds ONE circuit).
+zk_status witness_anon_gpu_enqueue(zk_r1cs* R, const zk_anonymous_statement* st, size_t np, int slot, hipStream_t stream, size_t index_base) {
+    using namespace zkwitdev;
+    ZK_TRY(witness_gpu_init(R));
+    static_assert(sizeof(AStmt) == sizeof(zk_anonymous_statement), "statement layout");
+    for (size_t i = 0; i < np; i++)
+        if (st[i].s_index >= ZK_ANONYMOUS_SIZE || st[i].t_index >= ZK_ANONYMOUS_SIZE)
+            return fail(ZK_ERR_INVALID_ARGUMENT, "statement " + std::to_string(index_base + i) + ": member index out of range");
+    ZK_TRY(R->z[slot].ensure(np * (size_t)A_NV * 32));
+    ZK_TRY(R->wit_st[slot].ensure(np * sizeof(AStmt)));
+    ZK_TRY(R->wit_bad[slot].ensure(np * 4));
+    ZK_TRY(R->pin_st[slot].ensure(np * sizeof(AStmt)));
+    ZK_TRY(R->pin_bad[slot].ensure(np * 4));
+    ZK_TRY(R->wit_pts.ensure(np * (size_t)AP_COUNT * 64));
+    ZK_TRY(R->wit_scratch.ensure((size_t)A1_ROLES * SCRATCH_SLOTS * np * 32));
+    memcpy(R->pin_st[slot].p, st, np * sizeof(AStmt));
+    HIP_TRY(hipMemcpyAsync(R->wit_st[slot].p, R->pin_st[slot].p, np * sizeof(AStmt), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(R->wit_bad[slot].p, 0xff, np * 4, stream));   // A_BAD_NONE
+    ACtx c;
+    c.z = R->z[slot].as<uint32_t>();
+    c.st = nullptr;
+    c.ast = R->wit_st[slot].as<AStmt>();
+    c.pts = R->wit_pts.as<uint32_t>();
+    c.table = R->wit_table.as<uint32_t>();
+    c.consts = R->wit_consts.as<uint32_t>();
+    c.scratch = R->wit_scratch.as<uint32_t>();
+    c.bad = R->wit_bad[slot].as<uint32_t>();
+    c.n = (uint32_t)np;
+    const unsigned b64 = (unsigned)((np + 63) / 64);
+    {
+        ProfScope ps("witness_gpu", stream);
+        ZK_LAUNCH(k_awit_decode, dim3((unsigned)((np * (2 + 4 * ANON) + 63) / 64)), dim3(64), 0, stream, c);
+        ZK_LAUNCH(k_awit_level1, dim3(b64, A1_ROLES), dim3(64), 0, stream, c);
+        ZK_LAUNCH(k_awit_level2, dim3(b64, A2_ROLES), dim3(64), 0, stream, c);
+        ZK_LAUNCH(k_awit_level3, dim3(b64, 2), dim3(64), 0, stream, c);
+        ZK_LAUNCH(k_awit_level4, dim3(b64), dim3(64), 0, stream, c);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(R->pin_bad[slot].p, R->wit_bad[slot].p, np * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(R->wit_done[slot], stream));
+    return ZK_OK;
+}
+// waits for the witness kernels of `slot`; a malformed statement is reported with its absolute index, in the words and the
+// order of the host calculator (zkamd.cpp anonymous_decode)
+zk_status witness_anon_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_base) {
+    using namespace zkwitdev;
+    HIP_TRY(hipEventSynchronize(R->wit_done[slot]));
+    const uint32_t* bad = R->pin_bad[slot].as<uint32_t>();
+    static const char* const scalars[3] = {"randomness", "alpha", "dec_key"};
+    static const char* const sets[4] = {"enc_keys", "left_ciphertexts", "enc_balances_left", "enc_balances_right"};
+    for (size_t i = 0; i < np; i++) {
+        const uint32_t code = bad[i];
+        if (code == A_BAD_NONE) continue;
+        const std::string who = "statement " + std::to_string(index_base + i) + ": ";
+        if (code <= A_BAD_DEC_KEY) return fail(ZK_ERR_INVALID_ARGUMENT, who + scalars[code] + " is not a canonical Fs scalar");
+        if (code == A_BAD_PGK) return fail(ZK_ERR_INVALID_ARGUMENT, who + "proof_generation_key is not a Jubjub point");
+        if (code == A_BAD_GEPOCH) return fail(ZK_ERR_INVALID_ARGUMENT, who + "g_epoch is not a Jubjub point");
+        const uint32_t k = (code - A_BAD_SET) / 4, set = (code - A_BAD_SET) % 4;
+        return fail(ZK_ERR_INVALID_ARGUMENT, who + sets[set] + "[" + std::to_string(k) + "] is not a Jubjub point");
+    }
+    return ZK_OK;
+}

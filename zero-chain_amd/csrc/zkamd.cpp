@@ -2101,6 +2101,21 @@ zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, con
     const size_t nv = ZK_ANONYMOUS_N_INPUTS + ZK_ANONYMOUS_N_AUX;
     size_t chunk = batch_chunk();
     if (chunk > 512) chunk = 512;   // domain 2^16: half the proofs of a transfer chunk fill the same workspaces
+    if (!witness_on_host()) {
+        // witness generation on the GPU (witness_anon_gpu.h), statement in: 1.7 KB instead of 1.6 MB of witness vector; the
+        // kernels of chunk k + 1 run beside the multiexps of chunk k (as zk_transfer_prove_batch)
+        if (circuit->device != p->device) return fail(ZK_ERR_INVALID_ARGUMENT, "parameters and circuit live on different devices");
+        int slot = 0;
+        ZK_TRY(witness_anon_gpu_enqueue(circuit, st, std::min(chunk, n), slot, g_copy_stream));
+        for (size_t first = 0; first < n; first += chunk) {
+            const size_t np = std::min(chunk, n - first), next = first + chunk;
+            ZK_TRY(witness_anon_gpu_finish(circuit, np, slot, first));
+            if (next < n) ZK_TRY(witness_anon_gpu_enqueue(circuit, st + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream, next));
+            ZK_TRY(prove_from_z(p, circuit, np, slot, rs + first * 64, proofs_out + first * 192));
+            slot ^= 1;
+        }
+        return ZK_OK;
+    }
     const size_t cap = std::min(chunk, n) * nv * 32;
     ZK_TRY(circuit->host_ensure(2 * cap));
     uint8_t* buf[2] = {(uint8_t*)circuit->host_z, (uint8_t*)circuit->host_z + cap};
@@ -2131,6 +2146,30 @@ zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, con
         if (rc != ZK_OK) return rc;
         if (next_rc != ZK_OK) return fail(next_rc, next_err);
         cur ^= 1;
+    }
+    return ZK_OK;
+}
+
+// The witness vectors the GPU generator of the anonymous circuit produces, copied back to the host (tests: element by
+// element against zk_anonymous_witness).  witness_out: n x (105 + 50429) x 32 bytes.
+zk_status zk_anonymous_witness_gpu(zk_r1cs* circuit, const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
+    if (!circuit || (n && (!st || !witness_out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (circuit->n_in != ZK_ANONYMOUS_N_INPUTS || circuit->n_aux != ZK_ANONYMOUS_N_AUX)
+        return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the anonymous-transfer circuit's");
+    ZK_TRY(use_device(circuit->device));
+    const size_t nv = ZK_ANONYMOUS_N_INPUTS + ZK_ANONYMOUS_N_AUX, chunk = 256;
+    for (size_t first = 0; first < n; first += chunk) {
+        const size_t np = std::min(chunk, n - first);
+        ZK_TRY(witness_anon_gpu_enqueue(circuit, st + first, np, 0, g_stream, first));
+        ZK_TRY(witness_anon_gpu_finish(circuit, np, 0, first));
+        if (!(flags & ZK_FR_MONTGOMERY)) {
+            const size_t cnt = np * nv;
+            ZK_LAUNCH(zkdev::k_fr_convert, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, g_stream, circuit->z[0].as<uint32_t>(),
+                      (const uint32_t*)circuit->z[0].as<uint32_t>(), 1u, cnt, (uint32_t*)nullptr);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipMemcpy(witness_out + first * nv * 32, circuit->z[0].p, np * nv * 32, hipMemcpyDeviceToHost));
     }
     return ZK_OK;
 }
