@@ -32,7 +32,11 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __restrict__
-#define ZK_SHARED static
+#ifdef ZK_EMU_NO_FIBERS
+#define ZK_SHARED static                /* sanitizer build: blocks run one after another, OS threads share the array */
+#else
+#define ZK_SHARED static thread_local   /* private to the block a worker of the emulation runs (tests/emu/emu_rt.cpp) */
+#endif
 
 struct emu_dim3 {
     unsigned x, y, z;
@@ -41,7 +45,7 @@ struct emu_dim3 {
 typedef emu_dim3 dim3;
 extern thread_local emu_dim3 threadIdx, blockIdx;
 extern emu_dim3 blockDim, gridDim;
-extern unsigned char* emu_dyn_shared;
+extern thread_local unsigned char* emu_dyn_shared;
 typedef int hipError_t;
 typedef void* hipStream_t;
 typedef void* hipEvent_t;
