@@ -399,7 +399,7 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
         if (!good) {
             bad[i] = 1;
             f1[i] = f1[n + i] = f2[i] = 1;   // decode nothing
-            memset(&sc[i * ni * 8], 0, (size_t)ni * 32);
+            if (ni) memset(&sc[i * ni * 8], 0, (size_t)ni * 32);   // (no inputs: `sc` is empty, nothing to index - UBSan, round 4)
         }
     }
     ZK_TRY(upload(V->in_g1, g1.data(), g1.size() * 4));
