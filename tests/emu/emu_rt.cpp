@@ -10,7 +10,7 @@
 // follow ucontext switches): blocks one after another, one OS thread per GPU thread for kernels with barriers.
 thread_local emu_dim3 threadIdx, blockIdx;
 emu_dim3 blockDim, gridDim;
-thread_local unsigned char* emu_dyn_shared = nullptr;
+unsigned char* emu_dyn_shared = nullptr;
 
 namespace {
 std::mutex g_mu;

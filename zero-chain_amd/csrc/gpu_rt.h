@@ -45,7 +45,11 @@ struct emu_dim3 {
 typedef emu_dim3 dim3;
 extern thread_local emu_dim3 threadIdx, blockIdx;
 extern emu_dim3 blockDim, gridDim;
-extern thread_local unsigned char* emu_dyn_shared;
+#ifdef ZK_EMU_NO_FIBERS
+extern unsigned char* emu_dyn_shared;                /* one block at a time, its OS threads share the pointer */
+#else
+extern thread_local unsigned char* emu_dyn_shared;   /* of the block the calling worker runs */
+#endif
 typedef int hipError_t;
 typedef void* hipStream_t;
 typedef void* hipEvent_t;

@@ -223,6 +223,8 @@ constexpr uint32_t MSM_RED_FAN = 16;   // buckets per level-1 node and children 
 // beta = measured cost of reducing one bucket relative to one mixed addition of the same group
 // (G1: 2-3 full additions of 14 products against a mixed addition of 10, plus the tree above;
 // G2: the same in Fq2, where the full addition no longer fits the register file).  `group` 1 / 2.
+// group: 1 = G1 jobs of a batch (level 1 of their reduction in assembly), 2 = G2, 3 = the small A jobs of a split batch,
+// 4 = a stand-alone G1 handle (zk_msm_create: compiled reduction)
 uint32_t pick_window(size_t n, int group) {
     const char* env = getenv(group == 2 ? "ZKAMD_WINDOW_BITS_G2" : group == 3 ? "ZKAMD_WINDOW_BITS_G1A" : "ZKAMD_WINDOW_BITS_G1");
     if (!env) env = getenv("ZKAMD_WINDOW_BITS");
@@ -232,7 +234,7 @@ uint32_t pick_window(size_t n, int group) {
     // above it, against 4 324 per mixed addition (round 3, compiled level 1: 6)
     // (group 3, the small A jobs of a split batch: their reduction is half latency - the levels above the assembly loop -
     //  so a bucket weighs more; 14 and 15 measured the same, profiles/r04_experiments.txt r04g: the narrower one it is)
-    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 12.0 : group == 3 ? 6.0 : 4.0);
+    const double beta = benv && atof(benv) > 0 ? atof(benv) : (group == 2 ? 12.0 : group == 1 ? 4.0 : 6.0);
     uint32_t best = 2;
     double best_cost = 1e300;
     for (uint32_t c = 2; c <= 22; c++) {
@@ -1685,7 +1687,8 @@ zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits,
     M->device = device;
     M->n = n;
     M->slice = (window_bits > 0 || variable) ? 0 : msm_slice(n);
-    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(M->slice ? M->slice : n, group);
+    // (a stand-alone handle is one or a few jobs: its reduction is the compiled few-jobs path, bucket cost 6 - group 4)
+    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(M->slice ? M->slice : n, group == 1 ? 4 : group);
     if (variable) {
         // digits of w bits at fixed positions, 255 / w jobs of 2^(w-1) buckets: minimise  n * 255 / w + beta * 2^(w-1) * 255 / w
         uint32_t w = window_bits > 0 ? (uint32_t)window_bits : 0u;
