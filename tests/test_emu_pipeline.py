@@ -108,6 +108,22 @@ def test_msm_two_level_sort_path(emu_lib, monkeypatch):
     pc.prover_small(emu_lib, 5, 3, 10, 12)
 
 
+def test_msm_staged_two_level_sort(emu_lib, monkeypatch):
+    """ZKAMD_SORT_STAGED=1 (an experiment of round 4, off by default): two-level sort, the records of the scatter pass staged in
+    LDS and written as runs.
+    More than eight jobs per launch set, several bins, a ragged scalar count per workgroup, split and unsplit G1 sets."""
+    monkeypatch.setenv("ZKAMD_ASM_MIN_PAIRS", "0")
+    monkeypatch.setenv("ZKAMD_SORT_STAGED", "1")
+    monkeypatch.setenv("ZKAMD_SORT_STAGED_MIN_BUCKETS", "1")
+    monkeypatch.setenv("ZKAMD_SORT_FINE_LOG", "2")
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "7")            # 32 buckets in 8 bins
+    monkeypatch.setenv("ZKAMD_SPLIT_MIN", "1")
+    pc.prover_batch(emu_lib, 9, 3, 40, 10, use_c_oracle=True)
+    monkeypatch.setenv("ZKAMD_SPLIT_G1", "0")
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")            # 8 buckets, two bins
+    pc.prover_batch(emu_lib, 10, 2, 700, 9, use_c_oracle=True)   # 700 aux: two workgroups of scalars per job
+
+
 def test_prover_from_witness(emu_lib):
     pc.prover_from_witness(emu_lib, 3, 3, 14, 3)
     pc.prover_from_witness(emu_lib, 4, 2, 9, 2, montgomery=True)

@@ -245,21 +245,25 @@ constexpr uint32_t MSM_COARSE_SCALARS = 1024;  // scalars per workgroup of passe
 
 static __global__ void __launch_bounds__(256)
 k_msm_coarse_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse, uint32_t* coarse_cnt,
-                   uint32_t* blockbase) {
+                   uint32_t* blockbase, uint32_t per_wg, uint32_t* blockcnt) {
     ZK_SHARED uint32_t h[MSM_COARSE_MAX];
     const MsmJob job = jobs[blockIdx.y];
     const uint32_t tid = threadIdx.x;
+    if (blockIdx.x * per_wg >= job.n && blockIdx.x) return;   // (jobs of a launch differ in size: nothing of this one here)
     for (uint32_t t = tid; t < n_coarse; t += blockDim.x) h[t] = 0;
     __syncthreads();
-    for (uint32_t e = 0; e < MSM_COARSE_SCALARS / 256; e++) {
-        const uint32_t i = blockIdx.x * MSM_COARSE_SCALARS + e * 256 + tid;
+    for (uint32_t e = 0; e < per_wg / 256; e++) {
+        const uint32_t i = blockIdx.x * per_wg + e * 256 + tid;
         if (i >= job.n || (job.map && job.map[i] < 0)) continue;
         msm_digits(job, i, c, [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[(mag >> 1) >> fine_log], 1u); });
     }
     __syncthreads();
     uint32_t* bb = blockbase + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n_coarse;
     uint32_t* jc = coarse_cnt + (size_t)blockIdx.y * n_coarse;
-    for (uint32_t t = tid; t < n_coarse; t += blockDim.x) bb[t] = h[t] ? atomicAdd(&jc[t], h[t]) : 0u;
+    for (uint32_t t = tid; t < n_coarse; t += blockDim.x) {
+        bb[t] = h[t] ? atomicAdd(&jc[t], h[t]) : 0u;
+        if (blockcnt) blockcnt[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n_coarse + t] = h[t];
+    }
 }
 
 // exclusive scan of n values per job (n <= a few thousand), one workgroup per job; total[job] = sum
@@ -295,18 +299,20 @@ k_msm_coarse_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, u
 // table index = position * n_table + base
 static __global__ void __launch_bounds__(256)
 k_msm_coarse_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse,
-                     const uint32_t* __restrict__ coarse_off, const uint32_t* __restrict__ blockbase, uint2* __restrict__ rec) {
+                     const uint32_t* __restrict__ coarse_off, const uint32_t* __restrict__ blockbase, uint2* __restrict__ rec,
+                     uint32_t per_wg) {
     ZK_SHARED uint32_t h[MSM_COARSE_MAX];
     const MsmJob job = jobs[blockIdx.y];
     const uint32_t tid = threadIdx.x;
+    if (blockIdx.x * per_wg >= job.n && blockIdx.x) return;
     const uint32_t* bb = blockbase + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n_coarse;
     const uint32_t* jo = coarse_off + (size_t)blockIdx.y * n_coarse;
     for (uint32_t t = tid; t < n_coarse; t += blockDim.x) h[t] = jo[t] + bb[t];
     __syncthreads();
     uint2* jrec = rec + job.pair_base;
     const uint32_t fmask = (1u << fine_log) - 1;
-    for (uint32_t e = 0; e < MSM_COARSE_SCALARS / 256; e++) {
-        const uint32_t i = blockIdx.x * MSM_COARSE_SCALARS + e * 256 + tid;
+    for (uint32_t e = 0; e < per_wg / 256; e++) {
+        const uint32_t i = blockIdx.x * per_wg + e * 256 + tid;
         if (i >= job.n) continue;
         const int32_t pos = job.map ? job.map[i] : (int32_t)i;
         if (pos < 0) continue;
@@ -316,6 +322,74 @@ k_msm_coarse_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_
             const uint32_t slot = atomicAdd(&h[b >> fine_log], 1u);
             jrec[slot] = make_uint2(b & fmask, ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u));
         });
+    }
+}
+
+// Pass 3 with the records STAGED in LDS (round 4, the batched prover's sort): a workgroup takes MSM_STAGE_SCALARS scalars of
+// a job, places the records of their digits into LDS grouped by coarse bin (the per-workgroup bin counts of pass 1 give
+// every bin its run), and writes every run with consecutive lanes to the range pass 1 reserved for it: whole cache lines
+// instead of one 32-byte sector per 4- or 8-byte store.  Measured on the single-workgroup sort (tools/sort_probe.py,
+// profiles/r04_experiments.txt): 13.2 of its 17.5 ms per chunk are the scattered stores of the pair words - 35 GB of
+// sector writes for 6 GB of pairs - not the recoding (2.3 ms per pass).
+constexpr uint32_t MSM_STAGE_SCALARS = 512;
+static __global__ void __launch_bounds__(256)
+k_msm_coarse_scatter_staged(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse,
+                            const uint32_t* __restrict__ coarse_off, const uint32_t* __restrict__ blockbase,
+                            const uint32_t* __restrict__ blockcnt, uint2* __restrict__ rec) {
+    ZK_DYN_SHARED(uint2, stage);                 // [MSM_STAGE_SCALARS * maxd] records
+    ZK_SHARED uint32_t run0[MSM_COARSE_MAX];     // first staged record of every bin
+    ZK_SHARED uint32_t fill[MSM_COARSE_MAX];     // records placed so far
+    ZK_SHARED uint32_t part[256];
+    const MsmJob job = jobs[blockIdx.y];
+    const uint32_t tid = threadIdx.x, nt = 256;
+    if (blockIdx.x * MSM_STAGE_SCALARS >= job.n && blockIdx.x) return;
+    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t* bb = blockbase + wg * n_coarse;
+    const uint32_t* hc = blockcnt + wg * n_coarse;
+    const uint32_t* jo = coarse_off + (size_t)blockIdx.y * n_coarse;
+    // exclusive scan of this workgroup's bin counts: thread t owns bins [t * per, ..)
+    const uint32_t per = (n_coarse + nt - 1) / nt;
+    uint32_t b0 = tid * per, b1 = b0 + per < n_coarse ? b0 + per : n_coarse;
+    if (b0 > n_coarse) b0 = n_coarse;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) sum += hc[b];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < nt; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        run0[b] = run;
+        fill[b] = 0;
+        run += hc[b];
+    }
+    __syncthreads();
+    const uint32_t fmask = (1u << fine_log) - 1;
+    for (uint32_t e = 0; e < MSM_STAGE_SCALARS / 256; e++) {
+        const uint32_t i = blockIdx.x * MSM_STAGE_SCALARS + e * 256 + tid;
+        if (i >= job.n) continue;
+        const int32_t pos = job.map ? job.map[i] : (int32_t)i;
+        if (pos < 0) continue;
+        const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
+        msm_digits(job, i, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
+            const uint32_t b = mag >> 1, bin = b >> fine_log;
+            const uint32_t k = atomicAdd(&fill[bin], 1u);
+            stage[run0[bin] + k] = make_uint2(b & fmask, ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u));
+        });
+    }
+    __syncthreads();
+    // every run to its reserved range, consecutive lanes on consecutive records; wave w takes bins w, w + 4, ...
+    uint2* jrec = rec + job.pair_base;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t bin = wave; bin < n_coarse; bin += nt / 64) {
+        const uint32_t n = hc[bin];
+        uint2* dst = jrec + jo[bin] + bb[bin];
+        const uint2* src = stage + run0[bin];
+        for (uint32_t k = lane; k < n; k += 64) dst[k] = src[k];
     }
 }
 
@@ -414,7 +488,7 @@ constexpr uint32_t MSM_SORT_THREADS = 1024;
 #endif
 static __global__ void __launch_bounds__(MSM_SORT_THREADS)
 k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint32_t* off, uint32_t* toff,
-               uint32_t* ntasks, uint32_t* pairs, uint32_t seg) {
+               uint32_t* ntasks, uint32_t* pairs, uint32_t seg, uint32_t dbg) {
     ZK_DYN_SHARED(uint32_t, h);   // [nb] histogram, then running slot cursors
     ZK_SHARED uint32_t part[MSM_SORT_THREADS];
     ZK_SHARED uint32_t tpart[MSM_SORT_THREADS];
@@ -464,12 +538,14 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
     if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
     __syncthreads();
     uint32_t* jpairs = pairs + job.pair_base;
+    if (dbg & 2u) return;   // diagnostics (ZKAMD_DEBUG_SORT): the count pass and the scan alone
     for (uint32_t i = tid; i < job.n; i += nt) {
         int32_t pos = job.map ? job.map[i] : (int32_t)i;
         if (pos < 0) continue;
         const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
         msm_digits(job, i, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
             uint32_t slot = atomicAdd(&h[mag >> 1], 1u);
+            if ((dbg & 1u) && slot != 0xffffffffu) return;   // diagnostics: everything but the scattered store
             jpairs[slot] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
         });
     }

@@ -519,13 +519,21 @@ struct MsmGroup {
         dim3 gridb((nb + 255) / 256, (unsigned)nj);
         // one workgroup per job sorts inside its LDS: right for a thousand jobs per launch, a 0.67 ms serial pass for
         // the one or two jobs of a proof made alone (4.83 -> 4.17 ms per proof with the many-workgroup sort instead)
-        const bool lds_sort = (size_t)nb * 4 <= 65536 && nj > MSM_FEW_JOBS && !getenv("ZKAMD_NO_LDS_SORT");
+        // ZKAMD_SORT_STAGED=1 (an experiment of round 4, off by default): for many jobs with thousands of buckets each, the
+        // two-level sort with the records of pass 3 STAGED in LDS, so that every store of the scatter pass leaves as whole
+        // runs (msm.h k_msm_coarse_scatter_staged).  The one-workgroup-per-job sort below spends 13.2 of its 17.5 ms per chunk
+        // on scattered 4-byte stores (tools/sort_probe.py), but the two-level path as it stands loses more in its second
+        // pass than the staging gains: 13.5 + 12.8 ms (unstaged: 8.6 + 11.3) - profiles/r04_experiments.txt, DESIGN.md 8.
+        const char* staged_env = getenv("ZKAMD_SORT_STAGED");
+        const uint32_t staged_min_nb = getenv("ZKAMD_SORT_STAGED_MIN_BUCKETS") ? (uint32_t)atoi(getenv("ZKAMD_SORT_STAGED_MIN_BUCKETS")) : 1024u;   // tests: 1
+        const bool staged = nj > MSM_FEW_JOBS && nb >= staged_min_nb && big_launch && staged_env && atoi(staged_env) == 1;
+        const bool lds_sort = !staged && (size_t)nb * 4 <= 65536 && nj > MSM_FEW_JOBS && !getenv("ZKAMD_NO_LDS_SORT");
         if (lds_sort) {
             // histogram + scan + scatter of a job inside one workgroup's LDS
             ProfScope ps("msm_sort_lds", st);
             ZK_LAUNCH_SYNC(zkdev::k_msm_sort_lds, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c,
                            cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(),
-                           pairs.as<uint32_t>(), seg);
+                           pairs.as<uint32_t>(), seg, getenv("ZKAMD_DEBUG_SORT") ? (uint32_t)atoi(getenv("ZKAMD_DEBUG_SORT")) : 0u);
         } else {
             // two-level counting sort, every per-digit atomic in LDS (msm.h)
             uint32_t fine_log = 7;
@@ -534,10 +542,12 @@ struct MsmGroup {
             if (fine_log > c - 2) fine_log = c - 2;
             const uint32_t fine = 1u << fine_log, n_coarse = nb >> fine_log;
             if (fine > zkdev::MSM_FINE_MAX) return fail(ZK_ERR_INVALID_ARGUMENT, "ZKAMD_SORT_FINE_LOG out of range");
-            dim3 gridc((max_n + zkdev::MSM_COARSE_SCALARS - 1) / zkdev::MSM_COARSE_SCALARS, (unsigned)nj);
+            const uint32_t per_wg = staged ? zkdev::MSM_STAGE_SCALARS : zkdev::MSM_COARSE_SCALARS;
+            dim3 gridc((max_n + per_wg - 1) / per_wg, (unsigned)nj);
             if (gridc.x == 0) gridc.x = 1;
             ZK_TRY(rank.ensure((size_t)(total ? total : 1) * sizeof(uint2)));          // (bucket in bin, pair) records
-            ZK_TRY(blockbase.ensure((size_t)gridc.x * nj * n_coarse * 4));
+            ZK_TRY(blockbase.ensure((size_t)gridc.x * nj * n_coarse * 4 * (staged ? 2 : 1)));   // reserved ranges | (staged) counts
+            uint32_t* blockcnt = staged ? blockbase.as<uint32_t>() + (size_t)gridc.x * nj * n_coarse : (uint32_t*)nullptr;
             ZK_TRY(coarse.ensure(4 * nj * (size_t)n_coarse * 4));                       // bin counts | offsets | tasks | first task
             uint32_t* coarse_cnt = coarse.as<uint32_t>();
             uint32_t* coarse_off = coarse_cnt + nj * (size_t)n_coarse;
@@ -547,15 +557,37 @@ struct MsmGroup {
             {
                 ProfScope ps("msm_sort_coarse", st);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_count, gridc, dim3(256), 0, st, dj, c, fine_log, n_coarse, coarse_cnt,
-                               blockbase.as<uint32_t>());
+                               blockbase.as<uint32_t>(), per_wg, blockcnt);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st,
                                (const uint32_t*)coarse_cnt, coarse_off, (uint32_t*)nullptr, n_coarse);
-                ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scatter, gridc, dim3(256), 0, st, dj, c, fine_log, n_coarse,
-                               (const uint32_t*)coarse_off, (const uint32_t*)blockbase.as<uint32_t>(), rank.as<uint2>());
+                if (staged) {
+                    const size_t shmem = (size_t)zkdev::MSM_STAGE_SCALARS * maxd * sizeof(uint2);
+#ifndef ZK_EMU
+                    if (shmem > 65536) {   // more than 64 KiB of dynamic LDS has to be asked for (the kernel's static 9 KiB count too)
+                        static std::mutex mu;
+                        static size_t raised[64] = {0};
+                        std::lock_guard<std::mutex> lock(mu);
+                        if (raised[g_device & 63] < shmem) {
+                            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(zkdev::k_msm_coarse_scatter_staged),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                            raised[g_device & 63] = shmem;
+                        }
+                    }
+#endif
+                    ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scatter_staged, gridc, dim3(256), shmem, st, dj, c, fine_log, n_coarse,
+                                   (const uint32_t*)coarse_off, (const uint32_t*)blockbase.as<uint32_t>(), (const uint32_t*)blockcnt,
+                                   rank.as<uint2>());
+                } else {
+                    ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scatter, gridc, dim3(256), 0, st, dj, c, fine_log, n_coarse,
+                                   (const uint32_t*)coarse_off, (const uint32_t*)blockbase.as<uint32_t>(), rank.as<uint2>(), per_wg);
+                }
             }
             {
                 ProfScope ps("msm_sort_fine", st);
-                ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort, dim3(n_coarse, (unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st, dj,
+                // (many jobs: a bin holds a few thousand records - a quarter of the threads does as well and leaves room for four
+                //  workgroups per CU)
+                ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort, dim3(n_coarse, (unsigned)nj),
+                               dim3(staged && zkdev::MSM_SORT_THREADS >= 256 ? 256u : zkdev::MSM_SORT_THREADS), 0, st, dj,
                                (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
                                cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st,
