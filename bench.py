@@ -804,6 +804,23 @@ def main():
             secondary["verify_batch"] = vb
         except Exception as exc:
             secondary["verify_batch"] = {"error": repr(exc)[:200]}
+        # (5) Parameters::read of the transfer key (10 MB, 132 k points): unchecked, and checked = on-curve + r-torsion test of
+        # every query point on the GPU (k_check_points: the reference's r * P per point, ec.rs:142-144, :675-688) - row f2
+        try:
+            loads = {}
+            for checked in (False, True):
+                t0 = time.perf_counter()
+                p2 = zk.Parameters.read(pk, checked=checked, device=dev_index, lib=lib)
+                loads["checked" if checked else "unchecked"] = round(time.perf_counter() - t0, 3)
+                p2.close()
+            n_pts = info["n_h"] + info["n_l"] + info["n_a"] + info["n_b_g1"] + info["n_b_g2"]
+            secondary["params_load"] = {"unchecked_s": loads["unchecked"], "checked_s": loads["checked"], "query_points": n_pts,
+                                        "key_bytes": len(pk),
+                                        "note": "zk_params_load incl. decoding, upload and the table of all 255 doublings (4.2 GB); checked "
+                                                "adds the curve and subgroup test of every point on the GPU.  The CPU port reads unchecked "
+                                                "only; the reference's checked read is one 255-bit scalar multiplication per point"}
+        except Exception as exc:
+            secondary["params_load"] = {"error": repr(exc)[:200]}
         # (3) the reference's own call pattern: one create_random_proof per transaction
         try:
             pa = helpers.to_assignment(zk, asg0)

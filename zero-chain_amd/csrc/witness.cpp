@@ -51,7 +51,6 @@ zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_
         ZK_LAUNCH(zkwitdev::k_wit_decode, dim3((unsigned)((np * 5 + 63) / 64)), dim3(64), 0, stream, c);
         ZK_LAUNCH(zkwitdev::k_wit_level1, dim3(b64, zkwitdev::L1_ROLES + (typed_inputs ? zkwitdev::L1_TYPED_ROLES : 0u)), dim3(64), 0, stream, c);
         ZK_LAUNCH(zkwitdev::k_wit_level2, dim3(b64, zkwitdev::L2_ROLES), dim3(64), 0, stream, c);
-        ZK_LAUNCH(zkwitdev::k_wit_level3, dim3(b64), dim3(64), 0, stream, c);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R->pin_bad[slot].p, R->wit_bad[slot].p, np * 4, hipMemcpyDeviceToHost, stream));

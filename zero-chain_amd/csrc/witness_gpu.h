@@ -17,9 +17,9 @@
 // of the first level; the eleven single additions come last).  One thread per (statement, gadget), gadgets of
 // one level in one launch, the gadget index in blockIdx.y so that a wave runs ONE gadget:
 //   k_wit_decode   5 threads per statement: Jubjub point decoding (edwards.rs:92-165)
-//   k_wit_level1   10 gadgets: bits / witnessed points / small-order checks, 6 fixed-base, 3 variable-base
-//   k_wit_level2   3 gadgets: 2 variable-base multiplications, rvk
-//   k_wit_level3   the additions that tie the ciphertexts together, the public inputs
+//   k_wit_level1   10 gadgets: bits / witnessed points / small-order checks, 6 fixed-base, 5 variable-base (r4: the two
+//                  multiplications by a fixed-base product run in the thread that makes that product: one level less)
+//   k_wit_level2   rvk and c_left_recipient | the additions that tie the ciphertexts together, the public inputs
 // Chains live in a per-thread scratch area in HBM laid out [slot][thread] (coalesced across a wave).
 #pragma once
 #include "dev_field.h"
@@ -448,7 +448,7 @@ k_wit_decode(Ctx c) {
     }
 }
 
-constexpr uint32_t L1_ROLES = 10, L2_ROLES = 3;
+constexpr uint32_t L1_ROLES = 10, L2_ROLES = 2;
 // roles L1_ROLES .. L1_ROLES + 3 of level 1, launched only for the wallet-level entries (gen_proof): the typed inputs of
 // the reference pass through Point::as_prime_order when they are read (EncryptionKey::read keys.rs:269-276,
 // Ciphertext::read elgamal.rs:117-133, g_epoch.rs:75; core/jubjub/src/curve/edwards.rs:319-330): [s]P == O for
@@ -513,18 +513,21 @@ k_wit_level1(Ctx c) {
             inputize(z, IN_GEPOCH, ge);
             break;
         }
-        case 1: {
+        case 1: {   // enc_key_sender = dec_key * G, then randomness * enc_key_sender in the same thread (r4: the multiplication
+                    // used to wait a whole level for a point an 84-step chain produces)
             const JP r = fixed_base_multiplication(c, sc, A(LAYOUT.fbm_eks), s.dec_key, 252);
             pt_st(c, p, P_EKS, r);
             inputize(z, IN_EKS, r);
+            pt_st(c, p, P_VAL_RLS, point_mul(c, sc, A(LAYOUT.mul_rls), r, s.randomness));
             break;
         }
         case 2: pt_st(c, p, P_AMOUNT_G, fixed_base_multiplication(c, sc, A(LAYOUT.fbm_amount), &s.amount, 32)); break;
         case 3: pt_st(c, p, P_FEE_G, fixed_base_multiplication(c, sc, A(LAYOUT.fbm_fee), &s.fee, 32)); break;
-        case 4: {
+        case 4: {   // c_right = randomness * G, then dec_key * c_right
             const JP r = fixed_base_multiplication(c, sc, A(LAYOUT.fbm_cright), s.randomness, 252);
             pt_st(c, p, P_CRIGHT, r);
             inputize(z, IN_CRIGHT, r);
+            pt_st(c, p, P_DKSR, point_mul(c, sc, A(LAYOUT.mul_dksr), r, s.dec_key));
             break;
         }
         case 5: pt_st(c, p, P_REMBAL_G, fixed_base_multiplication(c, sc, A(LAYOUT.fbm_rembal), &s.remaining_balance, 32)); break;
@@ -540,38 +543,23 @@ k_wit_level1(Ctx c) {
     }
 }
 
-// level 2: the multiplications by level-1 results, rvk
+// level 2 (r4: the former levels 2 and 3 side by side - neither needs the other): role 0 = rvk and c_left_recipient,
+// role 1 = the additions that tie the ciphertexts together
 static __global__ void __launch_bounds__(64)
 k_wit_level2(Ctx c) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, role = blockIdx.y;
     if (p >= c.n || c.bad[p]) return;
-    const Stmt& s = c.st[p];
     uint32_t* z = c.z + (size_t)p * NV * 8;
     uint32_t* aux = z + (size_t)N_IN * 8;
-    const Scratch sc = scratch_of(c, role, p);
     auto A = [&](uint32_t off) { return aux + (size_t)off * 8; };
-    switch (role) {
-        case 0: pt_st(c, p, P_VAL_RLS, point_mul(c, sc, A(LAYOUT.mul_rls), pt_ld(c, p, P_EKS), s.randomness)); break;
-        case 1: pt_st(c, p, P_DKSR, point_mul(c, sc, A(LAYOUT.mul_dksr), pt_ld(c, p, P_CRIGHT), s.dec_key)); break;
-        case 2: {
-            const JP rvk = point_add(c, A(LAYOUT.add_rvk), pt_ld(c, p, P_PGK), pt_ld(c, p, P_ALPHA_G));
-            assert_not_small_order(c, A(LAYOUT.so_rvk), rvk);
-            inputize(z, IN_RVK, rvk);
-            const JP clr = point_add(c, A(LAYOUT.add_clr), pt_ld(c, p, P_AMOUNT_G), pt_ld(c, p, P_VAL_RLR));
-            inputize(z, IN_CLR, clr);
-            break;
-        }
+    if (role == 0) {
+        const JP rvk = point_add(c, A(LAYOUT.add_rvk), pt_ld(c, p, P_PGK), pt_ld(c, p, P_ALPHA_G));
+        assert_not_small_order(c, A(LAYOUT.so_rvk), rvk);
+        inputize(z, IN_RVK, rvk);
+        const JP clr = point_add(c, A(LAYOUT.add_clr), pt_ld(c, p, P_AMOUNT_G), pt_ld(c, p, P_VAL_RLR));
+        inputize(z, IN_CLR, clr);
+        return;
     }
-}
-
-// level 3: the additions that tie the ciphertexts together
-static __global__ void __launch_bounds__(64)
-k_wit_level3(Ctx c) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= c.n || c.bad[p]) return;
-    uint32_t* z = c.z + (size_t)p * NV * 8;
-    uint32_t* aux = z + (size_t)N_IN * 8;
-    auto A = [&](uint32_t off) { return aux + (size_t)off * 8; };
     const JP amount_g = pt_ld(c, p, P_AMOUNT_G), fee_g = pt_ld(c, p, P_FEE_G), rls = pt_ld(c, p, P_VAL_RLS),
              dksr = pt_ld(c, p, P_DKSR);
     const JP cls = point_add(c, A(LAYOUT.add_cls), amount_g, rls);
