@@ -32,7 +32,7 @@ zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_
     ZK_TRY(R->pin_st[slot].ensure(np * sizeof(zkwitdev::Stmt)));
     ZK_TRY(R->pin_bad[slot].ensure(np * 4));
     ZK_TRY(R->wit_pts.ensure(np * (size_t)zkwitdev::P_COUNT * 64));
-    ZK_TRY(R->wit_scratch.ensure((size_t)zkwitdev::L1_ROLES * zkwitdev::SCRATCH_SLOTS * np * 32));
+    ZK_TRY(R->wit_scratch.ensure((size_t)zkwitdev::L1_SCRATCH_ROLES * zkwitdev::SCRATCH_SLOTS * np * 32));
     memcpy(R->pin_st[slot].p, st, np * sizeof(zkwitdev::Stmt));
     HIP_TRY(hipMemcpyAsync(R->wit_st[slot].p, R->pin_st[slot].p, np * sizeof(zkwitdev::Stmt), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemsetAsync(R->wit_bad[slot].p, 0, np * 4, stream));
@@ -50,6 +50,8 @@ zk_status witness_gpu_enqueue(zk_r1cs* R, const zk_transfer_statement* st, size_
         ProfScope ps("witness_gpu", stream);
         ZK_LAUNCH(zkwitdev::k_wit_decode, dim3((unsigned)((np * 5 + 63) / 64)), dim3(64), 0, stream, c);
         ZK_LAUNCH(zkwitdev::k_wit_level1, dim3(b64, zkwitdev::L1_ROLES + (typed_inputs ? zkwitdev::L1_TYPED_ROLES : 0u)), dim3(64), 0, stream, c);
+        ZK_LAUNCH(zkwitdev::k_wit_mul_affine, dim3(b64, zkwitdev::N_MULS * zkwitdev::MUL_SEGS), dim3(64), 0, stream, c);
+        ZK_LAUNCH(zkwitdev::k_wit_mul_fill, dim3(b64, zkwitdev::N_MULS * zkwitdev::MUL_FILL_CHUNKS), dim3(64), 0, stream, c);
         ZK_LAUNCH(zkwitdev::k_wit_level2, dim3(b64, zkwitdev::L2_ROLES), dim3(64), 0, stream, c);
     }
     HIP_TRY(hipGetLastError());
@@ -114,8 +116,12 @@ zk_status witness_anon_gpu_enqueue(zk_r1cs* R, const zk_anonymous_statement* st,
         ProfScope ps("witness_gpu", stream);
         ZK_LAUNCH(k_awit_decode, dim3((unsigned)((np * (2 + 4 * ANON) + 63) / 64)), dim3(64), 0, stream, c);
         ZK_LAUNCH(k_awit_level1, dim3(b64, A1_ROLES), dim3(64), 0, stream, c);
+        ZK_LAUNCH(k_awit_mul_affine, dim3(b64, (ANON + 1) * MUL_SEGS), dim3(64), 0, stream, c, 0u);
+        ZK_LAUNCH(k_awit_mul_fill, dim3(b64, (ANON + 1) * MUL_FILL_CHUNKS), dim3(64), 0, stream, c, 0u);
         ZK_LAUNCH(k_awit_level2, dim3(b64, A2_ROLES), dim3(64), 0, stream, c);
         ZK_LAUNCH(k_awit_level3, dim3(b64, 2), dim3(64), 0, stream, c);
+        ZK_LAUNCH(k_awit_mul_affine, dim3(b64, MUL_SEGS), dim3(64), 0, stream, c, A_MUL_CRD_SK);
+        ZK_LAUNCH(k_awit_mul_fill, dim3(b64, MUL_FILL_CHUNKS), dim3(64), 0, stream, c, A_MUL_CRD_SK);
         ZK_LAUNCH(k_awit_level4, dim3(b64), dim3(64), 0, stream, c);
     }
     HIP_TRY(hipGetLastError());

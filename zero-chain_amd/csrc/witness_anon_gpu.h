@@ -15,6 +15,8 @@
 //   k_awit_level2  the folds over level-1 results, the conditional selections, cr_d, rvk
 //   k_awit_level3  fold_t + amount_g;  cr_d * dec_key (the one multiplication by a level-2 result)
 //   k_awit_level4  remaining_g + cr_d * dec_key
+//   k_awit_mul_affine / _fill after levels 1 and 3: the multiplications' chains back to affine form and their values
+//                  (witness_gpu.h, "the same multiplication in three launches")
 #pragma once
 #include "witness_gpu.h"
 
@@ -201,7 +203,7 @@ k_awit_level1(ACtx c) {
     const Fr d2 = ld_fr(c.consts + 8);
     if (role >= A1_KMR) {   // enc_key_i * randomness
         const uint32_t i = role - A1_KMR;
-        apt_st(c, p, AP_KMR + i, point_mul(c, sc, A(ALAYOUT.mul_kmr + i * W_MUL), apt_ld(c, p, AP_KEYS + i), s.randomness));
+        point_mul_forward(c, sc, to_ext(apt_ld(c, p, AP_KEYS + i)), s.randomness);   // the rest: k_awit_mul_affine / _fill
         return;
     }
     switch (role) {
@@ -258,11 +260,7 @@ k_awit_level1(ACtx c) {
             break;
         }
         case A1_FBM_ALPHA: apt_st(c, p, AP_ALPHA_G, fixed_base_multiplication(c, sc, A(ALAYOUT.fbm_alpha), s.alpha, 252)); break;
-        case A1_NONCE: {
-            const JP r = point_mul(c, sc, A(ALAYOUT.mul_nonce), apt_ld(c, p, AP_GEPOCH), s.dec_key);
-            inputize(z, AIN_NONCE, r);
-            break;
-        }
+        case A1_NONCE: point_mul_forward(c, sc, to_ext(apt_ld(c, p, AP_GEPOCH)), s.dec_key); break;
         case A1_FOLD_S_KEYS: a_add_fold(c, sc, A(ALAYOUT.fold_s_keys), p, s_bins, AP_KEYS); break;
         case A1_FOLD_T_LEFT: a_add_fold(c, sc, A(ALAYOUT.fold_t_left), p, t_bins, AP_LEFT); break;
         case A1_FOLD_X_LEFT: a_add_fold(c, sc, A(ALAYOUT.fold_x_left), p, x_bins, AP_LEFT); break;
@@ -279,6 +277,43 @@ k_awit_level1(ACtx c) {
             }
             break;
         }
+    }
+}
+
+// the variable-base multiplications in three launches (witness_gpu.h: point_mul_forward / chain_segment_to_affine /
+// point_mul_fill): 0 .. 11 = enc_key_i * randomness, 12 = the nonce, 13 = cr_d * dec_key (level 3)
+constexpr uint32_t A_MUL_NONCE = ANON, A_MUL_CRD_SK = ANON + 1;
+struct AMulDesc {
+    uint32_t role, aux_off;
+    const uint32_t* words;
+};
+ZK_DI AMulDesc a_mul_desc(const AStmt& s, uint32_t m) {
+    if (m < ANON) return AMulDesc{A1_KMR + m, ALAYOUT.mul_kmr + m * W_MUL, s.randomness};
+    if (m == A_MUL_NONCE) return AMulDesc{A1_NONCE, ALAYOUT.mul_nonce, s.dec_key};
+    return AMulDesc{0, ALAYOUT.mul_crd_sk, s.dec_key};
+}
+static __global__ void __launch_bounds__(64)
+k_awit_mul_affine(ACtx c, uint32_t m0) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, m = m0 + blockIdx.y / MUL_SEGS, seg = blockIdx.y % MUL_SEGS;
+    if (p >= c.n || c.bad[p] != A_BAD_NONE) return;
+    chain_segment_to_affine(ascratch_of(c, a_mul_desc(c.ast[p], m).role, p), seg * MUL_SEG_LEN, (seg + 1) * MUL_SEG_LEN, 2 * MUL_BITS);
+}
+static __global__ void __launch_bounds__(64)
+k_awit_mul_fill(ACtx c, uint32_t m0) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, m = m0 + blockIdx.y / MUL_FILL_CHUNKS, ch = blockIdx.y % MUL_FILL_CHUNKS;
+    if (p >= c.n || c.bad[p] != A_BAD_NONE) return;
+    const AMulDesc md = a_mul_desc(c.ast[p], m);
+    const Scratch sc = ascratch_of(c, md.role, p);
+    uint32_t* z = c.z + (size_t)p * A_NV * 8;
+    point_mul_fill(c, sc, z + (size_t)(A_N_IN + md.aux_off) * 8, md.words, ch * MUL_FILL_BITS, (ch + 1) * MUL_FILL_BITS);
+    if (ch == MUL_FILL_CHUNKS - 1) {
+        const JP r = chain_affine(sc, 2 * MUL_BITS - 1);
+        if (m < ANON)
+            apt_st(c, p, AP_KMR + m, r);
+        else if (m == A_MUL_NONCE)
+            inputize(z, AIN_NONCE, r);
+        else
+            apt_st(c, p, AP_CRD_SK, r);
     }
 }
 
@@ -323,7 +358,7 @@ k_awit_level3(ACtx c) {
     uint32_t* aux = c.z + (size_t)p * A_NV * 8 + (size_t)A_N_IN * 8;
     auto A = [&](uint32_t off) { return aux + (size_t)off * 8; };
     if (role == 0)
-        apt_st(c, p, AP_CRD_SK, point_mul(c, ascratch_of(c, 0, p), A(ALAYOUT.mul_crd_sk), apt_ld(c, p, AP_CRD), s.dec_key));
+        point_mul_forward(c, ascratch_of(c, 0, p), to_ext(apt_ld(c, p, AP_CRD)), s.dec_key);
     else
         point_add(c, A(ALAYOUT.add_fold_t_amount), apt_ld(c, p, AP_FOLD_T), apt_ld(c, p, AP_AMOUNT_G));
 }

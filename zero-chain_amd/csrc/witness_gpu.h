@@ -17,9 +17,12 @@
 // of the first level; the eleven single additions come last).  One thread per (statement, gadget), gadgets of
 // one level in one launch, the gadget index in blockIdx.y so that a wave runs ONE gadget:
 //   k_wit_decode   5 threads per statement: Jubjub point decoding (edwards.rs:92-165)
-//   k_wit_level1   10 gadgets: bits / witnessed points / small-order checks, 6 fixed-base, 5 variable-base (r4: the two
-//                  multiplications by a fixed-base product run in the thread that makes that product: one level less)
-//   k_wit_level2   rvk and c_left_recipient | the additions that tie the ciphertexts together, the public inputs
+//   k_wit_level1   12 roles: bits / witnessed points / small-order checks, 6 fixed-base multiplications, the forward
+//                  chains of the 5 variable-base ones (r4: the two that multiply a fixed-base product recompute it in
+//                  extended coordinates instead of waiting a level for it)
+//   k_wit_mul_affine, k_wit_mul_fill   the chains back to affine form (8 threads per chain) and the gadgets' values (one
+//                  thread per 4 bits): r4, 60 % of the dependent products of a multiplication moved off the serial chain
+//   k_wit_level2   rvk and its small-order check | the additions that tie the ciphertexts together, the public inputs
 // Chains live in a per-thread scratch area in HBM laid out [slot][thread] (coalesced across a wave).
 #pragma once
 #include "dev_field.h"
@@ -294,6 +297,85 @@ ZKW_NOINLINE JP point_mul(const Ctx& c, const Scratch& sc, uint32_t* aux, const 
     return chain_affine(sc, 2 * n - 1);
 }
 
+// ---- the same multiplication in three launches (r4).  One thread per gadget makes a chain of ~8 600 dependent field
+// products (forward chain 3 400, back to affine 2 900, the gadget's values 2 300): 10 ms on the one wave per SIMD a batch of
+// 1024 statements gives it.  Only the forward chain is inherently serial: the way back to affine form splits into
+// segments with an inversion each, and every bit's values depend on four affine chain elements only.
+//   point_mul_forward  (in k_wit_level1)      chain elements (X, Y, Z) to scratch, base may be projective
+//   chain_segment_to_affine (k_wit_mul_affine) MUL_SEGS threads per chain
+//   point_mul_fill     (k_wit_mul_fill)       one thread per MUL_FILL_BITS bits
+constexpr uint32_t MUL_BITS = 252, MUL_SEGS = 8, MUL_SEG_LEN = 2 * MUL_BITS / MUL_SEGS, MUL_FILL_BITS = 4,
+                   MUL_FILL_CHUNKS = MUL_BITS / MUL_FILL_BITS;
+static_assert(MUL_SEG_LEN * MUL_SEGS == 2 * MUL_BITS && MUL_FILL_CHUNKS * MUL_FILL_BITS == MUL_BITS, "even split");
+ZKW_NOINLINE void point_mul_forward(const Ctx& c, const Scratch& sc, const EP& base, const uint32_t* words) {
+    const Fr d2 = ld_fr(c.consts + 8);
+    constexpr uint32_t n = MUL_BITS;
+    EP e = base, r;
+    bool have = false;
+    for (uint32_t i = 0; i < n; i++) {
+        if (i) e = ext_add(e, e, d2);
+        chain_put(sc, i, e);
+        if (bit_of(words, i)) {
+            r = have ? ext_add(r, e, d2) : e;
+            have = true;
+        }
+        if (have) {
+            chain_put(sc, n + i, r);
+        } else {   // still the neutral element
+            sc.st(3 * (n + i), Fr::zero());
+            sc.st(3 * (n + i) + 1, Fr::one());
+            sc.st(3 * (n + i) + 2, Fr::one());
+        }
+    }
+}
+// elements e0 .. e1-1 of a chain: (X, Y, Z) -> (x, y); prefix products in slots 3 * cap + e
+ZK_DI void chain_segment_to_affine(const Scratch& sc, uint32_t e0, uint32_t e1, uint32_t cap) {
+    Fr acc = Fr::one();
+    for (uint32_t e = e0; e < e1; e++) {
+        sc.st(3 * cap + e, acc);
+        acc = mul(acc, sc.ld(3 * e + 2));
+    }
+    Fr inv = fr_inv(acc);
+    for (uint32_t e = e1; e-- > e0;) {
+        const Fr zi = mul(inv, sc.ld(3 * cap + e));
+        inv = mul(inv, sc.ld(3 * e + 2));
+        sc.st(3 * e, mul(sc.ld(3 * e), zi));
+        sc.st(3 * e + 1, mul(sc.ld(3 * e + 1), zi));
+    }
+}
+// the gadget's values of bits i0 .. i1-1 from the affine chain (the layout point_mul writes)
+ZK_DI void point_mul_fill(const Ctx& c, const Scratch& sc, uint32_t* aux, const uint32_t* words, uint32_t i0, uint32_t i1) {
+    const Fr d = ld_fr(c.consts);
+    constexpr uint32_t n = MUL_BITS;
+    for (uint32_t i = i0; i < i1; i++) {
+        uint32_t* o = aux + (i ? 16 + (size_t)(i - 1) * 104 : 0);
+        const JP ai = chain_affine(sc, i);
+        if (i) {
+            fill_double(o, chain_affine(sc, i - 1), ai, d);
+            o += 40;
+        }
+        const JP sel = bit_of(words, i) ? ai : neutral();
+        st_fr(o, sel.x);
+        st_fr(o + 8, sel.y);
+        o += 16;
+        if (i) fill_add(o, chain_affine(sc, n + i - 1), sel, chain_affine(sc, n + i), d);
+    }
+}
+// the forward half of fixed_base_multiplication alone: the product in extended coordinates, nothing written
+ZKW_NOINLINE EP fixed_base_forward(const Ctx& c, const uint32_t* words, uint32_t nbits) {
+    const Fr d2 = ld_fr(c.consts + 8);
+    const uint32_t nw = (nbits + 2) / 3;
+    EP run;
+    for (uint32_t i = 0; i < nw; i++) {
+        const uint32_t b0 = bit_of(words, 3 * i), b1 = 3 * i + 1 < nbits ? bit_of(words, 3 * i + 1) : 0u,
+                       b2 = 3 * i + 2 < nbits ? bit_of(words, 3 * i + 2) : 0u;
+        const uint32_t* t = c.table + ((size_t)i * 8 + (b0 | (b1 << 1) | (b2 << 2))) * 16;
+        const JP looked{ld_fr(t), ld_fr(t + 8)};
+        run = i == 0 ? to_ext(looked) : ext_add(run, to_ext(looked), d2);
+    }
+    return run;
+}
+
 ZKW_NOINLINE JP point_add(const Ctx& c, uint32_t* aux, const JP& p, const JP& q) {
     const Fr d = ld_fr(c.consts), d2 = ld_fr(c.consts + 8);
     const EP r = ext_add(to_ext(p), to_ext(q), d2);
@@ -448,7 +530,7 @@ k_wit_decode(Ctx c) {
     }
 }
 
-constexpr uint32_t L1_ROLES = 10, L2_ROLES = 2;
+constexpr uint32_t L1_ROLES = 12, L1_SCRATCH_ROLES = 10, L2_ROLES = 2;
 // roles L1_ROLES .. L1_ROLES + 3 of level 1, launched only for the wallet-level entries (gen_proof): the typed inputs of
 // the reference pass through Point::as_prime_order when they are read (EncryptionKey::read keys.rs:269-276,
 // Ciphertext::read elgamal.rs:117-133, g_epoch.rs:75; core/jubjub/src/curve/edwards.rs:319-330): [s]P == O for
@@ -458,6 +540,11 @@ constexpr uint32_t L1_TYPED_ROLES = 4;
 constexpr uint32_t BAD_NOT_PRIME_ORDER = 16;   // flag bit 16 + k: point k (P_RECIP ..) has a torsion component
 ZK_DI Scratch scratch_of(const Ctx& c, uint32_t role, uint32_t p) {
     return Scratch{c.scratch + ((size_t)role * SCRATCH_SLOTS * c.n + p) * 8, c.n};
+}
+// a second, short chain inside a role's scratch (fixed-base chains use slots 0 .. 335 of the 2016)
+constexpr uint32_t FBM_SUB_SLOT = 1008;
+ZK_DI Scratch scratch_sub(const Ctx& c, uint32_t role, uint32_t p, uint32_t slot0) {
+    return Scratch{c.scratch + (((size_t)role * SCRATCH_SLOTS + slot0) * c.n + p) * 8, c.n};
 }
 ZK_DI bool is_prime_order(const Ctx& c, const JP& pt) {
     const uint64_t FS64[4] = ZK_JUBJUB_FS_MODULUS_64;
@@ -480,7 +567,7 @@ k_wit_level1(Ctx c) {
     const Stmt& s = c.st[p];
     uint32_t* z = c.z + (size_t)p * NV * 8;
     uint32_t* aux = z + (size_t)N_IN * 8;
-    const Scratch sc = scratch_of(c, role < L1_ROLES ? role : 0, p);
+    const Scratch sc = scratch_of(c, role < L1_SCRATCH_ROLES ? role : 0, p);
     auto A = [&](uint32_t off) { return aux + (size_t)off * 8; };
     switch (role) {
         default: {   // L1_ROLES + k: as_prime_order of typed input k
@@ -513,38 +600,96 @@ k_wit_level1(Ctx c) {
             inputize(z, IN_GEPOCH, ge);
             break;
         }
-        case 1: {   // enc_key_sender = dec_key * G, then randomness * enc_key_sender in the same thread (r4: the multiplication
-                    // used to wait a whole level for a point an 84-step chain produces)
-            const JP r = fixed_base_multiplication(c, sc, A(LAYOUT.fbm_eks), s.dec_key, 252);
-            pt_st(c, p, P_EKS, r);
-            inputize(z, IN_EKS, r);
-            pt_st(c, p, P_VAL_RLS, point_mul(c, sc, A(LAYOUT.mul_rls), r, s.randomness));
+        case 1:   // randomness * enc_key_sender: the forward chain, from the fixed-base product recomputed in extended
+                  // coordinates (role 10 makes that gadget's values; the machine is four fifths empty here, the chain is the cost)
+            point_mul_forward(c, sc, fixed_base_forward(c, s.dec_key, 252), s.randomness);
             break;
-        }
         case 2: pt_st(c, p, P_AMOUNT_G, fixed_base_multiplication(c, sc, A(LAYOUT.fbm_amount), &s.amount, 32)); break;
         case 3: pt_st(c, p, P_FEE_G, fixed_base_multiplication(c, sc, A(LAYOUT.fbm_fee), &s.fee, 32)); break;
-        case 4: {   // c_right = randomness * G, then dec_key * c_right
-            const JP r = fixed_base_multiplication(c, sc, A(LAYOUT.fbm_cright), s.randomness, 252);
-            pt_st(c, p, P_CRIGHT, r);
-            inputize(z, IN_CRIGHT, r);
-            pt_st(c, p, P_DKSR, point_mul(c, sc, A(LAYOUT.mul_dksr), r, s.dec_key));
+        case 4:   // dec_key * c_right, c_right = randomness * G (role 11)
+            point_mul_forward(c, sc, fixed_base_forward(c, s.randomness, 252), s.dec_key);
             break;
-        }
         case 5: pt_st(c, p, P_REMBAL_G, fixed_base_multiplication(c, sc, A(LAYOUT.fbm_rembal), &s.remaining_balance, 32)); break;
         case 6: pt_st(c, p, P_ALPHA_G, fixed_base_multiplication(c, sc, A(LAYOUT.fbm_alpha), s.alpha, 252)); break;
-        case 7: pt_st(c, p, P_VAL_RLR, point_mul(c, sc, A(LAYOUT.mul_rlr), pt_ld(c, p, P_RECIP), s.randomness)); break;
-        case 8: pt_st(c, p, P_DKSPR, point_mul(c, sc, A(LAYOUT.mul_dkspr), pt_ld(c, p, P_BALR), s.dec_key)); break;
-        case 9: {
-            const JP r = point_mul(c, sc, A(LAYOUT.mul_nonce), pt_ld(c, p, P_GEPOCH), s.dec_key);
-            pt_st(c, p, P_NONCE, r);
-            inputize(z, IN_NONCE, r);
+        case 7: point_mul_forward(c, sc, to_ext(pt_ld(c, p, P_RECIP)), s.randomness); break;
+        case 8: point_mul_forward(c, sc, to_ext(pt_ld(c, p, P_BALR)), s.dec_key); break;
+        case 9: point_mul_forward(c, sc, to_ext(pt_ld(c, p, P_GEPOCH)), s.dec_key); break;
+        case 10: {   // enc_key_sender = dec_key * G (scratch: the unused upper half of role 2's)
+            const JP r = fixed_base_multiplication(c, scratch_sub(c, 2, p, FBM_SUB_SLOT), A(LAYOUT.fbm_eks), s.dec_key, 252);
+            pt_st(c, p, P_EKS, r);
+            inputize(z, IN_EKS, r);
+            break;
+        }
+        case 11: {   // c_right = randomness * G
+            const JP r = fixed_base_multiplication(c, scratch_sub(c, 3, p, FBM_SUB_SLOT), A(LAYOUT.fbm_cright), s.randomness, 252);
+            pt_st(c, p, P_CRIGHT, r);
+            inputize(z, IN_CRIGHT, r);
             break;
         }
     }
 }
 
-// level 2 (r4: the former levels 2 and 3 side by side - neither needs the other): role 0 = rvk and c_left_recipient,
-// role 1 = the additions that tie the ciphertexts together
+// the five variable-base multiplications of the circuit: scratch role of the chain, the gadget's values, scalar, product
+struct MulDesc {
+    uint32_t role, aux_off, out;
+    const uint32_t* words;
+};
+ZK_DI MulDesc mul_desc(const Stmt& s, uint32_t m) {
+    switch (m) {
+        case 0: return MulDesc{1, LAYOUT.mul_rls, P_VAL_RLS, s.randomness};
+        case 1: return MulDesc{4, LAYOUT.mul_dksr, P_DKSR, s.dec_key};
+        case 2: return MulDesc{7, LAYOUT.mul_rlr, P_VAL_RLR, s.randomness};
+        case 3: return MulDesc{8, LAYOUT.mul_dkspr, P_DKSPR, s.dec_key};
+        default: return MulDesc{9, LAYOUT.mul_nonce, P_NONCE, s.dec_key};
+    }
+}
+constexpr uint32_t N_MULS = 5;
+// blockIdx.y = multiplication * MUL_SEGS + segment
+static __global__ void __launch_bounds__(64)
+k_wit_mul_affine(Ctx c) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y / MUL_SEGS, seg = blockIdx.y % MUL_SEGS;
+    if (p >= c.n || c.bad[p]) return;
+    const MulDesc md = mul_desc(c.st[p], m);
+    chain_segment_to_affine(scratch_of(c, md.role, p), seg * MUL_SEG_LEN, (seg + 1) * MUL_SEG_LEN, 2 * MUL_BITS);
+}
+// blockIdx.y = multiplication * MUL_FILL_CHUNKS + chunk of bits
+static __global__ void __launch_bounds__(64)
+k_wit_mul_fill(Ctx c) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y / MUL_FILL_CHUNKS, ch = blockIdx.y % MUL_FILL_CHUNKS;
+    if (p >= c.n || c.bad[p]) return;
+    const MulDesc md = mul_desc(c.st[p], m);
+    const Scratch sc = scratch_of(c, md.role, p);
+    uint32_t* z = c.z + (size_t)p * NV * 8;
+    point_mul_fill(c, sc, z + (size_t)(N_IN + md.aux_off) * 8, md.words, ch * MUL_FILL_BITS, (ch + 1) * MUL_FILL_BITS);
+    if (ch == MUL_FILL_CHUNKS - 1) {
+        const JP r = chain_affine(sc, 2 * MUL_BITS - 1);
+        pt_st(c, p, md.out, r);
+        if (md.out == P_NONCE) inputize(z, IN_NONCE, r);
+    }
+}
+
+// N extended points to affine form with one inversion
+template <int N>
+ZK_DI void batch_affine(const EP* e, JP* out) {
+    Fr pre[N];
+    Fr acc = Fr::one();
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        pre[i] = acc;
+        acc = mul(acc, e[i].Z);
+    }
+    Fr inv = fr_inv(acc);
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        const Fr zi = mul(inv, pre[i]);
+        inv = mul(inv, e[i].Z);
+        out[i] = JP{mul(e[i].X, zi), mul(e[i].Y, zi)};
+    }
+}
+
+// level 2 (r4: the former levels 2 and 3 side by side - neither needs the other; every role adds in extended
+// coordinates and inverts once): role 0 = rvk and its small-order check, role 1 = c_left_recipient and the additions
+// that tie the ciphertexts together
 static __global__ void __launch_bounds__(64)
 k_wit_level2(Ctx c) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, role = blockIdx.y;
@@ -552,25 +697,52 @@ k_wit_level2(Ctx c) {
     uint32_t* z = c.z + (size_t)p * NV * 8;
     uint32_t* aux = z + (size_t)N_IN * 8;
     auto A = [&](uint32_t off) { return aux + (size_t)off * 8; };
+    const Fr d = ld_fr(c.consts), d2 = ld_fr(c.consts + 8);
     if (role == 0) {
-        const JP rvk = point_add(c, A(LAYOUT.add_rvk), pt_ld(c, p, P_PGK), pt_ld(c, p, P_ALPHA_G));
-        assert_not_small_order(c, A(LAYOUT.so_rvk), rvk);
-        inputize(z, IN_RVK, rvk);
-        const JP clr = point_add(c, A(LAYOUT.add_clr), pt_ld(c, p, P_AMOUNT_G), pt_ld(c, p, P_VAL_RLR));
-        inputize(z, IN_CLR, clr);
+        const JP pgk = pt_ld(c, p, P_PGK), alpha_g = pt_ld(c, p, P_ALPHA_G);
+        EP e[4];
+        JP a[4];
+        e[0] = ext_add(to_ext(pgk), to_ext(alpha_g), d2);   // rvk
+        e[1] = ext_add(e[0], e[0], d2);                       // assert_not_small_order: three doublings
+        e[2] = ext_add(e[1], e[1], d2);
+        e[3] = ext_add(e[2], e[2], d2);
+        batch_affine<4>(e, a);
+        fill_add(A(LAYOUT.add_rvk), pgk, alpha_g, a[0], d);
+        uint32_t* so = A(LAYOUT.so_rvk);
+        fill_double(so, a[0], a[1], d);
+        fill_double(so + 40, a[1], a[2], d);
+        fill_double(so + 80, a[2], a[3], d);
+        st_fr(so + 120, a[3].x.is_zero() ? Fr::zero() : fr_inv(a[3].x));
+        inputize(z, IN_RVK, a[0]);
         return;
     }
     const JP amount_g = pt_ld(c, p, P_AMOUNT_G), fee_g = pt_ld(c, p, P_FEE_G), rls = pt_ld(c, p, P_VAL_RLS),
-             dksr = pt_ld(c, p, P_DKSR);
-    const JP cls = point_add(c, A(LAYOUT.add_cls), amount_g, rls);
-    const JP fls = point_add(c, A(LAYOUT.add_fls), fee_g, rls);
-    inputize(z, IN_CLS, cls);
-    inputize(z, IN_FLS, fls);
-    const JP bdksr = point_add(c, A(LAYOUT.add_bdksr), pt_ld(c, p, P_BALL), dksr);
-    point_add(c, A(LAYOUT.add_bileft), bdksr, dksr);
-    const JP vrb = point_add(c, A(LAYOUT.add_vrb), cls, pt_ld(c, p, P_REMBAL_G));
-    const JP vrbb = point_add(c, A(LAYOUT.add_vrbb), vrb, pt_ld(c, p, P_DKSPR));
-    point_add(c, A(LAYOUT.add_biright), fls, vrbb);
+             dksr = pt_ld(c, p, P_DKSR), rlr = pt_ld(c, p, P_VAL_RLR), ball = pt_ld(c, p, P_BALL),
+             rembal_g = pt_ld(c, p, P_REMBAL_G), dkspr = pt_ld(c, p, P_DKSPR);
+    enum { CLR, CLS, FLS, BDKSR, BILEFT, VRB, VRBB, BIRIGHT, N };
+    EP e[N];
+    JP a[N];
+    const EP x_rls = to_ext(rls), x_dksr = to_ext(dksr);
+    e[CLR] = ext_add(to_ext(amount_g), to_ext(rlr), d2);
+    e[CLS] = ext_add(to_ext(amount_g), x_rls, d2);
+    e[FLS] = ext_add(to_ext(fee_g), x_rls, d2);
+    e[BDKSR] = ext_add(to_ext(ball), x_dksr, d2);
+    e[BILEFT] = ext_add(e[BDKSR], x_dksr, d2);
+    e[VRB] = ext_add(e[CLS], to_ext(rembal_g), d2);
+    e[VRBB] = ext_add(e[VRB], to_ext(dkspr), d2);
+    e[BIRIGHT] = ext_add(e[FLS], e[VRBB], d2);
+    batch_affine<N>(e, a);
+    fill_add(A(LAYOUT.add_clr), amount_g, rlr, a[CLR], d);
+    inputize(z, IN_CLR, a[CLR]);
+    fill_add(A(LAYOUT.add_cls), amount_g, rls, a[CLS], d);
+    fill_add(A(LAYOUT.add_fls), fee_g, rls, a[FLS], d);
+    inputize(z, IN_CLS, a[CLS]);
+    inputize(z, IN_FLS, a[FLS]);
+    fill_add(A(LAYOUT.add_bdksr), ball, dksr, a[BDKSR], d);
+    fill_add(A(LAYOUT.add_bileft), a[BDKSR], dksr, a[BILEFT], d);
+    fill_add(A(LAYOUT.add_vrb), a[CLS], rembal_g, a[VRB], d);
+    fill_add(A(LAYOUT.add_vrbb), a[VRB], dkspr, a[VRBB], d);
+    fill_add(A(LAYOUT.add_biright), a[FLS], a[VRBB], a[BIRIGHT], d);
 }
 
 }  // namespace zkwitdev
