@@ -668,28 +668,9 @@ k_wit_mul_fill(Ctx c) {
     }
 }
 
-// N extended points to affine form with one inversion
-template <int N>
-ZK_DI void batch_affine(const EP* e, JP* out) {
-    Fr pre[N];
-    Fr acc = Fr::one();
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        pre[i] = acc;
-        acc = mul(acc, e[i].Z);
-    }
-    Fr inv = fr_inv(acc);
-#pragma unroll
-    for (int i = N - 1; i >= 0; i--) {
-        const Fr zi = mul(inv, pre[i]);
-        inv = mul(inv, e[i].Z);
-        out[i] = JP{mul(e[i].X, zi), mul(e[i].Y, zi)};
-    }
-}
-
 // level 2 (r4: the former levels 2 and 3 side by side - neither needs the other; every role adds in extended
-// coordinates and inverts once): role 0 = rvk and its small-order check, role 1 = c_left_recipient and the additions
-// that tie the ciphertexts together
+// coordinates, keeps the sums as a chain in its scratch and inverts once): role 0 = rvk and its small-order check,
+// role 1 = c_left_recipient and the additions that tie the ciphertexts together
 static __global__ void __launch_bounds__(64)
 k_wit_level2(Ctx c) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, role = blockIdx.y;
@@ -699,50 +680,56 @@ k_wit_level2(Ctx c) {
     auto A = [&](uint32_t off) { return aux + (size_t)off * 8; };
     const Fr d = ld_fr(c.consts), d2 = ld_fr(c.consts + 8);
     if (role == 0) {
+        const Scratch sc = scratch_of(c, 0, p);
         const JP pgk = pt_ld(c, p, P_PGK), alpha_g = pt_ld(c, p, P_ALPHA_G);
-        EP e[4];
-        JP a[4];
-        e[0] = ext_add(to_ext(pgk), to_ext(alpha_g), d2);   // rvk
-        e[1] = ext_add(e[0], e[0], d2);                       // assert_not_small_order: three doublings
-        e[2] = ext_add(e[1], e[1], d2);
-        e[3] = ext_add(e[2], e[2], d2);
-        batch_affine<4>(e, a);
-        fill_add(A(LAYOUT.add_rvk), pgk, alpha_g, a[0], d);
+        EP e = ext_add(to_ext(pgk), to_ext(alpha_g), d2);   // rvk
+        chain_put(sc, 0, e);
+        for (uint32_t k = 1; k < 4; k++) {                    // assert_not_small_order: three doublings
+            e = ext_add(e, e, d2);
+            chain_put(sc, k, e);
+        }
+        chain_to_affine(sc, 4, 504);
+        const JP rvk = chain_affine(sc, 0), a3 = chain_affine(sc, 3);
+        fill_add(A(LAYOUT.add_rvk), pgk, alpha_g, rvk, d);
         uint32_t* so = A(LAYOUT.so_rvk);
-        fill_double(so, a[0], a[1], d);
-        fill_double(so + 40, a[1], a[2], d);
-        fill_double(so + 80, a[2], a[3], d);
-        st_fr(so + 120, a[3].x.is_zero() ? Fr::zero() : fr_inv(a[3].x));
-        inputize(z, IN_RVK, a[0]);
+        for (uint32_t k = 0; k < 3; k++) fill_double(so + 40 * k, chain_affine(sc, k), chain_affine(sc, k + 1), d);
+        st_fr(so + 120, a3.x.is_zero() ? Fr::zero() : fr_inv(a3.x));
+        inputize(z, IN_RVK, rvk);
         return;
     }
-    const JP amount_g = pt_ld(c, p, P_AMOUNT_G), fee_g = pt_ld(c, p, P_FEE_G), rls = pt_ld(c, p, P_VAL_RLS),
-             dksr = pt_ld(c, p, P_DKSR), rlr = pt_ld(c, p, P_VAL_RLR), ball = pt_ld(c, p, P_BALL),
-             rembal_g = pt_ld(c, p, P_REMBAL_G), dkspr = pt_ld(c, p, P_DKSPR);
+    const Scratch sc = scratch_of(c, 2, p);
     enum { CLR, CLS, FLS, BDKSR, BILEFT, VRB, VRBB, BIRIGHT, N };
-    EP e[N];
-    JP a[N];
-    const EP x_rls = to_ext(rls), x_dksr = to_ext(dksr);
-    e[CLR] = ext_add(to_ext(amount_g), to_ext(rlr), d2);
-    e[CLS] = ext_add(to_ext(amount_g), x_rls, d2);
-    e[FLS] = ext_add(to_ext(fee_g), x_rls, d2);
-    e[BDKSR] = ext_add(to_ext(ball), x_dksr, d2);
-    e[BILEFT] = ext_add(e[BDKSR], x_dksr, d2);
-    e[VRB] = ext_add(e[CLS], to_ext(rembal_g), d2);
-    e[VRBB] = ext_add(e[VRB], to_ext(dkspr), d2);
-    e[BIRIGHT] = ext_add(e[FLS], e[VRBB], d2);
-    batch_affine<N>(e, a);
-    fill_add(A(LAYOUT.add_clr), amount_g, rlr, a[CLR], d);
-    inputize(z, IN_CLR, a[CLR]);
-    fill_add(A(LAYOUT.add_cls), amount_g, rls, a[CLS], d);
-    fill_add(A(LAYOUT.add_fls), fee_g, rls, a[FLS], d);
-    inputize(z, IN_CLS, a[CLS]);
-    inputize(z, IN_FLS, a[FLS]);
-    fill_add(A(LAYOUT.add_bdksr), ball, dksr, a[BDKSR], d);
-    fill_add(A(LAYOUT.add_bileft), a[BDKSR], dksr, a[BILEFT], d);
-    fill_add(A(LAYOUT.add_vrb), a[CLS], rembal_g, a[VRB], d);
-    fill_add(A(LAYOUT.add_vrbb), a[VRB], dkspr, a[VRBB], d);
-    fill_add(A(LAYOUT.add_biright), a[FLS], a[VRBB], a[BIRIGHT], d);
+    {
+        const EP x_amount = to_ext(pt_ld(c, p, P_AMOUNT_G)), x_rls = to_ext(pt_ld(c, p, P_VAL_RLS)), x_dksr = to_ext(pt_ld(c, p, P_DKSR));
+        chain_put(sc, CLR, ext_add(x_amount, to_ext(pt_ld(c, p, P_VAL_RLR)), d2));
+        const EP cls = ext_add(x_amount, x_rls, d2);
+        chain_put(sc, CLS, cls);
+        const EP fls = ext_add(to_ext(pt_ld(c, p, P_FEE_G)), x_rls, d2);
+        chain_put(sc, FLS, fls);
+        EP t = ext_add(to_ext(pt_ld(c, p, P_BALL)), x_dksr, d2);
+        chain_put(sc, BDKSR, t);
+        chain_put(sc, BILEFT, ext_add(t, x_dksr, d2));
+        t = ext_add(cls, to_ext(pt_ld(c, p, P_REMBAL_G)), d2);
+        chain_put(sc, VRB, t);
+        t = ext_add(t, to_ext(pt_ld(c, p, P_DKSPR)), d2);
+        chain_put(sc, VRBB, t);
+        chain_put(sc, BIRIGHT, ext_add(fls, t, d2));
+    }
+    chain_to_affine(sc, N, 504);
+    const JP amount_g = pt_ld(c, p, P_AMOUNT_G), rls = pt_ld(c, p, P_VAL_RLS), dksr = pt_ld(c, p, P_DKSR);
+    const JP clr = chain_affine(sc, CLR), cls = chain_affine(sc, CLS), fls = chain_affine(sc, FLS);
+    fill_add(A(LAYOUT.add_clr), amount_g, pt_ld(c, p, P_VAL_RLR), clr, d);
+    inputize(z, IN_CLR, clr);
+    fill_add(A(LAYOUT.add_cls), amount_g, rls, cls, d);
+    fill_add(A(LAYOUT.add_fls), pt_ld(c, p, P_FEE_G), rls, fls, d);
+    inputize(z, IN_CLS, cls);
+    inputize(z, IN_FLS, fls);
+    const JP bdksr = chain_affine(sc, BDKSR), vrb = chain_affine(sc, VRB), vrbb = chain_affine(sc, VRBB);
+    fill_add(A(LAYOUT.add_bdksr), pt_ld(c, p, P_BALL), dksr, bdksr, d);
+    fill_add(A(LAYOUT.add_bileft), bdksr, dksr, chain_affine(sc, BILEFT), d);
+    fill_add(A(LAYOUT.add_vrb), cls, pt_ld(c, p, P_REMBAL_G), vrb, d);
+    fill_add(A(LAYOUT.add_vrbb), vrb, pt_ld(c, p, P_DKSPR), vrbb, d);
+    fill_add(A(LAYOUT.add_biright), fls, vrbb, chain_affine(sc, BIRIGHT), d);
 }
 
 }  // namespace zkwitdev
