@@ -124,6 +124,21 @@ def test_msm_staged_two_level_sort(emu_lib, monkeypatch):
     pc.prover_batch(emu_lib, 10, 2, 700, 9, use_c_oracle=True)   # 700 aux: two workgroups of scalars per job
 
 
+def test_msm_two_level_sort_tiled_second_pass(emu_lib, monkeypatch):
+    """ZKAMD_SORT_TWO_LEVEL=1: the two-level sort for a batch, second pass k_msm_fine_sort_tile (256 threads per bin, the
+    sorted pairs of a bin staged in LDS and written as one run)."""
+    monkeypatch.setenv("ZKAMD_ASM_MIN_PAIRS", "0")
+    monkeypatch.setenv("ZKAMD_SORT_TWO_LEVEL", "1")
+    monkeypatch.setenv("ZKAMD_SORT_STAGED_MIN_BUCKETS", "1")
+    monkeypatch.setenv("ZKAMD_SORT_FINE_LOG", "2")
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "7")            # 32 buckets in 8 bins
+    monkeypatch.setenv("ZKAMD_SPLIT_MIN", "1")
+    pc.prover_batch(emu_lib, 9, 3, 40, 10, use_c_oracle=True)
+    monkeypatch.setenv("ZKAMD_SPLIT_G1", "0")
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")            # 8 buckets, two bins
+    pc.prover_batch(emu_lib, 10, 2, 700, 9, use_c_oracle=True)   # 700 aux: two workgroups of scalars per job
+
+
 def test_prover_from_witness(emu_lib):
     pc.prover_from_witness(emu_lib, 3, 3, 14, 3)
     pc.prover_from_witness(emu_lib, 4, 2, 9, 2, montgomery=True)

@@ -470,6 +470,96 @@ k_msm_fine_sort(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, 
     }
 }
 
+// The second pass for MANY jobs with a few thousand records per bin (round 4): 256 threads per bin, the bucket scan over
+// `fine` <= 256 counters, and the sorted pairs of a bin STAGED in LDS and written as one linear run - the bin's 16 KB window
+// leaves as whole cache lines whatever the other two thousand resident workgroups do to L2 (k_msm_fine_sort above scatters
+// 4-byte stores over its window and spends twenty 1024-thread barriers on a 128-entry scan).  The records are read twice;
+// the second read hits L2.  A bin with more than MSM_FINE_TILE records scatters straight to HBM as before.
+#ifdef ZK_EMU
+constexpr uint32_t MSM_FINE_TILE = 256;    // (the test-only emulation build: small cases reach both branches)
+#else
+constexpr uint32_t MSM_FINE_TILE = 6144;
+#endif
+static __global__ void __launch_bounds__(256)
+k_msm_fine_sort_tile(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, const uint32_t* __restrict__ coarse_cnt,
+                     const uint32_t* __restrict__ coarse_off, uint32_t fine, uint32_t nb, uint32_t* cnt, uint32_t* off, uint32_t* toff,
+                     uint32_t* bin_tasks, uint32_t* pairs, uint32_t seg) {
+    ZK_SHARED uint32_t h[256];
+    ZK_SHARED uint32_t part[256];
+    ZK_SHARED uint32_t tpart[256];
+    ZK_SHARED uint32_t out[MSM_FINE_TILE];
+    const uint32_t tid = threadIdx.x, bin = blockIdx.x, n_coarse = gridDim.x;
+    const MsmJob job = jobs[blockIdx.y];
+    const uint32_t n_rec = coarse_cnt[(size_t)blockIdx.y * n_coarse + bin];
+    const uint32_t first = job.pair_base + coarse_off[(size_t)blockIdx.y * n_coarse + bin];
+    h[tid] = 0;
+    __syncthreads();
+    {
+        uint32_t e = tid;
+        for (; e + 768 < n_rec; e += 1024) {
+            const uint32_t k0 = rec[first + e].x, k1 = rec[first + e + 256].x, k2 = rec[first + e + 512].x, k3 = rec[first + e + 768].x;
+            atomicAdd(&h[k0], 1u);
+            atomicAdd(&h[k1], 1u);
+            atomicAdd(&h[k2], 1u);
+            atomicAdd(&h[k3], 1u);
+        }
+        for (; e < n_rec; e += 256) atomicAdd(&h[rec[first + e].x], 1u);
+    }
+    __syncthreads();
+    const uint32_t k = tid < fine ? h[tid] : 0u, tk = (k + seg - 1) / seg;
+    part[tid] = k;
+    tpart[tid] = tk;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0, tv = tid >= d ? tpart[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        tpart[tid] += tv;
+        __syncthreads();
+    }
+    const uint32_t run = part[tid] - k, trun = tpart[tid] - tk;
+    if (tid < fine) {
+        const size_t b = (size_t)blockIdx.y * nb + (size_t)bin * fine + tid;
+        cnt[b] = k;
+        off[b] = first + run;
+        toff[b] = trun;
+        h[tid] = run;   // slot cursor of the bucket, relative to the bin's first pair
+    }
+    if (tid == 255) bin_tasks[(size_t)blockIdx.y * n_coarse + bin] = tpart[255];
+    __syncthreads();
+    const bool stage = n_rec <= MSM_FINE_TILE;
+    {
+        uint32_t e = tid;
+        for (; e + 768 < n_rec; e += 1024) {
+            const uint2 r0 = rec[first + e], r1 = rec[first + e + 256], r2 = rec[first + e + 512], r3 = rec[first + e + 768];
+            const uint32_t s0 = atomicAdd(&h[r0.x], 1u), s1 = atomicAdd(&h[r1.x], 1u), s2 = atomicAdd(&h[r2.x], 1u),
+                           s3 = atomicAdd(&h[r3.x], 1u);
+            if (stage) {
+                out[s0] = r0.y;
+                out[s1] = r1.y;
+                out[s2] = r2.y;
+                out[s3] = r3.y;
+            } else {
+                pairs[first + s0] = r0.y;
+                pairs[first + s1] = r1.y;
+                pairs[first + s2] = r2.y;
+                pairs[first + s3] = r3.y;
+            }
+        }
+        for (; e < n_rec; e += 256) {
+            const uint2 r = rec[first + e];
+            const uint32_t sl = atomicAdd(&h[r.x], 1u);
+            if (stage)
+                out[sl] = r.y;
+            else
+                pairs[first + sl] = r.y;
+        }
+    }
+    if (!stage) return;
+    __syncthreads();
+    for (uint32_t e = tid; e < n_rec; e += 256) pairs[first + e] = out[e];
+}
+
 // toff[b] += first task of b's bin; grid (blocks over the buckets, jobs)
 static __global__ void __launch_bounds__(256)
 k_msm_task_offsets(uint32_t* toff, const uint32_t* __restrict__ bin_tbase, uint32_t nb, uint32_t fine_log, uint32_t n_coarse) {

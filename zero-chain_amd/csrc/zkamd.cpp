@@ -527,7 +527,10 @@ struct MsmGroup {
         const char* staged_env = getenv("ZKAMD_SORT_STAGED");
         const uint32_t staged_min_nb = getenv("ZKAMD_SORT_STAGED_MIN_BUCKETS") ? (uint32_t)atoi(getenv("ZKAMD_SORT_STAGED_MIN_BUCKETS")) : 1024u;   // tests: 1
         const bool staged = nj > MSM_FEW_JOBS && nb >= staged_min_nb && big_launch && staged_env && atoi(staged_env) == 1;
-        const bool lds_sort = !staged && (size_t)nb * 4 <= 65536 && nj > MSM_FEW_JOBS && !getenv("ZKAMD_NO_LDS_SORT");
+        // ZKAMD_SORT_TWO_LEVEL=1: the two-level sort for the batch with the tiled second pass (k_msm_fine_sort_tile)
+        const char* two_env = getenv("ZKAMD_SORT_TWO_LEVEL");
+        const bool two_level = nj > MSM_FEW_JOBS && nb >= staged_min_nb && big_launch && two_env && atoi(two_env) == 1;
+        const bool lds_sort = !staged && !two_level && (size_t)nb * 4 <= 65536 && nj > MSM_FEW_JOBS && !getenv("ZKAMD_NO_LDS_SORT");
         if (lds_sort) {
             // histogram + scan + scatter of a job inside one workgroup's LDS
             ProfScope ps("msm_sort_lds", st);
@@ -586,10 +589,14 @@ struct MsmGroup {
                 ProfScope ps("msm_sort_fine", st);
                 // (many jobs: a bin holds a few thousand records - a quarter of the threads does as well and leaves room for four
                 //  workgroups per CU)
-                ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort, dim3(n_coarse, (unsigned)nj),
-                               dim3(staged && zkdev::MSM_SORT_THREADS >= 256 ? 256u : zkdev::MSM_SORT_THREADS), 0, st, dj,
-                               (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
-                               cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
+                if ((two_level || staged) && fine <= 256)
+                    ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort_tile, dim3(n_coarse, (unsigned)nj), dim3(256), 0, st, dj,
+                                   (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
+                                   cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
+                else
+                    ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort, dim3(n_coarse, (unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st, dj,
+                                   (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
+                                   cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st,
                                (const uint32_t*)bin_tasks, bin_tbase, ntasks.as<uint32_t>(), n_coarse);
                 ZK_LAUNCH(zkdev::k_msm_task_offsets, gridb, dim3(256), 0, st, toff.as<uint32_t>(), (const uint32_t*)bin_tbase, nb,
