@@ -364,6 +364,35 @@ def test_full_chunk_1024_every_proof_checked(gpu_lib):
         params.close()
 
 
+def test_full_chunk_two_level_sort_experiments_give_the_same_proofs(gpu_lib, monkeypatch):
+    """The sort experiments of round 4 at the bench's launch shape (they only engage for launches of >= 10^8 pairs): the
+    two-level sort with the tiled second pass (bins above and below its LDS stage), the staged first pass, the old second
+    pass - 1024 proofs each, byte-identical to the default one-workgroup-per-job sort."""
+    import zero_chain_amd as zk
+    from oracle import transfer_circuit as tc
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    n_distinct, n = 16, 1024
+    ws = [tc.make_witness(700 + i, amount=3 + 11 * i, fee=i % 3, balance=900 + 7 * i) for i in range(n_distinct)]
+    sts = zk.transfer_statements([tc.statement_dict(ws[i % n_distinct]) for i in range(n)])
+    rng = synth.SplitMix64(77)
+    rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
+    try:
+        base = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
+        for env in ({"ZKAMD_SORT_TWO_LEVEL": "1"}, {"ZKAMD_SORT_TWO_LEVEL": "1", "ZKAMD_SORT_FINE_LOG": "8"},
+                    {"ZKAMD_SORT_STAGED": "1"}, {"ZKAMD_NO_LDS_SORT": "1"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
+            for k in env:
+                monkeypatch.delenv(k)
+            assert got == base, env
+    finally:
+        mats.close()
+        params.close()
+
+
 def test_pipeline_two_lanes_full_chunks_every_proof_checked(gpu_lib, monkeypatch):
     """The bench's own launch shape: zk_pipeline with TWO lanes - the second lane proves on its
     own cloned workspaces and streams - fed four submits of one full 1024-statement chunk each, so both lanes take
