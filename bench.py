@@ -672,6 +672,20 @@ def main():
                         roof[short + "_valu_issue_frac"] = va["issue_frac"]
                 roof["others"] = others
                 roof["alone_ms_per_chunk"] = {g: round(v, 3) for g, v in alone.items()}
+                # the same launches against the committed profile of the same build (profiles/*_traffic.json: rocprofv3, every
+                # launch alone): boxes of the pool differ by a few per cent; a kernel group far off its profile is a property
+                # of the box of THIS run (one session of round 4 ran the two scratch-using assembly kernels 3x slower:
+                # profiles/r04k_*_slow_box.*) and is named here so that the line can be read for what it is
+                if tj:
+                    ratios = {g: round(alone[g] / tj["groups"][g]["ms_alone"], 3) for g in
+                              ("msm_accumulate_g1", "msm_accumulate_g2", "ntt", "msm_sort_lds", "msm_reduce_g1", "msm_reduce_g2")
+                              if g in alone and g in tj["groups"] and tj["groups"][g].get("ms_alone")}
+                    roof["alone_vs_profile"] = ratios
+                    off = {g: r for g, r in ratios.items() if r > 1.25}
+                    if off:
+                        roof["box_anomaly"] = {"groups_slower_than_their_profile": off, "profile": TRAFFIC,
+                                               "note": "these kernel groups ran alone > 25 % slower than in the committed rocprofv3 "
+                                                       "profile of the same build: the value of this line is not the build's"}
             except Exception as exc:   # a side measurement never costs the bench line
                 roof["alone"] = {"error": repr(exc)[:200]}
             finally:
