@@ -82,3 +82,21 @@ def test_reduction_loop_in_the_single_lane_interpreter(capsys):
     s = _load("sim_red_asm")
     s.main()
     assert "RED_G1 ok" in capsys.readouterr().out
+
+
+def test_assembly_kernels_use_no_scratch_memory():
+    """The kernels around the generated loops must not use scratch (private) memory: a loop that owns every VGPR pushes
+    whatever the compiler carries across it into scratch, and a dispatch that uses scratch runs under the runtime's
+    scratch-wave limit - on one box of round 4 at a third of its waves (profiles/r04k_*_slow_box.*).
+    Read from the gfx950 code objects inside the built library (tools/kernel_resources.py); no GPU needed."""
+    so = os.path.join(ROOT, "zero-chain_amd", "libzkamd.so")
+    llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
+    if not os.path.exists(so) or not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        pytest.skip("library not built or llvm tools absent")
+    res = _load("kernel_resources").kernel_resources(so)
+    hot = {n: r for n, r in res.items() if any(k in n for k in ("k_msm_accumulate_g1asm", "k_msm_accumulate_g2asm", "k_msm_reduce1_g1asm"))}
+    assert len(hot) == 5, sorted(hot)
+    for name, r in hot.items():
+        assert r["scratch"] == 0, (name, r)
+    # ... at the occupancy the loops were sized for: three waves per SIMD for G1 (<= 168 registers), two for the others
+    assert all(r["vgpr"] <= (168 if "g1asm" in n and "reduce1" not in n else 256) for n, r in hot.items()), hot
