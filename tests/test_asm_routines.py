@@ -6,6 +6,8 @@ checks the same routines as the hardware executes them (field KATs, every parity
 import importlib.util
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
