@@ -36,7 +36,6 @@ Everything emitted here is executed for one lane by tools/sim_madd_asm.py agains
 reaches a GPU (tests/test_asm_routines.py).
 """
 import os
-import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -547,17 +546,7 @@ def render(R, e, name, what, first_clobber=64):
     for l in e.lines:
         out.append('    "%s\\n\\t" \\' % l)
     out[-1] = out[-1][:-2]
-    # only the registers the loop names: the pads it never touches stay with the compiler, which then has somewhere to
-    # keep the few values that live across the loop (lane, task slot, a zero) - with every VGPR clobbered they went to
-    # scratch memory, and a kernel that uses scratch runs under the runtime's scratch-wave limit
-    used = set()
-    for l in e.lines:
-        for m in re.finditer(r"v\[(\d+):(\d+)\]", l):
-            used.update(range(int(m.group(1)), int(m.group(2)) + 1))
-        for m in re.finditer(r"\bv(\d+)\b", l):
-            used.add(int(m.group(1)))
-    assert max(used) < R.n_vgpr
-    clob = ["v%d" % i for i in range(first_clobber, R.n_vgpr) if i in used] + ["s%d" % i for i in R.clob_s] + ["vcc", "scc", "memory"]
+    clob = ["v%d" % i for i in range(first_clobber, R.n_vgpr)] + ["s%d" % i for i in R.clob_s] + ["vcc", "scc", "memory"]
     out.append("#define ZK_MADD_%s_ASM_CLOBBERS %s" % (name, ", ".join('"%s"' % c for c in clob)))
     out.append("#define ZK_MADD_%s_VGPRS %d" % (name, R.n_vgpr))
     return "\n".join(out) + "\n"

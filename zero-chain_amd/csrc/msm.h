@@ -810,10 +810,10 @@ k_msm_accumulate_wide(const Affine<F>* __restrict__ table, const uint32_t* __res
 #include "madd_asm.h"
 #define ZK_HAVE_MADD_ASM 1
 // a product of the signed loop: digits exactly normalised, top limb possibly negative, value in (-0.07 p, 2 p) -> [0, 2 p)
-ZK_DI Fq28 fq28_from_signed_product(const u32x16& v, uint32_t z = 0) {
+ZK_DI Fq28 fq28_from_signed_product(const u32x16& v) {
     Fq28 r = fq28_unvec(v);
     if ((int32_t)r.l[13] < 0) {
-        uint32_t c = z;
+        uint32_t c = 0;
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const uint32_t t = r.l[i] + Fq28Consts::P[i] + c;
@@ -825,13 +825,11 @@ ZK_DI Fq28 fq28_from_signed_product(const u32x16& v, uint32_t z = 0) {
     return r;
 }
 // spread(M) +- a signed lazy value (limbs above -(3 * 2^28 - 3)): the unsigned weakly normalised form, value < (M + 2) p
-// (`z` = 0 the compiler cannot see through, taken AFTER the assembly loop: without it the spread constants are hoisted
-//  into registers ahead of a loop that owns every VGPR, i.e. into scratch memory)
 template <int M, bool NEGATE>
-ZK_DI Fq28 fq28_from_signed(const u32x16& v, uint32_t z = 0) {
+ZK_DI Fq28 fq28_from_signed(const u32x16& v) {
     Fq28 r;
 #pragma unroll
-    for (int i = 0; i < 14; i++) r.l[i] = NEGATE ? (Fq28Spread<M>::V[i] + z) - v[i] : (Fq28Spread<M>::V[i] + z) + v[i];
+    for (int i = 0; i < 14; i++) r.l[i] = NEGATE ? Fq28Spread<M>::V[i] - v[i] : Fq28Spread<M>::V[i] + v[i];
     fq28_wnorm(r.l);
     return r;
 }
@@ -905,109 +903,80 @@ k_msm_accumulate_g1asm_persistent(const Affine<Fq28>* __restrict__ table, const 
 // Pass 5, G2: the same loop over Fq2 (madd_asm.h ZK_MADD_G2_ASM).  256 VGPRs = two waves per SIMD (the compiled
 // kernel above: 468 registers, one wave): X and ZZ in registers, W = sigma Y and ZZZ parked in LDS (224 bytes per lane,
 // [element quad][thread] x 16 bytes so that a wave's ds_read_b128 sweeps every bank once).
-// Nothing per-lane may be live across the loop - it owns all 256 VGPRs, so a carried value would live in scratch memory,
-// and a kernel that uses scratch at all runs under the runtime's scratch-wave limit (one box of round 4 ran this kernel at
-// a third of its waves: profiles/r04k_*_slow_box.*).  The task's (index, partial-sum slot, length) wait in LDS (`keep`),
-// the thread index is formed again from the execution mask (`wbase` = first thread of the wave, uniform), and the
-// constants of the conversion back are tied to a zero taken after the loop.
-ZK_DI uint32_t lane_of_wave(uint32_t z) { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)); }
-ZK_DI void g2asm_task(uint32_t t, uint32_t tid, uint32_t wbase, uint32_t z0, uint4 (*park)[128], uint4* keep, const Affine<Fq2x>* __restrict__ table,
-                       const uint32_t* __restrict__ pairs, const uint4* __restrict__ sorted, XYZZ<Fq2x>* __restrict__ tsums,
-                       uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+ZK_DI void g2asm_task(uint32_t t, uint4 (*park)[128], const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                       const uint4* __restrict__ sorted, XYZZ<Fq2x>* __restrict__ tsums, uint32_t* __restrict__ n_redo,
+                       uint32_t* __restrict__ redo) {
     static_assert(ZK_MADD_G2_VGPRS <= 256, "the loop must fit two waves per SIMD");
     static_assert(ZK_MADD_G2_LDS_QUAD_STRIDE == 128 * 16, "parking area laid out for 128-thread workgroups");
     const uint4 d = sorted[t];
     const uint32_t n = d.z;
-    if (n == 0) {
-        tsums[d.y] = XYZZ<Fq2x>::inf();
-        return;
-    }
-    const uint32_t* pp = pairs + d.x;
-    const uint32_t pr = pp[0];
-    const Affine<Fq2x> p = table[pr >> 1];
-    if (n == 1) {
-        tsums[d.y] = XYZZ<Fq2x>{p.x, (pr & 1u) ? neg_b<Fq2x::MO>(p.y) : p.y, Fq2x::one(), Fq2x::one()};
-        return;
-    }
-    {
-        auto put = [&](int slot, const Fq28& a, bool negate) {
+    XYZZ<Fq2x> acc = XYZZ<Fq2x>::inf();
+    if (n) {
+        const uint32_t* pp = pairs + d.x;
+        const uint32_t pr = pp[0];
+        const Affine<Fq2x> p = table[pr >> 1];
+        if (n == 1) {
+            acc = XYZZ<Fq2x>{p.x, (pr & 1u) ? neg_b<Fq2x::MO>(p.y) : p.y, Fq2x::one(), Fq2x::one()};
+        } else {
+            const uint32_t tid = threadIdx.x;
+            auto put = [&](int slot, const Fq28& a, bool negate) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t w[4];
+                for (int q = 0; q < 4; q++) {
+                    uint32_t w[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) w[j] = 4 * q + j < 14 ? (negate ? 0u - a.l[4 * q + j] : a.l[4 * q + j]) : 0u;
-                park[slot * 4 + q][tid] = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-        };
-        // (constants of THIS round, tied to its opaque zero z0: as loop invariants they would be carried across the loop
-        //  as whole 16-register vectors, in scratch)
-        Fq28 one = Fq28::one(), zero;
+                    for (int j = 0; j < 4; j++) w[j] = 4 * q + j < 14 ? (negate ? 0u - a.l[4 * q + j] : a.l[4 * q + j]) : 0u;
+                    park[slot * 4 + q][tid] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            };
+            auto get = [&](int slot) {
+                u32x16 v;
 #pragma unroll
-        for (int i = 0; i < 14; i++) {
-            one.l[i] += z0;
-            zero.l[i] = z0;
+                for (int q = 0; q < 4; q++) {
+                    const uint4 w = park[slot * 4 + q][tid];
+                    v[4 * q] = w.x;
+                    v[4 * q + 1] = w.y;
+                    v[4 * q + 2] = w.z;
+                    v[4 * q + 3] = w.w;
+                }
+                return v;
+            };
+            const Fq28 one = Fq28::one(), zero = Fq28::zero();
+            put(ZK_MADD_G2_LDS_W, p.y.c0, (pr & 1u) != 0);        // W = +-y as signed limbs (sigma = +1)
+            put(ZK_MADD_G2_LDS_W + 1, p.y.c1, (pr & 1u) != 0);
+            put(ZK_MADD_G2_LDS_ZZZ, one, false);
+            put(ZK_MADD_G2_LDS_ZZZ + 1, zero, false);
+            u32x16 X0 = fq28_vec(p.x.c0), X1 = fq28_vec(p.x.c1), ZZ0 = fq28_vec(one), ZZ1 = fq28_vec(zero);
+            const uint64_t pa = (uint64_t)(uintptr_t)pp, ta = (uint64_t)(uintptr_t)table;
+            X0[14] = (uint32_t)pa;
+            X0[15] = (uint32_t)(pa >> 32);
+            X1[14] = n;
+            ZZ0[14] = (uint32_t)ta;
+            ZZ0[15] = (uint32_t)(ta >> 32);
+            ZZ1[14] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)&park[0][tid];
+            asm volatile(ZK_MADD_G2_ASM
+                         : "+{v[0:15]}"(X0), "+{v[16:31]}"(X1), "+{v[32:47]}"(ZZ0), "+{v[48:63]}"(ZZ1)
+                         :
+                         : ZK_MADD_G2_ASM_CLOBBERS);
+            const bool flip = ((n - 1) & 1u) != 0;
+            // X is carry-normalised inside the loop, value in (-6 p, 2 p)
+            acc.x = Fq2x{fq28_from_signed<7, false>(X0), fq28_from_signed<7, false>(X1)};
+            const u32x16 w0 = get(ZK_MADD_G2_LDS_W), w1 = get(ZK_MADD_G2_LDS_W + 1);
+            acc.y = flip ? Fq2x{fq28_from_signed<3, true>(w0), fq28_from_signed<3, true>(w1)}
+                         : Fq2x{fq28_from_signed<2, false>(w0), fq28_from_signed<2, false>(w1)};
+            acc.zz = Fq2x{fq28_from_signed_product(ZZ0), fq28_from_signed_product(ZZ1)};
+            acc.zzz = Fq2x{fq28_from_signed_product(get(ZK_MADD_G2_LDS_ZZZ)), fq28_from_signed_product(get(ZK_MADD_G2_LDS_ZZZ + 1))};
+            if (acc.zz.is_zero_norm()) redo[atomicAdd(n_redo, 1u)] = t;
         }
-        put(ZK_MADD_G2_LDS_W, p.y.c0, (pr & 1u) != 0);        // W = +-y as signed limbs (sigma = +1)
-        put(ZK_MADD_G2_LDS_W + 1, p.y.c1, (pr & 1u) != 0);
-        put(ZK_MADD_G2_LDS_ZZZ, one, false);
-        put(ZK_MADD_G2_LDS_ZZZ + 1, zero, false);
-        keep[tid] = make_uint4(t, d.y, n, n);   // (no constant in it: the compiler would carry the vector for its zero)
-        u32x16 X0 = fq28_vec(p.x.c0), X1 = fq28_vec(p.x.c1), ZZ0 = fq28_vec(one), ZZ1 = fq28_vec(zero);
-        const uint64_t pa = (uint64_t)(uintptr_t)pp, ta = (uint64_t)(uintptr_t)table;
-        X0[14] = (uint32_t)pa;
-        X0[15] = (uint32_t)(pa >> 32);
-        X1[14] = n;
-        X1[15] = z0;
-        ZZ0[14] = (uint32_t)ta;
-        ZZ0[15] = (uint32_t)(ta >> 32);
-        ZZ1[14] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)&park[0][tid];
-        ZZ1[15] = z0;
-        asm volatile(ZK_MADD_G2_ASM
-                     : "+{v[0:15]}"(X0), "+{v[16:31]}"(X1), "+{v[32:47]}"(ZZ0), "+{v[48:63]}"(ZZ1)
-                     :
-                     : ZK_MADD_G2_ASM_CLOBBERS);
-        uint32_t z = 0;
-        asm volatile("" : "+s"(z));
-        const uint32_t tid2 = wbase + lane_of_wave(z);
-        const uint4 kp = keep[tid2];   // (t, slot of the partial sum, n)
-        auto get = [&](int slot) {
-            u32x16 v;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint4 w = park[slot * 4 + q][tid2];
-                v[4 * q] = w.x;
-                v[4 * q + 1] = w.y;
-                v[4 * q + 2] = w.z;
-                v[4 * q + 3] = w.w;
-            }
-            return v;
-        };
-        const bool flip = ((kp.z - 1) & 1u) != 0;
-        XYZZ<Fq2x> acc;
-        // X is carry-normalised inside the loop, value in (-6 p, 2 p)
-        acc.x = Fq2x{fq28_from_signed<7, false>(X0, z), fq28_from_signed<7, false>(X1, z)};
-        const u32x16 w0 = get(ZK_MADD_G2_LDS_W), w1 = get(ZK_MADD_G2_LDS_W + 1);
-        acc.y = flip ? Fq2x{fq28_from_signed<3, true>(w0, z), fq28_from_signed<3, true>(w1, z)}
-                     : Fq2x{fq28_from_signed<2, false>(w0, z), fq28_from_signed<2, false>(w1, z)};
-        acc.zz = Fq2x{fq28_from_signed_product(ZZ0, z), fq28_from_signed_product(ZZ1, z)};
-        acc.zzz = Fq2x{fq28_from_signed_product(get(ZK_MADD_G2_LDS_ZZZ), z), fq28_from_signed_product(get(ZK_MADD_G2_LDS_ZZZ + 1), z)};
-        // (indices widened with the opaque zero: a plain zero-extension takes its zero from a register set before the loop)
-        const uint64_t zhi = (uint64_t)z << 32;
-        if (acc.zz.is_zero_norm()) redo[atomicAdd(n_redo + z, 1u) | zhi] = kp.x;
-        tsums[kp.y | zhi] = acc;
     }
+    tsums[d.y] = acc;
 }
 static __global__ void __launch_bounds__(128, 2)
 k_msm_accumulate_g2asm(const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
                        const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq2x>* __restrict__ tsums,
                        uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
     ZK_SHARED uint4 park[16][128];
-    ZK_SHARED uint4 keep[128];
-    const uint32_t wbase = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u, tid = wbase + lane_of_wave(0u);
-    const uint32_t t = blockIdx.x * blockDim.x + tid;
-    uint32_t z = 0;
-    asm volatile("" : "+s"(z));
-    if (t < total[0]) g2asm_task(t, tid, wbase, z, park, keep, table, pairs, sorted, tsums, n_redo, redo);
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total[0]) g2asm_task(t, park, table, pairs, sorted, tsums, n_redo, redo);
 }
 // persistent form (see k_msm_accumulate_g1asm_persistent): a lane's LDS slots are its own, no barrier between tasks
 static __global__ void __launch_bounds__(128, 2)
@@ -1016,17 +985,13 @@ k_msm_accumulate_g2asm_persistent(const Affine<Fq2x>* __restrict__ table, const 
                                   XYZZ<Fq2x>* __restrict__ tsums, uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo,
                                   uint32_t* __restrict__ next) {
     ZK_SHARED uint4 park[16][128];
-    ZK_SHARED uint4 keep[128];
-    const uint32_t ntask = total[0], wbase = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u;
+    const uint32_t ntask = total[0], lane = threadIdx.x & 63u;
     for (;;) {
-        uint32_t z = 0;
-        asm volatile("" : "+s"(z));                 // (the lane index is formed again in every round: see g2asm_task)
-        const uint32_t lane = lane_of_wave(z);
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(next, 64u);
         base = __builtin_amdgcn_readfirstlane(base);
         if (base >= ntask) break;
-        if (base + lane < ntask) g2asm_task(base + lane, wbase + lane, wbase, z, park, keep, table, pairs, sorted, tsums, n_redo, redo);
+        if (base + lane < ntask) g2asm_task(base + lane, park, table, pairs, sorted, tsums, n_redo, redo);
     }
 }
 #endif
@@ -1051,18 +1016,15 @@ ZK_DI XYZZ<Fq28> red_asm_point(const u32x16& x, const u32x16& y, const u32x16& z
 static __global__ void __launch_bounds__(64, 2)
 k_msm_reduce1_g1asm(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
                     const uint32_t* __restrict__ task_base, XYZZ<Fq28>* __restrict__ S, XYZZ<Fq28>* __restrict__ A, uint32_t nb,
-                    uint32_t L, uint32_t* __restrict__ n_fallback, uint32_t* __restrict__ fallback) {
+                    uint32_t L, uint32_t* __restrict__ n_fallback) {
     static_assert(ZK_RED_G1_VGPRS <= 256, "the loop must fit two waves per SIMD");
     static_assert(sizeof(XYZZ<Fq28>) == 224, "the loop loads 224-byte partial sums");
     const uint32_t T = nb / L;
     const uint32_t bx = (blockIdx.x + blockIdx.y) % gridDim.x;   // XCD rotation, as in k_msm_suffix_buckets
-    // one wave per workgroup; the lane index comes from the execution mask, not from threadIdx: nothing per-lane has to
-    // survive the loop below, which owns every VGPR - a value carried across it would live in scratch memory, and a
-    // kernel that uses scratch runs under the runtime's scratch-wave limit (profiles/r04k_*_slow_box.*)
-    const uint32_t t = bx * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t t = bx * blockDim.x + threadIdx.x;
     if (t >= T) return;
     const uint32_t job = blockIdx.y;
-    size_t b0 = (size_t)job * nb + (size_t)t * L;
+    const size_t b0 = (size_t)job * nb + (size_t)t * L;
     const XYZZ<Fq28>* ts = tsums + task_base[job];
     u32x16 X = {}, Y = {}, ZZ = {}, ZZZ = {}, AX, AY, AZZ, AZZZ;
     const uint64_t pc = (uint64_t)(uintptr_t)(cnt + b0), pt = (uint64_t)(uintptr_t)(toff + b0), pp = (uint64_t)(uintptr_t)ts;
@@ -1078,39 +1040,21 @@ k_msm_reduce1_g1asm(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __rest
                    "={v[96:111]}"(AZZ), "={v[112:127]}"(AZZZ)
                  :
                  : ZK_RED_G1_ASM_CLOBBERS);
-    uint32_t opaque0 = 0;
-    asm volatile("" : "+s"(opaque0));   // (so that the index below is computed again instead of being kept)
-    const uint32_t t2 = bx * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, opaque0));
-    b0 = (size_t)job * nb + (size_t)t2 * L;
     const uint32_t flags = ZZZ[15];
     XYZZ<Fq28> run = red_asm_point(X, Y, ZZ, ZZZ, (flags & ZK_RED_FLAG_RUN_INF) != 0, (flags & ZK_RED_FLAG_RUN_RAW) != 0);
     XYZZ<Fq28> acc = red_asm_point(AX, AY, AZZ, AZZZ, (flags & ZK_RED_FLAG_ACC_INF) != 0, (flags & ZK_RED_FLAG_ACC_RAW) != 0);
-    // a special case somewhere in the node (or a bucket whose points cancelled): the node is listed for k_msm_reduce1_redo,
-    // the compiled addition that knows them all.  (Not done here: a call of the out-of-line product routines gives the
-    // kernel a stack, i.e. scratch memory, and with it the runtime's scratch-wave limit.)
-    if ((!(flags & ZK_RED_FLAG_RUN_INF) && run.zz.is_zero_norm()) || (!(flags & ZK_RED_FLAG_ACC_INF) && acc.zz.is_zero_norm()))
-        fallback[atomicAdd(n_fallback, 1u)] = job * T + t2;
-    S[(size_t)job * T + t2] = run;
-    A[(size_t)job * T + t2] = acc;
-}
-// the listed nodes again, by the compiled addition with all special cases (a few hundred of two million per launch set)
-static __global__ void __launch_bounds__(64, MsmOcc<Fq28>::red)
-k_msm_reduce1_redo(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
-                   const uint32_t* __restrict__ task_base, XYZZ<Fq28>* __restrict__ S, XYZZ<Fq28>* __restrict__ A, uint32_t nb,
-                   uint32_t L, const uint32_t* __restrict__ n_fallback, const uint32_t* __restrict__ fallback) {
-    const uint32_t T = nb / L, n = n_fallback[0];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t node = fallback[i], job = node / T, t = node % T;
-        const size_t b0 = (size_t)job * nb + (size_t)t * L;
-        const XYZZ<Fq28>* ts = tsums + task_base[job];
-        XYZZ<Fq28> run = XYZZ<Fq28>::inf(), acc = XYZZ<Fq28>::inf();
+    if ((!(flags & ZK_RED_FLAG_RUN_INF) && run.zz.is_zero_norm()) || (!(flags & ZK_RED_FLAG_ACC_INF) && acc.zz.is_zero_norm())) {
+        // a special case somewhere in the node (or a bucket whose points cancelled): the compiled addition knows them all
+        atomicAdd(n_fallback, 1u);   // diagnostics (ZKAMD_DEBUG_REDO)
+        run = XYZZ<Fq28>::inf();
+        acc = XYZZ<Fq28>::inf();
         for (int k = (int)L - 1; k >= 0; k--) {
             if (cnt[b0 + k]) run = xadd(run, ts[toff[b0 + k]]);
             if (k >= 1) acc = xadd(acc, run);
         }
-        S[node] = run;
-        A[node] = acc;
     }
+    S[(size_t)job * T + t] = run;
+    A[(size_t)job * T + t] = acc;
 }
 #endif
 // The level above the assembly loop: children k of a parent carry S_k (suffix sums R'_k already formed by k_msm_suffix)

@@ -294,7 +294,7 @@ template <class DF>
 static bool asm_reduce() { return false; }
 template <class DF>
 static void launch_red_asm(const zkdev::XYZZ<DF>*, const uint32_t*, const uint32_t*, const uint32_t*, zkdev::XYZZ<DF>*, zkdev::XYZZ<DF>*,
-                           uint32_t, uint32_t, dim3, hipStream_t, uint32_t*, uint32_t*) {}
+                           uint32_t, uint32_t, dim3, hipStream_t, uint32_t*) {}
 #ifdef ZK_HAVE_RED_ASM
 template <>
 bool asm_reduce<zkdev::Fq28>() {
@@ -304,10 +304,8 @@ bool asm_reduce<zkdev::Fq28>() {
 template <>
 void launch_red_asm<zkdev::Fq28>(const zkdev::XYZZ<zkdev::Fq28>* tsums, const uint32_t* cnt, const uint32_t* toff, const uint32_t* tbase,
                                  zkdev::XYZZ<zkdev::Fq28>* S, zkdev::XYZZ<zkdev::Fq28>* A, uint32_t nb, uint32_t L, dim3 grid,
-                                 hipStream_t st, uint32_t* n_fallback, uint32_t* fallback) {
-    ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm, grid, dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L, n_fallback, fallback);
-    ZK_LAUNCH(zkdev::k_msm_reduce1_redo, dim3(256), dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L, (const uint32_t*)n_fallback,
-              (const uint32_t*)fallback);
+                                 hipStream_t st, uint32_t* n_fallback) {
+    ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm, grid, dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L, n_fallback);
 }
 #endif
 #ifdef ZK_HAVE_MADD_ASM
@@ -623,7 +621,7 @@ struct MsmGroup {
             // 32-point tasks: `total` below the short-task threshold above) keeps the compiled kernel and saves the second launch
             if (asm_loop<DF>() && big_launch) {
                 // the generated assembly loop (msm.h, madd_asm.h), then the compiled loop over the few tasks it flagged
-                ZK_TRY(redo.ensure(std::max((size_t)total_tasks, (size_t)nj * T) * 4));   // (level 1 of the reduction lists its nodes here later)
+                ZK_TRY(redo.ensure((size_t)total_tasks * 4));
                 launch_asm_loop(table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>(), d_nredo,
                                 redo.as<uint32_t>(), (unsigned)((total_tasks + 127) / 128), st);
                 if (getenv("ZKAMD_DEBUG_REDO")) {   // diagnostics: how many tasks went to the second pass, and what they look like
@@ -685,9 +683,8 @@ struct MsmGroup {
                 // level 1 in assembly: S = R_0 (compact, one per node) and A = sum_{k>=1} R_k; then the first level above
                 // it, which forms W(parent) = 2M sum_{k>=1} R'_k + 2 sum_k A_k + R'_0 (msm.h k_msm_level2_acc) - run even
                 // for a single node per job, where it is just W = 2 A + S
-                ZK_TRY(redo.ensure((size_t)nj * T * 4));   // (the accumulation's second pass is done with its list by now)
                 launch_red_asm<DF>(tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(), R, Wa, nb, L,
-                                   grid(T), st, d_nfallback, redo.as<uint32_t>());
+                                   grid(T), st, d_nfallback);
                 if (getenv("ZKAMD_DEBUG_REDO")) {   // diagnostics: nodes of level 1 the assembly loop handed to the compiled addition
                     (void)hipStreamSynchronize(st);
                     uint32_t v[2] = {0, 0};
