@@ -81,8 +81,10 @@ static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 0; }
-enum { hipStreamNonBlocking = 1 };
+enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return 0; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return 0; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return 0; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
