@@ -470,70 +470,54 @@ k_msm_fine_sort(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, 
     }
 }
 
-// The second pass for MANY jobs with a few thousand records per bin (round 4): 256 threads per bin.  k_msm_fine_sort above
-// spends twenty 1024-thread barriers on a 128-entry scan and scatters 4-byte stores over its window; with 393 000 bins per
-// chunk what counts is the LATENCY of a bin (the first version of this kernel read the records twice and scanned with
-// sixteen barriers: 40 us per bin, 13.3 ms per chunk - profiles/r04_experiments.txt r04n).  Here a bin of up to
-// MSM_FINE_TILE records is read ONCE into registers (24 per thread, all loads in flight together), counted with LDS
-// atomics, scanned in two short serial steps (16 x 16 counters, one barrier between them), placed into an LDS stage and
-// written as one linear run: five barriers, one global read, one coalesced write.  Bigger bins take the old path
-// (two passes over the records, stores straight to HBM).
+// The second pass for MANY jobs with a few thousand records per bin (round 4): 256 threads per bin, the bucket scan over
+// `fine` <= 256 counters, and the sorted pairs of a bin STAGED in LDS and written as one linear run - the bin's 16 KB window
+// leaves as whole cache lines whatever the other two thousand resident workgroups do to L2 (k_msm_fine_sort above scatters
+// 4-byte stores over its window and spends twenty 1024-thread barriers on a 128-entry scan).  The records are read twice;
+// the second read hits L2.  A bin with more than MSM_FINE_TILE records scatters straight to HBM as before.
 #ifdef ZK_EMU
-constexpr uint32_t MSM_FINE_REG = 1;       // (the test-only emulation build: small cases reach both branches)
+constexpr uint32_t MSM_FINE_TILE = 256;    // (the test-only emulation build: small cases reach both branches)
 #else
-constexpr uint32_t MSM_FINE_REG = 24;
+constexpr uint32_t MSM_FINE_TILE = 6144;
 #endif
-constexpr uint32_t MSM_FINE_TILE = 256 * MSM_FINE_REG;
 static __global__ void __launch_bounds__(256)
 k_msm_fine_sort_tile(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, const uint32_t* __restrict__ coarse_cnt,
                      const uint32_t* __restrict__ coarse_off, uint32_t fine, uint32_t nb, uint32_t* cnt, uint32_t* off, uint32_t* toff,
                      uint32_t* bin_tasks, uint32_t* pairs, uint32_t seg) {
     ZK_SHARED uint32_t h[256];
-    ZK_SHARED uint32_t gsum[16];
-    ZK_SHARED uint32_t gtsum[16];
+    ZK_SHARED uint32_t part[256];
+    ZK_SHARED uint32_t tpart[256];
     ZK_SHARED uint32_t out[MSM_FINE_TILE];
     const uint32_t tid = threadIdx.x, bin = blockIdx.x, n_coarse = gridDim.x;
     const MsmJob job = jobs[blockIdx.y];
     const uint32_t n_rec = coarse_cnt[(size_t)blockIdx.y * n_coarse + bin];
     const uint32_t first = job.pair_base + coarse_off[(size_t)blockIdx.y * n_coarse + bin];
-    const bool stage = n_rec <= MSM_FINE_TILE;
-    uint2 r[MSM_FINE_REG];
     h[tid] = 0;
-    if (stage) {
-#pragma unroll
-        for (uint32_t i = 0; i < MSM_FINE_REG; i++) {
-            const uint32_t e = tid + 256u * i;
-            r[i] = e < n_rec ? rec[first + e] : make_uint2(0xffffffffu, 0u);
+    __syncthreads();
+    {
+        uint32_t e = tid;
+        for (; e + 768 < n_rec; e += 1024) {
+            const uint32_t k0 = rec[first + e].x, k1 = rec[first + e + 256].x, k2 = rec[first + e + 512].x, k3 = rec[first + e + 768].x;
+            atomicAdd(&h[k0], 1u);
+            atomicAdd(&h[k1], 1u);
+            atomicAdd(&h[k2], 1u);
+            atomicAdd(&h[k3], 1u);
         }
+        for (; e < n_rec; e += 256) atomicAdd(&h[rec[first + e].x], 1u);
     }
     __syncthreads();
-    if (stage) {
-#pragma unroll
-        for (uint32_t i = 0; i < MSM_FINE_REG; i++)
-            if (r[i].x != 0xffffffffu) atomicAdd(&h[r[i].x], 1u);
-    } else {
-        for (uint32_t e = tid; e < n_rec; e += 256) atomicAdd(&h[rec[first + e].x], 1u);
-    }
+    const uint32_t k = tid < fine ? h[tid] : 0u, tk = (k + seg - 1) / seg;
+    part[tid] = k;
+    tpart[tid] = tk;
     __syncthreads();
-    // exclusive scan of the `fine` <= 256 counters (and of the task counts): inside a group of 16 serially, then over the groups
-    const uint32_t k = tid < fine ? h[tid] : 0u, tk = (k + seg - 1) / seg, g0 = tid & ~15u;
-    uint32_t run = 0, trun = 0;
-    for (uint32_t j = g0; j < tid; j++) {
-        const uint32_t v = j < fine ? h[j] : 0u;
-        run += v;
-        trun += (v + seg - 1) / seg;
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0, tv = tid >= d ? tpart[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        tpart[tid] += tv;
+        __syncthreads();
     }
-    if ((tid & 15u) == 15u) {
-        gsum[tid >> 4] = run + k;
-        gtsum[tid >> 4] = trun + tk;
-    }
-    __syncthreads();
-    for (uint32_t g = 0; g < (tid >> 4); g++) {
-        run += gsum[g];
-        trun += gtsum[g];
-    }
-    if (tid == 255) bin_tasks[(size_t)blockIdx.y * n_coarse + bin] = trun + tk;
-    __syncthreads();   // (every thread has read the counters it needs: they become the slot cursors now)
+    const uint32_t run = part[tid] - k, trun = tpart[tid] - tk;
     if (tid < fine) {
         const size_t b = (size_t)blockIdx.y * nb + (size_t)bin * fine + tid;
         cnt[b] = k;
@@ -541,17 +525,37 @@ k_msm_fine_sort_tile(const MsmJob* __restrict__ jobs, const uint2* __restrict__ 
         toff[b] = trun;
         h[tid] = run;   // slot cursor of the bucket, relative to the bin's first pair
     }
+    if (tid == 255) bin_tasks[(size_t)blockIdx.y * n_coarse + bin] = tpart[255];
     __syncthreads();
-    if (!stage) {
-        for (uint32_t e = tid; e < n_rec; e += 256) {
-            const uint2 q = rec[first + e];
-            pairs[first + atomicAdd(&h[q.x], 1u)] = q.y;
+    const bool stage = n_rec <= MSM_FINE_TILE;
+    {
+        uint32_t e = tid;
+        for (; e + 768 < n_rec; e += 1024) {
+            const uint2 r0 = rec[first + e], r1 = rec[first + e + 256], r2 = rec[first + e + 512], r3 = rec[first + e + 768];
+            const uint32_t s0 = atomicAdd(&h[r0.x], 1u), s1 = atomicAdd(&h[r1.x], 1u), s2 = atomicAdd(&h[r2.x], 1u),
+                           s3 = atomicAdd(&h[r3.x], 1u);
+            if (stage) {
+                out[s0] = r0.y;
+                out[s1] = r1.y;
+                out[s2] = r2.y;
+                out[s3] = r3.y;
+            } else {
+                pairs[first + s0] = r0.y;
+                pairs[first + s1] = r1.y;
+                pairs[first + s2] = r2.y;
+                pairs[first + s3] = r3.y;
+            }
         }
-        return;
+        for (; e < n_rec; e += 256) {
+            const uint2 r = rec[first + e];
+            const uint32_t sl = atomicAdd(&h[r.x], 1u);
+            if (stage)
+                out[sl] = r.y;
+            else
+                pairs[first + sl] = r.y;
+        }
     }
-#pragma unroll
-    for (uint32_t i = 0; i < MSM_FINE_REG; i++)
-        if (r[i].x != 0xffffffffu) out[atomicAdd(&h[r[i].x], 1u)] = r[i].y;
+    if (!stage) return;
     __syncthreads();
     for (uint32_t e = tid; e < n_rec; e += 256) pairs[first + e] = out[e];
 }
