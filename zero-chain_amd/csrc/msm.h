@@ -480,82 +480,60 @@ constexpr uint32_t MSM_FINE_TILE = 256;    // (the test-only emulation build: sm
 #else
 constexpr uint32_t MSM_FINE_TILE = 6144;
 #endif
-// (Counters of r04z: 63 % of this kernel's busy cycles were LDS bank conflicts - 64 lanes of random keys into counters
-//  whose bank is the key.  The counters are therefore kept in 32 copies laid out [key][copy] with copy = lane mod 32: the
-//  bank of an atomic is the LANE, whatever the key; the scan walks a bucket's copies rotated by the thread index for the
-//  same reason and gives every copy its own run inside the bucket.  fine <= MSM_FINE_TILE_KEYS.)
-constexpr uint32_t MSM_FINE_TILE_KEYS = 128;
 static __global__ void __launch_bounds__(256)
 k_msm_fine_sort_tile(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, const uint32_t* __restrict__ coarse_cnt,
                      const uint32_t* __restrict__ coarse_off, uint32_t fine, uint32_t nb, uint32_t* cnt, uint32_t* off, uint32_t* toff,
                      uint32_t* bin_tasks, uint32_t* pairs, uint32_t seg) {
-    ZK_SHARED uint32_t h[MSM_FINE_TILE_KEYS * 32];
-    ZK_SHARED uint32_t gsum[16];
-    ZK_SHARED uint32_t gtsum[16];
-    ZK_SHARED uint32_t tot[256];
+    ZK_SHARED uint32_t h[256];
+    ZK_SHARED uint32_t part[256];
+    ZK_SHARED uint32_t tpart[256];
     ZK_SHARED uint32_t out[MSM_FINE_TILE];
-    const uint32_t tid = threadIdx.x, bin = blockIdx.x, n_coarse = gridDim.x, cp = tid & 31u;
+    const uint32_t tid = threadIdx.x, bin = blockIdx.x, n_coarse = gridDim.x;
     const MsmJob job = jobs[blockIdx.y];
     const uint32_t n_rec = coarse_cnt[(size_t)blockIdx.y * n_coarse + bin];
     const uint32_t first = job.pair_base + coarse_off[(size_t)blockIdx.y * n_coarse + bin];
-    for (uint32_t i = tid; i < MSM_FINE_TILE_KEYS * 32; i += 256) h[i] = 0;
+    h[tid] = 0;
     __syncthreads();
     {
         uint32_t e = tid;
         for (; e + 768 < n_rec; e += 1024) {
             const uint32_t k0 = rec[first + e].x, k1 = rec[first + e + 256].x, k2 = rec[first + e + 512].x, k3 = rec[first + e + 768].x;
-            atomicAdd(&h[k0 * 32 + cp], 1u);
-            atomicAdd(&h[k1 * 32 + cp], 1u);
-            atomicAdd(&h[k2 * 32 + cp], 1u);
-            atomicAdd(&h[k3 * 32 + cp], 1u);
+            atomicAdd(&h[k0], 1u);
+            atomicAdd(&h[k1], 1u);
+            atomicAdd(&h[k2], 1u);
+            atomicAdd(&h[k3], 1u);
         }
-        for (; e < n_rec; e += 256) atomicAdd(&h[rec[first + e].x * 32 + cp], 1u);
+        for (; e < n_rec; e += 256) atomicAdd(&h[rec[first + e].x], 1u);
     }
     __syncthreads();
-    // bucket totals over the copies (rotated: lane t starts at copy t, every lane in its own bank)
-    uint32_t k = 0;
-    if (tid < fine)
-        for (uint32_t c = 0; c < 32; c++) k += h[tid * 32 + ((c + tid) & 31u)];
-    tot[tid] = k;
+    const uint32_t k = tid < fine ? h[tid] : 0u, tk = (k + seg - 1) / seg;
+    part[tid] = k;
+    tpart[tid] = tk;
     __syncthreads();
-    // exclusive scan of the totals (and of the task counts): inside a group of 16 serially, then over the groups
-    const uint32_t tk = (k + seg - 1) / seg;
-    uint32_t run = 0, trun = 0;
-    for (uint32_t j = tid & ~15u; j < tid; j++) {
-        const uint32_t v = tot[j];
-        run += v;
-        trun += (v + seg - 1) / seg;
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0, tv = tid >= d ? tpart[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        tpart[tid] += tv;
+        __syncthreads();
     }
-    if ((tid & 15u) == 15u) {
-        gsum[tid >> 4] = run + k;
-        gtsum[tid >> 4] = trun + tk;
-    }
-    __syncthreads();
-    for (uint32_t g = 0; g < (tid >> 4); g++) {
-        run += gsum[g];
-        trun += gtsum[g];
-    }
-    if (tid == 255) bin_tasks[(size_t)blockIdx.y * n_coarse + bin] = trun + tk;
+    const uint32_t run = part[tid] - k, trun = tpart[tid] - tk;
     if (tid < fine) {
         const size_t b = (size_t)blockIdx.y * nb + (size_t)bin * fine + tid;
         cnt[b] = k;
         off[b] = first + run;
         toff[b] = trun;
-        uint32_t cur = run;   // slot cursors of the bucket's copies, relative to the bin's first pair
-        for (uint32_t c = 0; c < 32; c++) {
-            const uint32_t j = tid * 32 + ((c + tid) & 31u), v = h[j];
-            h[j] = cur;
-            cur += v;
-        }
+        h[tid] = run;   // slot cursor of the bucket, relative to the bin's first pair
     }
+    if (tid == 255) bin_tasks[(size_t)blockIdx.y * n_coarse + bin] = tpart[255];
     __syncthreads();
     const bool stage = n_rec <= MSM_FINE_TILE;
     {
         uint32_t e = tid;
         for (; e + 768 < n_rec; e += 1024) {
             const uint2 r0 = rec[first + e], r1 = rec[first + e + 256], r2 = rec[first + e + 512], r3 = rec[first + e + 768];
-            const uint32_t s0 = atomicAdd(&h[r0.x * 32 + cp], 1u), s1 = atomicAdd(&h[r1.x * 32 + cp], 1u),
-                           s2 = atomicAdd(&h[r2.x * 32 + cp], 1u), s3 = atomicAdd(&h[r3.x * 32 + cp], 1u);
+            const uint32_t s0 = atomicAdd(&h[r0.x], 1u), s1 = atomicAdd(&h[r1.x], 1u), s2 = atomicAdd(&h[r2.x], 1u),
+                           s3 = atomicAdd(&h[r3.x], 1u);
             if (stage) {
                 out[s0] = r0.y;
                 out[s1] = r1.y;
@@ -570,7 +548,7 @@ k_msm_fine_sort_tile(const MsmJob* __restrict__ jobs, const uint2* __restrict__ 
         }
         for (; e < n_rec; e += 256) {
             const uint2 r = rec[first + e];
-            const uint32_t sl = atomicAdd(&h[r.x * 32 + cp], 1u);
+            const uint32_t sl = atomicAdd(&h[r.x], 1u);
             if (stage)
                 out[sl] = r.y;
             else

@@ -589,7 +589,7 @@ struct MsmGroup {
                 ProfScope ps("msm_sort_fine", st);
                 // (many jobs: a bin holds a few thousand records - a quarter of the threads does as well and leaves room for four
                 //  workgroups per CU)
-                if ((two_level || staged) && fine <= zkdev::MSM_FINE_TILE_KEYS)
+                if ((two_level || staged) && fine <= 256)
                     ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort_tile, dim3(n_coarse, (unsigned)nj), dim3(256), 0, st, dj,
                                    (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
                                    cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
