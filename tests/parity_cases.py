@@ -201,6 +201,202 @@ def msm_edge_cases(lib):
     assert e.value.variant == "IoError"
 
 
+def _bad_uncompressed(group):
+    """The malformed uncompressed encodings of the reference's decoder tests (core/pairing/src/bls12_381/tests/mod.rs:
+    101-214 G1, :216-340 G2): [(encoding, what `into_affine_unchecked` says)], then [(encoding, what only the CHECKED
+    reader refuses)]."""
+    size, n_coord = (96, 2) if group == 1 else (192, 4)
+    z = bytes([0x40]) + bytes(size - 1)
+    one = helpers.golden_points("g1_uncompressed" if group == 1 else "g2_uncompressed")[1]
+    q_be = bls.Q_MOD.to_bytes(48, "big")
+    bad = []
+    bad.append((bytes([z[0] | 0x80]) + z[1:], "infinity with the compression flag"))
+    bad.append((bytes([z[0] | 0x20]) + z[1:], "infinity with the sort flag"))
+    for i in range(size):
+        e = bytearray(z)
+        e[i] |= 1
+        bad.append((bytes(e), "infinity with a non-zero byte %d" % i))
+    bad.append((bytes([one[0] | 0x80]) + one[1:], "a point with the compression flag"))
+    bad.append((bytes([one[0] | 0x20]) + one[1:], "a point with the sort flag"))
+    for k in range(n_coord):
+        e = bytearray(one)
+        e[48 * k:48 * (k + 1)] = q_be
+        bad.append((bytes(e), "coordinate %d = q" % k))
+        e[48 * k:48 * (k + 1)] = (bls.Q_MOD + 1).to_bytes(48, "big")
+        bad.append((bytes(e), "coordinate %d = q + 1" % k))
+    e = bytearray(one)
+    e[48 * (n_coord - 1):] = bytes([0xff] * 48)
+    bad.append((bytes(e), "last coordinate all ones"))
+    checked_only = []
+    e = bytearray(one)
+    e[:size // 2] = bytes(size // 2)                  # x = 0 with the generator's y: not on the curve (mod.rs:169-181)
+    checked_only.append((bytes(e), "not on the curve"))
+    cof = _cofactor_points()   # on the curve, outside the subgroup (mod.rs:183-212)
+    checked_only.append((bls.g1_uncompressed(cof[0]) if group == 1 else bls.g2_uncompressed(cof[1]), "not in the subgroup"))
+    return bad, checked_only
+
+
+def msm_decoder_refusals(lib):
+    """The device decoder of the bases (msm.h k_decode_uncompressed) behind zk_msm_create / zk_msm_create_variable and the
+    one-shot entries zk_msm_g1 / zk_msm_g2: every malformed encoding of the reference's tests is refused with IoError and
+    the index of the offending base; what only `into_affine` (checked) refuses passes unchecked and fails checked."""
+    for group in (1, 2):
+        size = 96 if group == 1 else 192
+        pts = helpers.golden_points("g1_uncompressed" if group == 1 else "g2_uncompressed")
+        good = [pts[3], pts[0], pts[7], pts[200]]      # (pts[0] is the point at infinity: a legal base)
+        bad, checked_only = _bad_uncompressed(group)
+        step = 1 if group == 1 else 3
+        for k, (enc, why) in enumerate(bad[::step] + bad[-8:]):
+            at = k % (len(good) + 1)
+            bases = b"".join(good[:at]) + enc + b"".join(good[at:])
+            for variable in (False, True):
+                with pytest.raises(zk.ZkError) as e:
+                    zk.MultiexpContext(group, bases, lib=lib, variable_base=variable)
+                assert e.value.variant == "IoError" and "base %d" % at in str(e.value), (why, str(e.value))
+            with pytest.raises(zk.ZkError) as e:
+                zk.multiexp(group, bases, [1] * (len(good) + 1), lib=lib)
+            assert e.value.variant == "IoError" and "base %d" % at in str(e.value), (why, str(e.value))
+        for enc, why in checked_only:
+            bases = good[0] + enc
+            zk.MultiexpContext(group, bases, checked=False, lib=lib).close()
+            with pytest.raises(zk.ZkError) as e:
+                zk.MultiexpContext(group, bases, checked=True, lib=lib)
+            assert e.value.variant == "IoError" and "point 1" in str(e.value) and why.split()[-1] in str(e.value), (why, str(e.value))
+        # the first refused encoding is the one named, whatever follows it
+        bases = good[0] + bad[0][0] + good[1] + bad[5][0]
+        with pytest.raises(zk.ZkError) as e:
+            zk.multiexp(group, bases, [1, 2, 3, 4], lib=lib)
+        assert "base 1" in str(e.value)
+
+
+def msm_oneshot(lib, n1=700, n2=90, seeds=(5, 6)):
+    """zk_msm_g1 / zk_msm_g2 (bellman multiexp called once over fresh bases): golden multiples with the point at infinity
+    among the bases, scalars 0, 1, r - 1 and equal (base, scalar) pairs; sum_i s_i (k_i G) == (sum_i s_i k_i) G; the empty
+    multiexp; a non-canonical scalar is refused with its index; a second call of another size reuses the cached handle."""
+    for group, n, seed in ((1, n1, seeds[0]), (2, n2, seeds[1]), (1, 37, 9), (1, 1, 3)):
+        pts = helpers.golden_points("g1_uncompressed" if group == 1 else "g2_uncompressed")
+        rng = synth.SplitMix64(seed)
+        ks = [rng.below(len(pts)) for _ in range(n)]
+        sc = [rng.field(bls.R_MOD) for _ in range(n)]
+        for i, special in enumerate((0, 1, bls.R_MOD - 1, 2, bls.R_MOD - 2, (1 << 254) + 1)):
+            if i < n:
+                sc[i] = special
+        if n > 8:
+            ks[7], sc[7] = ks[6], sc[6]
+            ks[8] = 0
+        got = zk.multiexp(group, b"".join(pts[k] for k in ks), sc, lib=lib)
+        want = sum(a * b for a, b in zip(ks, sc)) % bls.R_MOD
+        assert got == (helpers.g1_of(want) if group == 1 else helpers.g2_of(want)), (group, n)
+        size = 96 if group == 1 else 192
+        assert zk.multiexp(group, b"", [], lib=lib) == bytes([0x40]) + bytes(size - 1)
+        if n > 3:
+            sc[3] = bls.R_MOD
+            with pytest.raises(zk.ZkError) as e:
+                zk.multiexp(group, b"".join(pts[k] for k in ks), np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in sc), dtype=np.uint8), lib=lib)
+            assert e.value.variant == "InvalidArgument" and "scalar 3" in str(e.value)
+
+
+def prover_device_pointers(lib, alloc, seed=4, n_in=3, n_aux=14, n_proofs=5):
+    """zk_prove_batch_dev: a, b, c and the witness vectors of a batch already in device memory (allocated by the caller:
+    torch on the GPU, host memory under the emulation), plain and ZK_FR_MONTGOMERY; bytes == the discrete-log proof ==
+    zk_prove_batch on the same assignments.  The refusals of the entry: a null device pointer, a wrong input count."""
+    E = g.Bls12Engine()
+    circ = synth.ChainCircuit(seed, n_in, n_aux)
+    P = g.generate_parameters(E, circ.r1cs, *helpers.TOXIC, scalars_only=True)
+    pk = params_io.write_parameters_from_scalars(P.sc, n_in, threads=4)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    try:
+        asgs, rs = [], []
+        rng = synth.SplitMix64(seed + 77)
+        for i in range(n_proofs):
+            inputs, aux = circ.witness(seed * 31 + i)
+            asgs.append(g.assign(E, circ.r1cs, inputs, aux))
+            rs.append((rng.field(bls.R_MOD), rng.field(bls.R_MOD)))
+        n_rows = len(asgs[0].a)
+        host = [p.write() for p in zk.create_proofs([helpers.to_assignment(zk, a) for a in asgs], params, rs)]
+        for montgomery in (False, True):
+            conv = (lambda vals: [bls.fr_to_mont(v) for v in vals]) if montgomery else (lambda vals: vals)
+            bufs = []
+            for vec in ("a", "b", "c", "wit"):
+                data = b"".join(helpers.le(conv(getattr(a, vec) if vec != "wit" else a.inputs + a.aux)) for a in asgs)
+                arr = np.frombuffer(data, dtype=np.uint8)
+                ptr, upload, download, free = alloc(arr.size)
+                upload(ptr, arr)
+                bufs.append((ptr, free))
+            try:
+                a0 = asgs[0]
+                args = (a0.a_aux_density, a0.b_input_density, a0.b_aux_density, rs)
+                got = zk.create_proofs_dev(params, n_proofs, n_rows, n_in, n_aux, bufs[0][0], bufs[1][0], bufs[2][0], bufs[3][0], *args,
+                                           montgomery=montgomery)
+                for asg, (r, s), pf, h in zip(asgs, rs, got, host):
+                    assert pf.write() == h == helpers.expected_proof_trapdoor(P, asg, r, s), montgomery
+                with pytest.raises(zk.ZkError) as e:
+                    zk.create_proofs_dev(params, n_proofs, n_rows, n_in, n_aux, bufs[0][0], None, bufs[2][0], bufs[3][0], *args)
+                assert e.value.variant == "AssignmentMissing"
+                with pytest.raises(zk.ZkError) as e:
+                    zk.create_proofs_dev(params, n_proofs, n_rows, n_in + 1, n_aux, bufs[0][0], bufs[1][0], bufs[2][0], bufs[3][0], *args)
+                assert e.value.variant == "MalformedVerifyingKey"
+                assert zk.create_proofs_dev(params, 0, n_rows, n_in, n_aux, bufs[0][0], bufs[1][0], bufs[2][0], bufs[3][0], *args[:3], []) == []
+            finally:
+                for ptr, free in bufs:
+                    free(ptr)
+    finally:
+        params.close()
+
+
+def runtime_hooks(lib, on_gpu):
+    """The entries around the compute path that only bench.py used to call: zk_set_host_threads (the encoding legs give
+    the same bytes on one thread and on many), zk_params_get_windows (widths in range, [0] = zk_params_info.window_bits),
+    zk_bind_host_to_device (answers; a device out of range is refused on the GPU build), zk_profile_* (the named kernel
+    groups of a multiexp are counted - and take time on a GPU), zk_stream (the stream the work was enqueued on)."""
+    r1, asg, P, pk = helpers.small_case(2, 3, 11, 13)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    try:
+        w = params.windows
+        assert len(w) == 4 and all(2 <= x <= 22 for x in w) and w[0] == params.info["window_bits"]
+        pa = helpers.to_assignment(zk, asg)
+        rs = [(3 + i, 11 * i + 5) for i in range(6)]
+        zk.set_host_threads(1, lib=lib)
+        one = [p.write() for p in zk.create_proofs([pa] * len(rs), params, rs)]
+        zk.set_host_threads(3, lib=lib)
+        many = [p.write() for p in zk.create_proofs([pa] * len(rs), params, rs)]
+        zk.set_host_threads(0, lib=lib)
+        assert one == many == [helpers.expected_proof_trapdoor(P, asg, r, s) for r, s in rs]
+    finally:
+        params.close()
+    node, cpus = zk.bind_host_to_device(0, lib=lib)
+    assert node >= -1 and (cpus >= 1 or not on_gpu)
+    if on_gpu:
+        with pytest.raises(zk.ZkError) as e:
+            zk.bind_host_to_device(1 << 20, lib=lib)
+        assert e.value.variant == "InvalidArgument"
+    pts = helpers.golden_points("g1_uncompressed")
+    ctx = zk.MultiexpContext(1, b"".join(pts[1 + i % 200] for i in range(500)), lib=lib)
+    try:
+        with zk.KernelTimer(lib) as t:
+            ctx.run(list(range(1, 501)))
+            ctx.run(list(range(2, 502)))
+            n_acc, ms_acc = t.get("msm_accumulate_g1")
+            n_red, ms_red = t.get("msm_reduce_g1")
+            assert t.get("no_such_group") == (0, 0.0)
+        assert n_acc == 2 and n_red == 2
+        if on_gpu:
+            assert ms_acc > 0 and ms_red > 0
+        with zk.KernelTimer(lib) as t:          # a fresh begin starts from zero; nothing is recorded after end
+            assert t.get("msm_accumulate_g1")[0] == 0
+        ctx.run(list(range(1, 501)))
+        st = zk.stream(lib=lib)
+        assert (st != 0) == on_gpu               # (the emulation has no streams)
+        if on_gpu:
+            import torch
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.ExternalStream(st))
+            ev.synchronize()
+            assert ev.query()
+    finally:
+        ctx.close()
+
+
 def prover_small(lib, seed, n_in, n_aux, n_con, checked=True, montgomery=False):
     r1, asg, P, pk = helpers.small_case(seed, n_in, n_aux, n_con)
     params = zk.Parameters.read(pk, checked=checked, lib=lib)

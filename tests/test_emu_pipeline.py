@@ -52,6 +52,40 @@ def test_msm_edges(emu_lib):
     pc.msm_edge_cases(emu_lib)
 
 
+def test_msm_decoder_refusals(emu_lib):
+    pc.msm_decoder_refusals(emu_lib)
+
+
+def test_msm_oneshot_entries(emu_lib):
+    pc.msm_oneshot(emu_lib, n1=150, n2=40)
+
+
+def test_prover_device_pointers(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
+    pc.prover_device_pointers(emu_lib, _host_alloc(emu_lib))
+
+
+def test_runtime_hooks(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
+    pc.runtime_hooks(emu_lib, on_gpu=False)
+
+
+def test_msm_many_workgroup_sort(emu_lib, monkeypatch):
+    """ZKAMD_SORT_WGS = G: the batch's sort with G workgroups per job (msm.h k_msm_msort_*), job-major and XCD-major
+    numbering, a ragged split of the scalars, split and unsplit G1 launch sets."""
+    monkeypatch.setenv("ZKAMD_ASM_MIN_PAIRS", "0")
+    monkeypatch.setenv("ZKAMD_SORT_WGS", "3")
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "7")
+    monkeypatch.setenv("ZKAMD_SPLIT_MIN", "1")
+    pc.prover_batch(emu_lib, 9, 3, 40, 10, use_c_oracle=True)
+    monkeypatch.setenv("ZKAMD_SORT_XCD", "0")
+    monkeypatch.setenv("ZKAMD_SORT_WGS", "5")
+    monkeypatch.setenv("ZKAMD_SPLIT_G1", "0")
+    pc.prover_batch(emu_lib, 10, 2, 700, 16, use_c_oracle=True)   # 16 jobs: the XCD-major numbering applies when it is on
+    monkeypatch.setenv("ZKAMD_SORT_XCD", "1")
+    pc.prover_batch(emu_lib, 11, 2, 90, 16, use_c_oracle=True)
+
+
 def test_prover_small_checked(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
     pc.prover_small(emu_lib, 1, 3, 10, 12)
@@ -106,37 +140,6 @@ def test_msm_two_level_sort_path(emu_lib, monkeypatch):
     pc.msm_golden_vectors(emu_lib, 2, 60, 6)                  # 16 buckets in 2 bins
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "7")
     pc.prover_small(emu_lib, 5, 3, 10, 12)
-
-
-def test_msm_staged_two_level_sort(emu_lib, monkeypatch):
-    """ZKAMD_SORT_STAGED=1 (an experiment of round 4, off by default): two-level sort, the records of the scatter pass staged in
-    LDS and written as runs.
-    More than eight jobs per launch set, several bins, a ragged scalar count per workgroup, split and unsplit G1 sets."""
-    monkeypatch.setenv("ZKAMD_ASM_MIN_PAIRS", "0")
-    monkeypatch.setenv("ZKAMD_SORT_STAGED", "1")
-    monkeypatch.setenv("ZKAMD_SORT_STAGED_MIN_BUCKETS", "1")
-    monkeypatch.setenv("ZKAMD_SORT_FINE_LOG", "2")
-    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "7")            # 32 buckets in 8 bins
-    monkeypatch.setenv("ZKAMD_SPLIT_MIN", "1")
-    pc.prover_batch(emu_lib, 9, 3, 40, 10, use_c_oracle=True)
-    monkeypatch.setenv("ZKAMD_SPLIT_G1", "0")
-    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")            # 8 buckets, two bins
-    pc.prover_batch(emu_lib, 10, 2, 700, 9, use_c_oracle=True)   # 700 aux: two workgroups of scalars per job
-
-
-def test_msm_two_level_sort_tiled_second_pass(emu_lib, monkeypatch):
-    """ZKAMD_SORT_TWO_LEVEL=1: the two-level sort for a batch, second pass k_msm_fine_sort_tile (256 threads per bin, the
-    sorted pairs of a bin staged in LDS and written as one run)."""
-    monkeypatch.setenv("ZKAMD_ASM_MIN_PAIRS", "0")
-    monkeypatch.setenv("ZKAMD_SORT_TWO_LEVEL", "1")
-    monkeypatch.setenv("ZKAMD_SORT_STAGED_MIN_BUCKETS", "1")
-    monkeypatch.setenv("ZKAMD_SORT_FINE_LOG", "2")
-    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "7")            # 32 buckets in 8 bins
-    monkeypatch.setenv("ZKAMD_SPLIT_MIN", "1")
-    pc.prover_batch(emu_lib, 9, 3, 40, 10, use_c_oracle=True)
-    monkeypatch.setenv("ZKAMD_SPLIT_G1", "0")
-    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")            # 8 buckets, two bins
-    pc.prover_batch(emu_lib, 10, 2, 700, 9, use_c_oracle=True)   # 700 aux: two workgroups of scalars per job
 
 
 def test_prover_from_witness(emu_lib):

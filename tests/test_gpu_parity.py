@@ -364,35 +364,6 @@ def test_full_chunk_1024_every_proof_checked(gpu_lib):
         params.close()
 
 
-def test_full_chunk_two_level_sort_experiments_give_the_same_proofs(gpu_lib, monkeypatch):
-    """The sort experiments of round 4 at the bench's launch shape (they only engage for launches of >= 10^8 pairs): the
-    two-level sort with the tiled second pass (bins above and below its LDS stage), the staged first pass, the old second
-    pass - 1024 proofs each, byte-identical to the default one-workgroup-per-job sort."""
-    import zero_chain_amd as zk
-    from oracle import transfer_circuit as tc
-    r1, asgs, P, pk = helpers.transfer_case(1)
-    n_distinct, n = 16, 1024
-    ws = [tc.make_witness(700 + i, amount=3 + 11 * i, fee=i % 3, balance=900 + 7 * i) for i in range(n_distinct)]
-    sts = zk.transfer_statements([tc.statement_dict(ws[i % n_distinct]) for i in range(n)])
-    rng = synth.SplitMix64(77)
-    rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
-    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
-    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
-    try:
-        base = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
-        for env in ({"ZKAMD_SORT_TWO_LEVEL": "1"}, {"ZKAMD_SORT_TWO_LEVEL": "1", "ZKAMD_SORT_FINE_LOG": "8"},
-                    {"ZKAMD_SORT_STAGED": "1"}, {"ZKAMD_NO_LDS_SORT": "1"}):
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            got = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
-            for k in env:
-                monkeypatch.delenv(k)
-            assert got == base, env
-    finally:
-        mats.close()
-        params.close()
-
-
 def test_pipeline_two_lanes_full_chunks_every_proof_checked(gpu_lib, monkeypatch):
     """The bench's own launch shape: zk_pipeline with TWO lanes - the second lane proves on its
     own cloned workspaces and streams - fed four submits of one full 1024-statement chunk each, so both lanes take
@@ -670,3 +641,66 @@ def test_msm_variable_base_2p17_vs_table(gpu_lib):
     finally:
         a.close()
         b.close()
+
+
+def test_msm_decoder_refusals(gpu_lib):
+    pc.msm_decoder_refusals(gpu_lib)
+
+
+def test_msm_oneshot_entries(gpu_lib):
+    pc.msm_oneshot(gpu_lib)
+
+
+def test_msm_oneshot_2p16_vs_bellman_algorithm(gpu_lib):
+    """zk_msm_g1 / zk_msm_g2 on distinct random bases with witness-like scalars (12 % zero / one): the one-shot
+    variable-base Pippenger == the C restatement of bellman's multiexp, byte for byte (2^16 G1 points, 2^13 G2)."""
+    import zero_chain_amd as zk
+    for group, n, seed in ((1, 1 << 16, 31), (2, 1 << 13, 32)):
+        rng = synth.SplitMix64(seed)
+        ks = [rng.field(bls.R_MOD) for _ in range(n)]
+        bases = cport.fixed_base_mul(group, helpers.le(ks), 8)
+        sc = [rng.below(2) if rng.below(100) < 12 else rng.field(bls.R_MOD) for _ in range(n)]
+        want = cport.Bases(group, bases).multiexp(helpers.le(sc), 8)
+        assert zk.multiexp(group, bases, sc, lib=gpu_lib) == want
+        # a second call on the cached handle with other scalars, then a smaller one
+        sc2 = [rng.field(bls.R_MOD) for _ in range(n)]
+        assert zk.multiexp(group, bases, sc2, lib=gpu_lib) == cport.Bases(group, bases).multiexp(helpers.le(sc2), 8)
+        m = n // 3
+        size = 96 if group == 1 else 192
+        assert zk.multiexp(group, bases[:size * m], sc[:m], lib=gpu_lib) == cport.Bases(group, bases[:size * m]).multiexp(helpers.le(sc[:m]), 8)
+
+
+def test_prover_device_pointers(gpu_lib):
+    pc.prover_device_pointers(gpu_lib, _torch_alloc())
+
+
+def test_runtime_hooks(gpu_lib):
+    pc.runtime_hooks(gpu_lib, on_gpu=True)
+
+
+def test_full_chunk_many_workgroup_sort_gives_the_same_proofs(gpu_lib, monkeypatch):
+    """ZKAMD_SORT_WGS (msm.h k_msm_msort_*: G workgroups per job, job-major) at the bench's launch shape - it engages for
+    the many-jobs launch sets only: 1024 proofs, byte-identical to the one-workgroup-per-job sort's, for G = 4 and 16 and
+    both numberings of the workgroups."""
+    import zero_chain_amd as zk
+    from oracle import transfer_circuit as tc
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    n_distinct, n = 16, 1024
+    ws = [tc.make_witness(700 + i, amount=3 + 11 * i, fee=i % 3, balance=900 + 7 * i) for i in range(n_distinct)]
+    sts = zk.transfer_statements([tc.statement_dict(ws[i % n_distinct]) for i in range(n)])
+    rng = synth.SplitMix64(77)
+    rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
+    try:
+        base = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
+        for env in ({"ZKAMD_SORT_WGS": "16"}, {"ZKAMD_SORT_WGS": "4", "ZKAMD_SORT_XCD": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            got = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
+            for k in env:
+                monkeypatch.delenv(k)
+            assert got == base, env
+    finally:
+        mats.close()
+        params.close()

@@ -25,22 +25,14 @@ rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(B)]
 base = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
 mode = sys.argv[1] if len(sys.argv) > 1 else "debug"
 CONFIGS = {
-    "staged": (("lds sort", {"ZKAMD_SORT_STAGED": "0"}), ("staged fine_log 7", {"ZKAMD_SORT_STAGED": "1"}),
-                      ("staged fine_log 6", {"ZKAMD_SORT_STAGED": "1", "ZKAMD_SORT_FINE_LOG": "6"}),
-                      ("staged fine_log 8", {"ZKAMD_SORT_STAGED": "1", "ZKAMD_SORT_FINE_LOG": "8"}),
-                      ("staged fine_log 5", {"ZKAMD_SORT_STAGED": "1", "ZKAMD_SORT_FINE_LOG": "5"}),
-                      ("unstaged two-level", {"ZKAMD_SORT_STAGED": "0", "ZKAMD_NO_LDS_SORT": "1"})),
-    # the tiled second pass (k_msm_fine_sort_tile): plain and staged first pass, bins of 64 / 128 / 256 buckets
-    "tiled": (("lds sort", {}), ("two-level tiled fine_log 7", {"ZKAMD_SORT_TWO_LEVEL": "1"}),
-              ("two-level tiled fine_log 6", {"ZKAMD_SORT_TWO_LEVEL": "1", "ZKAMD_SORT_FINE_LOG": "6"}),
-              ("two-level tiled fine_log 8", {"ZKAMD_SORT_TWO_LEVEL": "1", "ZKAMD_SORT_FINE_LOG": "8"}),
-              ("staged + tiled fine_log 7", {"ZKAMD_SORT_STAGED": "1"}),
-              ("old second pass (NO_LDS_SORT)", {"ZKAMD_NO_LDS_SORT": "1"}), ("lds sort", {})),
+    # round 5: G workgroups per job, job-major (msm.h k_msm_msort_*), against the one-workgroup-per-job sort
+    "wgs": (("lds sort (1 WG / job)", {}),) + tuple(("G = %d, xcd-major %d" % (g, x), {"ZKAMD_SORT_WGS": str(g), "ZKAMD_SORT_XCD": str(x)})
+                                                      for g in (2, 4, 8, 16, 32) for x in (1, 0)) + (("lds sort (1 WG / job)", {}),),
 }
 if mode in CONFIGS:
     # the two-level sorts against the one-workgroup sort: same proofs, the sort groups timed
     for name, env in CONFIGS[mode]:
-        for k in ("ZKAMD_SORT_STAGED", "ZKAMD_SORT_FINE_LOG", "ZKAMD_NO_LDS_SORT", "ZKAMD_SORT_TWO_LEVEL"):
+        for k in ("ZKAMD_SORT_WGS", "ZKAMD_SORT_XCD", "ZKAMD_NO_LDS_SORT"):
             os.environ.pop(k, None)
         os.environ.update(env)
         got = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))

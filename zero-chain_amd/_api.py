@@ -24,7 +24,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
                    ZK_NTT_OUT_BITREV)
 
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs", "read_proofs",
-           "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs",
+           "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs", "create_proofs_dev", "stream", "bind_host_to_device", "KernelTimer",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "xt_fields", "gen_proof", "XT_FIELDS",
            "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_witness_gpu", "anonymous_prove_batch",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
@@ -43,6 +43,36 @@ def load_library():
 def set_host_threads(n, lib=None):
     """zk_set_host_threads: host threads for the CPU-side legs (witness calculation, encoding); 0 = default."""
     (lib or _lib.load()).zk_set_host_threads(int(n))
+
+
+def bind_host_to_device(device=0, lib=None):
+    """zk_bind_host_to_device: pin the calling thread (and the threads it starts) to the CPUs of the GPU's NUMA node.
+    Returns (numa node or -1, CPUs the thread may run on)."""
+    lib = lib or _lib.load()
+    node, cpus = C.c_int(-1), C.c_int(0)
+    lib.check(lib.zk_bind_host_to_device(int(device), C.byref(node), C.byref(cpus)))
+    return node.value, cpus.value
+
+
+class KernelTimer:
+    """zk_profile_begin / zk_profile_get / zk_profile_end: HIP-event timing of the library's named kernel groups.
+    with KernelTimer(lib) as t: ...;  t.get("msm_accumulate_g1") -> (launches, total ms)."""
+
+    def __init__(self, lib=None):
+        self._lib = lib or _lib.load()
+
+    def __enter__(self):
+        self._lib.zk_profile_begin()
+        return self
+
+    def get(self, name):
+        ms = C.c_double(0)
+        n = self._lib.zk_profile_get(name.encode(), C.byref(ms))
+        return int(n), float(ms.value)
+
+    def __exit__(self, *exc):
+        self._lib.zk_profile_end()
+        return False
 
 
 def scalars_to_bytes(values):
@@ -167,6 +197,14 @@ class Parameters:
         if writer is not None:
             writer.write(self._pk)
         return self._pk
+
+    @property
+    def windows(self):
+        """zk_params_get_windows: the recoding widths in use - (C' jobs of a batch, A jobs, both G1 jobs of a few proofs
+        made alone, the G2 job)."""
+        w = (C.c_uint32 * 4)()
+        self._lib.check(self._lib.zk_params_get_windows(self._h, w))
+        return tuple(int(x) for x in w)
 
     @property
     def vk(self):
@@ -323,8 +361,15 @@ def verify_proofs(pvk, proofs, public_inputs):
 
 
 def verify_proof(pvk, proof, public_inputs):
-    """verifier.rs:32-63 for one proof."""
-    return verify_proofs(pvk, [proof], [list(public_inputs)])[0]
+    """verifier.rs:32-63 for one proof, through the one-proof entry zk_verify_proof."""
+    pb = _u8(proof.write() if isinstance(proof, Proof) else bytes(proof))
+    if pb.size != PROOF_SIZE:
+        raise ValueError("a proof is %d bytes" % PROOF_SIZE)
+    vals = list(public_inputs)
+    ib = scalars_to_bytes(vals) if vals else np.zeros(0, dtype=np.uint8)
+    ok = C.c_int(0)
+    pvk._lib.check(pvk._lib.zk_verify_proof(pvk._h, _ptr(pb), _ptr(ib) if ib.size else None, len(vals), C.byref(ok)))
+    return bool(ok.value)
 
 
 PROOF_READ_REASONS = {1: "bad encoding", 2: "not on the curve", 3: "not in the subgroup", 4: "point at infinity"}
@@ -412,6 +457,21 @@ def create_proofs(assignments, params, rs):
     rsb = scalars_to_bytes([x for pair in rs for x in pair])
     out = np.zeros(PROOF_SIZE * n, dtype=np.uint8)
     lib.check(lib.zk_prove_batch(params._h, n, arr, _ptr(rsb), _ptr(out)))
+    ob = out.tobytes()
+    return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
+
+
+def create_proofs_dev(params, n, n_rows, n_inputs, n_aux, d_a, d_b, d_c, d_wit, a_aux_density, b_input_density, b_aux_density, rs,
+                      montgomery=False):
+    """zk_prove_batch_dev: n proofs of one circuit whose assignments are already in HBM.  d_a / d_b / d_c: device pointers
+    (ints) to [n][n_rows][32] bytes, d_wit to [n][n_inputs + n_aux][32]; densities: host byte arrays shared by the batch;
+    rs = [(r, s), ...] on the host."""
+    lib = params._lib
+    da, dbi, dba = _u8(a_aux_density), _u8(b_input_density), _u8(b_aux_density)
+    bt = _lib.BatchDev(n_rows, n_inputs, n_aux, ZK_FR_MONTGOMERY if montgomery else 0, d_a, d_b, d_c, d_wit, _ptr(da), _ptr(dbi), _ptr(dba))
+    rsb = scalars_to_bytes([x for pair in rs for x in pair])
+    out = np.zeros(PROOF_SIZE * max(n, 1), dtype=np.uint8)
+    lib.check(lib.zk_prove_batch_dev(params._h, n, C.byref(bt), _ptr(rsb), _ptr(out)))
     ob = out.tobytes()
     return [Proof(ob[i * PROOF_SIZE:(i + 1) * PROOF_SIZE]) for i in range(n)]
 
@@ -857,12 +917,31 @@ class MultiexpContext:
 
 
 def multiexp(group, bases, scalars, lib=None):
-    """One-shot multiexp over uncompressed bases; returns the uncompressed result."""
-    ctx = MultiexpContext(group, bases, lib=lib)
-    try:
-        return ctx.run(scalars)
-    finally:
-        ctx.close()
+    """bellman multiexp(FullDensity) called once: the one-shot entries zk_msm_g1 / zk_msm_g2 (variable-base Pippenger over
+    fresh bases, the encodings decoded on the device, no table of doublings).  bases: n x 96 / 192 bytes uncompressed;
+    scalars: ints or n x 32 bytes plain little-endian; returns the uncompressed result."""
+    lib = lib or load_library()
+    if group not in (1, 2):
+        raise ValueError("group must be 1 (G1) or 2 (G2)")
+    size = 96 if group == 1 else 192
+    bb = _u8(bases)
+    if bb.size % size:
+        raise ValueError("bases: %d bytes is not a whole number of %d-byte points" % (bb.size, size))
+    n = bb.size // size
+    sb = _u8(scalars) if isinstance(scalars, (np.ndarray, bytes, bytearray)) else (scalars_to_bytes(scalars) if len(scalars) else np.zeros(0, dtype=np.uint8))
+    if sb.size != 32 * n:
+        raise ValueError("%d bases but %d bytes of scalars" % (n, sb.size))
+    out = np.zeros(size, dtype=np.uint8)
+    fn = lib.zk_msm_g1 if group == 1 else lib.zk_msm_g2
+    lib.check(fn(_ptr(bb) if n else None, _ptr(sb) if n else None, n, _ptr(out)))
+    return out.tobytes()
+
+
+def stream(lib=None):
+    """The hipStream_t (as an integer) the library enqueues its work on for the calling thread (zk_stream): what a caller
+    records events on, or makes its own streams wait for, when it feeds zk_*_dev entries from its own kernels."""
+    lib = lib or load_library()
+    return lib.zk_stream() or 0
 
 
 class EvaluationDomain:

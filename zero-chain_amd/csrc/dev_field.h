@@ -384,6 +384,7 @@ struct Fq28Consts {
     static constexpr uint32_t KIN[14] = ZK_FQ28_KIN;
     static constexpr uint32_t KOUT[14] = ZK_FQ28_KOUT;
     static constexpr uint32_t KINV[14] = ZK_FQ28_KINV;
+    static constexpr uint32_t R2[14] = ZK_FQ28_R2;
     static constexpr uint32_t B[14] = ZK_FQ28_B;
     static constexpr uint32_t INV = ZK_FQ28_INV;
 };

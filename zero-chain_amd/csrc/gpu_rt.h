@@ -62,6 +62,11 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 void emu_barrier_wait();
 static inline void __syncthreads() { emu_barrier_wait(); }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicMin(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }

@@ -70,16 +70,9 @@ inline zk_status use_device(int device) {
     DevCtx*& c = g_ctxs[device * 16 + g_lane];
     if (!c) {
         DevCtx* fresh = new DevCtx();
-        // ZKAMD_STREAM_PRIO="main,side,copy" (an A/B knob; HIP: lower = more urgent, the device's range is clamped): the
-        // priorities of a lane's three streams - the copy stream carries the next chunk's witness kernels
-        int prio[3] = {0, 0, 0};
-        if (const char* env = getenv("ZKAMD_STREAM_PRIO")) sscanf(env, "%d,%d,%d", &prio[0], &prio[1], &prio[2]);
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        for (int& v : prio) v = v < greatest ? greatest : v > least ? least : v;
-        if (hipStreamCreateWithPriority(&fresh->stream, hipStreamDefault, prio[0]) != hipSuccess ||
-            hipStreamCreateWithPriority(&fresh->stream2, hipStreamDefault, prio[1]) != hipSuccess ||
-            hipStreamCreateWithPriority(&fresh->copy, hipStreamNonBlocking, prio[2]) != hipSuccess ||
+        if (hipStreamCreateWithFlags(&fresh->stream, hipStreamDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&fresh->stream2, hipStreamDefault) != hipSuccess ||
+            hipStreamCreateWithFlags(&fresh->copy, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreate(&fresh->ev_fork) != hipSuccess || hipEventCreate(&fresh->ev_join) != hipSuccess) {
             delete fresh;
             g_ctxs.erase(device * 16 + g_lane);

@@ -245,7 +245,7 @@ constexpr uint32_t MSM_COARSE_SCALARS = 1024;  // scalars per workgroup of passe
 
 static __global__ void __launch_bounds__(256)
 k_msm_coarse_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse, uint32_t* coarse_cnt,
-                   uint32_t* blockbase, uint32_t per_wg, uint32_t* blockcnt) {
+                   uint32_t* blockbase, uint32_t per_wg) {
     ZK_SHARED uint32_t h[MSM_COARSE_MAX];
     const MsmJob job = jobs[blockIdx.y];
     const uint32_t tid = threadIdx.x;
@@ -260,10 +260,7 @@ k_msm_coarse_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_lo
     __syncthreads();
     uint32_t* bb = blockbase + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n_coarse;
     uint32_t* jc = coarse_cnt + (size_t)blockIdx.y * n_coarse;
-    for (uint32_t t = tid; t < n_coarse; t += blockDim.x) {
-        bb[t] = h[t] ? atomicAdd(&jc[t], h[t]) : 0u;
-        if (blockcnt) blockcnt[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n_coarse + t] = h[t];
-    }
+    for (uint32_t t = tid; t < n_coarse; t += blockDim.x) bb[t] = h[t] ? atomicAdd(&jc[t], h[t]) : 0u;
 }
 
 // exclusive scan of n values per job (n <= a few thousand), one workgroup per job; total[job] = sum
@@ -322,74 +319,6 @@ k_msm_coarse_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_
             const uint32_t slot = atomicAdd(&h[b >> fine_log], 1u);
             jrec[slot] = make_uint2(b & fmask, ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u));
         });
-    }
-}
-
-// Pass 3 with the records STAGED in LDS (round 4, the batched prover's sort): a workgroup takes MSM_STAGE_SCALARS scalars of
-// a job, places the records of their digits into LDS grouped by coarse bin (the per-workgroup bin counts of pass 1 give
-// every bin its run), and writes every run with consecutive lanes to the range pass 1 reserved for it: whole cache lines
-// instead of one 32-byte sector per 4- or 8-byte store.  Measured on the single-workgroup sort (tools/sort_probe.py,
-// profiles/r04_experiments.txt): 13.2 of its 17.5 ms per chunk are the scattered stores of the pair words - 35 GB of
-// sector writes for 6 GB of pairs - not the recoding (2.3 ms per pass).
-constexpr uint32_t MSM_STAGE_SCALARS = 512;
-static __global__ void __launch_bounds__(256)
-k_msm_coarse_scatter_staged(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t fine_log, uint32_t n_coarse,
-                            const uint32_t* __restrict__ coarse_off, const uint32_t* __restrict__ blockbase,
-                            const uint32_t* __restrict__ blockcnt, uint2* __restrict__ rec) {
-    ZK_DYN_SHARED(uint2, stage);                 // [MSM_STAGE_SCALARS * maxd] records
-    ZK_SHARED uint32_t run0[MSM_COARSE_MAX];     // first staged record of every bin
-    ZK_SHARED uint32_t fill[MSM_COARSE_MAX];     // records placed so far
-    ZK_SHARED uint32_t part[256];
-    const MsmJob job = jobs[blockIdx.y];
-    const uint32_t tid = threadIdx.x, nt = 256;
-    if (blockIdx.x * MSM_STAGE_SCALARS >= job.n && blockIdx.x) return;
-    const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
-    const uint32_t* bb = blockbase + wg * n_coarse;
-    const uint32_t* hc = blockcnt + wg * n_coarse;
-    const uint32_t* jo = coarse_off + (size_t)blockIdx.y * n_coarse;
-    // exclusive scan of this workgroup's bin counts: thread t owns bins [t * per, ..)
-    const uint32_t per = (n_coarse + nt - 1) / nt;
-    uint32_t b0 = tid * per, b1 = b0 + per < n_coarse ? b0 + per : n_coarse;
-    if (b0 > n_coarse) b0 = n_coarse;
-    uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++) sum += hc[b];
-    part[tid] = sum;
-    __syncthreads();
-    for (uint32_t d = 1; d < nt; d <<= 1) {
-        const uint32_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = tid ? part[tid - 1] : 0;
-    for (uint32_t b = b0; b < b1; b++) {
-        run0[b] = run;
-        fill[b] = 0;
-        run += hc[b];
-    }
-    __syncthreads();
-    const uint32_t fmask = (1u << fine_log) - 1;
-    for (uint32_t e = 0; e < MSM_STAGE_SCALARS / 256; e++) {
-        const uint32_t i = blockIdx.x * MSM_STAGE_SCALARS + e * 256 + tid;
-        if (i >= job.n) continue;
-        const int32_t pos = job.map ? job.map[i] : (int32_t)i;
-        if (pos < 0) continue;
-        const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
-        msm_digits(job, i, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
-            const uint32_t b = mag >> 1, bin = b >> fine_log;
-            const uint32_t k = atomicAdd(&fill[bin], 1u);
-            stage[run0[bin] + k] = make_uint2(b & fmask, ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u));
-        });
-    }
-    __syncthreads();
-    // every run to its reserved range, consecutive lanes on consecutive records; wave w takes bins w, w + 4, ...
-    uint2* jrec = rec + job.pair_base;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t bin = wave; bin < n_coarse; bin += nt / 64) {
-        const uint32_t n = hc[bin];
-        uint2* dst = jrec + jo[bin] + bb[bin];
-        const uint2* src = stage + run0[bin];
-        for (uint32_t k = lane; k < n; k += 64) dst[k] = src[k];
     }
 }
 
@@ -468,96 +397,6 @@ k_msm_fine_sort(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, 
         const uint2 r = rec[first + e];
         pairs[first + atomicAdd(&h[r.x], 1u)] = r.y;
     }
-}
-
-// The second pass for MANY jobs with a few thousand records per bin (round 4): 256 threads per bin, the bucket scan over
-// `fine` <= 256 counters, and the sorted pairs of a bin STAGED in LDS and written as one linear run - the bin's 16 KB window
-// leaves as whole cache lines whatever the other two thousand resident workgroups do to L2 (k_msm_fine_sort above scatters
-// 4-byte stores over its window and spends twenty 1024-thread barriers on a 128-entry scan).  The records are read twice;
-// the second read hits L2.  A bin with more than MSM_FINE_TILE records scatters straight to HBM as before.
-#ifdef ZK_EMU
-constexpr uint32_t MSM_FINE_TILE = 256;    // (the test-only emulation build: small cases reach both branches)
-#else
-constexpr uint32_t MSM_FINE_TILE = 6144;
-#endif
-static __global__ void __launch_bounds__(256)
-k_msm_fine_sort_tile(const MsmJob* __restrict__ jobs, const uint2* __restrict__ rec, const uint32_t* __restrict__ coarse_cnt,
-                     const uint32_t* __restrict__ coarse_off, uint32_t fine, uint32_t nb, uint32_t* cnt, uint32_t* off, uint32_t* toff,
-                     uint32_t* bin_tasks, uint32_t* pairs, uint32_t seg) {
-    ZK_SHARED uint32_t h[256];
-    ZK_SHARED uint32_t part[256];
-    ZK_SHARED uint32_t tpart[256];
-    ZK_SHARED uint32_t out[MSM_FINE_TILE];
-    const uint32_t tid = threadIdx.x, bin = blockIdx.x, n_coarse = gridDim.x;
-    const MsmJob job = jobs[blockIdx.y];
-    const uint32_t n_rec = coarse_cnt[(size_t)blockIdx.y * n_coarse + bin];
-    const uint32_t first = job.pair_base + coarse_off[(size_t)blockIdx.y * n_coarse + bin];
-    h[tid] = 0;
-    __syncthreads();
-    {
-        uint32_t e = tid;
-        for (; e + 768 < n_rec; e += 1024) {
-            const uint32_t k0 = rec[first + e].x, k1 = rec[first + e + 256].x, k2 = rec[first + e + 512].x, k3 = rec[first + e + 768].x;
-            atomicAdd(&h[k0], 1u);
-            atomicAdd(&h[k1], 1u);
-            atomicAdd(&h[k2], 1u);
-            atomicAdd(&h[k3], 1u);
-        }
-        for (; e < n_rec; e += 256) atomicAdd(&h[rec[first + e].x], 1u);
-    }
-    __syncthreads();
-    const uint32_t k = tid < fine ? h[tid] : 0u, tk = (k + seg - 1) / seg;
-    part[tid] = k;
-    tpart[tid] = tk;
-    __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
-        const uint32_t v = tid >= d ? part[tid - d] : 0, tv = tid >= d ? tpart[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        tpart[tid] += tv;
-        __syncthreads();
-    }
-    const uint32_t run = part[tid] - k, trun = tpart[tid] - tk;
-    if (tid < fine) {
-        const size_t b = (size_t)blockIdx.y * nb + (size_t)bin * fine + tid;
-        cnt[b] = k;
-        off[b] = first + run;
-        toff[b] = trun;
-        h[tid] = run;   // slot cursor of the bucket, relative to the bin's first pair
-    }
-    if (tid == 255) bin_tasks[(size_t)blockIdx.y * n_coarse + bin] = tpart[255];
-    __syncthreads();
-    const bool stage = n_rec <= MSM_FINE_TILE;
-    {
-        uint32_t e = tid;
-        for (; e + 768 < n_rec; e += 1024) {
-            const uint2 r0 = rec[first + e], r1 = rec[first + e + 256], r2 = rec[first + e + 512], r3 = rec[first + e + 768];
-            const uint32_t s0 = atomicAdd(&h[r0.x], 1u), s1 = atomicAdd(&h[r1.x], 1u), s2 = atomicAdd(&h[r2.x], 1u),
-                           s3 = atomicAdd(&h[r3.x], 1u);
-            if (stage) {
-                out[s0] = r0.y;
-                out[s1] = r1.y;
-                out[s2] = r2.y;
-                out[s3] = r3.y;
-            } else {
-                pairs[first + s0] = r0.y;
-                pairs[first + s1] = r1.y;
-                pairs[first + s2] = r2.y;
-                pairs[first + s3] = r3.y;
-            }
-        }
-        for (; e < n_rec; e += 256) {
-            const uint2 r = rec[first + e];
-            const uint32_t sl = atomicAdd(&h[r.x], 1u);
-            if (stage)
-                out[sl] = r.y;
-            else
-                pairs[first + sl] = r.y;
-        }
-    }
-    if (!stage) return;
-    __syncthreads();
-    for (uint32_t e = tid; e < n_rec; e += 256) pairs[first + e] = out[e];
 }
 
 // toff[b] += first task of b's bin; grid (blocks over the buckets, jobs)
@@ -641,6 +480,111 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
     }
 }
 
+// The same sort with G workgroups per job (round 5; ZKAMD_SORT_WGS = G): k_msm_sort_lds keeps ALL jobs of a launch live at
+// once - a thousand 4 MB output windows, far beyond every cache, so each scattered 4-byte store leaves the chip as its own
+// 32-byte sector.  Here the launch is job-major: workgroup g of job j takes the scalars [g n / G, (g + 1) n / G), and with
+// two workgroups resident per CU only 512 / G jobs are live at a time (G = 16: 32 jobs, ~128 MB of pairs - inside the
+// 256 MiB Infinity Cache).
+//   1. k_msm_msort_count    LDS histogram of the workgroup's digits; one global atomic per (workgroup, non-empty bucket)
+//                           adds it to the job's histogram `cnt` and returns the workgroup's first slot inside the bucket
+//   2. k_msm_msort_scan     one workgroup per job: exclusive scans of cnt -> off / toff / ntasks (the middle of k_msm_sort_lds)
+//   3. k_msm_msort_scatter  the workgroups recode again with LDS cursors = bucket offset + their reserved slot
+// wgbase is [job][workgroup][bucket].  xcd_major: workgroups 8 apart (the same XCD) work on the same job, so that the
+// stores into one bucket's run meet in ONE L2.
+ZK_DI void msort_ids(uint32_t G, uint32_t nj, uint32_t xcd_major, uint32_t* job, uint32_t* g) {
+    const uint32_t lin = blockIdx.x;
+    if (xcd_major && (nj & 7u) == 0) {
+        const uint32_t xcd = lin & 7u, slot = lin >> 3;
+        *job = (slot / G) * 8 + xcd;
+        *g = slot % G;
+    } else {
+        *job = lin / G;
+        *g = lin % G;
+    }
+}
+static __global__ void __launch_bounds__(MSM_SORT_THREADS)
+k_msm_msort_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t G, uint32_t nj, uint32_t xcd_major, uint32_t* cnt,
+                  uint32_t* wgbase) {
+    ZK_DYN_SHARED(uint32_t, h);   // [nb]
+    uint32_t jix, g;
+    msort_ids(G, nj, xcd_major, &jix, &g);
+    const MsmJob job = jobs[jix];
+    const uint32_t nb = 1u << (c - 2), tid = threadIdx.x, nt = MSM_SORT_THREADS;
+    for (uint32_t b = tid; b < nb; b += nt) h[b] = 0;
+    __syncthreads();
+    const uint32_t per = (job.n + G - 1) / G, i0 = g * per, i1 = i0 + per < job.n ? i0 + per : job.n;
+    for (uint32_t i = i0 + tid; i < i1; i += nt) {
+        if (job.map && job.map[i] < 0) continue;
+        msm_digits(job, i, c, [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[mag >> 1], 1u); });
+    }
+    __syncthreads();
+    uint32_t* jcnt = cnt + (size_t)jix * nb;
+    uint32_t* wb = wgbase + ((size_t)jix * G + g) * nb;
+    for (uint32_t b = tid; b < nb; b += nt) wb[b] = h[b] ? atomicAdd(&jcnt[b], h[b]) : 0u;
+}
+static __global__ void __launch_bounds__(MSM_SORT_THREADS)
+k_msm_msort_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ cnt, uint32_t* off, uint32_t* toff,
+                 uint32_t* ntasks, uint32_t seg) {
+    ZK_SHARED uint32_t part[MSM_SORT_THREADS];
+    ZK_SHARED uint32_t tpart[MSM_SORT_THREADS];
+    const MsmJob job = jobs[blockIdx.x];
+    const uint32_t nb = 1u << (c - 2), tid = threadIdx.x, nt = MSM_SORT_THREADS;
+    const uint32_t* jcnt = cnt + (size_t)blockIdx.x * nb;
+    const uint32_t per = (nb + nt - 1) / nt;
+    uint32_t b0 = tid * per, b1 = b0 + per < nb ? b0 + per : nb;
+    if (b0 > nb) b0 = nb;
+    uint32_t sum = 0, tsum = 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t k = jcnt[b];
+        sum += k;
+        tsum += (k + seg - 1) / seg;
+    }
+    part[tid] = sum;
+    tpart[tid] = tsum;
+    __syncthreads();
+    for (uint32_t d = 1; d < nt; d <<= 1) {
+        const uint32_t v = tid >= d ? part[tid - d] : 0, tv = tid >= d ? tpart[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        tpart[tid] += tv;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0, trun = tid ? tpart[tid - 1] : 0;
+    uint32_t* joff = off + (size_t)blockIdx.x * nb;
+    uint32_t* jtoff = toff + (size_t)blockIdx.x * nb;
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint32_t k = jcnt[b];
+        joff[b] = job.pair_base + run;
+        jtoff[b] = trun;
+        run += k;
+        trun += (k + seg - 1) / seg;
+    }
+    if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
+}
+static __global__ void __launch_bounds__(MSM_SORT_THREADS)
+k_msm_msort_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t G, uint32_t nj, uint32_t xcd_major,
+                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ wgbase, uint32_t* pairs) {
+    ZK_DYN_SHARED(uint32_t, h);   // [nb] slot cursors, absolute positions in `pairs`
+    uint32_t jix, g;
+    msort_ids(G, nj, xcd_major, &jix, &g);
+    const MsmJob job = jobs[jix];
+    const uint32_t nb = 1u << (c - 2), tid = threadIdx.x, nt = MSM_SORT_THREADS;
+    const uint32_t* joff = off + (size_t)jix * nb;
+    const uint32_t* wb = wgbase + ((size_t)jix * G + g) * nb;
+    for (uint32_t b = tid; b < nb; b += nt) h[b] = joff[b] + wb[b];
+    __syncthreads();
+    const uint32_t per = (job.n + G - 1) / G, i0 = g * per, i1 = i0 + per < job.n ? i0 + per : job.n;
+    for (uint32_t i = i0 + tid; i < i1; i += nt) {
+        const int32_t pos = job.map ? job.map[i] : (int32_t)i;
+        if (pos < 0) continue;
+        const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
+        msm_digits(job, i, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
+            const uint32_t slot = atomicAdd(&h[mag >> 1], 1u);
+            pairs[slot] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
+        });
+    }
+}
+
 // A bucket of k points becomes nt = ceil(k / seg) tasks of EQUAL length (n_long of len + 1 points,
 // then n_short of len): the tasks of a launch run in rounds over the thread slots of the GPU, and a
 // round lasts as long as its longest task - cutting 102 points into 64 + 38 instead of 51 + 51 left
@@ -710,8 +654,10 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
                  uint32_t seg, uint32_t* n_light, uint32_t* light) {
     ZK_SHARED uint32_t h[MSM_SEG_MAX];
     ZK_SHARED uint32_t start[MSM_SEG_MAX];
+    ZK_SHARED uint32_t lists[4];   // heavy / light buckets of this workgroup, then the two ranges it reserved
     const uint32_t tid = threadIdx.x, job = blockIdx.y;
     if (tid < seg) h[tid] = 0;
+    if (tid < 4) lists[tid] = 0;
     __syncthreads();
     uint32_t b = blockIdx.x * blockDim.x + tid;
     TaskCut tc = {0, 0, 1};
@@ -727,8 +673,20 @@ k_msm_task_place(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ 
         h[tid] = 0;
     }
     __syncthreads();
-    if (tc.n_long + tc.n_short > merge_inline) heavy[atomicAdd(n_heavy, 1u)] = job * nb + b;
-    else if (light && tc.n_long + tc.n_short > 1) light[atomicAdd(n_light, 1u)] = job * nb + b;   // 2 .. merge_inline partials
+    // the heavy / light lists: slots are taken from LDS counters and ONE global atomic per workgroup and list reserves the
+    // range (a variable-base multiexp has every bucket on the light list: 155 000 atomics on one address were 1.5 ms)
+    {
+        const uint32_t nt_b = tc.n_long + tc.n_short;
+        const bool is_heavy = b < nb && nt_b > merge_inline, is_light = b < nb && !is_heavy && light && nt_b > 1;   // light: 2 .. merge_inline partials
+        uint32_t slot = 0;
+        if (is_heavy) slot = atomicAdd(&lists[0], 1u);
+        if (is_light) slot = atomicAdd(&lists[1], 1u);
+        __syncthreads();
+        if (tid < 2 && lists[tid]) lists[2 + tid] = atomicAdd(tid ? n_light : n_heavy, lists[tid]);
+        __syncthreads();
+        if (is_heavy) heavy[lists[2] + slot] = job * nb + b;
+        if (is_light) light[lists[3] + slot] = job * nb + b;
+    }
     if (tc.n_long + tc.n_short) {
         const uint32_t o = off[(size_t)job * nb + b], ti = task_base[job] + toff[(size_t)job * nb + b];
         if (tc.n_long) {
@@ -1621,6 +1579,93 @@ k_import_affine(const uint32_t* __restrict__ src, Affine<F>* dst, uint32_t n) {
     fld_import(p.y, src + (size_t)i * 2 * W + W);
     dst[i] = p;
 }
+// ---------------------------------------------------------------------------------------------
+// Point decoding on the device: the uncompressed encodings of the reference (G1: x | y, ec.rs:666-753; G2: x.c1 | x.c0 |
+// y.c1 | y.c0, ec.rs:1303-1427; 48-byte big-endian coordinates, three flag bits on top of the first) -> affine table
+// entries in the kernels' field representation.  What `into_affine_unchecked` accepts is accepted: the compression flag and
+// the sort flag must be clear, the infinity flag demands an otherwise all-zero encoding (-> (0, 0), map = -1: a legal
+// multiexp base that contributes nothing), every coordinate must be < q.  Membership of the curve and of the subgroup is
+// k_check_points' business.  The host decoders (host_math.h g1_from_uncompressed / g2_from_uncompressed) give the same
+// verdicts; they cost 0.11 s for 2^20 points on one core where this kernel takes 0.1 ms.
+// stat[0] = smallest index of a refused encoding (0xffffffff: none), stat[1] = points at infinity met.
+// ---------------------------------------------------------------------------------------------
+ZK_DI uint32_t zk_bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
+// 48 big-endian bytes at src (12 words as a little-endian load sees them) -> the integer's 12 little-endian words;
+// all_zero &= (value == 0), the return value is (value < q)
+ZK_DI bool be48_words(const uint32_t* __restrict__ src, uint32_t (&w)[12], uint32_t first_word_mask, uint32_t& any) {
+    const uint4* q = reinterpret_cast<const uint4*>(src);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    const uint32_t in[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = zk_bswap32(in[11 - i]);
+    w[11] &= first_word_mask;
+    uint32_t o = 0, bo = 0, co;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        o |= w[i];
+        (void)__builtin_subc(w[i], FqCfg::P[i], bo, &co);
+        bo = co;
+    }
+    any |= o;
+    return bo != 0;   // a borrow out of w - q: w < q
+}
+ZK_DI void fld_from_canon(Fq28& d, const uint32_t (&w)[12]) { d = mul(fq28_unpack(w), Fq28::from_const(Fq28Consts::R2)); }
+ZK_DI void fld_from_canon(Fq32& d, const uint32_t (&w)[12]) {
+    Fq32 v;
+#pragma unroll
+    for (int i = 0; i < 12; i++) v.l[i] = w[i];
+    d = mul(v, Fq32::r2());
+}
+// one field element of the encoding at src (advanced past it); `first`: it carries the flag bits (masked off here)
+ZK_DI bool fld_decode(Fq28& d, const uint32_t*& src, bool first, uint32_t& any) {
+    uint32_t w[12];
+    const bool ok = be48_words(src, w, first ? 0x1fffffffu : 0xffffffffu, any);
+    src += 12;
+    fld_from_canon(d, w);
+    return ok;
+}
+template <class F2>
+ZK_DI bool fld_decode_fq2(F2& d, const uint32_t*& src, bool first, uint32_t& any) {
+    uint32_t w1[12], w0[12];
+    const bool ok1 = be48_words(src, w1, first ? 0x1fffffffu : 0xffffffffu, any);   // c1 first (ec.rs:1408-1426)
+    const bool ok0 = be48_words(src + 12, w0, 0xffffffffu, any);
+    src += 24;
+    fld_from_canon(d.c1, w1);
+    fld_from_canon(d.c0, w0);
+    return ok1 && ok0;
+}
+ZK_DI bool fld_decode(Fq2x& d, const uint32_t*& src, bool first, uint32_t& any) { return fld_decode_fq2(d, src, first, any); }
+ZK_DI bool fld_decode(Fq2& d, const uint32_t*& src, bool first, uint32_t& any) { return fld_decode_fq2(d, src, first, any); }
+
+template <class F>
+static __global__ void __launch_bounds__(128)
+k_decode_uncompressed(const uint32_t* __restrict__ src, Affine<F>* dst, int32_t* map, uint32_t* stat, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int W = HostWords<F>::N;                  // 12 / 24 words per coordinate
+    const uint32_t* p = src + (size_t)i * 2 * W;
+    const uint32_t flags = zk_bswap32(p[0]) >> 29;      // bit 2: compressed, bit 1: infinity, bit 0: sort (ec.rs:666-700)
+    Affine<F> a;
+    uint32_t any = 0;
+    const bool okx = fld_decode(a.x, p, true, any);
+    const bool oky = fld_decode(a.y, p, false, any);
+    bool bad = (flags & 4u) != 0;
+    bool inf = false;
+    if (!bad) {
+        if (flags & 2u) {
+            bad = (flags & 1u) != 0 || any != 0;        // the infinity encoding is 0x40 followed by zeros
+            inf = !bad;
+        } else {
+            bad = (flags & 1u) != 0 || !okx || !oky;
+        }
+    }
+    if (bad || inf) a = Affine<F>{F::zero(), F::zero()};
+    dst[i] = a;
+    if (map) map[i] = inf || bad ? -1 : (int32_t)i;
+    if (bad) atomicMin(&stat[0], i);
+    if (inf) atomicAdd(&stat[1], 1u);
+}
+
 template <class F>
 static __global__ void __launch_bounds__(64)
 k_export_xyzz(const XYZZ<F>* __restrict__ src, uint32_t* dst, uint32_t n) {

@@ -261,6 +261,15 @@ k_fr_convert(uint32_t* out, const uint32_t* __restrict__ in, uint32_t from, size
     st_fr(out + i * 8, from ? from_mont(v) : to_mont(v));
 }
 
+// stat[0] = smallest index of a scalar that is not < r (0xffffffff: none) - the device form of the host loop a caller's
+// plain scalars used to pass through before a multiexp (2^20 scalars: 10 ms on one core, 20 us here)
+static __global__ void __launch_bounds__(256)
+k_fr_first_noncanonical(const uint32_t* __restrict__ in, size_t count, uint32_t* stat) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    if (fr_geq_r(ld_fr(in + i * 8))) atomicMin(&stat[0], (uint32_t)i);
+}
+
 // out[i] = a[i] * b[i] as raw Montgomery limbs (a*b*R^-1): lets the tests run the reference's
 // literal field KATs (fr.rs:1239-1340, fq.rs:2562-2672) through the device multiplier.
 template <class C>

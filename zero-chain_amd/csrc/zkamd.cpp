@@ -371,6 +371,7 @@ struct MsmGroup {
     PinBuf pin_jobs;
     std::vector<uint32_t> tbase_h;
     size_t bytes = 0;
+    DevBuf dstat;   // [first refused encoding | points at infinity] of the last decode_enqueue (msm.h k_decode_uncompressed)
 
     // with_table = false: variable-base mode - only the bases themselves are kept (slice 0), every job takes ONE
     // digit of every scalar (msm.h msm_digits)
@@ -381,6 +382,55 @@ struct MsmGroup {
         nb = 1u << (c - 2);
         n_points = o.n_points;
         table.borrow(o.table);
+    }
+    // Slice 0 of the table from the reference's uncompressed encodings (n x 96 / 192 bytes on the HOST), decoded on the
+    // device: upload into `raw`, k_decode_uncompressed into the table, `map` (n entries) = position or -1 for a point at
+    // infinity.  Everything is enqueued on st; decode_finish() reads the verdict once the stream has been waited for.
+    zk_status decode_enqueue(const uint8_t* bases, size_t n, uint32_t c_, bool with_table, DevBuf& raw, DevBuf& map, hipStream_t st) {
+        c = c_;
+        maxd = with_table ? zkdev::msm_max_digits(c) : 1u;
+        nb = 1u << (c - 2);
+        n_points = n;
+        const uint32_t npos = with_table ? zkdev::MSM_NPOS : 1u;
+        if ((uint64_t)n_points * npos >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "doubling table too large");
+        const size_t tb = sizeof(DAffine) * n_points * npos;
+        ZK_TRY(table.ensure(tb ? tb : 1));
+        bytes = tb;
+        ZK_TRY(dstat.ensure(8));
+        HIP_TRY(hipMemsetAsync(dstat.p, 0xff, 4, st));
+        HIP_TRY(hipMemsetAsync((uint8_t*)dstat.p + 4, 0, 4, st));
+        if (!n) return ZK_OK;
+        const size_t enc = sizeof(HAffine);   // 96 / 192: an uncompressed encoding is as long as the host's affine point
+        ZK_TRY(raw.ensure(enc * n));
+        ZK_TRY(map.ensure(4 * n));
+        HIP_TRY(hipMemcpyAsync(raw.p, bases, enc * n, hipMemcpyHostToDevice, st));
+        ZK_LAUNCH(zkdev::k_decode_uncompressed<DF>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, st, (const uint32_t*)raw.as<uint32_t>(),
+                  table.as<DAffine>(), map.as<int32_t>(), dstat.as<uint32_t>(), (uint32_t)n);
+        HIP_TRY(hipGetLastError());
+        return ZK_OK;
+    }
+    // after the stream was waited for: ZK_ERR_IO naming the first refused encoding, else *n_inf = points at infinity
+    zk_status decode_finish(const char* what, uint32_t* n_inf) {
+        uint32_t v[2] = {0xffffffffu, 0};
+        HIP_TRY(hipMemcpy(v, dstat.p, 8, hipMemcpyDeviceToHost));
+        if (v[0] != 0xffffffffu)
+            return fail(ZK_ERR_IO, std::string("invalid ") + (sizeof(HAffine) == 96 ? "G1" : "G2") + " encoding at " + what + " " + std::to_string(v[0]));
+        *n_inf = v[1];
+        return ZK_OK;
+    }
+    // the table of doublings over a slice 0 that is already in place; checked: curve + subgroup test of every base first
+    zk_status finish_build(bool checked, const char* what, bool with_table) {
+        if (!n_points) return ZK_OK;
+        if (checked) ZK_TRY((check_points_dev<HF, DF>(table.as<DAffine>(), n_points, what)));
+        if (with_table) {
+            DevBuf scratch;   // chunk of un-normalised slices + prefix products, freed after the build
+            ZK_TRY(scratch.ensure((size_t)zkdev::MSM_TABLE_CHUNK * 5 * sizeof(DF) * n_points));
+            ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3((unsigned)((n_points + 127) / 128)), dim3(128), 0, g_stream, table.as<DAffine>(),
+                      (uint32_t)n_points, zkdev::MSM_NPOS, scratch.as<DF>());
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(g_stream));
+        }
+        return ZK_OK;
     }
     zk_status build(const std::vector<HAffine>& pts, uint32_t c_, bool checked, const char* what, bool with_table = true) {
         c = c_;
@@ -403,16 +453,7 @@ struct MsmGroup {
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(g_stream));
         }
-        if (checked) ZK_TRY((check_points_dev<HF, DF>(table.as<DAffine>(), n_points, what)));
-        if (with_table) {
-            DevBuf scratch;   // chunk of un-normalised slices + prefix products, freed after the build
-            ZK_TRY(scratch.ensure((size_t)zkdev::MSM_TABLE_CHUNK * 5 * sizeof(DF) * n_points));
-            ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3(blocks), dim3(128), 0, g_stream, table.as<DAffine>(),
-                      (uint32_t)n_points, zkdev::MSM_NPOS, scratch.as<DF>());
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(g_stream));
-        }
-        return ZK_OK;
+        return finish_build(checked, what, with_table);
     }
 
     // jobs[i].pair_base is filled in here.  Everything, including the copy of the results (one XYZZ
@@ -462,7 +503,10 @@ struct MsmGroup {
         ZK_TRY(ntasks.ensure(nj * 4));
         ZK_TRY(tbase.ensure(nj * 4));
         ZK_TRY(hist.ensure((2 * n_class + 6) * 4));     // [length histogram | placement cursors | total | #heavy | #redo | next task block | #light | #level-1 nodes recomputed]
-        const bool few = nj <= MSM_FEW_JOBS;   // latency-optimised bucket reduction (msm.h, passes 5c and 6)
+        // the latency-optimised form of the launch set (many-workgroup sort, bit-plane tail of the bucket reduction: msm.h,
+        // passes 1-3, 5c and 6): one or a few jobs - and the digit positions of ONE variable-base multiexp, a dozen or two
+        // jobs over the same large scalar vector, which are as far from filling the machine per job as a lone job is
+        const bool few = nj <= MSM_FEW_JOBS || jobs[0].vb_digit != 0;
         const uint32_t merge_inline = nj >= 64 || few ? 8u : 2u;
         const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
         ZK_TRY(heavy.ensure(heavy_cap * 4));
@@ -486,7 +530,7 @@ struct MsmGroup {
         const char* min_env = getenv("ZKAMD_ASM_MIN_PAIRS");
         const bool big_launch = total >= (min_env ? (uint64_t)atoll(min_env) : 4000000ull);
         // level 1 of the reduction in assembly: many-jobs launches only (the few-jobs tail folds level 1 differently)
-        const bool red_asm = asm_reduce<DF>() && big_launch && nj > MSM_FEW_JOBS;
+        const bool red_asm = asm_reduce<DF>() && big_launch && !few;
         uint32_t L = pick_fan((uint64_t)nj * nb);
         if (red_asm) {
             // buckets per node of the assembly loop (a power of two): 32 - half the nodes for the compiled levels above
@@ -519,19 +563,22 @@ struct MsmGroup {
         dim3 gridb((nb + 255) / 256, (unsigned)nj);
         // one workgroup per job sorts inside its LDS: right for a thousand jobs per launch, a 0.67 ms serial pass for
         // the one or two jobs of a proof made alone (4.83 -> 4.17 ms per proof with the many-workgroup sort instead)
-        // ZKAMD_SORT_STAGED=1 (an experiment of round 4, off by default): for many jobs with thousands of buckets each, the
-        // two-level sort with the records of pass 3 STAGED in LDS, so that every store of the scatter pass leaves as whole
-        // runs (msm.h k_msm_coarse_scatter_staged).  The one-workgroup-per-job sort below spends 13.2 of its 17.5 ms per chunk
-        // on scattered 4-byte stores (tools/sort_probe.py), but the two-level path as it stands loses more in its second
-        // pass than the staging gains: 13.5 + 12.8 ms (unstaged: 8.6 + 11.3) - profiles/r04_experiments.txt, DESIGN.md 8.
-        const char* staged_env = getenv("ZKAMD_SORT_STAGED");
-        const uint32_t staged_min_nb = getenv("ZKAMD_SORT_STAGED_MIN_BUCKETS") ? (uint32_t)atoi(getenv("ZKAMD_SORT_STAGED_MIN_BUCKETS")) : 1024u;   // tests: 1
-        const bool staged = nj > MSM_FEW_JOBS && nb >= staged_min_nb && big_launch && staged_env && atoi(staged_env) == 1;
-        // ZKAMD_SORT_TWO_LEVEL=1: the two-level sort for the batch with the tiled second pass (k_msm_fine_sort_tile)
-        const char* two_env = getenv("ZKAMD_SORT_TWO_LEVEL");
-        const bool two_level = nj > MSM_FEW_JOBS && nb >= staged_min_nb && big_launch && two_env && atoi(two_env) == 1;
-        const bool lds_sort = !staged && !two_level && (size_t)nb * 4 <= 65536 && nj > MSM_FEW_JOBS && !getenv("ZKAMD_NO_LDS_SORT");
-        if (lds_sort) {
+        const bool lds_sort = (size_t)nb * 4 <= 65536 && !few && !getenv("ZKAMD_NO_LDS_SORT");
+        // ZKAMD_SORT_WGS = G > 1: G workgroups per job, job-major (msm.h k_msm_msort_*; round 5's sort experiment)
+        const uint32_t sort_wgs = lds_sort && getenv("ZKAMD_SORT_WGS") ? (uint32_t)atoi(getenv("ZKAMD_SORT_WGS")) : 0u;
+        if (lds_sort && sort_wgs > 1 && sort_wgs <= 256) {
+            ProfScope ps("msm_sort_lds", st);
+            const uint32_t G = sort_wgs, xcd_major = getenv("ZKAMD_SORT_XCD") ? (uint32_t)atoi(getenv("ZKAMD_SORT_XCD")) : 1u;
+            ZK_TRY(blockbase.ensure(nj * (size_t)G * nb * 4));
+            HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, st));
+            ZK_LAUNCH_SYNC(zkdev::k_msm_msort_count, dim3((unsigned)(nj * G)), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c, G,
+                           (uint32_t)nj, xcd_major, cnt.as<uint32_t>(), blockbase.as<uint32_t>());
+            ZK_LAUNCH_SYNC(zkdev::k_msm_msort_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st, dj, c,
+                           (const uint32_t*)cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(), seg);
+            ZK_LAUNCH_SYNC(zkdev::k_msm_msort_scatter, dim3((unsigned)(nj * G)), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c, G,
+                           (uint32_t)nj, xcd_major, (const uint32_t*)off.as<uint32_t>(), (const uint32_t*)blockbase.as<uint32_t>(),
+                           pairs.as<uint32_t>());
+        } else if (lds_sort) {
             // histogram + scan + scatter of a job inside one workgroup's LDS
             ProfScope ps("msm_sort_lds", st);
             ZK_LAUNCH_SYNC(zkdev::k_msm_sort_lds, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c,
@@ -545,12 +592,11 @@ struct MsmGroup {
             if (fine_log > c - 2) fine_log = c - 2;
             const uint32_t fine = 1u << fine_log, n_coarse = nb >> fine_log;
             if (fine > zkdev::MSM_FINE_MAX) return fail(ZK_ERR_INVALID_ARGUMENT, "ZKAMD_SORT_FINE_LOG out of range");
-            const uint32_t per_wg = staged ? zkdev::MSM_STAGE_SCALARS : zkdev::MSM_COARSE_SCALARS;
+            const uint32_t per_wg = zkdev::MSM_COARSE_SCALARS;
             dim3 gridc((max_n + per_wg - 1) / per_wg, (unsigned)nj);
             if (gridc.x == 0) gridc.x = 1;
             ZK_TRY(rank.ensure((size_t)(total ? total : 1) * sizeof(uint2)));          // (bucket in bin, pair) records
-            ZK_TRY(blockbase.ensure((size_t)gridc.x * nj * n_coarse * 4 * (staged ? 2 : 1)));   // reserved ranges | (staged) counts
-            uint32_t* blockcnt = staged ? blockbase.as<uint32_t>() + (size_t)gridc.x * nj * n_coarse : (uint32_t*)nullptr;
+            ZK_TRY(blockbase.ensure((size_t)gridc.x * nj * n_coarse * 4));   // the range a workgroup reserved in every bin
             ZK_TRY(coarse.ensure(4 * nj * (size_t)n_coarse * 4));                       // bin counts | offsets | tasks | first task
             uint32_t* coarse_cnt = coarse.as<uint32_t>();
             uint32_t* coarse_off = coarse_cnt + nj * (size_t)n_coarse;
@@ -560,43 +606,17 @@ struct MsmGroup {
             {
                 ProfScope ps("msm_sort_coarse", st);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_count, gridc, dim3(256), 0, st, dj, c, fine_log, n_coarse, coarse_cnt,
-                               blockbase.as<uint32_t>(), per_wg, blockcnt);
+                               blockbase.as<uint32_t>(), per_wg);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st,
                                (const uint32_t*)coarse_cnt, coarse_off, (uint32_t*)nullptr, n_coarse);
-                if (staged) {
-                    const size_t shmem = (size_t)zkdev::MSM_STAGE_SCALARS * maxd * sizeof(uint2);
-#ifndef ZK_EMU
-                    if (shmem > 65536) {   // more than 64 KiB of dynamic LDS has to be asked for (the kernel's static 9 KiB count too)
-                        static std::mutex mu;
-                        static size_t raised[64] = {0};
-                        std::lock_guard<std::mutex> lock(mu);
-                        if (raised[g_device & 63] < shmem) {
-                            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(zkdev::k_msm_coarse_scatter_staged),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-                            raised[g_device & 63] = shmem;
-                        }
-                    }
-#endif
-                    ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scatter_staged, gridc, dim3(256), shmem, st, dj, c, fine_log, n_coarse,
-                                   (const uint32_t*)coarse_off, (const uint32_t*)blockbase.as<uint32_t>(), (const uint32_t*)blockcnt,
-                                   rank.as<uint2>());
-                } else {
-                    ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scatter, gridc, dim3(256), 0, st, dj, c, fine_log, n_coarse,
-                                   (const uint32_t*)coarse_off, (const uint32_t*)blockbase.as<uint32_t>(), rank.as<uint2>(), per_wg);
-                }
+                ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scatter, gridc, dim3(256), 0, st, dj, c, fine_log, n_coarse,
+                               (const uint32_t*)coarse_off, (const uint32_t*)blockbase.as<uint32_t>(), rank.as<uint2>(), per_wg);
             }
             {
                 ProfScope ps("msm_sort_fine", st);
-                // (many jobs: a bin holds a few thousand records - a quarter of the threads does as well and leaves room for four
-                //  workgroups per CU)
-                if ((two_level || staged) && fine <= 256)
-                    ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort_tile, dim3(n_coarse, (unsigned)nj), dim3(256), 0, st, dj,
-                                   (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
-                                   cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
-                else
-                    ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort, dim3(n_coarse, (unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st, dj,
-                                   (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
-                                   cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
+                ZK_LAUNCH_SYNC(zkdev::k_msm_fine_sort, dim3(n_coarse, (unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st, dj,
+                               (const uint2*)rank.as<uint2>(), (const uint32_t*)coarse_cnt, (const uint32_t*)coarse_off, fine, nb,
+                               cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), bin_tasks, pairs.as<uint32_t>(), seg);
                 ZK_LAUNCH_SYNC(zkdev::k_msm_coarse_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st,
                                (const uint32_t*)bin_tasks, bin_tbase, ntasks.as<uint32_t>(), n_coarse);
                 ZK_LAUNCH(zkdev::k_msm_task_offsets, gridb, dim3(256), 0, st, toff.as<uint32_t>(), (const uint32_t*)bin_tbase, nb,
@@ -1686,7 +1706,7 @@ struct zk_msm {
     size_t slice = 0;   // > 0: the multiexp runs as ceil(n / slice) independent jobs (msm_slice below)
     MsmG1 g1;
     MsmG2 g2;
-    DevBuf map, scal, conv;
+    DevBuf map, scal, conv, sstat;
     bool has_map = false;
     uint32_t vb_window = 0;   // > 0: variable-base mode with this many bits per digit (no doubling table)
 };
@@ -1711,6 +1731,45 @@ size_t msm_slice(size_t n) {
     return 0;
 }
 
+// Digits of w bits at fixed positions: W = ceil(255 / w) jobs of 2^(w-1) buckets each.  Minimise, in mixed additions,
+//   W * (n + beta * 2^(w-1))      (beta = the cost of reducing one bucket, as in pick_window)
+// over the widths whose bucket histogram the sort can hold; a width whose TOP digit is left with only a few bits
+// (255 mod w small) sends all n points of that job into a handful of buckets - thousands of task partials merged by a
+// few workgroups behind everybody else - so its last job is priced at a full one plus that merge.
+uint32_t pick_vb_window(size_t n, int group) {
+    double best = 1e300;
+    uint32_t w = 2;
+    const double beta = group == 2 ? 12.0 : 6.0;
+    for (uint32_t k = 2; k <= 20; k++) {
+        const uint32_t W = (255 + k - 1) / k, top_bits = 255 - (W - 1) * k;
+        double cost = (double)W * ((double)(n ? n : 1) + beta * (double)((size_t)1 << (k - 1)));
+        if (top_bits + 4 < k) cost += 0.15 * (double)(n ? n : 1);   // the degenerate top digit (measured: 0.4 ms at 2^20 points)
+        if (cost < best) {
+            best = cost;
+            w = k;
+        }
+    }
+    return w;
+}
+
+zk_status msm_configure(zk_msm* M, int group, size_t n, int window_bits, bool variable, uint32_t* c_out) {
+    M->group = group;
+    M->n = n;
+    M->slice = (window_bits > 0 || variable) ? 0 : msm_slice(n);
+    M->vb_window = 0;
+    // (a stand-alone handle is one or a few jobs: its reduction is the compiled few-jobs path, bucket cost 6 - group 4)
+    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(M->slice ? M->slice : n, group == 1 ? 4 : group);
+    if (variable) {
+        const uint32_t w = window_bits > 0 ? (uint32_t)window_bits : pick_vb_window(n, group);
+        if (w < 2 || w > 20) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 20] for the variable-base mode");
+        M->vb_window = w;
+        c = w + 1;   // odd magnitudes < 2^w share the kernels' bucket layout for c = w + 1
+    }
+    if (c < 2 || c > 22) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 22]");
+    *c_out = c;
+    return ZK_OK;
+}
+
 zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out,
                      bool variable = false) {
     if (group != 1 && group != 2) return fail(ZK_ERR_INVALID_ARGUMENT, "group must be 1 (G1) or 2 (G2)");
@@ -1722,58 +1781,25 @@ zk_status msm_create(int group, const uint8_t* bases, size_t n, int window_bits,
         zk_msm* p;
         ~Guard() { delete p; }
     } guard{M};
-    M->group = group;
     M->device = device;
-    M->n = n;
-    M->slice = (window_bits > 0 || variable) ? 0 : msm_slice(n);
-    // (a stand-alone handle is one or a few jobs: its reduction is the compiled few-jobs path, bucket cost 6 - group 4)
-    uint32_t c = window_bits > 0 ? (uint32_t)window_bits : pick_window(M->slice ? M->slice : n, group == 1 ? 4 : group);
-    if (variable) {
-        // digits of w bits at fixed positions, 255 / w jobs of 2^(w-1) buckets: minimise  n * 255 / w + beta * 2^(w-1) * 255 / w
-        uint32_t w = window_bits > 0 ? (uint32_t)window_bits : 0u;
-        if (!w) {
-            double best = 1e300;
-            const double beta = group == 2 ? 12.0 : 6.0;
-            for (uint32_t k = 2; k <= 20; k++) {
-                const double cost = (255.0 / k) * ((double)(n ? n : 1) + beta * (double)((size_t)1 << (k - 1)));
-                if (cost < best) {
-                    best = cost;
-                    w = k;
-                }
-            }
-        }
-        if (w < 2 || w > 20) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 20] for the variable-base mode");
-        M->vb_window = w;
-        c = w + 1;   // odd magnitudes < 2^w share the kernels' bucket layout for c = w + 1
-    }
-    if (c < 2 || c > 22) return fail(ZK_ERR_INVALID_ARGUMENT, "window_bits out of range [2, 22]");
-    // points at infinity are legal multiexp bases: they are mapped out (map = -1)
-    std::vector<int32_t> map(n);
-    bool any_inf = false;
+    uint32_t c = 0;
+    ZK_TRY(msm_configure(M, group, n, window_bits, variable, &c));
+    // the encodings are decoded on the device (msm.h k_decode_uncompressed: 0.1 ms for 2^20 points, the host loop it
+    // replaces 0.11 s); points at infinity are legal multiexp bases: they are mapped out (map = -1)
+    DevBuf raw;
+    uint32_t n_inf = 0;
     if (group == 1) {
-        std::vector<HG1A> pts(n);
-        for (size_t i = 0; i < n; i++) {
-            if (zkhost::g1_from_uncompressed(bases + i * 96, &pts[i]) != zkhost::DEC_OK)
-                return fail(ZK_ERR_IO, "invalid G1 encoding at base " + std::to_string(i));
-            map[i] = pts[i].is_inf() ? -1 : (int32_t)i;
-            any_inf |= pts[i].is_inf();
-        }
-        ZK_TRY(M->g1.build(pts, c, checked != 0, "bases", !variable));
+        ZK_TRY(M->g1.decode_enqueue(bases, n, c, !variable, raw, M->map, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        ZK_TRY(M->g1.decode_finish("base", &n_inf));
+        ZK_TRY(M->g1.finish_build(checked != 0, "bases", !variable));
     } else {
-        std::vector<HG2A> pts(n);
-        for (size_t i = 0; i < n; i++) {
-            if (zkhost::g2_from_uncompressed(bases + i * 192, &pts[i]) != zkhost::DEC_OK)
-                return fail(ZK_ERR_IO, "invalid G2 encoding at base " + std::to_string(i));
-            map[i] = pts[i].is_inf() ? -1 : (int32_t)i;
-            any_inf |= pts[i].is_inf();
-        }
-        ZK_TRY(M->g2.build(pts, c, checked != 0, "bases", !variable));
+        ZK_TRY(M->g2.decode_enqueue(bases, n, c, !variable, raw, M->map, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        ZK_TRY(M->g2.decode_finish("base", &n_inf));
+        ZK_TRY(M->g2.finish_build(checked != 0, "bases", !variable));
     }
-    if (any_inf) {
-        ZK_TRY(M->map.ensure(n * 4));
-        HIP_TRY(hipMemcpy(M->map.p, map.data(), n * 4, hipMemcpyHostToDevice));
-        M->has_map = true;
-    }
+    M->has_map = n_inf != 0;
     guard.p = nullptr;
     *out = M;
     return ZK_OK;
@@ -1851,13 +1877,83 @@ zk_status check_scalars(const uint8_t* scalars, size_t n, uint32_t flags) {
     return ZK_OK;
 }
 
+// the caller's plain scalars must be < r (fr.rs:276-289: FrRepr -> Fr fails otherwise); the scalars of a multiexp are
+// checked on the device, beside the multiexp
+zk_status scalars_check_enqueue(zk_msm* M, const void* d_scalars, uint32_t flags, hipStream_t st) {
+    ZK_TRY(M->sstat.ensure(4));
+    HIP_TRY(hipMemsetAsync(M->sstat.p, 0xff, 4, st));
+    if (!(flags & ZK_FR_MONTGOMERY) && M->n)
+        ZK_LAUNCH(zkdev::k_fr_first_noncanonical, dim3((unsigned)((M->n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_scalars,
+                  M->n, M->sstat.as<uint32_t>());
+    return ZK_OK;
+}
+zk_status scalars_check_finish(zk_msm* M) {
+    uint32_t v = 0xffffffffu;
+    HIP_TRY(hipMemcpy(&v, M->sstat.p, 4, hipMemcpyDeviceToHost));
+    if (v != 0xffffffffu) return fail(ZK_ERR_INVALID_ARGUMENT, "scalar " + std::to_string(v) + " is not < r");
+    return ZK_OK;
+}
+
 zk_status msm_run(zk_msm* M, const uint8_t* scalars, uint32_t flags, uint8_t* out) {
     if (!M || (!scalars && M->n) || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     ZK_TRY(use_device(M->device));
-    ZK_TRY(check_scalars(scalars, M->n, flags));
     ZK_TRY(M->scal.ensure(M->n * 32 + 32));
-    if (M->n) HIP_TRY(hipMemcpy(M->scal.p, scalars, M->n * 32, hipMemcpyHostToDevice));
-    return msm_run_dev(M, M->scal.p, flags, out);
+    if (M->n) HIP_TRY(hipMemcpyAsync(M->scal.p, scalars, M->n * 32, hipMemcpyHostToDevice, g_stream));
+    ZK_TRY(scalars_check_enqueue(M, M->scal.p, flags, g_stream));
+    uint8_t res[192];
+    ZK_TRY(msm_run_dev(M, M->scal.p, flags, res));   // waits for the stream
+    ZK_TRY(scalars_check_finish(M));
+    memcpy(out, res, M->group == 1 ? 96 : 192);
+    return ZK_OK;
+}
+
+// One-shot multiexp over fresh bases (zk_msm_g1 / zk_msm_g2 = bellman's multiexp(FullDensity) called once): variable-base
+// Pippenger - no table of doublings is built for bases that are used once - with the encodings decoded on the device and
+// ONE wait for the whole call: upload, decode, scalar check, the bucket passes of every digit position, then the verdicts
+// and the window sums come back together.  The handle (workspaces, the slice of decoded bases) is kept per (device, group)
+// and reused by the next call, so a caller that makes many such calls pays for the allocations once; calls are serialised.
+struct OneShotCache {
+    std::mutex mu;
+    std::map<int, zk_msm*> handles;   // key: device * 4 + group
+    std::map<int, DevBuf*> raws;      // the uploaded encodings (never freed: static destructors run after the HIP runtime's)
+    DevBuf* raw(int key) {
+        DevBuf*& r = raws[key];
+        if (!r) r = new DevBuf();
+        return r;
+    }
+};
+OneShotCache g_oneshot;
+
+zk_status msm_oneshot(int group, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
+    if ((!bases || !scalars) && n) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null output");
+    const int dev = g_device >= 0 ? g_device : 0;
+    ZK_TRY(use_device(dev));
+    std::lock_guard<std::mutex> lock(g_oneshot.mu);
+    const int key = dev * 4 + group;
+    zk_msm*& M = g_oneshot.handles[key];
+    if (!M) {
+        M = new (std::nothrow) zk_msm();
+        if (!M) return fail(ZK_ERR_OUT_OF_MEMORY, "host allocation failed");
+        M->device = dev;
+    }
+    uint32_t c = 0;
+    ZK_TRY(msm_configure(M, group, n, 0, true, &c));
+    DevBuf& raw = *g_oneshot.raw(key);
+    if (group == 1) ZK_TRY(M->g1.decode_enqueue(bases, n, c, false, raw, M->map, g_stream));
+    else ZK_TRY(M->g2.decode_enqueue(bases, n, c, false, raw, M->map, g_stream));
+    M->has_map = true;   // (whether a base is the point at infinity is not known before the wait: always consult the map)
+    ZK_TRY(M->scal.ensure(n * 32 + 32));
+    if (n) HIP_TRY(hipMemcpyAsync(M->scal.p, scalars, n * 32, hipMemcpyHostToDevice, g_stream));
+    ZK_TRY(scalars_check_enqueue(M, M->scal.p, 0, g_stream));
+    uint8_t res[192];
+    ZK_TRY(msm_run_dev(M, M->scal.p, 0, res));   // waits for the stream
+    uint32_t n_inf = 0;
+    if (group == 1) ZK_TRY(M->g1.decode_finish("base", &n_inf));
+    else ZK_TRY(M->g2.decode_finish("base", &n_inf));
+    ZK_TRY(scalars_check_finish(M));
+    memcpy(out, res, group == 1 ? 96 : 192);
+    return ZK_OK;
 }
 
 zk_status ntt_run_dev(zk_ntt* T, void* d_data, uint32_t batch, uint32_t flags) {
@@ -3087,15 +3183,7 @@ zk_status zk_msm_run(zk_msm* m, const uint8_t* scalars, uint32_t flags, uint8_t*
 zk_status zk_msm_run_dev(zk_msm* m, const void* d_scalars, uint32_t flags, uint8_t* out) { return msm_run_dev(m, d_scalars, flags, out); }
 void zk_msm_free(zk_msm* m) { delete m; }
 
-static zk_status msm_oneshot(int group, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
-    zk_msm* m = nullptr;
-    int dev = g_device >= 0 ? g_device : 0;
-    zk_status st = zk_msm_create(group, bases, n, 0, 0, dev, &m);
-    if (st != ZK_OK) return st;
-    st = zk_msm_run(m, scalars, 0, out);
-    zk_msm_free(m);
-    return st;
-}
+// (the device this host thread selected last through any other entry, else device 0)
 zk_status zk_msm_g1(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
     return msm_oneshot(1, bases, scalars, n, out);
 }
