@@ -475,21 +475,26 @@ def main():
         if cnt:
             kernels[name] = {"launches": cnt, "total_ms": round(ms.value, 3)}
     lib.zk_profile_end()
+    # which form of the two scratch-using assembly kernels this rank's device runs, and the load-time comparison behind it
+    # (zk_kernel_forms; a device whose first form measured > 1.4 x the scratch-free one takes the latter: VERDICT r4 item 2)
+    forms = zk.kernel_forms(dev_index, lib=lib)
     per_rank = [{"rank": 0, "proofs_per_s": round(B * K / timing["prove_s"], 1), "gather_ms_per_step": 0.0,
                  "numa_node": numa_node.value, "cpus": len(os.sched_getaffinity(0)), "host_threads": host_threads,
-                 "setup_s": round(setup_s, 2)}]
+                 "setup_s": round(setup_s, 2), "kernel_forms": forms}]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # every rank's own rate (submit of its K steps -> its last proof) and what the gather cost it
         mine = torch.tensor([timing["prove_s"], timing["gather_s"], float(numa_node.value), float(len(os.sched_getaffinity(0))),
-                             float(host_threads), setup_s, float(lanes_used)], dtype=torch.float64, device=gather_dev)
-        allr = [torch.zeros(7, dtype=torch.float64, device=gather_dev) for _ in range(world)]
+                             float(host_threads), setup_s, float(lanes_used), float(forms["g2_accumulate"]), float(forms["reduce_level1"])]
+                            + [float(x) for x in forms["ms"]], dtype=torch.float64, device=gather_dev)
+        allr = [torch.zeros(13, dtype=torch.float64, device=gather_dev) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "proofs_per_s": round(B * K / float(x[0]), 1), "gather_ms_per_step": round(float(x[1]) / K * 1e3, 2),
                      "numa_node": int(x[2]), "cpus": int(x[3]), "host_threads": int(x[4]), "setup_s": round(float(x[5]), 2),
-                     "pipeline_lanes": int(x[6])}
+                     "pipeline_lanes": int(x[6]),
+                     "kernel_forms": {"g2_accumulate": int(x[7]), "reduce_level1": int(x[8]), "ms": [round(float(v), 4) for v in x[9:13]]}}
                     for r, x in enumerate(allr)]
 
     # ---- parity gates: EVERY step of the timed region (two pipeline lanes alternate the chunks; VERDICT r2: the
@@ -873,6 +878,10 @@ def main():
                    "window_bits": info["window_bits"], "window_bits_all": window_bits_all(lib, params), "batch_chunk": chunk, "host_cores": cores, "host_threads_per_rank": host_threads,
                    "parallelism": "dp%d (independent proofs, contiguous blocks, %s gather of 192 B/proof/step)" % (world, "gloo" if one_gpu else "RCCL"),
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend, "pipeline_lanes": lanes_used, "per_rank": per_rank,
+                   # `value` is all proofs / the SLOWEST rank's wall time (barrier to barrier, the contract); the sum of the ranks'
+                   # own rates says what the GPUs delivered when one of them lagged (a slow device, a late start)
+                   "sum_of_rank_rates_proofs_per_s": round(sum(r["proofs_per_s"] for r in per_rank), 1),
+                   "slowest_rank_vs_median": round(min(r["proofs_per_s"] for r in per_rank) / sorted(r["proofs_per_s"] for r in per_rank)[len(per_rank) // 2], 3),
                    "proofs_checked_vs_oracle": checked, "proofs_checked_from_other_ranks": cross_rank,
                    "proofs_verified_by_product_verifier": verified, "verify_ms_per_step": None if verify_ms is None else round(verify_ms, 1), "setup_s": round(setup_s, 2), "statements_s": round(statements_s, 2), "generate_parameters_s": round(keygen_s, 2),
                    "hbm_gb": {"total": round(hbm_total_b / 1e9, 1), "free_after_timed_region": round(hbm_free_b / 1e9, 1)}},
@@ -980,36 +989,98 @@ def run_micro(lib, zk, dev):
                               "(SURVEY.md section 8(d) secondary point); identity checked"}
     # variable-base figures (no table of doublings: Pippenger over the bases themselves) - the like-for-like
     # "2^20-point Pippenger MSM" of BASELINE config 2, reported FIRST
+    cores = usable_cores()
     try:
         nv = 1 << 20
-        t0 = time.perf_counter()
         vctx = zk.MultiexpContext(1, bases[:96 * nv], lib=lib, variable_base=True)
         one = vctx.run_dev(d_sc.data_ptr())
-        dtv = time.perf_counter() - t0
         assert one == res, "variable-base 2^20 multiexp differs from the table form"
         vctx.run_dev(d_sc.data_ptr())
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            vctx.run_dev(d_sc.data_ptr())
-        dtr = (time.perf_counter() - t0) / reps
+        with zk.KernelTimer(lib) as kt:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                vctx.run_dev(d_sc.data_ptr())
+            dtr = (time.perf_counter() - t0) / reps
+            vkern = {name: round(kt.get(name)[1] / reps, 3) for name in KERNEL_NAMES if kt.get(name)[0]}
         assert vctx.run_dev(d_wl.data_ptr()) == res_wl, "variable-base witness-like multiexp differs from the table form"
         t0 = time.perf_counter()
         for _ in range(reps):
             vctx.run_dev(d_wl.data_ptr())
         dtr_wl = (time.perf_counter() - t0) / reps
         vctx.close()
+        # the one-shot entry (zk_msm_g1 = bellman's multiexp called once): 96 MB of fresh encodings and 32 MB of scalars from
+        # pageable host memory every call; upload, decoding on the device, scalar check, the bucket passes, one wait
+        bases_np = np.frombuffer(bases, dtype=np.uint8)
+        assert zk.multiexp(1, bases_np, sc, lib=lib) == res, "zk_msm_g1 differs from the table form"
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            zk.multiexp(1, bases_np, sc, lib=lib)
+        dtv = (time.perf_counter() - t0) / reps
+        # CPU baseline of config 2: the C restatement of bellman's multiexp (c = ceil(ln n), one thread per window, running-sum
+        # bucket reduction) on the SAME inputs, all cores and one thread; its bytes must be the GPU's
+        cb = cport.Bases(1, bases)
+        t0 = time.perf_counter()
+        cpu_res = cb.multiexp(sc.tobytes(), cores)
+        cpu_all = time.perf_counter() - t0
+        assert cpu_res == res, "the CPU port's 2^20 multiexp differs from the GPU's"
+        nsub = 1 << 16   # one thread: a 2^16-point prefix (the full size is ~15 s of one core)
+        t0 = time.perf_counter()
+        cport.Bases(1, bases[:96 * nsub]).multiexp(sc.tobytes()[:32 * nsub], 1)
+        cpu_one = time.perf_counter() - t0
         out["msm_g1_2p20_variable_base"] = {
             "mscalar_per_s": round(nv / dtr / 1e6, 3), "ms": round(dtr * 1e3, 3),
             "gbps_algorithmic": round(128.0 * nv / dtr / 1e9, 3), "frac_of_hbm_peak": round(128.0 * nv / dtr / 1e9 / HBM_PEAK_GBPS, 5),
+            "kernel_ms": vkern,
+            "accumulate_share": round(vkern.get("msm_accumulate_g1", 0.0) / (dtr * 1e3), 3),
             "one_shot_mscalar_per_s": round(nv / dtv / 1e6, 3), "one_shot_ms": round(dtv * 1e3, 3),
             "inputs": inputs_note,
+            "cpu_baseline": {"value": round(nv / cpu_all / 1e6, 4), "unit": "Mscalar/s", "cores": min(cores, 19), "kind": "port",
+                             "seconds": round(cpu_all, 3),
+                             "single_thread_value": round(nsub / cpu_one / 1e6, 4), "single_thread_sample": "2^16-point prefix, %.2f s" % cpu_one,
+                             "sample": "the full 2^20-point multiexp once (oracle/c/zkoracle.c zo_multiexp: bellman's algorithm, c = 14, "
+                                       "19 windows = at most 19 threads of the %d cores); result byte-identical to the GPU's" % cores},
             "note": "BASELINE config 2, like for like: zk_msm_create_variable = signed-digit Pippenger over the bases "
-                    "themselves, one bucket pass per digit position, host Horner fold; 'ms' = bases resident (decoded "
-                    "once), scalars in HBM; 'one_shot' = decode + upload of 2^20 fresh bases + the multiexp; identity "
-                    "sum s_i (k_i G) == (sum s_i k_i) G checked through the table form, which this result equals"}
+                    "themselves, one bucket pass per digit position (w = 15: 17 positions of 16 384 buckets), host Horner fold; "
+                    "'ms' = bases resident (decoded once), scalars in HBM; 'one_shot' = zk_msm_g1: upload of 2^20 fresh "
+                    "encodings + scalars, decoding on the device, the multiexp; equal to the table form's result, to the "
+                    "identity sum s_i (k_i G) == (sum s_i k_i) G and to the CPU port's bytes"}
         witness_like["variable_base"] = {"mscalar_per_s": round(nv / dtr_wl / 1e6, 3), "ms": round(dtr_wl * 1e3, 3)}
     except Exception as exc:
         out["msm_g1_2p20_variable_base"] = {"error": repr(exc)[:200]}
+    # the G2 loop alone: 2^17 points (224 B per term), variable base and the one-shot entry, against the CPU port's bytes
+    try:
+        n2 = 1 << 17
+        bases2 = cport.fixed_base_mul(2, fields_to_u8(ks[:n2]).tobytes(), min(64, cores))
+        sc2 = sc[:32 * n2]
+        d_sc2 = torch.from_numpy(sc2.copy()).to(dev)
+        cb2 = cport.Bases(2, bases2)
+        t0 = time.perf_counter()
+        want2 = cb2.multiexp(sc2.tobytes(), cores)
+        cpu2 = time.perf_counter() - t0
+        g2ctx = zk.MultiexpContext(2, bases2, lib=lib, variable_base=True)
+        assert g2ctx.run_dev(d_sc2.data_ptr()) == want2, "2^17 G2 multiexp differs from the CPU port's"
+        with zk.KernelTimer(lib) as kt:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                g2ctx.run_dev(d_sc2.data_ptr())
+            dt2 = (time.perf_counter() - t0) / reps
+            k2 = {name: round(kt.get(name)[1] / reps, 3) for name in KERNEL_NAMES if kt.get(name)[0]}
+        g2ctx.close()
+        b2np = np.frombuffer(bases2, dtype=np.uint8)
+        assert zk.multiexp(2, b2np, sc2, lib=lib) == want2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            zk.multiexp(2, b2np, sc2, lib=lib)
+        dt2o = (time.perf_counter() - t0) / reps
+        out["msm_g2_2p17"] = {"mscalar_per_s": round(n2 / dt2 / 1e6, 3), "ms": round(dt2 * 1e3, 3),
+                              "gbps_algorithmic": round(224.0 * n2 / dt2 / 1e9, 3), "frac_of_hbm_peak": round(224.0 * n2 / dt2 / 1e9 / HBM_PEAK_GBPS, 5),
+                              "kernel_ms": k2, "one_shot_ms": round(dt2o * 1e3, 3),
+                              "inputs": "bases k_i G2 for the first 2^17 k_i of seed 1, the first 2^17 scalars of seed 2",
+                              "cpu_baseline": {"value": round(n2 / cpu2 / 1e6, 4), "unit": "Mscalar/s", "cores": min(cores, 22), "kind": "port",
+                                               "seconds": round(cpu2, 3), "sample": "the full 2^17-point G2 multiexp once; result byte-identical to the GPU's"},
+                              "note": "variable-base Pippenger over G2 (the Fq2 accumulation loop alone: 224 algorithmic bytes per term)"}
+    except Exception as exc:
+        out["msm_g2_2p17"] = {"error": repr(exc)[:200]}
     out["msm_g1_2p20"] = fixed
     out["msm_g1_2p20_witness_like"] = witness_like
     ctx.close()
@@ -1036,6 +1107,27 @@ def run_micro(lib, zk, dev):
                             "frac_of_hbm_peak": round(2 * 64.0 * n / dt / 1e9 / HBM_PEAK_GBPS, 5),
                             "inputs": "SplitMix64(3).field(r), 2^20 elements (BASELINE.md section 3); forward + inverse round trip checked"}
     lib.zk_ntt_free(t)
+    # CPU baseline of config 3: the C restatement of bellman's EvaluationDomain (best_fft: radix-2, log_cpus-way split) on the
+    # same input - fft, then icoset_fft - all cores and one thread; the pair's result compared with the GPU's through zk_ntt_fr
+    try:
+        host = ntt_in.tobytes()
+        times = {}
+        for th in (cores, 1):
+            t0 = time.perf_counter()
+            mid = cport.fft(host, 20, inverse=False, coset=False, threads=th)
+            fin = cport.fft(mid, 20, inverse=True, coset=True, threads=th)
+            times[th] = time.perf_counter() - t0
+        dom = np.frombuffer(host, dtype=np.uint8).copy()
+        lib.check(lib.zk_ntt_fr(dom.ctypes.data, 20, 0, 0))
+        lib.check(lib.zk_ntt_fr(dom.ctypes.data, 20, 1, 1))
+        assert dom.tobytes() == fin, "the CPU port's 2^20 fft + icoset_fft differs from the GPU's"
+        out["ntt_pair_2p20"]["cpu_baseline"] = {"value": round(times[cores] * 1e3, 3), "unit": "ms per pair", "cores": cores, "kind": "port",
+                                                "single_thread_value": round(times[1] * 1e3, 3),
+                                                "gbps_algorithmic": round(2 * 64.0 * n / times[cores] / 1e9, 3),
+                                                "sample": "one fft + one icoset_fft of the same 2^20 elements (oracle/c/zkoracle.c zo_fft), "
+                                                          "incl. the ctypes copy of 2 x 32 MB; result byte-identical to the GPU's"}
+    except Exception as exc:
+        out["ntt_pair_2p20"]["cpu_baseline"] = {"error": repr(exc)[:200]}
     return out
 
 

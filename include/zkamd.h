@@ -428,6 +428,14 @@ void zk_profile_begin(void);
 /* returns the number of launches of `kernel` recorded since begin; *total_ms their summed time */
 int zk_profile_get(const char* kernel, double* total_ms);
 void zk_profile_end(void);
+/* Two of the generated assembly kernels (the G2 bucket accumulation, level 1 of the G1 bucket reduction) exist in two
+ * forms: the first keeps a few values in scratch memory across the loop, the second is scratch-free (1-2 % slower on a
+ * healthy device, 3x faster on a device whose runtime caps the waves of scratch-using dispatches).  zk_params_load times
+ * both on the device when the first key is loaded there and keeps the choice for the process (ZKAMD_KERNEL_FORM = scratch |
+ * free overrides).  forms_out[0 / 1] = the form in use for the G2 accumulation / the reduction (0 = first, 1 = scratch-
+ * free); ms_out = the comparison [G2 first, G2 scratch-free, reduction first, reduction scratch-free], zeros before any key
+ * was loaded on the device.  No reference counterpart. */
+zk_status zk_kernel_forms(int device, uint32_t forms_out[2], float ms_out[4]);
 /* the HIP stream (hipStream_t) all work of this library is enqueued on */
 void* zk_stream(void);
 zk_status zk_synchronize(void);

@@ -89,18 +89,19 @@ def test_reduction_loop_in_the_single_lane_interpreter(capsys):
 def test_assembly_kernels_resources():
     """The kernels around the generated loops, read from the gfx950 code objects inside the built library
     (tools/kernel_resources.py; no GPU needed): the occupancy the loops were sized for (three waves per SIMD for G1: at
-    most 168 registers; two for G2 and the reduction loop), no scratch memory in the G1 accumulation kernels, and no more
-    than the few words the compiler carries across the loops that own every VGPR in the other two (G2 accumulation 144 B,
-    level 1 of the reduction 72 B per lane).  Making those two scratch-free as well was built and measured in round 4
-    (tools/experiments/scratch_free_asm_kernels.patch): same durations alone, 3 % SLOWER overlapped step - DESIGN.md 4.1."""
+    most 168 registers; two for G2 and the reduction loop), no scratch memory in the G1 accumulation kernels, no more than
+    the few words the compiler carries across the loops that own every VGPR in the FIRST form of the other two (G2
+    accumulation 144 B, level 1 of the reduction 72 B per lane) - and NONE in their scratch-free second form (`_sf`), which
+    zk_params_load selects on a device where the first form runs under a low scratch-wave limit."""
     so = os.path.join(ROOT, "zero-chain_amd", "libzkamd.so")
     llvm = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "llvm", "bin")
     if not os.path.exists(so) or not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
         pytest.skip("library not built or llvm tools absent")
     res = _load("kernel_resources").kernel_resources(so)
     hot = {n: r for n, r in res.items() if any(k in n for k in ("k_msm_accumulate_g1asm", "k_msm_accumulate_g2asm", "k_msm_reduce1_g1asm"))}
-    assert len(hot) == 5, sorted(hot)
+    assert len(hot) == 8, sorted(hot)
+    assert sum(1 for n in hot if "_sf" in n) == 3
     for name, r in hot.items():
         g1acc = "accumulate_g1asm" in name
         assert r["vgpr"] <= (168 if g1acc else 256), (name, r)
-        assert r["scratch"] <= (0 if g1acc else 160), (name, r)
+        assert r["scratch"] <= (0 if g1acc or "_sf" in name else 160), (name, r)

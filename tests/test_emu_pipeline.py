@@ -70,22 +70,6 @@ def test_runtime_hooks(emu_lib, monkeypatch):
     pc.runtime_hooks(emu_lib, on_gpu=False)
 
 
-def test_msm_many_workgroup_sort(emu_lib, monkeypatch):
-    """ZKAMD_SORT_WGS = G: the batch's sort with G workgroups per job (msm.h k_msm_msort_*), job-major and XCD-major
-    numbering, a ragged split of the scalars, split and unsplit G1 launch sets."""
-    monkeypatch.setenv("ZKAMD_ASM_MIN_PAIRS", "0")
-    monkeypatch.setenv("ZKAMD_SORT_WGS", "3")
-    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "7")
-    monkeypatch.setenv("ZKAMD_SPLIT_MIN", "1")
-    pc.prover_batch(emu_lib, 9, 3, 40, 10, use_c_oracle=True)
-    monkeypatch.setenv("ZKAMD_SORT_XCD", "0")
-    monkeypatch.setenv("ZKAMD_SORT_WGS", "5")
-    monkeypatch.setenv("ZKAMD_SPLIT_G1", "0")
-    pc.prover_batch(emu_lib, 10, 2, 700, 16, use_c_oracle=True)   # 16 jobs: the XCD-major numbering applies when it is on
-    monkeypatch.setenv("ZKAMD_SORT_XCD", "1")
-    pc.prover_batch(emu_lib, 11, 2, 90, 16, use_c_oracle=True)
-
-
 def test_prover_small_checked(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
     pc.prover_small(emu_lib, 1, 3, 10, 12)

@@ -678,29 +678,36 @@ def test_runtime_hooks(gpu_lib):
     pc.runtime_hooks(gpu_lib, on_gpu=True)
 
 
-def test_full_chunk_many_workgroup_sort_gives_the_same_proofs(gpu_lib, monkeypatch):
-    """ZKAMD_SORT_WGS (msm.h k_msm_msort_*: G workgroups per job, job-major) at the bench's launch shape - it engages for
-    the many-jobs launch sets only: 1024 proofs, byte-identical to the one-workgroup-per-job sort's, for G = 4 and 16 and
-    both numberings of the workgroups."""
+def test_kernel_form_selection(gpu_lib):
+    """the two scratch-using assembly kernels exist in two forms and zk_params_load picks per device by
+    timing both (zkamd.cpp calibrate_kernel_forms).  Three fresh processes prove the same 1024 statements (every proof
+    verified): as the device decides; with the first form's measured time tripled (ZKAMD_INJECT_SCRATCH_SLOW=1: what the slow
+    box of round 4 looked like) - the scratch-free forms must be picked; with ZKAMD_KERNEL_FORM=free.  Same bytes each time."""
+    import json
+    import os
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "form_probe.py")
+
+    def run(extra):
+        env = dict(os.environ)
+        for k in ("ZKAMD_INJECT_SCRATCH_SLOW", "ZKAMD_KERNEL_FORM", "ZKAMD_NO_CALIBRATE"):
+            env.pop(k, None)
+        env.update(extra)
+        out = subprocess.run([sys.executable, probe, "1024"], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
+    base = run({})
+    ms = base["forms"]["ms"]
+    assert base["verified"] == 1024 and all(x > 0 for x in ms), base
+    assert base["forms"]["g2_accumulate"] == int(ms[0] > 1.4 * ms[1]) and base["forms"]["reduce_level1"] == int(ms[2] > 1.4 * ms[3])
+    slow = run({"ZKAMD_INJECT_SCRATCH_SLOW": "1"})
+    assert (slow["forms"]["g2_accumulate"], slow["forms"]["reduce_level1"]) == (1, 1), slow
+    assert slow["verified"] == 1024 and slow["sha256"] == base["sha256"]
+    forced = run({"ZKAMD_KERNEL_FORM": "free", "ZKAMD_NO_CALIBRATE": "1"})
+    assert (forced["forms"]["g2_accumulate"], forced["forms"]["reduce_level1"]) == (1, 1) and forced["sha256"] == base["sha256"]
+    # this process decided too (the keys the other tests loaded): the query answers for device 0
     import zero_chain_amd as zk
-    from oracle import transfer_circuit as tc
-    r1, asgs, P, pk = helpers.transfer_case(1)
-    n_distinct, n = 16, 1024
-    ws = [tc.make_witness(700 + i, amount=3 + 11 * i, fee=i % 3, balance=900 + 7 * i) for i in range(n_distinct)]
-    sts = zk.transfer_statements([tc.statement_dict(ws[i % n_distinct]) for i in range(n)])
-    rng = synth.SplitMix64(77)
-    rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
-    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
-    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
-    try:
-        base = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
-        for env in ({"ZKAMD_SORT_WGS": "16"}, {"ZKAMD_SORT_WGS": "4", "ZKAMD_SORT_XCD": "0"}):
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
-            got = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
-            for k in env:
-                monkeypatch.delenv(k)
-            assert got == base, env
-    finally:
-        mats.close()
-        params.close()
+    here = zk.kernel_forms(0, lib=gpu_lib)
+    assert set(here) == {"g2_accumulate", "reduce_level1", "ms"} and here["g2_accumulate"] in (0, 1)

@@ -27,6 +27,11 @@ lib = zk.load_library()
 rng = np.random.default_rng(5)
 raw = rng.integers(0, 256, size=192 * 7, dtype=np.uint8)
 assert zk.gather_proofs(raw, 7, dist=dist, device=dev, dst=0) == raw.tobytes()
+# step after step through the cached exchange buffers (the page-locked staging tensor is rewritten every call: ADVICE r4),
+# the device named by a string
+for k in range(12):
+    blk = rng.integers(0, 256, size=192 * 7, dtype=np.uint8)
+    assert zk.gather_proofs(blk, 7, dist=dist, device="cuda:0", dst=0) == blk.tobytes(), k
 # prove_sharded on the GPU: the rank proves its (whole) block and the proofs come back through the RCCL gather
 r1, asg, P, pk = helpers.small_case(2, 3, 30, 33)
 params = zk.Parameters.read(pk, checked=False, lib=lib)

@@ -539,6 +539,18 @@ def gen_loop_g2():
     return R, e
 
 
+def used_vgprs(lines):
+    """every VGPR an emitted line names, singly (v7) or in a range (v[4:7])"""
+    import re
+    used = set()
+    for l in lines:
+        for m in re.finditer(r"v\[(\d+):(\d+)\]", l):
+            used.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", l):
+            used.add(int(m.group(1)))
+    return used
+
+
 def render(R, e, name, what, first_clobber=64):
     out = ["// The bucket-accumulation loop of the %s multiexp: %s, %d VGPRs." % (name, what, R.n_vgpr),
            "// per step: %d VALU + %d SALU + %d VMEM instructions" % (body_counts(e)),
@@ -548,6 +560,14 @@ def render(R, e, name, what, first_clobber=64):
     out[-1] = out[-1][:-2]
     clob = ["v%d" % i for i in range(first_clobber, R.n_vgpr)] + ["s%d" % i for i in R.clob_s] + ["vcc", "scc", "memory"]
     out.append("#define ZK_MADD_%s_ASM_CLOBBERS %s" % (name, ", ".join('"%s"' % c for c in clob)))
+    # ..._CLOBBERS_MIN: only the registers the loop names.  The pads it never touches stay with the compiler, which then has
+    # somewhere to keep the few values that live across the loop; with EVERY VGPR clobbered they go to scratch memory, and a
+    # kernel that uses scratch runs under the runtime's scratch-wave limit (the scratch-free second form of the kernels,
+    # msm.h k_msm_accumulate_g2asm*_sf, selected per device at load time: zkamd.cpp calibrate_kernel_forms)
+    used = used_vgprs(e.lines)
+    assert max(used) < R.n_vgpr
+    clob_min = ["v%d" % i for i in range(first_clobber, R.n_vgpr) if i in used] + ["s%d" % i for i in R.clob_s] + ["vcc", "scc", "memory"]
+    out.append("#define ZK_MADD_%s_ASM_CLOBBERS_MIN %s" % (name, ", ".join('"%s"' % c for c in clob_min)))
     out.append("#define ZK_MADD_%s_VGPRS %d" % (name, R.n_vgpr))
     return "\n".join(out) + "\n"
 

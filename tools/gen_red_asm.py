@@ -225,6 +225,10 @@ def render(R, e):
     out[-1] = out[-1][:-2]
     clob = ["v%d" % i for i in range(128, R.n_vgpr)] + ["s%d" % i for i in R.clob_s] + ["vcc", "scc", "memory"]
     out.append("#define ZK_RED_G1_ASM_CLOBBERS %s" % ", ".join('"%s"' % c for c in clob))
+    used = gm.used_vgprs(e.lines)   # (see gen_madd_asm.render: the clobber list of the scratch-free form of the kernel)
+    assert max(used) < R.n_vgpr
+    clob_min = ["v%d" % i for i in range(128, R.n_vgpr) if i in used] + ["s%d" % i for i in R.clob_s] + ["vcc", "scc", "memory"]
+    out.append("#define ZK_RED_G1_ASM_CLOBBERS_MIN %s" % ", ".join('"%s"' % c for c in clob_min))
     out.append("#define ZK_RED_G1_VGPRS %d" % R.n_vgpr)
     out.append("#define ZK_RED_FLAG_RUN_INF %d\n#define ZK_RED_FLAG_ACC_INF %d\n#define ZK_RED_FLAG_RUN_RAW %d\n#define ZK_RED_FLAG_ACC_RAW %d"
                % (FLAG_RUN_INF, FLAG_ACC_INF, FLAG_RUN_RAW, FLAG_ACC_RAW))

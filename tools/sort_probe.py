@@ -25,7 +25,7 @@ rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(B)]
 base = b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs))
 mode = sys.argv[1] if len(sys.argv) > 1 else "debug"
 CONFIGS = {
-    # round 5: G workgroups per job, job-major (msm.h k_msm_msort_*), against the one-workgroup-per-job sort
+    # round 5: G workgroups per job, job-major (tools/experiments/r05_many_workgroup_sort.patch), against the one-workgroup-per-job sort
     "wgs": (("lds sort (1 WG / job)", {}),) + tuple(("G = %d, xcd-major %d" % (g, x), {"ZKAMD_SORT_WGS": str(g), "ZKAMD_SORT_XCD": str(x)})
                                                       for g in (2, 4, 8, 16, 32) for x in (1, 0)) + (("lds sort (1 WG / job)", {}),),
 }

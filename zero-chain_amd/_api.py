@@ -24,7 +24,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
                    ZK_NTT_OUT_BITREV)
 
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs", "read_proofs",
-           "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs", "create_proofs_dev", "stream", "bind_host_to_device", "KernelTimer",
+           "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs", "create_proofs_dev", "stream", "bind_host_to_device", "KernelTimer", "kernel_forms",
            "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "xt_fields", "gen_proof", "XT_FIELDS",
            "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_witness_gpu", "anonymous_prove_batch",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
@@ -52,6 +52,15 @@ def bind_host_to_device(device=0, lib=None):
     node, cpus = C.c_int(-1), C.c_int(0)
     lib.check(lib.zk_bind_host_to_device(int(device), C.byref(node), C.byref(cpus)))
     return node.value, cpus.value
+
+
+def kernel_forms(device=0, lib=None):
+    """zk_kernel_forms: which form of the two scratch-using assembly kernels the device runs and the load-time comparison it
+    was chosen by: {"g2_accumulate": 0 | 1, "reduce_level1": 0 | 1, "ms": [g2 first, g2 scratch-free, red first, red sf]}."""
+    lib = lib or _lib.load()
+    forms, ms = (C.c_uint32 * 2)(), (C.c_float * 4)()
+    lib.check(lib.zk_kernel_forms(int(device), forms, ms))
+    return {"g2_accumulate": int(forms[0]), "reduce_level1": int(forms[1]), "ms": [round(float(x), 4) for x in ms]}
 
 
 class KernelTimer:

@@ -157,6 +157,7 @@ _PROTOS = {
     "zk_profile_begin": (None, []),
     "zk_profile_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_double)]),
     "zk_profile_end": (None, []),
+    "zk_kernel_forms": (C.c_int32, [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "zk_stream": (C.c_void_p, []),
     "zk_synchronize": (C.c_int32, []),
 }

@@ -60,7 +60,7 @@ def gather_proofs(local_proofs, n_total, dist=None, device=None, dst=0):
         raise ValueError("rank %d: expected %d proofs, got %d bytes" % (rank, hi - lo, local.size))
     cap = max(shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)) * PROOF_SIZE
     if device is not None:
-        dev = device
+        dev = torch.device(device)       # (a string such as "cuda:0" is accepted)
     elif dist.get_backend() == "nccl":     # RCCL moves device memory only: default to this rank's current GPU
         dev = torch.device("cuda", torch.cuda.current_device())
     else:
@@ -77,14 +77,22 @@ def gather_proofs(local_proofs, n_total, dist=None, device=None, dst=0):
         send = torch.zeros(cap, dtype=torch.uint8, device=dev) if on_gpu else stage
         recv = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == dst else None
         back = torch.empty(world * cap, dtype=torch.uint8, pin_memory=on_gpu) if rank == dst else None
-        bufs = _GATHER_BUFS[key] = (stage, send, recv, back)
+        copied = torch.cuda.Event() if on_gpu else None   # the staging tensor's last copy to the device has run
+        bufs = _GATHER_BUFS[key] = (stage, send, recv, back, copied)
         if len(_GATHER_BUFS) > 8:          # a handful of shapes at most; never grow without bound
             _GATHER_BUFS.pop(next(iter(_GATHER_BUFS)))
-    stage, send, recv, back = bufs
+    stage, send, recv, back, copied = bufs
+    # The staging tensor is reused by the next call: on a rank that is not `dst` nothing below waits for the asynchronous copy
+    # out of it (under RCCL the collective only orders streams), so a caller that gathers step after step in a loop would
+    # overwrite step k's block on the host before its copy has run and send step k + 1's proofs twice.  The event
+    # recorded behind the copy is waited for before the tensor is written again.
+    if copied is not None:
+        copied.synchronize()
     if local.size:
         stage[:local.size] = torch.from_numpy(np.ascontiguousarray(local))
     if send is not stage:
         send.copy_(stage, non_blocking=True)
+        copied.record(torch.cuda.current_stream(send.device))
     dist.gather(send, recv, dst=dst)
     if rank != dst:
         return None

@@ -480,111 +480,6 @@ k_msm_sort_lds(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t* cnt, uint3
     }
 }
 
-// The same sort with G workgroups per job (round 5; ZKAMD_SORT_WGS = G): k_msm_sort_lds keeps ALL jobs of a launch live at
-// once - a thousand 4 MB output windows, far beyond every cache, so each scattered 4-byte store leaves the chip as its own
-// 32-byte sector.  Here the launch is job-major: workgroup g of job j takes the scalars [g n / G, (g + 1) n / G), and with
-// two workgroups resident per CU only 512 / G jobs are live at a time (G = 16: 32 jobs, ~128 MB of pairs - inside the
-// 256 MiB Infinity Cache).
-//   1. k_msm_msort_count    LDS histogram of the workgroup's digits; one global atomic per (workgroup, non-empty bucket)
-//                           adds it to the job's histogram `cnt` and returns the workgroup's first slot inside the bucket
-//   2. k_msm_msort_scan     one workgroup per job: exclusive scans of cnt -> off / toff / ntasks (the middle of k_msm_sort_lds)
-//   3. k_msm_msort_scatter  the workgroups recode again with LDS cursors = bucket offset + their reserved slot
-// wgbase is [job][workgroup][bucket].  xcd_major: workgroups 8 apart (the same XCD) work on the same job, so that the
-// stores into one bucket's run meet in ONE L2.
-ZK_DI void msort_ids(uint32_t G, uint32_t nj, uint32_t xcd_major, uint32_t* job, uint32_t* g) {
-    const uint32_t lin = blockIdx.x;
-    if (xcd_major && (nj & 7u) == 0) {
-        const uint32_t xcd = lin & 7u, slot = lin >> 3;
-        *job = (slot / G) * 8 + xcd;
-        *g = slot % G;
-    } else {
-        *job = lin / G;
-        *g = lin % G;
-    }
-}
-static __global__ void __launch_bounds__(MSM_SORT_THREADS)
-k_msm_msort_count(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t G, uint32_t nj, uint32_t xcd_major, uint32_t* cnt,
-                  uint32_t* wgbase) {
-    ZK_DYN_SHARED(uint32_t, h);   // [nb]
-    uint32_t jix, g;
-    msort_ids(G, nj, xcd_major, &jix, &g);
-    const MsmJob job = jobs[jix];
-    const uint32_t nb = 1u << (c - 2), tid = threadIdx.x, nt = MSM_SORT_THREADS;
-    for (uint32_t b = tid; b < nb; b += nt) h[b] = 0;
-    __syncthreads();
-    const uint32_t per = (job.n + G - 1) / G, i0 = g * per, i1 = i0 + per < job.n ? i0 + per : job.n;
-    for (uint32_t i = i0 + tid; i < i1; i += nt) {
-        if (job.map && job.map[i] < 0) continue;
-        msm_digits(job, i, c, [&](uint32_t, uint32_t, uint32_t mag, bool) { atomicAdd(&h[mag >> 1], 1u); });
-    }
-    __syncthreads();
-    uint32_t* jcnt = cnt + (size_t)jix * nb;
-    uint32_t* wb = wgbase + ((size_t)jix * G + g) * nb;
-    for (uint32_t b = tid; b < nb; b += nt) wb[b] = h[b] ? atomicAdd(&jcnt[b], h[b]) : 0u;
-}
-static __global__ void __launch_bounds__(MSM_SORT_THREADS)
-k_msm_msort_scan(const MsmJob* __restrict__ jobs, uint32_t c, const uint32_t* __restrict__ cnt, uint32_t* off, uint32_t* toff,
-                 uint32_t* ntasks, uint32_t seg) {
-    ZK_SHARED uint32_t part[MSM_SORT_THREADS];
-    ZK_SHARED uint32_t tpart[MSM_SORT_THREADS];
-    const MsmJob job = jobs[blockIdx.x];
-    const uint32_t nb = 1u << (c - 2), tid = threadIdx.x, nt = MSM_SORT_THREADS;
-    const uint32_t* jcnt = cnt + (size_t)blockIdx.x * nb;
-    const uint32_t per = (nb + nt - 1) / nt;
-    uint32_t b0 = tid * per, b1 = b0 + per < nb ? b0 + per : nb;
-    if (b0 > nb) b0 = nb;
-    uint32_t sum = 0, tsum = 0;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t k = jcnt[b];
-        sum += k;
-        tsum += (k + seg - 1) / seg;
-    }
-    part[tid] = sum;
-    tpart[tid] = tsum;
-    __syncthreads();
-    for (uint32_t d = 1; d < nt; d <<= 1) {
-        const uint32_t v = tid >= d ? part[tid - d] : 0, tv = tid >= d ? tpart[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        tpart[tid] += tv;
-        __syncthreads();
-    }
-    uint32_t run = tid ? part[tid - 1] : 0, trun = tid ? tpart[tid - 1] : 0;
-    uint32_t* joff = off + (size_t)blockIdx.x * nb;
-    uint32_t* jtoff = toff + (size_t)blockIdx.x * nb;
-    for (uint32_t b = b0; b < b1; b++) {
-        const uint32_t k = jcnt[b];
-        joff[b] = job.pair_base + run;
-        jtoff[b] = trun;
-        run += k;
-        trun += (k + seg - 1) / seg;
-    }
-    if (tid == nt - 1) ntasks[blockIdx.x] = tpart[nt - 1];
-}
-static __global__ void __launch_bounds__(MSM_SORT_THREADS)
-k_msm_msort_scatter(const MsmJob* __restrict__ jobs, uint32_t c, uint32_t G, uint32_t nj, uint32_t xcd_major,
-                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ wgbase, uint32_t* pairs) {
-    ZK_DYN_SHARED(uint32_t, h);   // [nb] slot cursors, absolute positions in `pairs`
-    uint32_t jix, g;
-    msort_ids(G, nj, xcd_major, &jix, &g);
-    const MsmJob job = jobs[jix];
-    const uint32_t nb = 1u << (c - 2), tid = threadIdx.x, nt = MSM_SORT_THREADS;
-    const uint32_t* joff = off + (size_t)jix * nb;
-    const uint32_t* wb = wgbase + ((size_t)jix * G + g) * nb;
-    for (uint32_t b = tid; b < nb; b += nt) h[b] = joff[b] + wb[b];
-    __syncthreads();
-    const uint32_t per = (job.n + G - 1) / G, i0 = g * per, i1 = i0 + per < job.n ? i0 + per : job.n;
-    for (uint32_t i = i0 + tid; i < i1; i += nt) {
-        const int32_t pos = job.map ? job.map[i] : (int32_t)i;
-        if (pos < 0) continue;
-        const uint32_t tbase = job.table_base + (uint32_t)pos, tstride = job.n_table;
-        msm_digits(job, i, c, [&](uint32_t, uint32_t bit, uint32_t mag, bool negative) {
-            const uint32_t slot = atomicAdd(&h[mag >> 1], 1u);
-            pairs[slot] = ((tbase + bit * tstride) << 1) | (negative ? 1u : 0u);
-        });
-    }
-}
-
 // A bucket of k points becomes nt = ceil(k / seg) tasks of EQUAL length (n_long of len + 1 points,
 // then n_short of len): the tasks of a launch run in rounds over the thread slots of the GPU, and a
 // round lasts as long as its longest task - cutting 102 points into 64 + 38 instead of 51 + 51 left
@@ -768,10 +663,12 @@ k_msm_accumulate_wide(const Affine<F>* __restrict__ table, const uint32_t* __res
 #include "madd_asm.h"
 #define ZK_HAVE_MADD_ASM 1
 // a product of the signed loop: digits exactly normalised, top limb possibly negative, value in (-0.07 p, 2 p) -> [0, 2 p)
-ZK_DI Fq28 fq28_from_signed_product(const u32x16& v) {
+// (`z`: a zero the compiler cannot see through, taken AFTER an assembly loop - the scratch-free second forms of the kernels
+//  below pass it so that no constant of the conversion is hoisted across a loop that owns every VGPR, i.e. into scratch)
+ZK_DI Fq28 fq28_from_signed_product(const u32x16& v, uint32_t z = 0) {
     Fq28 r = fq28_unvec(v);
     if ((int32_t)r.l[13] < 0) {
-        uint32_t c = 0;
+        uint32_t c = z;
 #pragma unroll
         for (int i = 0; i < 13; i++) {
             const uint32_t t = r.l[i] + Fq28Consts::P[i] + c;
@@ -784,10 +681,10 @@ ZK_DI Fq28 fq28_from_signed_product(const u32x16& v) {
 }
 // spread(M) +- a signed lazy value (limbs above -(3 * 2^28 - 3)): the unsigned weakly normalised form, value < (M + 2) p
 template <int M, bool NEGATE>
-ZK_DI Fq28 fq28_from_signed(const u32x16& v) {
+ZK_DI Fq28 fq28_from_signed(const u32x16& v, uint32_t z = 0) {
     Fq28 r;
 #pragma unroll
-    for (int i = 0; i < 14; i++) r.l[i] = NEGATE ? Fq28Spread<M>::V[i] - v[i] : Fq28Spread<M>::V[i] + v[i];
+    for (int i = 0; i < 14; i++) r.l[i] = NEGATE ? (Fq28Spread<M>::V[i] + z) - v[i] : (Fq28Spread<M>::V[i] + z) + v[i];
     fq28_wnorm(r.l);
     return r;
 }
@@ -952,7 +849,155 @@ k_msm_accumulate_g2asm_persistent(const Affine<Fq2x>* __restrict__ table, const 
         if (base + lane < ntask) g2asm_task(base + lane, park, table, pairs, sorted, tsums, n_redo, redo);
     }
 }
+// ---- the SCRATCH-FREE second form of the G2 kernels (round 5; round 4's tools/experiments patch, now selected per device).
+// A loop that owns all 256 VGPRs forces whatever the compiler keeps across it into scratch memory (the kernels above: 84 /
+// 144 B per lane), and a dispatch that uses scratch runs under the runtime's scratch-wave limit: one box in seventeen ran
+// exactly those kernels at a THIRD of their speed (profiles/r04k_*_slow_box.*).  Here nothing per-lane is live across the
+// loop: its clobber list names only the registers it touches (ZK_MADD_G2_ASM_CLOBBERS_MIN), the task's (index, partial-sum
+// slot, length) wait in LDS (`keep`), the thread index is formed again from the execution mask (`wbase` = first thread of the
+// wave, uniform), and the constants of the conversion back are tied to a zero taken after the loop: 0 bytes of scratch.
+// On a healthy box this form measured the same alone and 1.7 % slower in the overlapped step, so it is NOT the default:
+// zkamd.cpp times both forms on the device when a key is loaded and takes this one only where the first is clearly slower.
+ZK_DI uint32_t lane_of_wave(uint32_t z) { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z)); }
+ZK_DI void g2asm_task_sf(uint32_t t, uint32_t tid, uint32_t wbase, uint32_t z0, uint4 (*park)[128], uint4* keep, const Affine<Fq2x>* __restrict__ table,
+                          const uint32_t* __restrict__ pairs, const uint4* __restrict__ sorted, XYZZ<Fq2x>* __restrict__ tsums,
+                          uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+    const uint4 d = sorted[t];
+    const uint32_t n = d.z;
+    if (n == 0) {
+        tsums[d.y] = XYZZ<Fq2x>::inf();
+        return;
+    }
+    const uint32_t* pp = pairs + d.x;
+    const uint32_t pr = pp[0];
+    const Affine<Fq2x> p = table[pr >> 1];
+    if (n == 1) {
+        tsums[d.y] = XYZZ<Fq2x>{p.x, (pr & 1u) ? neg_b<Fq2x::MO>(p.y) : p.y, Fq2x::one(), Fq2x::one()};
+        return;
+    }
+    auto put = [&](int slot, const Fq28& a, bool negate) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = 4 * q + j < 14 ? (negate ? 0u - a.l[4 * q + j] : a.l[4 * q + j]) : 0u;
+            park[slot * 4 + q][tid] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    };
+    // (constants of THIS round, tied to its opaque zero z0: as loop invariants they would be carried across the loop as
+    //  whole 16-register vectors, in scratch)
+    Fq28 one = Fq28::one(), zero;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        one.l[i] += z0;
+        zero.l[i] = z0;
+    }
+    put(ZK_MADD_G2_LDS_W, p.y.c0, (pr & 1u) != 0);        // W = +-y as signed limbs (sigma = +1)
+    put(ZK_MADD_G2_LDS_W + 1, p.y.c1, (pr & 1u) != 0);
+    put(ZK_MADD_G2_LDS_ZZZ, one, false);
+    put(ZK_MADD_G2_LDS_ZZZ + 1, zero, false);
+    keep[tid] = make_uint4(t, d.y, n, n);   // (no constant in it: the compiler would carry the vector for its zero)
+    u32x16 X0 = fq28_vec(p.x.c0), X1 = fq28_vec(p.x.c1), ZZ0 = fq28_vec(one), ZZ1 = fq28_vec(zero);
+    const uint64_t pa = (uint64_t)(uintptr_t)pp, ta = (uint64_t)(uintptr_t)table;
+    X0[14] = (uint32_t)pa;
+    X0[15] = (uint32_t)(pa >> 32);
+    X1[14] = n;
+    X1[15] = z0;
+    ZZ0[14] = (uint32_t)ta;
+    ZZ0[15] = (uint32_t)(ta >> 32);
+    ZZ1[14] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)&park[0][tid];
+    ZZ1[15] = z0;
+    asm volatile(ZK_MADD_G2_ASM
+                 : "+{v[0:15]}"(X0), "+{v[16:31]}"(X1), "+{v[32:47]}"(ZZ0), "+{v[48:63]}"(ZZ1)
+                 :
+                 : ZK_MADD_G2_ASM_CLOBBERS_MIN);
+    uint32_t z = 0;
+    asm volatile("" : "+s"(z));
+    const uint32_t tid2 = wbase + lane_of_wave(z);
+    const uint4 kp = keep[tid2];   // (t, slot of the partial sum, n)
+    auto get = [&](int slot) {
+        u32x16 v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 w = park[slot * 4 + q][tid2];
+            v[4 * q] = w.x;
+            v[4 * q + 1] = w.y;
+            v[4 * q + 2] = w.z;
+            v[4 * q + 3] = w.w;
+        }
+        return v;
+    };
+    const bool flip = ((kp.z - 1) & 1u) != 0;
+    XYZZ<Fq2x> acc;
+    acc.x = Fq2x{fq28_from_signed<7, false>(X0, z), fq28_from_signed<7, false>(X1, z)};
+    const u32x16 w0 = get(ZK_MADD_G2_LDS_W), w1 = get(ZK_MADD_G2_LDS_W + 1);
+    acc.y = flip ? Fq2x{fq28_from_signed<3, true>(w0, z), fq28_from_signed<3, true>(w1, z)}
+                 : Fq2x{fq28_from_signed<2, false>(w0, z), fq28_from_signed<2, false>(w1, z)};
+    acc.zz = Fq2x{fq28_from_signed_product(ZZ0, z), fq28_from_signed_product(ZZ1, z)};
+    acc.zzz = Fq2x{fq28_from_signed_product(get(ZK_MADD_G2_LDS_ZZZ), z), fq28_from_signed_product(get(ZK_MADD_G2_LDS_ZZZ + 1), z)};
+    // (indices widened with the opaque zero: a plain zero-extension takes its zero from a register set before the loop)
+    const uint64_t zhi = (uint64_t)z << 32;
+    if (acc.zz.is_zero_norm()) redo[atomicAdd(n_redo + z, 1u) | zhi] = kp.x;
+    tsums[kp.y | zhi] = acc;
+}
+static __global__ void __launch_bounds__(128, 2)
+k_msm_accumulate_g2asm_sf(const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                          const uint4* __restrict__ sorted, const uint32_t* __restrict__ total, XYZZ<Fq2x>* __restrict__ tsums,
+                          uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo) {
+    ZK_SHARED uint4 park[16][128];
+    ZK_SHARED uint4 keep[128];
+    const uint32_t wbase = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u, tid = wbase + lane_of_wave(0u);
+    const uint32_t t = blockIdx.x * blockDim.x + tid;
+    uint32_t z = 0;
+    asm volatile("" : "+s"(z));
+    if (t < total[0]) g2asm_task_sf(t, tid, wbase, z, park, keep, table, pairs, sorted, tsums, n_redo, redo);
+}
+static __global__ void __launch_bounds__(128, 2)
+k_msm_accumulate_g2asm_persistent_sf(const Affine<Fq2x>* __restrict__ table, const uint32_t* __restrict__ pairs,
+                                     const uint4* __restrict__ sorted, const uint32_t* __restrict__ total,
+                                     XYZZ<Fq2x>* __restrict__ tsums, uint32_t* __restrict__ n_redo, uint32_t* __restrict__ redo,
+                                     uint32_t* __restrict__ next) {
+    ZK_SHARED uint4 park[16][128];
+    ZK_SHARED uint4 keep[128];
+    const uint32_t ntask = total[0], wbase = __builtin_amdgcn_readfirstlane(threadIdx.x) & ~63u;
+    for (;;) {
+        uint32_t z = 0;
+        asm volatile("" : "+s"(z));                 // (the lane index is formed again in every round: see g2asm_task_sf)
+        const uint32_t lane = lane_of_wave(z);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(next, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= ntask) break;
+        if (base + lane < ntask) g2asm_task_sf(base + lane, wbase + lane, wbase, z, park, keep, table, pairs, sorted, tsums, n_redo, redo);
+    }
+}
 #endif
+// Synthetic inputs for the load-time comparison of the two forms of the scratch-using kernels (zkamd.cpp
+// calibrate_kernel_forms): `ntasks` accumulation tasks of `len` pairs each over pseudo-random entries of a real table, and
+// bucket sums that are real points of a real table.
+ZK_DI uint32_t calib_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+static __global__ void __launch_bounds__(256)
+k_calib_tasks(uint32_t* pairs, uint4* sorted, uint32_t* total, uint32_t ntasks, uint32_t len, uint32_t n_table) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) total[0] = ntasks;
+    if (i < ntasks) sorted[i] = make_uint4(i * len, i, len, 0);
+    if (i < ntasks * len) pairs[i] = ((calib_hash(i) % n_table) << 1) | (calib_hash(~i) & 1u);
+}
+template <class F>
+static __global__ void __launch_bounds__(256)
+k_calib_buckets(const Affine<F>* __restrict__ table, uint32_t n_table, XYZZ<F>* sums, uint32_t n_sums, uint32_t* cnt, uint32_t* toff,
+                uint32_t n_buckets) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_sums) sums[i] = XYZZ<F>::from_affine(table[calib_hash(i) % n_table]);
+    if (i < n_buckets) {
+        cnt[i] = 1;
+        toff[i] = calib_hash(i ^ 0x5bd1e995u) % n_sums;
+    }
+}
+
 // Pass 6, level 1, G1: the generated assembly loop of red_asm.h (tools/gen_red_asm.py).  One thread per node of L
 // buckets walks them from the top down with BOTH accumulators in registers (run = the suffix sum R_k, acc = sum of R_k
 // over k >= 1) and writes S = R_0 and A = acc: nothing but the bucket sums is read, no suffix array goes through HBM
@@ -1013,6 +1058,65 @@ k_msm_reduce1_g1asm(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __rest
     }
     S[(size_t)job * T + t] = run;
     A[(size_t)job * T + t] = acc;
+}
+// The scratch-free second form of level 1 (see k_msm_accumulate_g2asm_sf): the lane index comes from the execution mask
+// before and again after the loop, the clobber list names only what the loop touches, and a node with a special case is
+// LISTED for k_msm_reduce1_redo instead of being recomputed here (a call of the out-of-line product routines gives a kernel
+// a stack, i.e. scratch memory).
+static __global__ void __launch_bounds__(64, 2)
+k_msm_reduce1_g1asm_sf(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
+                       const uint32_t* __restrict__ task_base, XYZZ<Fq28>* __restrict__ S, XYZZ<Fq28>* __restrict__ A, uint32_t nb,
+                       uint32_t L, uint32_t* __restrict__ n_fallback, uint32_t* __restrict__ fallback) {
+    const uint32_t T = nb / L;
+    const uint32_t bx = (blockIdx.x + blockIdx.y) % gridDim.x;   // XCD rotation, as in k_msm_suffix_buckets
+    const uint32_t t = bx * 64u + lane_of_wave(0u);
+    if (t >= T) return;
+    const uint32_t job = blockIdx.y;
+    size_t b0 = (size_t)job * nb + (size_t)t * L;
+    const XYZZ<Fq28>* ts = tsums + task_base[job];
+    u32x16 X = {}, Y = {}, ZZ = {}, ZZZ = {}, AX, AY, AZZ, AZZZ;
+    const uint64_t pc = (uint64_t)(uintptr_t)(cnt + b0), pt = (uint64_t)(uintptr_t)(toff + b0), pp = (uint64_t)(uintptr_t)ts;
+    X[14] = (uint32_t)pc;
+    X[15] = (uint32_t)(pc >> 32);
+    Y[14] = (uint32_t)pt;
+    Y[15] = (uint32_t)(pt >> 32);
+    ZZ[14] = (uint32_t)pp;
+    ZZ[15] = (uint32_t)(pp >> 32);
+    ZZZ[14] = L;
+    asm volatile(ZK_RED_G1_ASM
+                 : "+{v[0:15]}"(X), "+{v[16:31]}"(Y), "+{v[32:47]}"(ZZ), "+{v[48:63]}"(ZZZ), "={v[64:79]}"(AX), "={v[80:95]}"(AY),
+                   "={v[96:111]}"(AZZ), "={v[112:127]}"(AZZZ)
+                 :
+                 : ZK_RED_G1_ASM_CLOBBERS_MIN);
+    uint32_t opaque0 = 0;
+    asm volatile("" : "+s"(opaque0));   // (so that the index below is computed again instead of being kept)
+    const uint32_t t2 = bx * 64u + lane_of_wave(opaque0);
+    const uint32_t flags = ZZZ[15];
+    XYZZ<Fq28> run = red_asm_point(X, Y, ZZ, ZZZ, (flags & ZK_RED_FLAG_RUN_INF) != 0, (flags & ZK_RED_FLAG_RUN_RAW) != 0);
+    XYZZ<Fq28> acc = red_asm_point(AX, AY, AZZ, AZZZ, (flags & ZK_RED_FLAG_ACC_INF) != 0, (flags & ZK_RED_FLAG_ACC_RAW) != 0);
+    if ((!(flags & ZK_RED_FLAG_RUN_INF) && run.zz.is_zero_norm()) || (!(flags & ZK_RED_FLAG_ACC_INF) && acc.zz.is_zero_norm()))
+        fallback[atomicAdd(n_fallback, 1u)] = job * T + t2;
+    S[(size_t)job * T + t2] = run;
+    A[(size_t)job * T + t2] = acc;
+}
+// the listed nodes again, by the compiled addition with all special cases (a few hundred of two million per launch set)
+static __global__ void __launch_bounds__(64, MsmOcc<Fq28>::red)
+k_msm_reduce1_redo(const XYZZ<Fq28>* __restrict__ tsums, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ toff,
+                   const uint32_t* __restrict__ task_base, XYZZ<Fq28>* __restrict__ S, XYZZ<Fq28>* __restrict__ A, uint32_t nb,
+                   uint32_t L, const uint32_t* __restrict__ n_fallback, const uint32_t* __restrict__ fallback) {
+    const uint32_t T = nb / L, n = n_fallback[0];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t node = fallback[i], job = node / T, t = node % T;
+        const size_t b0 = (size_t)job * nb + (size_t)t * L;
+        const XYZZ<Fq28>* ts = tsums + task_base[job];
+        XYZZ<Fq28> run = XYZZ<Fq28>::inf(), acc = XYZZ<Fq28>::inf();
+        for (int k = (int)L - 1; k >= 0; k--) {
+            if (cnt[b0 + k]) run = xadd(run, ts[toff[b0 + k]]);
+            if (k >= 1) acc = xadd(acc, run);
+        }
+        S[node] = run;
+        A[node] = acc;
+    }
 }
 #endif
 // The level above the assembly loop: children k of a parent carry S_k (suffix sums R'_k already formed by k_msm_suffix)

@@ -281,6 +281,25 @@ zk_status check_points_host(const std::vector<zkhost::Affine<HF>>& pts, const ch
     return st;
 }
 
+// Which form of the two scratch-using assembly kernels a device runs (msm.h: the G2 accumulation loop and level 1 of the G1
+// reduction; 0 = the first form, 84 - 144 B of scratch per lane; 1 = the scratch-free second form).  Decided per device
+// when the first key is loaded there (calibrate_kernel_forms below); ZKAMD_KERNEL_FORM = scratch | free overrides.
+struct KernelForms {
+    bool done = false;
+    uint32_t form[2] = {0, 0};          // [G2 accumulation, G1 reduction level 1]
+    float ms[4] = {0, 0, 0, 0};         // the comparison: [G2 first form, G2 scratch-free, reduction first form, reduction scratch-free]
+};
+std::mutex g_forms_mu;
+KernelForms g_forms[64];
+static uint32_t kernel_form(int which) {
+    static const int forced = [] {
+        const char* e = getenv("ZKAMD_KERNEL_FORM");
+        return !e ? -1 : !strcmp(e, "free") ? 1 : !strcmp(e, "scratch") ? 0 : -1;
+    }();
+    if (forced >= 0) return (uint32_t)forced;
+    return g_forms[g_device & 63].form[which];   // (written once, before the device's first proving launch)
+}
+
 // The accumulation kernels run the generated assembly loops (msm.h k_msm_accumulate_g1asm / _g2asm) unless
 // ZKAMD_G1_ASM=0 / ZKAMD_G2_ASM=0 (A/B switches) or the build has none (the x86 emulation build).
 template <class DF>
@@ -294,7 +313,7 @@ template <class DF>
 static bool asm_reduce() { return false; }
 template <class DF>
 static void launch_red_asm(const zkdev::XYZZ<DF>*, const uint32_t*, const uint32_t*, const uint32_t*, zkdev::XYZZ<DF>*, zkdev::XYZZ<DF>*,
-                           uint32_t, uint32_t, dim3, hipStream_t, uint32_t*) {}
+                           uint32_t, uint32_t, dim3, hipStream_t, uint32_t*, uint32_t*) {}
 #ifdef ZK_HAVE_RED_ASM
 template <>
 bool asm_reduce<zkdev::Fq28>() {
@@ -304,8 +323,15 @@ bool asm_reduce<zkdev::Fq28>() {
 template <>
 void launch_red_asm<zkdev::Fq28>(const zkdev::XYZZ<zkdev::Fq28>* tsums, const uint32_t* cnt, const uint32_t* toff, const uint32_t* tbase,
                                  zkdev::XYZZ<zkdev::Fq28>* S, zkdev::XYZZ<zkdev::Fq28>* A, uint32_t nb, uint32_t L, dim3 grid,
-                                 hipStream_t st, uint32_t* n_fallback) {
-    ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm, grid, dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L, n_fallback);
+                                 hipStream_t st, uint32_t* n_fallback, uint32_t* fallback) {
+    if (kernel_form(1)) {
+        // the scratch-free form lists the nodes with a special case; the compiled addition takes them in a second launch
+        ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm_sf, grid, dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L, n_fallback, fallback);
+        ZK_LAUNCH(zkdev::k_msm_reduce1_redo, dim3(256), dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L, (const uint32_t*)n_fallback,
+                  (const uint32_t*)fallback);
+    } else {
+        ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm, grid, dim3(64), 0, st, tsums, cnt, toff, tbase, S, A, nb, L, n_fallback);
+    }
 }
 #endif
 #ifdef ZK_HAVE_MADD_ASM
@@ -341,7 +367,15 @@ template <>
 void launch_asm_loop<zkdev::Fq2x>(const zkdev::Affine<zkdev::Fq2x>* table, const uint32_t* pairs, const uint4* sorted,
                                   const uint32_t* d_total, zkdev::XYZZ<zkdev::Fq2x>* tsums, uint32_t* d_nredo, uint32_t* redo,
                                   unsigned blocks, hipStream_t st) {
-    if (persist_wgs(2) > 0 && blocks > 256u * (unsigned)persist_wgs(2))
+    const bool persistent = persist_wgs(2) > 0 && blocks > 256u * (unsigned)persist_wgs(2);
+    if (kernel_form(0)) {
+        if (persistent)
+            ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm_persistent_sf, dim3(256u * (unsigned)persist_wgs(2)), dim3(128), 0, st, table, pairs,
+                           sorted, d_total, tsums, d_nredo, redo, d_nredo + 1);
+        else
+            ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm_sf, dim3(blocks), dim3(128), 0, st, table, pairs, sorted, d_total, tsums, d_nredo,
+                           redo);
+    } else if (persistent)
         ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm_persistent, dim3(256u * (unsigned)persist_wgs(2)), dim3(128), 0, st, table, pairs,
                        sorted, d_total, tsums, d_nredo, redo, d_nredo + 1);
     else
@@ -564,21 +598,7 @@ struct MsmGroup {
         // one workgroup per job sorts inside its LDS: right for a thousand jobs per launch, a 0.67 ms serial pass for
         // the one or two jobs of a proof made alone (4.83 -> 4.17 ms per proof with the many-workgroup sort instead)
         const bool lds_sort = (size_t)nb * 4 <= 65536 && !few && !getenv("ZKAMD_NO_LDS_SORT");
-        // ZKAMD_SORT_WGS = G > 1: G workgroups per job, job-major (msm.h k_msm_msort_*; round 5's sort experiment)
-        const uint32_t sort_wgs = lds_sort && getenv("ZKAMD_SORT_WGS") ? (uint32_t)atoi(getenv("ZKAMD_SORT_WGS")) : 0u;
-        if (lds_sort && sort_wgs > 1 && sort_wgs <= 256) {
-            ProfScope ps("msm_sort_lds", st);
-            const uint32_t G = sort_wgs, xcd_major = getenv("ZKAMD_SORT_XCD") ? (uint32_t)atoi(getenv("ZKAMD_SORT_XCD")) : 1u;
-            ZK_TRY(blockbase.ensure(nj * (size_t)G * nb * 4));
-            HIP_TRY(hipMemsetAsync(cnt.p, 0, n_buckets * 4, st));
-            ZK_LAUNCH_SYNC(zkdev::k_msm_msort_count, dim3((unsigned)(nj * G)), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c, G,
-                           (uint32_t)nj, xcd_major, cnt.as<uint32_t>(), blockbase.as<uint32_t>());
-            ZK_LAUNCH_SYNC(zkdev::k_msm_msort_scan, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), 0, st, dj, c,
-                           (const uint32_t*)cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(), seg);
-            ZK_LAUNCH_SYNC(zkdev::k_msm_msort_scatter, dim3((unsigned)(nj * G)), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c, G,
-                           (uint32_t)nj, xcd_major, (const uint32_t*)off.as<uint32_t>(), (const uint32_t*)blockbase.as<uint32_t>(),
-                           pairs.as<uint32_t>());
-        } else if (lds_sort) {
+        if (lds_sort) {
             // histogram + scan + scatter of a job inside one workgroup's LDS
             ProfScope ps("msm_sort_lds", st);
             ZK_LAUNCH_SYNC(zkdev::k_msm_sort_lds, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c,
@@ -641,7 +661,7 @@ struct MsmGroup {
             // 32-point tasks: `total` below the short-task threshold above) keeps the compiled kernel and saves the second launch
             if (asm_loop<DF>() && big_launch) {
                 // the generated assembly loop (msm.h, madd_asm.h), then the compiled loop over the few tasks it flagged
-                ZK_TRY(redo.ensure((size_t)total_tasks * 4));
+                ZK_TRY(redo.ensure(std::max((size_t)total_tasks, (size_t)nj * T) * 4));   // (level 1 of the reduction may list its nodes here later)
                 launch_asm_loop(table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>(), d_nredo,
                                 redo.as<uint32_t>(), (unsigned)((total_tasks + 127) / 128), st);
                 if (getenv("ZKAMD_DEBUG_REDO")) {   // diagnostics: how many tasks went to the second pass, and what they look like
@@ -703,8 +723,9 @@ struct MsmGroup {
                 // level 1 in assembly: S = R_0 (compact, one per node) and A = sum_{k>=1} R_k; then the first level above
                 // it, which forms W(parent) = 2M sum_{k>=1} R'_k + 2 sum_k A_k + R'_0 (msm.h k_msm_level2_acc) - run even
                 // for a single node per job, where it is just W = 2 A + S
+                ZK_TRY(redo.ensure(std::max((size_t)total_tasks, (size_t)nj * T) * 4));   // (the accumulation's second pass is done with its list by now)
                 launch_red_asm<DF>(tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(), R, Wa, nb, L,
-                                   grid(T), st, d_nfallback);
+                                   grid(T), st, d_nfallback, redo.as<uint32_t>());
                 if (getenv("ZKAMD_DEBUG_REDO")) {   // diagnostics: nodes of level 1 the assembly loop handed to the compiled addition
                     (void)hipStreamSynchronize(st);
                     uint32_t v[2] = {0, 0};
@@ -937,6 +958,8 @@ struct zk_params {
 
 namespace {
 
+zk_status calibrate_kernel_forms(zk_params* P);
+
 zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk_params** out) {
     ZK_TRY(use_device(device));
     zk_params* P = new (std::nothrow) zk_params();
@@ -1021,8 +1044,121 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     ZK_TRY(P->g2.build(pts2, c2, checked != 0, "parameters (G2)"));
     P->g2_lone.alias(P->g2, getenv("ZKAMD_WINDOW_BITS_G2") || c2 <= 10 ? c2 : 10u);
     ZK_TRY(P->ntt.init(P->log_m));
+    ZK_TRY(calibrate_kernel_forms(P));
     guard.p = nullptr;
     *out = P;
+    return ZK_OK;
+}
+
+// Load-time choice between the two forms of the scratch-using assembly kernels.  One box in seventeen of
+// round 4 ran the first form of exactly these two kernels at a third of its speed in every process (204 instead of 67.6 ms,
+// 11.7 instead of 4.0: profiles/r04k_*_slow_box.*) - what a low scratch-wave limit looks like - while on a healthy box the
+// scratch-free form is 1-2 % slower in the overlapped step.  So: when the first key is loaded on a device, one machine-filling
+// launch of each form over synthetic tasks on the key's own tables (0.4 ms each, twice), and the scratch-free form is taken
+// where the first form is slower than 1.4 x it.  ZKAMD_INJECT_SCRATCH_SLOW=1 (tests) triples the first form's measured time.
+zk_status calibrate_kernel_forms(zk_params* P) {
+#if defined(ZK_HAVE_MADD_ASM) && defined(ZK_HAVE_RED_ASM)
+    std::lock_guard<std::mutex> lock(g_forms_mu);
+    KernelForms& F = g_forms[P->device & 63];
+    if (F.done) return ZK_OK;
+    const uint32_t n2 = (uint32_t)std::min<size_t>(P->g2.n_points * (size_t)zkdev::MSM_NPOS, 1u << 24);
+    const uint32_t n1 = (uint32_t)std::min<size_t>(P->g1.n_points * (size_t)zkdev::MSM_NPOS, 1u << 24);
+    if (n1 < 1024 || n2 < 1024 || getenv("ZKAMD_NO_CALIBRATE")) {   // (a toy key: nothing to measure on, the first form stays)
+        F.done = true;
+        return ZK_OK;
+    }
+    typedef zkdev::XYZZ<zkdev::Fq28> P1;
+    typedef zkdev::XYZZ<DevFq2> P2;
+    hipEvent_t ev[2];
+    HIP_TRY(hipEventCreate(&ev[0]));
+    HIP_TRY(hipEventCreate(&ev[1]));
+    struct EvGuard {
+        hipEvent_t* e;
+        ~EvGuard() {
+            (void)hipEventDestroy(e[0]);
+            (void)hipEventDestroy(e[1]);
+        }
+    } evg{ev};
+    auto timed = [&](auto&& launch, float* best) -> zk_status {
+        *best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {   // (the first repetition warms the instruction cache and is not counted)
+            HIP_TRY(hipEventRecord(ev[0], g_stream));
+            launch();
+            HIP_TRY(hipEventRecord(ev[1], g_stream));
+            HIP_TRY(hipEventSynchronize(ev[1]));
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+            if (rep && ms < *best) *best = ms;
+        }
+        HIP_TRY(hipGetLastError());
+        return ZK_OK;
+    };
+    {   // the G2 accumulation loop: 262 144 tasks of 8 pairs, the persistent launch of the prover
+        const uint32_t ntasks = 1u << 18, len = 8;
+        DevBuf pairs, sorted, tsums, ctr, redo;
+        ZK_TRY(pairs.ensure((size_t)ntasks * len * 4));
+        ZK_TRY(sorted.ensure((size_t)ntasks * sizeof(uint4)));
+        ZK_TRY(tsums.ensure((size_t)ntasks * sizeof(P2)));
+        ZK_TRY(ctr.ensure(16));
+        ZK_TRY(redo.ensure((size_t)ntasks * 4));
+        ZK_LAUNCH(zkdev::k_calib_tasks, dim3(ntasks * len / 256), dim3(256), 0, g_stream, pairs.as<uint32_t>(), sorted.as<uint4>(),
+                  ctr.as<uint32_t>(), ntasks, len, n2);
+        const unsigned wgs = 256u * (unsigned)std::max(persist_wgs(2), 1);
+        auto reset = [&] { (void)hipMemsetAsync(ctr.as<uint32_t>() + 1, 0, 12, g_stream); };
+        ZK_TRY(timed([&] {
+            reset();
+            ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm_persistent, dim3(wgs), dim3(128), 0, g_stream, P->g2.table.as<zkdev::Affine<DevFq2>>(),
+                           (const uint32_t*)pairs.as<uint32_t>(), (const uint4*)sorted.as<uint4>(), (const uint32_t*)ctr.as<uint32_t>(),
+                           tsums.as<P2>(), ctr.as<uint32_t>() + 1, redo.as<uint32_t>(), ctr.as<uint32_t>() + 2);
+        }, &F.ms[0]));
+        ZK_TRY(timed([&] {
+            reset();
+            ZK_LAUNCH_SYNC(zkdev::k_msm_accumulate_g2asm_persistent_sf, dim3(wgs), dim3(128), 0, g_stream, P->g2.table.as<zkdev::Affine<DevFq2>>(),
+                           (const uint32_t*)pairs.as<uint32_t>(), (const uint4*)sorted.as<uint4>(), (const uint32_t*)ctr.as<uint32_t>(),
+                           tsums.as<P2>(), ctr.as<uint32_t>() + 1, redo.as<uint32_t>(), ctr.as<uint32_t>() + 2);
+        }, &F.ms[1]));
+    }
+    {   // level 1 of the G1 reduction: 256 jobs of 4 096 buckets in nodes of 8 = 131 072 threads, one machine of waves
+        const uint32_t nj = 256, nb = 4096, L = 8, T = nb / L, n_sums = 1u << 16;
+        DevBuf sums, cnt, toff, tbase, S, A, ctr, list;
+        ZK_TRY(sums.ensure((size_t)n_sums * sizeof(P1)));
+        ZK_TRY(cnt.ensure((size_t)nj * nb * 4));
+        ZK_TRY(toff.ensure((size_t)nj * nb * 4));
+        ZK_TRY(tbase.ensure(nj * 4));
+        ZK_TRY(S.ensure((size_t)nj * T * sizeof(P1)));
+        ZK_TRY(A.ensure((size_t)nj * T * sizeof(P1)));
+        ZK_TRY(ctr.ensure(4));
+        ZK_TRY(list.ensure((size_t)nj * T * 4));
+        HIP_TRY(hipMemsetAsync(tbase.p, 0, nj * 4, g_stream));
+        ZK_LAUNCH(zkdev::k_calib_buckets<zkdev::Fq28>, dim3(nj * nb / 256), dim3(256), 0, g_stream,
+                  (const zkdev::Affine<zkdev::Fq28>*)P->g1.table.as<zkdev::Affine<zkdev::Fq28>>(), n1, sums.as<P1>(), n_sums, cnt.as<uint32_t>(),
+                  toff.as<uint32_t>(), nj * nb);
+        const dim3 grid(T / 64, nj);
+        ZK_TRY(timed([&] {
+            (void)hipMemsetAsync(ctr.p, 0, 4, g_stream);
+            ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm, grid, dim3(64), 0, g_stream, (const P1*)sums.as<P1>(), (const uint32_t*)cnt.as<uint32_t>(),
+                      (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), S.as<P1>(), A.as<P1>(), nb, L, ctr.as<uint32_t>());
+        }, &F.ms[2]));
+        ZK_TRY(timed([&] {
+            (void)hipMemsetAsync(ctr.p, 0, 4, g_stream);
+            ZK_LAUNCH(zkdev::k_msm_reduce1_g1asm_sf, grid, dim3(64), 0, g_stream, (const P1*)sums.as<P1>(), (const uint32_t*)cnt.as<uint32_t>(),
+                      (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), S.as<P1>(), A.as<P1>(), nb, L, ctr.as<uint32_t>(),
+                      list.as<uint32_t>());
+            ZK_LAUNCH(zkdev::k_msm_reduce1_redo, dim3(256), dim3(64), 0, g_stream, (const P1*)sums.as<P1>(), (const uint32_t*)cnt.as<uint32_t>(),
+                      (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), S.as<P1>(), A.as<P1>(), nb, L,
+                      (const uint32_t*)ctr.as<uint32_t>(), (const uint32_t*)list.as<uint32_t>());
+        }, &F.ms[3]));
+    }
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    const float slow = getenv("ZKAMD_INJECT_SCRATCH_SLOW") && atoi(getenv("ZKAMD_INJECT_SCRATCH_SLOW")) ? 3.0f : 1.0f;
+    F.ms[0] *= slow;
+    F.ms[2] *= slow;
+    F.form[0] = F.ms[0] > 1.4f * F.ms[1] ? 1u : 0u;
+    F.form[1] = F.ms[2] > 1.4f * F.ms[3] ? 1u : 0u;
+    F.done = true;
+#else
+    (void)P;
+#endif
     return ZK_OK;
 }
 
@@ -3292,6 +3428,18 @@ void zk_profile_end(void) {
     }
     g_recs.clear();
     g_prof = false;
+}
+zk_status zk_kernel_forms(int device, uint32_t forms_out[2], float ms_out[4]) {
+    if (device < 0 || device >= 64) return fail(ZK_ERR_INVALID_ARGUMENT, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_forms_mu);
+    const KernelForms& F = g_forms[device];
+    const char* e = getenv("ZKAMD_KERNEL_FORM");
+    const int forced = !e ? -1 : !strcmp(e, "free") ? 1 : !strcmp(e, "scratch") ? 0 : -1;
+    for (int i = 0; i < 2; i++)
+        if (forms_out) forms_out[i] = forced >= 0 ? (uint32_t)forced : F.form[i];
+    for (int i = 0; i < 4; i++)
+        if (ms_out) ms_out[i] = F.ms[i];
+    return ZK_OK;
 }
 void* zk_stream(void) { return (void*)g_stream; }
 zk_status zk_synchronize(void) {
