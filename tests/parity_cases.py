@@ -1161,6 +1161,15 @@ def anonymous_witness_gpu_matches_host(lib, n=3):
                 with pytest.raises(zk.ZkError) as e:
                     run(zk.anonymous_statements([items[1 % n], bad]))
                 assert e.value.variant == "InvalidArgument" and "statement 1" in str(e.value) and what in str(e.value), str(e.value)
+        # the FIRST malformed statement is the one reported, whatever is wrong with the later ones (a bad member index behind
+        # a bad point, and the other way round; inside one statement the index check comes first) - ADVICE r4
+        bad_index, bad_point = dict(d, t_index=99), dict(d, enc_keys=keys)
+        for batch, what in (([bad_point, bad_index], "statement 0: enc_keys[7]"), ([bad_index, bad_point], "statement 0: member index"),
+                            ([items[1 % n], dict(bad_point, s_index=12), bad_point], "statement 1: member index")):
+            for run in (lambda s: zk.anonymous_witness(s, lib=lib), lambda s: zk.anonymous_witness_gpu(mats, s)):
+                with pytest.raises(zk.ZkError) as e:
+                    run(zk.anonymous_statements(batch))
+                assert e.value.variant == "InvalidArgument" and what in str(e.value), (what, str(e.value))
     finally:
         mats.close()
 

@@ -22,6 +22,7 @@ struct zk_r1cs {
     zkrt::DevBuf wit_st[2], wit_bad[2], wit_pts, wit_table, wit_consts, wit_scratch;
     zkrt::PinBuf pin_st[2], pin_bad[2];
     hipEvent_t wit_done[2] = {nullptr, nullptr};
+    size_t anon_index_bad[2] = {(size_t)-1, (size_t)-1};   // first statement of the slot whose member indices are out of range
     bool wit_ready = false;
     // pinned host buffer of zk_transfer_prove_batch in host-witness mode (witness vectors of one chunk)
     void* host_z = nullptr;

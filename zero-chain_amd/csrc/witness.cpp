@@ -88,9 +88,6 @@ zk_status witness_anon_gpu_enqueue(zk_r1cs* R, const zk_anonymous_statement* st,
     using namespace zkwitdev;
     ZK_TRY(witness_gpu_init(R));
     static_assert(sizeof(AStmt) == sizeof(zk_anonymous_statement), "statement layout");
-    for (size_t i = 0; i < np; i++)
-        if (st[i].s_index >= ZK_ANONYMOUS_SIZE || st[i].t_index >= ZK_ANONYMOUS_SIZE)
-            return fail(ZK_ERR_INVALID_ARGUMENT, "statement " + std::to_string(index_base + i) + ": member index out of range");
     ZK_TRY(R->z[slot].ensure(np * (size_t)A_NV * 32));
     ZK_TRY(R->wit_st[slot].ensure(np * sizeof(AStmt)));
     ZK_TRY(R->wit_bad[slot].ensure(np * 4));
@@ -99,6 +96,19 @@ zk_status witness_anon_gpu_enqueue(zk_r1cs* R, const zk_anonymous_statement* st,
     ZK_TRY(R->wit_pts.ensure(np * (size_t)AP_COUNT * 64));
     ZK_TRY(R->wit_scratch.ensure((size_t)A1_ROLES * SCRATCH_SLOTS * np * 32));
     memcpy(R->pin_st[slot].p, st, np * sizeof(AStmt));
+    // A member index out of range is reported by witness_anon_gpu_finish, in statement order with everything else the
+    // kernels find - exactly where the host calculator reports it (zkamd.cpp anonymous_decode; ADVICE r4: refused here, a
+    // bad index in chunk k + 1 was reported before chunk k had been proved).  The kernels see the index clamped.
+    R->anon_index_bad[slot] = (size_t)-1;
+    {
+        zk_anonymous_statement* ps = (zk_anonymous_statement*)R->pin_st[slot].p;
+        for (size_t i = 0; i < np; i++)
+            if (ps[i].s_index >= ZK_ANONYMOUS_SIZE || ps[i].t_index >= ZK_ANONYMOUS_SIZE) {
+                if (R->anon_index_bad[slot] == (size_t)-1) R->anon_index_bad[slot] = i;
+                ps[i].s_index = 0;
+                ps[i].t_index = 1;
+            }
+    }
     HIP_TRY(hipMemcpyAsync(R->wit_st[slot].p, R->pin_st[slot].p, np * sizeof(AStmt), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemsetAsync(R->wit_bad[slot].p, 0xff, np * 4, stream));   // A_BAD_NONE
     ACtx c;
@@ -138,6 +148,9 @@ zk_status witness_anon_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_
     static const char* const scalars[3] = {"randomness", "alpha", "dec_key"};
     static const char* const sets[4] = {"enc_keys", "left_ciphertexts", "enc_balances_left", "enc_balances_right"};
     for (size_t i = 0; i < np; i++) {
+        // (the index check comes first inside a statement, as in anonymous_decode)
+        if (i == R->anon_index_bad[slot])
+            return fail(ZK_ERR_INVALID_ARGUMENT, "statement " + std::to_string(index_base + i) + ": member index out of range");
         const uint32_t code = bad[i];
         if (code == A_BAD_NONE) continue;
         const std::string who = "statement " + std::to_string(index_base + i) + ": ";

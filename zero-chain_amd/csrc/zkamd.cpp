@@ -1034,7 +1034,9 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
         ZK_TRY((check_points_host<zkhost::Fq2, DevFq2>(std::vector<HG2A>{beta_g2, gamma_g2, delta_g2}, "vk (G2: beta | gamma | delta)")));
     }
     // two G1 jobs per proof: A, and the merged C' = H + L + r * B1 - each with the width of its own size
-    const uint32_t c_avg = pick_window(((size_t)P->n_h + P->n_l + P->n_a + P->n_b1) / 2, 1);
+    // (a few proofs made alone never reach the assembly level 1 of the reduction: bucket cost of the compiled few-jobs
+    //  path, group 4 - ADVICE r4; the split launch sets below: group 1 / 3)
+    const uint32_t c_avg = pick_window(((size_t)P->n_h + P->n_l + P->n_a + P->n_b1) / 2, getenv("ZKAMD_SPLIT_G1") && atoi(getenv("ZKAMD_SPLIT_G1")) == 0 ? 1 : 4);
     P->split_g1 = !(getenv("ZKAMD_SPLIT_G1") && atoi(getenv("ZKAMD_SPLIT_G1")) == 0);
     const uint32_t c1 = P->split_g1 ? pick_window((size_t)P->n_h + P->n_l + P->n_b1, 1) : c_avg;
     const uint32_t c2 = pick_window(P->n_b2, 2);
@@ -2362,9 +2364,10 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
 }
 
 // Statement -> proof for the anonymous-transfer circuit (core/proofs/src/anonymous.rs:165: create_random_proof of
-// AnonymousTransfer): the native host witness calculator (transfer_witness.h: synthesize_anonymous) on the host cores,
-// the witnesses of chunk k + 1 computed while the GPU proves chunk k.  (The transfer circuit's generator runs on the
-// GPU; this circuit keeps the host calculator - its fingerprint is unpinned by the reference, see DESIGN.md.)
+// AnonymousTransfer): witness generation on the GPU (witness_anon_gpu.h, round 4), the kernels of chunk k + 1 beside the
+// proving of chunk k; ZKAMD_WITNESS=host keeps the native host calculator (transfer_witness.h: synthesize_anonymous) on
+// the host cores.  Both paths prove every chunk before the first malformed statement's and report that statement in the
+// same words.
 zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_anonymous_statement* st, const uint8_t* rs,
                                    uint8_t* proofs_out) {
     if (!p || !circuit || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
@@ -2380,15 +2383,20 @@ zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, con
         // kernels of chunk k + 1 run beside the multiexps of chunk k (as zk_transfer_prove_batch)
         if (circuit->device != p->device) return fail(ZK_ERR_INVALID_ARGUMENT, "parameters and circuit live on different devices");
         int slot = 0;
-        ZK_TRY(witness_anon_gpu_enqueue(circuit, st, std::min(chunk, n), slot, g_copy_stream));
-        for (size_t first = 0; first < n; first += chunk) {
+        zk_status rc = witness_anon_gpu_enqueue(circuit, st, std::min(chunk, n), slot, g_copy_stream);
+        for (size_t first = 0; first < n && rc == ZK_OK; first += chunk) {
             const size_t np = std::min(chunk, n - first), next = first + chunk;
-            ZK_TRY(witness_anon_gpu_finish(circuit, np, slot, first));
-            if (next < n) ZK_TRY(witness_anon_gpu_enqueue(circuit, st + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream, next));
-            ZK_TRY(prove_from_z(p, circuit, np, slot, rs + first * 64, proofs_out + first * 192));
+            rc = witness_anon_gpu_finish(circuit, np, slot, first);
+            if (rc == ZK_OK && next < n) rc = witness_anon_gpu_enqueue(circuit, st + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream, next);
+            if (rc == ZK_OK) rc = prove_from_z(p, circuit, np, slot, rs + first * 64, proofs_out + first * 192);
             slot ^= 1;
         }
-        return ZK_OK;
+        if (rc != ZK_OK) {
+            const std::string why = g_err;
+            (void)hipStreamSynchronize(g_copy_stream);   // no witness kernel of a later chunk stays in flight behind an error
+            g_err = why;
+        }
+        return rc;
     }
     const size_t cap = std::min(chunk, n) * nv * 32;
     ZK_TRY(circuit->host_ensure(2 * cap));
@@ -3115,7 +3123,10 @@ struct zk_pipeline {
                 // pipeline degrades to fewer lanes instead of failing in the middle of a batch.
                 std::unique_lock<std::mutex> lk(mu);
                 if (have_nxt) q_wit.push_front(nxt);
-                q_wit.push_front(cur);
+                // (only the job that did NOT get proved goes back: when starting the NEXT job is what ran out of memory, the
+                //  current one is finished and counted - ADVICE r4)
+                if (rc == ZK_OK && !skip) in_flight--;
+                else q_wit.push_front(cur);
                 live_lanes--;
                 zk_params* mine = Pl[lane];
                 zk_r1cs* mine_r = Rl[lane];
