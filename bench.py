@@ -814,10 +814,26 @@ def main():
                 lib.zk_profile_end()
                 assert all(okv) and len(okv) == reps * B
                 vb["n_%d" % (reps * B)] = {"ms": round(dt * 1e3, 1), "proofs_per_s": round(reps * B / dt, 1), "stages_ms": stages}
+                # the same proofs through ONE combined check per chunk (zk_verify_batch_rlc: rho_i-weighted Miller loops, one
+                # final exponentiation)
+                assert all(zk.verify_proofs(pvk3, pr, pi, rlc=True))
+                lib.zk_profile_begin()
+                t0 = time.perf_counter()
+                okr = zk.verify_proofs(pvk3, pr, pi, rlc=True)
+                dtr = time.perf_counter() - t0
+                stages_r = {}
+                for name in ("verify_decode", "verify_decode_g1", "verify_rlc_scale", "verify_inputs", "verify_prepare", "verify_miller", "verify_final"):
+                    ms = C.c_double(0)
+                    if lib.zk_profile_get(name.encode(), C.byref(ms)):
+                        stages_r[name] = round(ms.value, 2)
+                lib.zk_profile_end()
+                assert all(okr) and len(okr) == reps * B
+                vb["rlc_n_%d" % (reps * B)] = {"ms": round(dtr * 1e3, 1), "proofs_per_s": round(reps * B / dtr, 1), "stages_ms": stages_r}
             bad = last.copy()
             bad[192 * 5 + 100] ^= 1          # one byte of C of proof 5
             okv = zk.verify_proofs(pvk3, bad, pub.reshape(-1))
             assert not okv[5] and sum(okv) == B - 1, "the verifier accepted a damaged proof"
+            assert zk.verify_proofs(pvk3, bad, pub.reshape(-1), rlc=True) == okv, "the combined check and the per-proof verifier disagree"
             pvk3.close()
             vb["note"] = "zk_verify_batch on the last step's proofs (x1, x8): parse, decode + r-torsion tests, input accumulator, " \
                          "line preparation, three Miller loops and the final exponentiation on six lanes each; a damaged proof is refused"

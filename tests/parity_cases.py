@@ -865,6 +865,84 @@ def verifier_small_circuit(lib, seed=5, n_in=3, n_aux=12, n_con=14):
         params.close()
 
 
+def verifier_rlc(lib, n=20, seed=8, capfd=None):
+    """zk_verify_batch_rlc (one combined check per chunk: rho_i-weighted Miller loops, ONE final exponentiation, the per-proof
+    verifier behind it) gives EXACTLY zk_verify_batch's verdicts: a batch of proofs of different statements, all good; one /
+    several invalid proofs; two proofs whose errors cancel in an unweighted sum (C_i + D, C_j - D: what the random weights
+    are for); a malformed encoding, a point at infinity, a non-canonical input, a wrong input; batches too small for the
+    combined check; the empty batch."""
+    E = g.Bls12Engine()
+    n_in, n_aux = 3, 12
+    circ = synth.ChainCircuit(seed, n_in, n_aux)
+    P = g.generate_parameters(E, circ.r1cs, *helpers.TOXIC, scalars_only=True)
+    pk = params_io.write_parameters_from_scalars(P.sc, n_in, threads=4)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    pvk = zk.prepare_verifying_key(params)
+    try:
+        rng = synth.SplitMix64(seed + 31)
+        proofs, inputs = [], []
+        for i in range(n):
+            inp, aux = circ.witness(seed * 1000 + i)
+            asg = g.assign(E, circ.r1cs, inp, aux)
+            proofs.append(helpers.expected_proof_trapdoor(P, asg, rng.field(bls.R_MOD), rng.field(bls.R_MOD)))
+            inputs.append(list(asg.inputs[1:]))
+        assert len({tuple(x) for x in inputs}) > 1
+
+        def both(pr, ins):
+            a = zk.verify_proofs(pvk, pr, ins)
+            b = zk.verify_proofs(pvk, pr, ins, rlc=True)
+            assert a == b, (a, b)
+            return b
+        if capfd is not None:
+            capfd.readouterr()
+        assert both(proofs, inputs) == [True] * n
+        if capfd is not None:   # ... and it was the combined check that said so, not the fallback (ZKAMD_DEBUG_RLC=1)
+            assert "chunk of %d proofs: combined check passed, every proof well-formed: yes" % n in capfd.readouterr().err
+        assert both(proofs[:3], inputs[:3]) == [True] * 3          # below the combined check's minimum
+        assert zk.verify_proofs(pvk, [], [], rlc=True) == []
+        # one invalid proof (the C of another statement), then several
+        bad = list(proofs)
+        bad[5] = proofs[5][:144] + proofs[6][144:]
+        assert both(bad, inputs) == [i != 5 for i in range(n)]
+        bad[0] = proofs[1]
+        bad[n - 1] = proofs[n - 1][:48] + proofs[2][48:144] + proofs[n - 1][144:]
+        assert both(bad, inputs) == [i not in (0, 5, n - 1) for i in range(n)]
+        # errors that cancel in an unweighted sum of the C's
+        D = bls.G1.mul(bls.G1_GEN, 0x1234567)
+        dec = [params_io.read_proof(pf) for pf in proofs[:2]]
+        enc = lambda pt: bls.g1_compressed(bls.G1.to_affine(pt))
+        c0 = bls.G1.add_mixed(D, dec[0][2])
+        c1 = bls.G1.add_mixed(bls.G1.neg(D), dec[1][2])
+        twist = [proofs[0][:144] + enc(c0), proofs[1][:144] + enc(c1)] + proofs[2:]
+        if capfd is not None:
+            capfd.readouterr()
+        assert both(twist, inputs) == [False, False] + [True] * (n - 2)
+        if capfd is not None:   # every point decodes and sits in the subgroup: it is the weighted product that refuses
+            assert "combined check FAILED, every proof well-formed: yes" in capfd.readouterr().err
+        # malformed, infinity, inputs
+        mal = list(proofs)
+        mal[3] = bytes([proofs[3][0] & 0x7f]) + proofs[3][1:]
+        assert both(mal, inputs) == [i != 3 for i in range(n)]
+        mal = list(proofs)
+        mal[7] = proofs[7][:48] + bytes([0xc0]) + bytes(95) + proofs[7][144:]
+        assert both(mal, inputs) == [i != 7 for i in range(n)]
+        wrong = [list(x) for x in inputs]
+        wrong[4][0] = (wrong[4][0] + 1) % bls.R_MOD
+        assert both(proofs, wrong) == [i != 4 for i in range(n)]
+        if inputs[2][1] + bls.R_MOD < 1 << 256:
+            ib = b"".join(b"".join(int(v + (bls.R_MOD if (i, j) == (2, 1) else 0)).to_bytes(32, "little") for j, v in enumerate(row))
+                          for i, row in enumerate(inputs))
+            arr = np.frombuffer(b"".join(proofs), dtype=np.uint8)
+            ibn = np.frombuffer(ib, dtype=np.uint8)
+            assert zk.verify_proofs(pvk, arr, ibn, rlc=True) == zk.verify_proofs(pvk, arr, ibn) == [i != 2 for i in range(n)]
+        with pytest.raises(zk.ZkError) as e:
+            zk.verify_proofs(pvk, proofs[:1], [inputs[0] + [1]], rlc=True)
+        assert e.value.variant == "MalformedVerifyingKey"
+    finally:
+        pvk.close()
+        params.close()
+
+
 def scalars_to_bytes_list(values):
     return zk.scalars_to_bytes(values)
 

@@ -119,3 +119,18 @@ def test_every_declared_entry_point_has_a_caller_in_the_tests():
             continue
         unreached.append(s)
     assert not unreached, "entry points no test calls: %s" % unreached
+
+
+def test_c_program_proves_on_several_devices_from_one_process(tmp_path, emu_lib):
+    """tests/abi_multi.c: the multi-device pattern for a single-process host (the reference's zface / core/proofs): N
+    pthreads, each binds to its device's NUMA node, loads the key on its device and proves its contiguous block straight
+    into its range of ONE caller buffer; every proof verified, the buffer equal to the one-call result.  Strict C99 against
+    include/zkamd.h; here the three-constraint circuit under the x86 emulation build, in the GPU suite also the transfer
+    circuit through zk_pipeline_*."""
+    import subprocess
+    exe = str(tmp_path / "abi_multi")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_multi.c"), "-ldl", "-lpthread", "-o", exe])
+    for threads, n in ((2, 7), (3, 2), (1, 0)):
+        out = subprocess.check_output([exe, emu_lib.path, "small", str(threads), str(n)], timeout=600).decode()
+        assert "abi_multi ok: %d small-circuit proofs from %d threads" % (n, threads) in out, out

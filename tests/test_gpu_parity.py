@@ -711,3 +711,55 @@ def test_kernel_form_selection(gpu_lib):
     import zero_chain_amd as zk
     here = zk.kernel_forms(0, lib=gpu_lib)
     assert set(here) == {"g2_accumulate", "reduce_level1", "ms"} and here["g2_accumulate"] in (0, 1)
+
+
+def test_c_program_proves_on_several_devices_from_one_process(gpu_lib, tmp_path):
+    """tests/abi_multi.c against the product library: two host threads, each with its own key handle and pipeline on
+    device 0 (the test box has one GPU; on a node the device list names one device per thread), 96 transfer statements
+    cut into two contiguous blocks of ONE output buffer - every proof verified, the buffer byte-identical to one
+    zk_transfer_prove_batch call; then the small circuit with three threads."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_multi")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "abi_multi.c"), "-ldl", "-lpthread", "-o", exe])
+    out = subprocess.run([exe, gpu_lib.path, "transfer", "2", "96", "0,0"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "abi_multi ok: 96 transfer proofs from 2 threads on devices [0,0]" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([exe, gpu_lib.path, "small", "3", "10"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "abi_multi ok: 10 small-circuit proofs from 3 threads" in out.stdout, out.stdout + out.stderr
+
+
+def test_verifier_rlc(gpu_lib, monkeypatch, capfd):
+    monkeypatch.setenv("ZKAMD_DEBUG_RLC", "1")
+    pc.verifier_rlc(gpu_lib, n=40, capfd=capfd)
+
+
+def test_verifier_rlc_full_chunk(gpu_lib):
+    """The combined check at the bench's size: 1024 transfer proofs from statements, all accepted in one check; with three
+    of them damaged the verdicts are the per-proof verifier's (the chunk falls back)."""
+    import zero_chain_amd as zk
+    from oracle import transfer_circuit as tc
+    r1, asgs, P, pk = helpers.transfer_case(1)
+    n_distinct, n = 16, 1024
+    ws = [tc.make_witness(4100 + i, amount=2 + 5 * i, fee=i % 4, balance=700 + 13 * i) for i in range(n_distinct)]
+    sts = zk.transfer_statements([tc.statement_dict(ws[i % n_distinct]) for i in range(n)])
+    rng = synth.SplitMix64(4242)
+    rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
+    pvk = zk.prepare_verifying_key(params)
+    try:
+        raw = np.frombuffer(b"".join(p.write() for p in zk.transfer_prove_batch(mats, params, sts, rs)), dtype=np.uint8).copy()
+        w = zk.transfer_witness(sts, lib=gpu_lib).reshape(n, -1)
+        inputs = np.ascontiguousarray(w[:, 32:zk.TRANSFER_N_INPUTS * 32])
+        assert zk.verify_proofs(pvk, raw, inputs, rlc=True) == [True] * n
+        bad = raw.copy()
+        bad[192 * 9:192 * 10], bad[192 * 10:192 * 11] = raw[192 * 10:192 * 11].copy(), raw[192 * 9:192 * 10].copy()
+        bad[192 * 800 + 150] ^= 4
+        ok = zk.verify_proofs(pvk, bad, inputs, rlc=True)
+        assert ok == zk.verify_proofs(pvk, bad, inputs) and [i for i, v in enumerate(ok) if not v] == [9, 10, 800]
+    finally:
+        pvk.close()
+        mats.close()
+        params.close()

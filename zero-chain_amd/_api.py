@@ -330,7 +330,7 @@ def prepare_verifying_key(vk, device=None, lib=None):
     return PreparedVerifyingKey(lib, h)
 
 
-def verify_proofs(pvk, proofs, public_inputs):
+def verify_proofs(pvk, proofs, public_inputs, rlc=False):
     """n independent verify_proof calls on the GPU (zk_verify_batch).  proofs: list of Proof / 192-byte strings
     (or one n x 192 byte array); public_inputs: per proof the list of Fr values WITHOUT the leading ONE (or one
     n x n_inputs x 32 byte array, plain little-endian).  Returns a list of bools; raises ZkError
@@ -364,8 +364,8 @@ def verify_proofs(pvk, proofs, public_inputs):
     if ib.size != n * n_inputs * 32:
         raise ValueError("public_inputs: %d bytes, expected %d" % (ib.size, n * n_inputs * 32))
     ok = np.zeros(max(n, 1), dtype=np.uint8)
-    pvk._lib.check(pvk._lib.zk_verify_batch(pvk._h, n, _ptr(pb) if pb.size else None, _ptr(ib) if ib.size else None, n_inputs,
-                                             _ptr(ok)))
+    fn = pvk._lib.zk_verify_batch_rlc if rlc else pvk._lib.zk_verify_batch   # rlc: one combined check per chunk, per-proof on failure
+    pvk._lib.check(fn(pvk._h, n, _ptr(pb) if pb.size else None, _ptr(ib) if ib.size else None, n_inputs, _ptr(ok)))
     return [bool(x) for x in ok[:n]]
 
 

@@ -138,6 +138,7 @@ _PROTOS = {
     "zk_vk_num_inputs": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "zk_vk_free": (None, [C.c_void_p]),
     "zk_verify_batch": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zk_verify_batch_rlc": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "zk_verify_proof": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "zk_proof_read_batch": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "zk_anonymous_prove_batch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(AnonymousStatement), C.c_void_p,

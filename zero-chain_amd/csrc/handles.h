@@ -62,5 +62,5 @@ zk_status witness_anon_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_
 // proofs are this library's own fresh results (gen_proof's self-check) - decoded without the r-torsion test.
 namespace zkrt {
 zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,
-                       bool own_proofs);
+                       bool own_proofs, bool rlc = false);
 }

@@ -898,4 +898,142 @@ k_verify_flags(const uint32_t* __restrict__ st_g1, const uint32_t* __restrict__ 
     skip[i] = (bad ? 5u : 0u) | (acc_inf[i] ? 2u : 0u);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batch verification with a random linear combination (verifier.rs:32-63 over a batch).
+// n proofs (A_i, B_i, C_i) with input accumulators acc_i all verify iff, up to probability 2^-128 over the rho_i,
+//     prod_i e(rho_i A_i, B_i) * e(sum_i rho_i acc_i, -gamma) * e(sum_i rho_i C_i, -delta) = e(alpha, beta)^(sum_i rho_i):
+// n + 2 Miller loops instead of 3 n, ONE final exponentiation instead of n, and the accumulator becomes one
+// multiexp over ic with the n_ic scalars  s_0 = sum rho_i,  s_j = sum_i rho_i x_ij  (formed on the host).
+// What it buys is THROUGHPUT on large batches: a batch of verifications is a bundle of serial chains (decoding -> line
+// preparation -> Miller loop -> final exponentiation) and the length of that chain is the same here.
+// ---------------------------------------------------------------------------------------------
+// rho_i * A_i (affine, into slot i of the pair array) and rho_i * C_i (extended, for the sum).  g1: [2n][24] words, the
+// decoded A then C points; rho: [n][4] words.
+static __global__ void __launch_bounds__(64, 1)
+k_rlc_scale(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ rho, uint32_t* __restrict__ a_out,
+            XYZZ<Fq32>* __restrict__ c_out, uint32_t n) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const uint32_t i = t < n ? t : t - n;
+    const Affine<Fq32> p{fq_ld(g1 + (size_t)t * 24), fq_ld(g1 + (size_t)t * 24 + 12)};
+    const uint32_t* r = rho + (size_t)i * 4;
+    XYZZ<Fq32> acc = XYZZ<Fq32>::inf();
+#pragma unroll 1
+    for (int b = 127; b >= 0; b--) {
+        acc = xdbl(acc);
+        if ((r[b >> 5] >> (b & 31)) & 1u) madd(acc, p, false);
+    }
+    if (t < n) {
+        const Affine<Fq32> a = to_affine(acc);
+        fq_st(a_out + (size_t)i * 24, a.x);
+        fq_st(a_out + (size_t)i * 24 + 12, a.y);
+    } else {
+        c_out[i] = acc;
+    }
+}
+// out[block] = sum of in[block * 256 .. block * 256 + 255] (four points per lane, then a tree in LDS)
+static __global__ void __launch_bounds__(64, 1)
+k_g1_sum(const XYZZ<Fq32>* __restrict__ in, uint32_t n, XYZZ<Fq32>* __restrict__ out) {
+    ZK_SHARED XYZZ<Fq32> sm[64];
+    const uint32_t tid = threadIdx.x, base = blockIdx.x * 256;
+    XYZZ<Fq32> acc = XYZZ<Fq32>::inf();
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t i = base + k * 64 + tid;
+        if (i < n) acc = xadd(acc, in[i]);
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    for (uint32_t st = 32; st >= 1; st >>= 1) {
+        if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
+        __syncthreads();
+    }
+    if (tid == 0) out[blockIdx.x] = sm[0];
+}
+// sum_j s_j ic_j over the doubling table of ic (table[k][j] = 2^k ic_j), s: [n_ic][8] words plain; thread (j, quarter) adds
+// the table entries at the set bits of its 64-bit quarter of s_j, a tree in LDS adds the partial sums.  One workgroup.
+constexpr uint32_t RLC_IN_THREADS = 256;
+static __global__ void __launch_bounds__(RLC_IN_THREADS, 1)
+k_rlc_inputs(const Affine<Fq>* __restrict__ table, const uint32_t* __restrict__ s, XYZZ<Fq>* __restrict__ out, uint32_t n_ic) {
+    ZK_SHARED XYZZ<Fq> sm[RLC_IN_THREADS];
+    const uint32_t tid = threadIdx.x;
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    for (uint32_t u = tid; u < 4 * n_ic; u += RLC_IN_THREADS) {
+        const uint32_t j = u >> 2, q = u & 3u;
+        for (uint32_t k = 64 * q; k < 64 * q + 64 && k < 255; k++)
+            if ((s[(size_t)j * 8 + (k >> 5)] >> (k & 31)) & 1u) madd(acc, table[(size_t)k * n_ic + j], false);
+    }
+    sm[tid] = acc;
+    __syncthreads();
+    for (uint32_t st = RLC_IN_THREADS / 2; st >= 1; st >>= 1) {
+        if (tid < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
+        __syncthreads();
+    }
+    if (tid == 0) out[0] = sm[0];
+}
+// the two shared points, affine, into slots n and n + 1 of the pair array; flags[0 / 1] = 1 where one is the point at infinity
+static __global__ void __launch_bounds__(64, 1)
+k_rlc_shared_points(const XYZZ<Fq>* __restrict__ acc, const XYZZ<Fq32>* __restrict__ csum, uint32_t* __restrict__ a_out,
+                    uint32_t* __restrict__ inf, uint32_t n) {
+    if (threadIdx.x == 0) {
+        const XYZZ<Fq> p = acc[0];
+        inf[0] = p.is_inf() ? 1u : 0u;
+        const Affine<Fq> a = to_affine(p);
+        fld_export(a.x, a_out + (size_t)n * 24);
+        fld_export(a.y, a_out + (size_t)n * 24 + 12);
+    } else if (threadIdx.x == 1) {
+        const XYZZ<Fq32> p = csum[0];
+        inf[1] = p.is_inf() ? 1u : 0u;
+        const Affine<Fq32> a = to_affine(p);
+        fq_st(a_out + (size_t)(n + 1) * 24, a.x);
+        fq_st(a_out + (size_t)(n + 1) * 24 + 12, a.y);
+    }
+}
+// skip[i] for the n + 2 pairs of the combined check, all_valid[0] = every proof of the batch decoded (st_* as k_verify_flags)
+static __global__ void __launch_bounds__(256)
+k_rlc_flags(const uint32_t* __restrict__ st_g1, const uint32_t* __restrict__ st_g2, const uint32_t* __restrict__ host_bad,
+            const uint32_t* __restrict__ inf, uint32_t* __restrict__ skip, uint32_t* __restrict__ all_valid, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        if (host_bad[i] || st_g1[i] || st_g1[n + i] || st_g2[i]) atomicMin(all_valid, 0u);
+        skip[i] = 0;
+    } else if (i < n + 2) {
+        skip[i] = inf[i - n];   // an accumulator / a C sum at infinity drops out of the product (mod.rs:50-54)
+    }
+}
+// out[g] = product of in[g], in[g + groups], ... (g < groups <= gridDim.x * WIDE_GROUPS), six lanes per element
+static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+k_f12_prod_wide(const F12* __restrict__ in, uint32_t m, F12* __restrict__ out, uint32_t groups) {
+    ZK_SHARED WideLds lds;
+    const uint32_t tid = threadIdx.x;
+    const Wide w = wide_of(lds, tid);
+    const uint32_t gid = blockIdx.x * WIDE_GROUPS + tid / WIDE_LANES;
+    const bool real = tid < WIDE_GROUPS * WIDE_LANES && gid < groups;
+    const F2 one = f2_sel(w.i == 0, F2::one(), F2::zero());
+    F2 acc = one;
+    const uint32_t trips = (m + groups - 1) / groups;
+#pragma unroll 1
+    for (uint32_t k = 0; k < trips; k++) {
+        const uint32_t idx = gid + k * groups;
+        const bool have = real && idx < m;
+        const F2 v = have ? *f12_coef(&in[idx], w.i) : one;
+        acc = wide_mul(w, acc, v);
+    }
+    if (real) *f12_coef(&out[gid], w.i) = acc;
+}
+// out = base^e for base in the cyclotomic subgroup (e(alpha, beta)), e: nbits bits in little-endian words; one group
+static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+k_f12_pow_wide(const F12* __restrict__ base, const uint32_t* __restrict__ e, uint32_t nbits, F12* __restrict__ out) {
+    ZK_SHARED WideLds lds;
+    const uint32_t tid = threadIdx.x;
+    const Wide w = wide_of(lds, tid);
+    const F2 a = *f12_coef(base, w.i);
+    F2 t = f2_sel(w.i == 0, F2::one(), F2::zero());
+#pragma unroll 1
+    for (int b = (int)nbits - 1; b >= 0; b--) {
+        t = wide_cyc_sqr(w, t);
+        if ((e[b >> 5] >> (b & 31)) & 1u) t = wide_mul(w, t, a);
+    }
+    if (tid < WIDE_LANES) *f12_coef(out, w.i) = t;
+}
+
 }  // namespace zkdev

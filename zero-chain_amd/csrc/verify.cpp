@@ -12,6 +12,7 @@
 
 #include "host_common.h"
 #include "host_math.h"
+#include "blake2s.h"
 #include "pairing.h"
 
 using namespace zkrt;
@@ -119,6 +120,9 @@ struct zk_vk {
     // per-batch workspaces
     DevBuf in_g1, in_g2, fl_g1, fl_g2, aff_g1, aff_g2, st_g1, st_g2, scal, part, acc, acc_inf, host_bad, skip, valid, f, ok;
     DevBuf prep_b;   // line coefficients of the batch's own B points (the lane-parallel Miller loop reads every pair prepared)
+    // the random-linear-combination check (verify_chunk_rlc): rho_i, the n_ic input scalars, rho_i A_i | acc | C sum, rho_i C_i and
+    // its partial sums, the accumulator, flags, the exponent and e(alpha, beta)^S, the product tree, two Fq12 ones
+    DevBuf rlc_rho, rlc_s, rlc_pts, rlc_c, rlc_csum, rlc_acc, rlc_inf, rlc_all, rlc_exp, rlc_want, rlc_prod, rlc_fe;
     // the G1 decoder and the input accumulator run beside the G2 decoder on the lane's side streams
     hipEvent_t ev_join[2] = {nullptr, nullptr};
     ~zk_vk() {
@@ -507,17 +511,232 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     return ZK_OK;
 }
 
+// The whole chunk in ONE combined check (pairing.h, "Batch verification with a random linear combination"):
+//   prod_i e(rho_i A_i, B_i) * e(sum_j s_j ic_j, -gamma) * e(sum_i rho_i C_i, -delta) == e(alpha, beta)^(sum_i rho_i)
+// with rho_i = 128 bits of Blake2s(digest of the batch, i): the coefficients are fixed by the proofs and inputs they
+// weigh (Fiat-Shamir), no randomness source is needed and a run can be repeated.  *decided = true: every proof of the
+// chunk verifies (probability of a wrong accept 2^-128 per attempt).  *decided = false: a proof of the chunk is malformed
+// or invalid, or the combined check failed - the caller runs the per-proof verifier, which names the culprits.
+zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t* inputs, bool own_proofs, bool* decided) {
+    *decided = false;
+    const uint32_t ni = V->n_ic - 1;
+    if (V->gamma_inf || V->delta_inf || !ni) return ZK_OK;   // degenerate keys: the per-proof path knows them
+    std::vector<uint32_t> g1((size_t)2 * n * 12), g2((size_t)n * 24), f1(2 * n), f2(n), bad(n, 0);
+    static const uint64_t RMOD[4] = ZK_FR_P_64;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* p = proofs + i * 192;
+        if (!(parse_g1_compressed(p, &g1[i * 12], &f1[i]) && parse_g2_compressed(p + 48, &g2[i * 24], &f2[i]) &&
+              parse_g1_compressed(p + 144, &g1[(n + i) * 12], &f1[n + i])))
+            return ZK_OK;
+        for (uint32_t j = 0; j < ni; j++) {
+            const uint8_t* s = inputs + (i * ni + j) * 32;
+            uint64_t v[4];
+            memcpy(v, s, 32);
+            bool lt = false;
+            for (int k = 3; k >= 0; k--) {
+                if (v[k] < RMOD[k]) {
+                    lt = true;
+                    break;
+                }
+                if (v[k] > RMOD[k]) break;
+            }
+            if (!lt) return ZK_OK;   // not a canonical Fr
+        }
+    }
+    // rho_i and the scalars of the shared points
+    uint8_t seed[32];
+    {
+        static const uint8_t pers[8] = {'z', 'k', 'a', 'm', 'd', 'r', 'l', 'c'};
+        zkhash::Blake2s h(pers);
+        h.update_u64be(n);
+        h.update(proofs, n * 192);
+        h.update(inputs, n * (size_t)ni * 32);
+        h.finish(seed);
+    }
+    std::vector<uint32_t> rho(n * 4);
+    std::vector<zkhost::Fr> rho_m(n);
+    const unsigned nth = host_threads(n, 16);
+    std::vector<std::vector<zkhost::Fr>> part(nth, std::vector<zkhost::Fr>(ni + 1, zkhost::Fr::zero()));
+    auto work = [&](unsigned t) {
+        for (size_t i = n * t / nth; i < n * (t + 1) / nth; i++) {
+            uint8_t d[32];
+            zkhash::Blake2s h;
+            h.update(seed, 32);
+            h.update_u64be(i);
+            h.finish(d);
+            memcpy(&rho[i * 4], d, 16);
+            if (!(rho[i * 4] | rho[i * 4 + 1] | rho[i * 4 + 2] | rho[i * 4 + 3])) rho[i * 4] = 1;
+            zkhost::Fr r = zkhost::Fr::zero();
+            memcpy(r.l, &rho[i * 4], 16);
+            const zkhost::Fr rm = r.to_mont();
+            part[t][0] = part[t][0] + rm;
+            for (uint32_t j = 0; j < ni; j++) {
+                zkhost::Fr x;
+                memcpy(x.l, inputs + (i * ni + j) * 32, 32);   // plain: rho R * x / R = rho x, plain
+                part[t][1 + j] = part[t][1 + j] + rm * x;
+            }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nth; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    std::vector<uint32_t> sv((size_t)(ni + 1) * 8), ev(8);
+    for (uint32_t j = 0; j <= ni; j++) {
+        zkhost::Fr a = zkhost::Fr::zero();
+        for (unsigned t = 0; t < nth; t++) a = a + part[t][j];
+        if (j == 0) a = a.from_mont();   // sum of rho_i R -> plain; the others are plain already
+        memcpy(&sv[(size_t)j * 8], a.l, 32);
+    }
+    memcpy(ev.data(), sv.data(), 32);   // the exponent of e(alpha, beta): sum rho_i mod r (its order)
+    const size_t m = n + 2;
+    ZK_TRY(upload(V->in_g1, g1.data(), g1.size() * 4));
+    ZK_TRY(upload(V->in_g2, g2.data(), g2.size() * 4));
+    ZK_TRY(upload(V->fl_g1, f1.data(), f1.size() * 4));
+    ZK_TRY(upload(V->fl_g2, f2.data(), f2.size() * 4));
+    ZK_TRY(upload(V->host_bad, bad.data(), bad.size() * 4));
+    ZK_TRY(upload(V->rlc_rho, rho.data(), rho.size() * 4));
+    ZK_TRY(upload(V->rlc_s, sv.data(), sv.size() * 4));
+    ZK_TRY(upload(V->rlc_exp, ev.data(), 32));
+    ZK_TRY(V->aff_g1.ensure((size_t)2 * n * 96));
+    ZK_TRY(V->aff_g2.ensure(n * 192));
+    ZK_TRY(V->st_g1.ensure(2 * n * 4));
+    ZK_TRY(V->st_g2.ensure(n * 4));
+    ZK_TRY(V->skip.ensure(m * 4));
+    ZK_TRY(V->f.ensure(3 * m * sizeof(F12)));
+    ZK_TRY(V->ok.ensure(4));
+    ZK_TRY(V->prep_b.ensure(m * COEF_WORDS * 4));
+    ZK_TRY(V->rlc_pts.ensure(m * 96));
+    ZK_TRY(V->rlc_c.ensure(n * sizeof(zkdev::XYZZ<zkdev::Fq32>)));
+    ZK_TRY(V->rlc_csum.ensure(((n + 255) / 256 + 1) * sizeof(zkdev::XYZZ<zkdev::Fq32>)));
+    ZK_TRY(V->rlc_acc.ensure(sizeof(DG1)));
+    ZK_TRY(V->rlc_inf.ensure(8));
+    ZK_TRY(V->rlc_all.ensure(4));
+    ZK_TRY(V->rlc_want.ensure(sizeof(F12)));
+    ZK_TRY(V->rlc_prod.ensure(2 * (m / 12 + 2) * sizeof(F12)));
+    if (!V->rlc_fe.cap) {   // [product | 1 | 1]: what k_final_exp_wide multiplies for its one item
+        std::vector<uint32_t> ones(3 * 144, 0);
+        static const uint32_t R32[12] = ZK_FQ_R_32;
+        for (int k = 1; k < 3; k++) memcpy(&ones[(size_t)k * 144], R32, 48);
+        ZK_TRY(upload(V->rlc_fe, ones.data(), ones.size() * 4));
+    }
+    const unsigned b64 = (unsigned)((n + 63) / 64);
+    for (int k = 0; k < 2; k++)
+        if (!V->ev_join[k]) HIP_TRY(hipEventCreate(&V->ev_join[k]));
+    HIP_TRY(hipMemsetAsync(V->rlc_all.p, 0xff, 4, g_stream));
+    HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
+    HIP_TRY(hipStreamWaitEvent(g_stream2, g_ev_fork, 0));
+    HIP_TRY(hipStreamWaitEvent(g_copy_stream, g_ev_fork, 0));
+    {   // main stream: B decoded, its lines prepared (the r-torsion test rides on the preparation)
+        ProfScope ps("verify_decode");
+        ZK_LAUNCH(zkdev::k_decode_g2, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->in_g2.as<uint32_t>(),
+                  (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n, 0u);
+    }
+    {
+        ProfScope ps("verify_prepare");
+        ZK_LAUNCH(zkdev::k_g2_prepare, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g2.as<uint32_t>(),
+                  V->prep_b.as<uint32_t>(), (uint32_t)n, own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>());
+    }
+    {   // side stream: A and C decoded, scaled by rho_i, the C's summed
+        ProfScope ps("verify_decode_g1", g_stream2);
+        ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, g_stream2,
+                  (const uint32_t*)V->in_g1.as<uint32_t>(), (const uint32_t*)V->fl_g1.as<uint32_t>(), V->aff_g1.as<uint32_t>(),
+                  V->st_g1.as<uint32_t>(), (uint32_t)(2 * n), own_proofs ? 0u : 1u);
+    }
+    {
+        ProfScope ps("verify_rlc_scale", g_stream2);
+        typedef zkdev::XYZZ<zkdev::Fq32> P32;
+        ZK_LAUNCH(zkdev::k_rlc_scale, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, g_stream2, (const uint32_t*)V->aff_g1.as<uint32_t>(),
+                  (const uint32_t*)V->rlc_rho.as<uint32_t>(), V->rlc_pts.as<uint32_t>(), V->rlc_c.as<P32>(), (uint32_t)n);
+        const uint32_t nb1 = (uint32_t)((n + 255) / 256);
+        ZK_LAUNCH_SYNC(zkdev::k_g1_sum, dim3(nb1), dim3(64), 0, g_stream2, (const P32*)V->rlc_c.as<P32>(), (uint32_t)n, V->rlc_csum.as<P32>() + 1);
+        ZK_LAUNCH_SYNC(zkdev::k_g1_sum, dim3(1), dim3(64), 0, g_stream2, (const P32*)(V->rlc_csum.as<P32>() + 1), nb1, V->rlc_csum.as<P32>());
+    }
+    HIP_TRY(hipEventRecord(V->ev_join[0], g_stream2));
+    {   // copy stream: e(alpha, beta)^S and the accumulator sum_j s_j ic_j
+        ProfScope ps("verify_inputs", g_copy_stream);
+        ZK_LAUNCH_SYNC(zkdev::k_rlc_inputs, dim3(1), dim3(zkdev::RLC_IN_THREADS), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
+                       (const uint32_t*)V->rlc_s.as<uint32_t>(), V->rlc_acc.as<DG1>(), V->n_ic);
+        // (sum rho_i < n 2^128 needs no reduction mod r: the exponent has ~140 bits, not 255)
+        uint32_t nbits = 256;
+        while (nbits > 1 && !((ev[(nbits - 1) >> 5] >> ((nbits - 1) & 31)) & 1u)) nbits--;
+        ZK_LAUNCH_SYNC(zkdev::k_f12_pow_wide, dim3(1), dim3(zkdev::WIDE_THREADS), 0, g_copy_stream, (const F12*)V->alpha_beta.as<F12>(),
+                       (const uint32_t*)V->rlc_exp.as<uint32_t>(), nbits, V->rlc_want.as<F12>());
+    }
+    HIP_TRY(hipEventRecord(V->ev_join[1], g_copy_stream));
+    HIP_TRY(hipStreamWaitEvent(g_stream, V->ev_join[0], 0));
+    HIP_TRY(hipStreamWaitEvent(g_stream, V->ev_join[1], 0));
+    ZK_LAUNCH(zkdev::k_rlc_shared_points, dim3(1), dim3(64), 0, g_stream, (const DG1*)V->rlc_acc.as<DG1>(),
+              (const zkdev::XYZZ<zkdev::Fq32>*)V->rlc_csum.as<zkdev::XYZZ<zkdev::Fq32>>(), V->rlc_pts.as<uint32_t>(), V->rlc_inf.as<uint32_t>(),
+              (uint32_t)n);
+    ZK_LAUNCH(zkdev::k_rlc_flags, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, g_stream, (const uint32_t*)V->st_g1.as<uint32_t>(),
+              (const uint32_t*)V->st_g2.as<uint32_t>(), (const uint32_t*)V->host_bad.as<uint32_t>(), (const uint32_t*)V->rlc_inf.as<uint32_t>(),
+              V->skip.as<uint32_t>(), V->rlc_all.as<uint32_t>(), (uint32_t)n);
+    // the key's prepared -gamma and -delta behind the batch's own lines: pairs n and n + 1
+    HIP_TRY(hipMemcpyAsync(V->prep_b.as<uint32_t>() + n * COEF_WORDS, V->prep[0].p, COEF_WORDS * 4, hipMemcpyDeviceToDevice, g_stream));
+    HIP_TRY(hipMemcpyAsync(V->prep_b.as<uint32_t>() + (n + 1) * COEF_WORDS, V->prep[1].p, COEF_WORDS * 4, hipMemcpyDeviceToDevice, g_stream));
+    {
+        ProfScope ps("verify_miller");
+        ZK_LAUNCH_SYNC(zkdev::k_miller_loop_wide, dim3((unsigned)((m + zkdev::WIDE_GROUPS - 1) / zkdev::WIDE_GROUPS), 1), dim3(zkdev::WIDE_THREADS), 0,
+                       g_stream, (const uint32_t*)V->rlc_pts.as<uint32_t>(), (const uint32_t*)V->prep_b.as<uint32_t>(), (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)V->skip.as<uint32_t>(),
+                       V->f.as<F12>(), (uint32_t)m);
+    }
+    {
+        ProfScope ps("verify_final");
+        // the product of the n + 2 Miller functions: a tree of groups of twelve
+        const F12* src = V->f.as<F12>();
+        F12* bufs[2] = {V->rlc_prod.as<F12>(), V->rlc_prod.as<F12>() + (m / 12 + 2)};
+        uint32_t cnt = (uint32_t)m;
+        int which = 0;
+        while (cnt > 1) {
+            const uint32_t groups = (cnt + 11) / 12;
+            F12* dst = groups == 1 ? V->rlc_fe.as<F12>() : bufs[which];
+            ZK_LAUNCH_SYNC(zkdev::k_f12_prod_wide, dim3((groups + zkdev::WIDE_GROUPS - 1) / zkdev::WIDE_GROUPS), dim3(zkdev::WIDE_THREADS), 0, g_stream,
+                           src, cnt, dst, groups);
+            src = dst;
+            cnt = groups;
+            which ^= 1;
+        }
+        ZK_LAUNCH_SYNC(zkdev::k_final_exp_wide, dim3(1), dim3(zkdev::WIDE_THREADS), 0, g_stream, (const F12*)V->rlc_fe.as<F12>(),
+                       (const uint32_t*)V->gam.as<uint32_t>(), (const F12*)V->rlc_want.as<F12>(), (const uint32_t*)nullptr, V->ok.as<uint32_t>(),
+                       (F12*)nullptr, 1u);
+    }
+    HIP_TRY(hipGetLastError());
+    uint32_t okv = 0, allv = 0;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(&okv, V->ok.p, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&allv, V->rlc_all.p, 4, hipMemcpyDeviceToHost));
+    *decided = okv == 1 && allv != 0;
+    if (getenv("ZKAMD_DEBUG_RLC"))   // tests: was the chunk really decided by the combined check?
+        fprintf(stderr, "[rlc] chunk of %zu proofs: combined check %s, every proof well-formed: %s\n", n, okv == 1 ? "passed" : "FAILED",
+                allv ? "yes" : "NO");
+    return ZK_OK;
+}
+
 }  // namespace
 
 namespace zkrt {
+// rlc: try the random-linear-combination check on every chunk first (verify_chunk_rlc) and fall back to the per-proof
+// verifier only for a chunk it cannot vouch for
 zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,
-                       bool own_proofs) {
+                       bool own_proofs, bool rlc) {
     if (!vk || (n && (!proofs || !ok_out)) || (n && n_inputs && !public_inputs)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     // verifier.rs:38-40
     if (n_inputs + 1 != vk->ic.size()) return fail(ZK_ERR_MALFORMED_VERIFYING_KEY, "number of public inputs + 1 differs from ic");
     ZK_TRY(use_device(vk->device));
     for (size_t first = 0; first < n; first += VERIFY_CHUNK) {
         const size_t np = std::min(VERIFY_CHUNK, n - first);
+        if (rlc && np >= 8) {
+            bool decided = false;
+            ZK_TRY(verify_chunk_rlc(vk, np, proofs + first * 192, public_inputs + first * n_inputs * 32, own_proofs, &decided));
+            if (decided) {
+                memset(ok_out + first, 1, np);
+                continue;
+            }
+        }
         ZK_TRY(verify_chunk(vk, np, proofs + first * 192, public_inputs + first * n_inputs * 32, ok_out + first, own_proofs));
     }
     return ZK_OK;
@@ -576,7 +795,11 @@ void zk_vk_free(zk_vk* vk) { delete vk; }
 
 zk_status zk_verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
                           uint8_t* ok_out) {
-    return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false);
+    return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false, false);
+}
+zk_status zk_verify_batch_rlc(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
+                              uint8_t* ok_out) {
+    return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false, true);
 }
 zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_t* status_out) {
     if (!vk || (n && (!proofs || !status_out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
