@@ -908,20 +908,31 @@ k_verify_flags(const uint32_t* __restrict__ st_g1, const uint32_t* __restrict__ 
 // preparation -> Miller loop -> final exponentiation) and the length of that chain is the same here.
 // ---------------------------------------------------------------------------------------------
 // rho_i * A_i (affine, into slot i of the pair array) and rho_i * C_i (extended, for the sum).  g1: [2n][24] words, the
-// decoded A then C points; rho: [n][4] words.
+// decoded A then C points; rho: [n][4] words = (a_i, b_i), two 64-bit halves with rho_i = a_i + b_i lambda, lambda = -x^2 the
+// eigenvalue of phi(x, y) = (beta x, y) on the r-torsion (the endomorphism of the G1 subgroup test above).  (a, b) -> a + b
+// lambda mod r is injective on [0, 2^64)^2 - the lattice of pairs with a + b lambda = 0 has no non-zero vector shorter than
+// ~2^127 - so rho_i still ranges over 2^128 values, and rho P = a P + b phi(P) is ONE 64-step double-and-add over
+// {P, phi(P), P + phi(P)}: 64 doublings + ~48 additions instead of 128 + 64.
 static __global__ void __launch_bounds__(64, 1)
 k_rlc_scale(const uint32_t* __restrict__ g1, const uint32_t* __restrict__ rho, uint32_t* __restrict__ a_out,
             XYZZ<Fq32>* __restrict__ c_out, uint32_t n) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 2 * n) return;
     const uint32_t i = t < n ? t : t - n;
+    const uint32_t beta[12] = ZK_G1_BETA_MONT_32;
     const Affine<Fq32> p{fq_ld(g1 + (size_t)t * 24), fq_ld(g1 + (size_t)t * 24 + 12)};
+    const Affine<Fq32> q{mul(fq32_const(beta), p.x), p.y};                  // phi(P)
+    XYZZ<Fq32> pq = XYZZ<Fq32>::from_affine(p);
+    madd(pq, q, false);                                                     // P + phi(P) = -phi^2(P): never infinity for P != O
     const uint32_t* r = rho + (size_t)i * 4;
     XYZZ<Fq32> acc = XYZZ<Fq32>::inf();
 #pragma unroll 1
-    for (int b = 127; b >= 0; b--) {
+    for (int b = 63; b >= 0; b--) {
         acc = xdbl(acc);
-        if ((r[b >> 5] >> (b & 31)) & 1u) madd(acc, p, false);
+        const uint32_t ba = (r[b >> 5] >> (b & 31)) & 1u, bb = (r[2 + (b >> 5)] >> (b & 31)) & 1u;
+        if (ba & bb) acc = xadd(acc, pq);
+        else if (ba) madd(acc, p, false);
+        else if (bb) madd(acc, q, false);
     }
     if (t < n) {
         const Affine<Fq32> a = to_affine(acc);
@@ -1032,6 +1043,24 @@ k_f12_pow_wide(const F12* __restrict__ base, const uint32_t* __restrict__ e, uin
     for (int b = (int)nbits - 1; b >= 0; b--) {
         t = wide_cyc_sqr(w, t);
         if ((e[b >> 5] >> (b & 31)) & 1u) t = wide_mul(w, t, a);
+    }
+    if (tid < WIDE_LANES) *f12_coef(out, w.i) = t;
+}
+// out = base0^e0 * base1^e1 in one chain (both bases in the cyclotomic subgroup; e0 | e1: 4 words each, nbits <= 128)
+static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+k_f12_pow2_wide(const F12* __restrict__ base0, const F12* __restrict__ base1, const uint32_t* __restrict__ e, uint32_t nbits,
+                F12* __restrict__ out) {
+    ZK_SHARED WideLds lds;
+    const uint32_t tid = threadIdx.x;
+    const Wide w = wide_of(lds, tid);
+    const F2 a0 = *f12_coef(base0, w.i), a1 = *f12_coef(base1, w.i);
+    const F2 a01 = wide_mul(w, a0, a1);
+    F2 t = f2_sel(w.i == 0, F2::one(), F2::zero());
+#pragma unroll 1
+    for (int b = (int)nbits - 1; b >= 0; b--) {
+        t = wide_cyc_sqr(w, t);
+        const uint32_t b0 = (e[b >> 5] >> (b & 31)) & 1u, b1 = (e[4 + (b >> 5)] >> (b & 31)) & 1u;   // uniform over the block
+        if (b0 | b1) t = wide_mul(w, t, (b0 & b1) ? a01 : b0 ? a0 : a1);
     }
     if (tid < WIDE_LANES) *f12_coef(out, w.i) = t;
 }

@@ -123,6 +123,7 @@ struct zk_vk {
     // the random-linear-combination check (verify_chunk_rlc): rho_i, the n_ic input scalars, rho_i A_i | acc | C sum, rho_i C_i and
     // its partial sums, the accumulator, flags, the exponent and e(alpha, beta)^S, the product tree, two Fq12 ones
     DevBuf rlc_rho, rlc_s, rlc_pts, rlc_c, rlc_csum, rlc_acc, rlc_inf, rlc_all, rlc_exp, rlc_want, rlc_prod, rlc_fe;
+    DevBuf rlc_ab_lambda;   // e(alpha, beta)^lambda, lambda = -x^2 (the coefficients are a_i + b_i lambda: pairing.h k_rlc_scale)
     // the G1 decoder and the input accumulator run beside the G2 decoder on the lane's side streams
     hipEvent_t ev_join[2] = {nullptr, nullptr};
     ~zk_vk() {
@@ -543,20 +544,55 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
             if (!lt) return ZK_OK;   // not a canonical Fr
         }
     }
-    // rho_i and the scalars of the shared points
+    // seed = Blake2s(n | digests of the leaves), a leaf = 256 consecutive proofs with their inputs: the leaves are hashed by
+    // the host threads side by side (7 MB in one stream was 7 ms of the 8192-proof call), the seed does not depend on how many
     uint8_t seed[32];
+    static const uint8_t pers[8] = {'z', 'k', 'a', 'm', 'd', 'r', 'l', 'c'};
+    const unsigned nth = host_threads(n, 16);
     {
-        static const uint8_t pers[8] = {'z', 'k', 'a', 'm', 'd', 'r', 'l', 'c'};
+        const size_t LEAF = 256, n_leaves = (n + LEAF - 1) / LEAF;
+        std::vector<uint8_t> dig(n_leaves * 32);
+        auto leaf_work = [&](unsigned t) {
+            for (size_t l = n_leaves * t / nth; l < n_leaves * (t + 1) / nth; l++) {
+                const size_t lo = l * LEAF, cnt = std::min(LEAF, n - lo);
+                zkhash::Blake2s h(pers);
+                h.update_u64be(l);
+                h.update(proofs + lo * 192, cnt * 192);
+                h.update(inputs + lo * (size_t)ni * 32, cnt * (size_t)ni * 32);
+                h.finish(&dig[l * 32]);
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nth; t++) th.emplace_back(leaf_work, t);
+        leaf_work(0);
+        for (auto& x : th) x.join();
         zkhash::Blake2s h(pers);
         h.update_u64be(n);
-        h.update(proofs, n * 192);
-        h.update(inputs, n * (size_t)ni * 32);
+        h.update(dig.data(), dig.size());
         h.finish(seed);
     }
+    // rho_i = a_i + b_i lambda with (a_i, b_i) = 2 x 64 bits of Blake2s(seed, i); lambda = -x^2 mod r (pairing.h k_rlc_scale)
     std::vector<uint32_t> rho(n * 4);
-    std::vector<zkhost::Fr> rho_m(n);
-    const unsigned nth = host_threads(n, 16);
-    std::vector<std::vector<zkhost::Fr>> part(nth, std::vector<zkhost::Fr>(ni + 1, zkhost::Fr::zero()));
+    zkhost::Fr lambda_m;
+    {
+        const unsigned __int128 x2 = (unsigned __int128)ZK_BLS_X_ABS * ZK_BLS_X_ABS;
+        zkhost::Fr l = zkhost::Fr::zero();
+        l.l[0] = (uint64_t)x2;
+        l.l[1] = (uint64_t)(x2 >> 64);
+        uint64_t bo = 0;
+        for (int k = 0; k < 4; k++) {   // r - x^2
+            const unsigned __int128 d = (unsigned __int128)RMOD[k] - l.l[k] - bo;
+            l.l[k] = (uint64_t)d;
+            bo = (uint64_t)(d >> 64) & 1u;
+        }
+        lambda_m = l.to_mont();
+    }
+    struct Part {
+        std::vector<zkhost::Fr> s;
+        unsigned __int128 sa = 0, sb = 0;
+    };
+    std::vector<Part> part(nth);
+    for (auto& pt : part) pt.s.assign(ni + 1, zkhost::Fr::zero());
     auto work = [&](unsigned t) {
         for (size_t i = n * t / nth; i < n * (t + 1) / nth; i++) {
             uint8_t d[32];
@@ -566,14 +602,19 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
             h.finish(d);
             memcpy(&rho[i * 4], d, 16);
             if (!(rho[i * 4] | rho[i * 4 + 1] | rho[i * 4 + 2] | rho[i * 4 + 3])) rho[i * 4] = 1;
-            zkhost::Fr r = zkhost::Fr::zero();
-            memcpy(r.l, &rho[i * 4], 16);
-            const zkhost::Fr rm = r.to_mont();
-            part[t][0] = part[t][0] + rm;
+            uint64_t ab[2];
+            memcpy(ab, &rho[i * 4], 16);
+            part[t].sa += ab[0];
+            part[t].sb += ab[1];
+            zkhost::Fr a = zkhost::Fr::zero(), b = zkhost::Fr::zero();
+            a.l[0] = ab[0];
+            b.l[0] = ab[1];
+            const zkhost::Fr rm = a.to_mont() + b.to_mont() * lambda_m;   // rho_i R
+            part[t].s[0] = part[t].s[0] + rm;
             for (uint32_t j = 0; j < ni; j++) {
                 zkhost::Fr x;
                 memcpy(x.l, inputs + (i * ni + j) * 32, 32);   // plain: rho R * x / R = rho x, plain
-                part[t][1 + j] = part[t][1 + j] + rm * x;
+                part[t].s[1 + j] = part[t].s[1 + j] + rm * x;
             }
         }
     };
@@ -583,14 +624,22 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
         work(0);
         for (auto& x : th) x.join();
     }
-    std::vector<uint32_t> sv((size_t)(ni + 1) * 8), ev(8);
+    std::vector<uint32_t> sv((size_t)(ni + 1) * 8), ev(8, 0);
+    unsigned __int128 sa = 0, sb = 0;
+    for (unsigned t = 0; t < nth; t++) {
+        sa += part[t].sa;
+        sb += part[t].sb;
+    }
     for (uint32_t j = 0; j <= ni; j++) {
         zkhost::Fr a = zkhost::Fr::zero();
-        for (unsigned t = 0; t < nth; t++) a = a + part[t][j];
+        for (unsigned t = 0; t < nth; t++) a = a + part[t].s[j];
         if (j == 0) a = a.from_mont();   // sum of rho_i R -> plain; the others are plain already
         memcpy(&sv[(size_t)j * 8], a.l, 32);
     }
-    memcpy(ev.data(), sv.data(), 32);   // the exponent of e(alpha, beta): sum rho_i mod r (its order)
+    // the exponent of e(alpha, beta) in the same decomposed form: sum a_i | sum b_i (< n 2^64 each), for
+    // e(alpha, beta)^(sum a_i) * (e(alpha, beta)^lambda)^(sum b_i)
+    memcpy(&ev[0], &sa, 16);
+    memcpy(&ev[4], &sb, 16);
     const size_t m = n + 2;
     ZK_TRY(upload(V->in_g1, g1.data(), g1.size() * 4));
     ZK_TRY(upload(V->in_g2, g2.data(), g2.size() * 4));
@@ -659,11 +708,22 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
         ProfScope ps("verify_inputs", g_copy_stream);
         ZK_LAUNCH_SYNC(zkdev::k_rlc_inputs, dim3(1), dim3(zkdev::RLC_IN_THREADS), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
                        (const uint32_t*)V->rlc_s.as<uint32_t>(), V->rlc_acc.as<DG1>(), V->n_ic);
-        // (sum rho_i < n 2^128 needs no reduction mod r: the exponent has ~140 bits, not 255)
-        uint32_t nbits = 256;
-        while (nbits > 1 && !((ev[(nbits - 1) >> 5] >> ((nbits - 1) & 31)) & 1u)) nbits--;
-        ZK_LAUNCH_SYNC(zkdev::k_f12_pow_wide, dim3(1), dim3(zkdev::WIDE_THREADS), 0, g_copy_stream, (const F12*)V->alpha_beta.as<F12>(),
-                       (const uint32_t*)V->rlc_exp.as<uint32_t>(), nbits, V->rlc_want.as<F12>());
+        if (!V->rlc_ab_lambda.cap) {   // once per key: e(alpha, beta)^lambda
+            uint32_t lam[8];
+            const zkhost::Fr lp = lambda_m.from_mont();
+            memcpy(lam, lp.l, 32);
+            DevBuf dl;
+            ZK_TRY(dl.ensure(32));
+            HIP_TRY(hipMemcpy(dl.p, lam, 32, hipMemcpyHostToDevice));
+            ZK_TRY(V->rlc_ab_lambda.ensure(sizeof(F12)));
+            ZK_LAUNCH_SYNC(zkdev::k_f12_pow_wide, dim3(1), dim3(zkdev::WIDE_THREADS), 0, g_copy_stream, (const F12*)V->alpha_beta.as<F12>(),
+                           (const uint32_t*)dl.as<uint32_t>(), 255u, V->rlc_ab_lambda.as<F12>());
+            HIP_TRY(hipStreamSynchronize(g_copy_stream));
+        }
+        uint32_t nbits = 128;
+        while (nbits > 1 && !(((ev[(nbits - 1) >> 5] | ev[4 + ((nbits - 1) >> 5)]) >> ((nbits - 1) & 31)) & 1u)) nbits--;
+        ZK_LAUNCH_SYNC(zkdev::k_f12_pow2_wide, dim3(1), dim3(zkdev::WIDE_THREADS), 0, g_copy_stream, (const F12*)V->alpha_beta.as<F12>(),
+                       (const F12*)V->rlc_ab_lambda.as<F12>(), (const uint32_t*)V->rlc_exp.as<uint32_t>(), nbits, V->rlc_want.as<F12>());
     }
     HIP_TRY(hipEventRecord(V->ev_join[1], g_copy_stream));
     HIP_TRY(hipStreamWaitEvent(g_stream, V->ev_join[0], 0));
