@@ -1456,18 +1456,15 @@ ZK_DI F fq_pow_qm2_unrolled(const F& a) {
 // of 12 words) - for kernels where ONE thread inverts ONE element and the chain of 570 dependent products of the
 // Fermat form is the whole run time (the final into_affine of a proof made alone: 0.66 -> 0.1 ms).  Divergent
 // loops: not for kernels with a full machine of lanes.  inv_gcd(0) = 0.
-ZK_DI Fq28 inv_gcd(const Fq28& a) {
-    uint32_t u[12], v[12], x1[12], x2[12];
-    fq28_export(a, u);   // x * 2^384 mod p, canonical
-    uint32_t any = 0;
+// y = u^-1 mod q for a canonical integer 0 < u < q (12 little-endian words); u is consumed
+ZK_DI void gcd_inv_words(uint32_t (&u)[12], uint32_t (&y)[12]) {
+    uint32_t v[12], x1[12], x2[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        any |= u[i];
         v[i] = FqCfg::P[i];
         x1[i] = i == 0 ? 1u : 0u;
         x2[i] = 0;
     }
-    if (!any) return Fq28::zero();
     auto is_one = [](const uint32_t (&w)[12]) {
         uint32_t r = w[0] ^ 1u;
 #pragma unroll
@@ -1535,12 +1532,40 @@ ZK_DI Fq28 inv_gcd(const Fq28& a) {
             sub_mod(x2, x1);
         }
     }
-    // (x * 2^384)^-1 as an integer -> x^-1 in the device's Montgomery form
     const bool first = is_one(u);
-    uint32_t y[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) y[i] = first ? x1[i] : x2[i];
+}
+ZK_DI Fq28 inv_gcd(const Fq28& a) {
+    uint32_t u[12], y[12];
+    fq28_export(a, u);   // x * 2^384 mod p, canonical
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) any |= u[i];
+    if (!any) return Fq28::zero();
+    gcd_inv_words(u, y);
+    // (x * 2^384)^-1 as an integer -> x^-1 in the device's Montgomery form
     return mul(fq28_unpack(y), Fq28::from_const(Fq28Consts::KINV));
+}
+// the same for the saturated representation (the pairing kernels): a.l = x R canonical, (x R)^-1 R^3 / R = x^-1 R
+ZK_DI Fq32 inv_gcd(const Fq32& a) {
+    uint32_t u[12], y[12];
+    uint32_t any = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        u[i] = a.l[i];
+        any |= u[i];
+    }
+    if (!any) return Fq32::zero();
+    gcd_inv_words(u, y);
+    const uint32_t r3[12] = ZK_FQ_R3_32;
+    Fq32 t, k;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        t.l[i] = y[i];
+        k.l[i] = r3[i];
+    }
+    return mul(t, k);
 }
 ZK_DI Fq2x inv_gcd(const Fq2x& a) {
     Fq28 n = add(sqr(a.c0), sqr(a.c1));

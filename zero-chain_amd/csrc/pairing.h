@@ -507,62 +507,97 @@ k_final_exp(const F12* __restrict__ f_in, const uint32_t* __restrict__ gam, cons
 }
 
 // ---------------------------------------------------------------------------------------------
-// Lane-parallel Fq12 (r3).  The kernels above give a proof (or a pair) ONE thread: a verification is then a bundle
-// of serial chains, and what it costs is the length of the chain.  Here SIX lanes share an Fq12 element: in the
-// basis 1, w, ..., w^5 over Fq2 (w^6 = xi; the tower's c0.cj sits at w^(2j), c1.cj at w^(2j+1)) lane i holds the
-// coefficient of w^i, operands meet in LDS, and every lane computes ITS coefficient of the result:
-//     product        c_k = sum_(i+j = k) a_i b_j + xi sum_(i+j = k+6) a_i b_j              6 Fq2 products per lane (serial: 18)
-//     square         the same with a_i a_j = a_j a_i folded                               4                     (12)
-//     line product   f (l0 + l1 w^2 + l4 w^3)                                             3                     (13)
-//     cyclotomic square   lanes i, i + 3 share one Fq4 square (a + b s)^2 = (a^2 + xi b^2, 2 a b)     2         (9 squarings)
-// Same instructions on every lane (operands and weights come from small tables indexed by the lane), so a wave runs
-// ten elements at once without divergence; Frobenius and conjugation touch each coefficient alone; the one inversion
-// of a final exponentiation is done redundantly by all six lanes.  All 64 threads of a block take every barrier: the
-// four spare lanes and the groups past the end of the batch work on a slot of their own and store nothing.
+// Lane-parallel Fq12: EIGHTEEN lanes per element (r5; round 3 had six).  The one-thread kernels above give a proof (or a
+// pair) ONE thread: a verification is then a bundle of serial chains, and what it costs is the length of the chain.
+// Round 3 put the six Fq2 coefficients of an element (basis 1, w, ..., w^5 over Fq2, w^6 = xi; the tower's c0.cj sits at
+// w^(2j), c1.cj at w^(2j+1)) on six lanes: a product was 6 Fq2 products in a row per lane instead of 18.  An Fq2 product is
+// itself three Fq products (Karatsuba: x0 y0, x1 y1, (x0 + x1)(y0 + y1)), so each coefficient now takes THREE lanes and a lane
+// carries ONE Fq value, its VIEW of the coefficient x = x0 + x1 u:
+//     s = 0: x0        s = 1: x1        s = 2: x0 + x1
+// Every linear map of x acts on all three views alike (add, sub, neg, dbl, conjugation of the Fq12, selects), and a product
+// is: every lane multiplies ITS views of the operands (6 Fq products per lane for a full Fq12 product - one per term of the
+// convolution - instead of 18), the three partial sums P0, P1, P2 of a coefficient meet in LDS, and each lane forms its view
+// of the result from them (lo = the terms with i + j = k, hi = the terms that wrap and take the factor xi = 1 + u):
+//     view 0 = (P0 - P1)lo        + (2 P0 - P2)hi          [Re(lo) + Re(hi) - Im(hi)]
+//     view 1 = (P2 - P0 - P1)lo   + (P2 - 2 P1)hi          [Im(lo) + Re(hi) + Im(hi)]
+//     view 2 = (P2 - 2 P1)lo      + (2 P0 - 2 P1)hi        [their sum]
+// Chains are 2.8x shorter: product 18 -> 6 Fq products in a row, square 12 -> 4, line product 13 -> 5, cyclotomic square 6 -> 2.
+// A wave holds three elements (54 lanes); the ten spare lanes take every barrier on a slot of their own and store nothing.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t WIDE_LANES = 6, WIDE_GROUPS = 10, WIDE_THREADS = 64, WIDE_SLOTS = 11;
-struct WideLds {
-    F2 xa[WIDE_SLOTS][WIDE_LANES];
-    F2 xb[WIDE_SLOTS][WIDE_LANES];
-    uint32_t flag[WIDE_SLOTS];
+constexpr uint32_t W3_LANES = 18, W3_GROUPS = 3, W3_THREADS = 64, W3_SLOTS = 4;
+struct W3Lds {
+    Fq32 xa[W3_SLOTS][6][3];    // operand a / the element itself: [coefficient][view]
+    Fq32 xb[W3_SLOTS][6][3];    // operand b / intermediate values
+    Fq32 plo[W3_SLOTS][6][3];   // partial sums of the terms that do not wrap
+    Fq32 phi[W3_SLOTS][6][3];   // ... and of those that take the factor xi
+    uint32_t flag[W3_SLOTS];
 };
-struct Wide {
-    F2* xa;          // this element's six exchange slots (operand a / the element itself)
-    F2* xb;          // operand b / intermediate values
+struct W3 {
+    Fq32 (*xa)[3];
+    Fq32 (*xb)[3];
+    Fq32 (*plo)[3];
+    Fq32 (*phi)[3];
     uint32_t* flag;
-    uint32_t i;      // the coefficient this lane owns
+    uint32_t i, s;   // the coefficient and the view this lane holds
 };
-ZK_DI Wide wide_of(WideLds& l, uint32_t tid) {
-    const uint32_t g = tid / WIDE_LANES;
-    return Wide{l.xa[g], l.xb[g], &l.flag[g], tid % WIDE_LANES};
+ZK_DI W3 w3_of(W3Lds& l, uint32_t tid) {
+    const uint32_t g = tid / W3_LANES < W3_GROUPS ? tid / W3_LANES : W3_GROUPS;
+    const uint32_t r = tid - g * W3_LANES;   // the spare lanes: 0 .. 9, distinct (coefficient, view) pairs of slot 3
+    return W3{l.xa[g], l.xb[g], l.plo[g], l.phi[g], &l.flag[g], (r / 3) % 6, r % 3};
 }
-ZK_DI F2 f2_sel(bool c, const F2& a, const F2& b) {
-    F2 r;
+ZK_DI Fq32 fq_sel(bool c, const Fq32& a, const Fq32& b) {
+    Fq32 r;
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
-        r.c0.l[k] = c ? a.c0.l[k] : b.c0.l[k];
-        r.c1.l[k] = c ? a.c1.l[k] : b.c1.l[k];
+    for (int k = 0; k < 12; k++) r.l[k] = c ? a.l[k] : b.l[k];
+    return r;
+}
+ZK_DI Fq32 w3_one(const W3& w) { return fq_sel(w.i == 0 && w.s != 1, Fq32::one(), Fq32::zero()); }   // views of 1: (1, 0, 1)
+// this lane's view of an Fq2 in memory (24 words: c0 | c1) / of an Fq12's coefficient
+ZK_DI Fq32 w3_ld(const uint32_t* p, uint32_t s) {
+    const Fq32 x = fq_ld(p + (s == 1 ? 12 : 0));
+    return s == 2 ? add(x, fq_ld(p + 12)) : x;
+}
+ZK_DI const F2* f12_coef(const F12* f, uint32_t i) { return reinterpret_cast<const F2*>(f) + (i & 1u) * 3 + (i >> 1); }
+ZK_DI F2* f12_coef(F12* f, uint32_t i) { return reinterpret_cast<F2*>(f) + (i & 1u) * 3 + (i >> 1); }
+ZK_DI Fq32 w3_ld12(const W3& w, const F12* f) { return w3_ld(reinterpret_cast<const uint32_t*>(f12_coef(f, w.i)), w.s); }
+ZK_DI void w3_st12(const W3& w, F12* f, const Fq32& v) {
+    if (w.s < 2) fq_st(reinterpret_cast<uint32_t*>(f12_coef(f, w.i)) + 12 * w.s, v);
+}
+// the lane's view of the result from the partial sums of its coefficient (table above); with_hi is uniform
+ZK_DI Fq32 w3_combine(const W3& w, bool with_hi) {
+    const uint32_t s = w.s;
+    const Fq32(&lo)[3] = w.plo[w.i];
+    Fq32 r = sub(lo[s == 0 ? 0 : 2], lo[s == 1 ? 0 : 1]);
+    r = sub(r, fq_sel(s == 0, Fq32::zero(), lo[1]));
+    if (with_hi) {
+        const Fq32(&hi)[3] = w.phi[w.i];
+        Fq32 y1 = hi[s == 1 ? 2 : 0], y2 = hi[s == 0 ? 2 : 1];
+        y1 = fq_sel(s != 1, dbl(y1), y1);
+        y2 = fq_sel(s != 0, dbl(y2), y2);
+        r = add(r, sub(y1, y2));
     }
     return r;
 }
 // a * b
-ZK_DI F2 wide_mul(const Wide& w, const F2& a, const F2& b) {
-    w.xa[w.i] = a;
-    w.xb[w.i] = b;
+ZK_DI Fq32 w3_mul(const W3& w, const Fq32& a, const Fq32& b) {
+    w.xa[w.i][w.s] = a;
+    w.xb[w.i][w.s] = b;
     __syncthreads();
-    F2 lo = F2::zero(), hi = F2::zero();
+    Fq32 lo = Fq32::zero(), hi = Fq32::zero();
 #pragma unroll 1
-    for (uint32_t j = 0; j < WIDE_LANES; j++) {
+    for (uint32_t j = 0; j < 6; j++) {
         const bool wrap = j > w.i;
-        const F2 t = f2_mul(w.xa[j], w.xb[wrap ? w.i + WIDE_LANES - j : w.i - j]);
-        lo = f2_sel(wrap, lo, add(lo, t));
-        hi = f2_sel(wrap, add(hi, t), hi);
+        const Fq32 t = mul(w.xa[j][w.s], w.xb[wrap ? w.i + 6 - j : w.i - j][w.s]);
+        lo = fq_sel(wrap, lo, add(lo, t));
+        hi = fq_sel(wrap, add(hi, t), hi);
     }
+    w.plo[w.i][w.s] = lo;
+    w.phi[w.i][w.s] = hi;
     __syncthreads();
-    return add(lo, f2_mul_xi(hi));
+    return w3_combine(w, true);
 }
 // a^2: the unordered pairs (j, j') with j + j' = k (mod 6); code = j | j' << 3 | doubled << 6 | wrapped << 7 | used << 8
-ZK_DI F2 wide_sqr(const Wide& w, const F2& a) {
+ZK_DI Fq32 w3_sqr(const W3& w, const Fq32& a) {
     constexpr uint16_t T[6][4] = {
         {0x100 | 0 | 0 << 3, 0x1c0 | 1 | 5 << 3, 0x1c0 | 2 | 4 << 3, 0x180 | 3 | 3 << 3},
         {0x140 | 0 | 1 << 3, 0x1c0 | 2 | 5 << 3, 0x1c0 | 3 | 4 << 3, 0},
@@ -571,92 +606,297 @@ ZK_DI F2 wide_sqr(const Wide& w, const F2& a) {
         {0x140 | 0 | 4 << 3, 0x140 | 1 | 3 << 3, 0x100 | 2 | 2 << 3, 0x180 | 5 | 5 << 3},
         {0x140 | 0 | 5 << 3, 0x140 | 1 | 4 << 3, 0x140 | 2 | 3 << 3, 0},
     };
-    w.xa[w.i] = a;
+    w.xa[w.i][w.s] = a;
     __syncthreads();
-    F2 lo = F2::zero(), hi = F2::zero();
+    Fq32 lo = Fq32::zero(), hi = Fq32::zero();
 #pragma unroll 1
-    for (uint32_t s = 0; s < 4; s++) {
-        const uint32_t code = T[w.i][s];
-        F2 t = f2_mul(w.xa[code & 7u], w.xa[(code >> 3) & 7u]);
-        t = f2_sel((code & 0x40u) != 0, f2_dbl(t), t);
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t code = T[w.i][k];
+        Fq32 t = mul(w.xa[code & 7u][w.s], w.xa[(code >> 3) & 7u][w.s]);
+        t = fq_sel((code & 0x40u) != 0, dbl(t), t);
         const bool used = (code & 0x100u) != 0, wrap = (code & 0x80u) != 0;
-        lo = f2_sel(used && !wrap, add(lo, t), lo);
-        hi = f2_sel(used && wrap, add(hi, t), hi);
+        lo = fq_sel(used && !wrap, add(lo, t), lo);
+        hi = fq_sel(used && wrap, add(hi, t), hi);
     }
+    w.plo[w.i][w.s] = lo;
+    w.phi[w.i][w.s] = hi;
     __syncthreads();
-    return add(lo, f2_mul_xi(hi));
+    return w3_combine(w, true);
 }
-// f * (l0 + l1 w^2 + l4 w^3): the line of the Miller loop (constant term at 1, b x_P at v = w^2, a y_P at v w = w^3)
-ZK_DI F2 wide_mul_line(const Wide& w, const F2& f, const F2& l0, const F2& l1, const F2& l4) {
-    w.xa[w.i] = f;
+// f * (l0 + l1 w^2 + l4 w^3): the line of the Miller loop (constant term at 1, b x_P at v = w^2, a y_P at v w = w^3);
+// l0, l1, l4: this lane's views of the three Fq2 coefficients
+ZK_DI Fq32 w3_mul_line(const W3& w, const Fq32& f, const Fq32& l0, const Fq32& l1, const Fq32& l4) {
+    w.xa[w.i][w.s] = f;
     __syncthreads();
     const uint32_t i = w.i;
-    F2 r = f2_mul(f, l0);
-    const F2 t1 = f2_mul(w.xa[i >= 2 ? i - 2 : i + 4], l1), t4 = f2_mul(w.xa[i >= 3 ? i - 3 : i + 3], l4);
-    r = add(r, f2_sel(i >= 2, t1, f2_mul_xi(t1)));
-    r = add(r, f2_sel(i >= 3, t4, f2_mul_xi(t4)));
+    const Fq32 t0 = mul(f, l0);
+    const Fq32 t1 = mul(w.xa[i >= 2 ? i - 2 : i + 4][w.s], l1), t4 = mul(w.xa[i >= 3 ? i - 3 : i + 3][w.s], l4);
+    const Fq32 z = Fq32::zero();
+    w.plo[i][w.s] = add(add(t0, fq_sel(i >= 2, t1, z)), fq_sel(i >= 3, t4, z));
+    w.phi[i][w.s] = add(fq_sel(i >= 2, z, t1), fq_sel(i >= 3, z, t4));
     __syncthreads();
-    return r;
+    return w3_combine(w, true);
 }
-// a^2 in the cyclotomic subgroup (f12_cyc_sqr): the Fq4 pairs are (w^i, w^(i+3)); lane i < 3 computes t0 = a^2 + xi b^2 of
-// its pair, lane i + 3 computes t1 = 2 a b, and the new coefficients are 3 t -+ 2 z with the pairs cross-wired as there
-ZK_DI F2 wide_cyc_sqr(const Wide& w, const F2& z) {
-    const uint32_t i = w.i;
+// xi * x from the three views of x: (x0 - x1, x0 + x1, 2 x0)
+ZK_DI Fq32 w3_xi_view(const Fq32 (&v)[3], uint32_t s) {
+    return s == 0 ? sub(v[0], v[1]) : s == 1 ? v[2] : dbl(v[0]);
+}
+// a^2 in the cyclotomic subgroup (f12_cyc_sqr): the Fq4 pairs are (w^i, w^(i+3)); the lanes of coefficient i < 3 compute
+// t0 = a^2 + xi b^2 of their pair, those of i + 3 compute t1 = 2 a b, and the new coefficients are 3 t -+ 2 z with the pairs
+// cross-wired as there
+ZK_DI Fq32 w3_cyc_sqr(const W3& w, const Fq32& z) {
+    const uint32_t i = w.i, s = w.s;
     const bool low = i < 3;
-    w.xa[i] = z;
+    w.xa[i][s] = z;
     __syncthreads();
-    const F2 a = w.xa[low ? i : i - 3], b = w.xa[low ? i + 3 : i];
-    const F2 m1 = f2_mul(a, low ? a : b), m2 = f2_mul(b, b);
-    w.xb[i] = f2_sel(low, add(m1, f2_mul_xi(m2)), f2_dbl(m1));
+    const Fq32 a = w.xa[low ? i : i - 3][s], b = w.xa[low ? i + 3 : i][s];
+    const Fq32 m1 = mul(a, low ? a : b), m2 = mul(b, b);
+    w.plo[i][s] = fq_sel(low, m1, dbl(m1));
+    w.phi[i][s] = fq_sel(low, m2, Fq32::zero());
+    __syncthreads();
+    w.xb[i][s] = w3_combine(w, true);
     __syncthreads();
     constexpr uint32_t SRC[6] = {0, 5, 1, 3, 2, 4};
-    F2 t = w.xb[SRC[i]];
-    t = f2_sel(i == 1, f2_mul_xi(t), t);
-    const F2 d = f2_sel((i & 1u) != 0, add(t, z), sub(t, z));
-    __syncthreads();
-    return add(f2_dbl(d), t);                                      // 3 t +- 2 z = 2 (t +- z) + t
+    const Fq32(&src)[3] = w.xb[SRC[i]];
+    const Fq32 t = i == 1 ? w3_xi_view(src, s) : src[s];
+    __syncthreads();                                               // (the next operation may write xb at once)
+    const Fq32 d = (i & 1u) ? add(t, z) : sub(t, z);
+    return add(dbl(d), t);                                         // 3 t +- 2 z = 2 (t +- z) + t
 }
-ZK_DI F2 wide_conj(const Wide& w, const F2& a) { return f2_sel((w.i & 1u) != 0, neg(a), a); }   // a^(q^6): w -> -w
-ZK_DI F2 wide_frob(const Wide& w, const F2& a, int k, const uint32_t* __restrict__ gam) {       // a^(q^k), k = 1, 2
-    const F2 x = (k & 1) ? f2_conj(a) : a;
-    const F2 y = f2_mul(x, f2_ld(gam + ((size_t)(k - 1) * 6 + w.i) * 24));
-    return f2_sel(w.i == 0, x, y);
-}
-// tower element <-> lanes: the coefficient of w^i is F12's (i & 1 ? c1 : c0).c(i >> 1)
-ZK_DI const F2* f12_coef(const F12* f, uint32_t i) { return reinterpret_cast<const F2*>(f) + (i & 1u) * 3 + (i >> 1); }
-ZK_DI F2* f12_coef(F12* f, uint32_t i) { return reinterpret_cast<F2*>(f) + (i & 1u) * 3 + (i >> 1); }
-// 1 / a: every lane gathers the element and inverts it (the chain is the Fq inversion inside; six copies cost no time)
-ZK_DI F2 wide_inv(const Wide& w, const F2& a) {
-    w.xa[w.i] = a;
+ZK_DI Fq32 w3_conj(const W3& w, const Fq32& a) { return (w.i & 1u) ? neg(a) : a; }   // a^(q^6): w -> -w
+// a^(q^k), k = 1, 2: conj^k of the coefficient times xi^(i (q^k - 1) / 6) - the coefficient's lanes gather it and each
+// multiplies for itself (three times per final exponentiation: not worth a split)
+ZK_DI Fq32 w3_frob(const W3& w, const Fq32& a, int k, const uint32_t* __restrict__ gam) {
+    w.xa[w.i][w.s] = a;
     __syncthreads();
-    F12 t, r;
-    for (uint32_t j = 0; j < WIDE_LANES; j++) *f12_coef(&t, j) = w.xa[j];
+    const F2 x{w.xa[w.i][0], (k & 1) ? neg(w.xa[w.i][1]) : w.xa[w.i][1]};
     __syncthreads();
-    f12_inv(r, t);
-    return *f12_coef(&r, w.i);
+    const F2 y = w.i == 0 ? x : f2_mul(x, f2_ld(gam + ((size_t)(k - 1) * 6 + w.i) * 24));
+    return w.s == 0 ? y.c0 : w.s == 1 ? y.c1 : add(y.c0, y.c1);
 }
-ZK_DI F2 wide_exp_x(const Wide& w, const F2& a) {   // f12_exp_x
-    F2 t = a;
+// 1 / a = conj(a) / N(a) over the tower: the norm to Fq6 and its inverse's numerators through the lane products (N = a0^2 -
+// v a1^2 is the even-w part of a * conj(a)), the norm to Fq2 and then to Fq, ONE inversion in Fq by the Euclidean algorithm
+// (identical on the eighteen lanes of an element: no divergence inside it; 0.1 ms against 0.9 for the Fermat chain), and
+// back.  The element's lanes gather what they need through LDS; the few Fq2 products of the Fq6 inversion are done by every
+// lane for itself.
+ZK_DI Fq32 w3_inv(const W3& w, const Fq32& a) {
+    // n = a * conj(a): its odd coefficients vanish, the even ones are the Fq6 element N = n0 + n2 v + n4 v^2
+    const Fq32 ac = w3_conj(w, a);
+    const Fq32 n = w3_mul(w, a, ac);
+    w.xb[w.i][w.s] = n;
+    __syncthreads();
+    const F2 n0{w.xb[0][0], w.xb[0][1]}, n1{w.xb[2][0], w.xb[2][1]}, n2{w.xb[4][0], w.xb[4][1]};
+    __syncthreads();
+    // f6_inv(N): A = n0^2 - xi n1 n2, B = xi n2^2 - n0 n1, C = n1^2 - n0 n2, norm = n0 A + xi (n2 B + n1 C)
+    const F2 A = sub(f2_sqr(n0), f2_mul_xi(f2_mul(n1, n2)));
+    const F2 B = sub(f2_mul_xi(f2_sqr(n2)), f2_mul(n0, n1));
+    const F2 C = sub(f2_sqr(n1), f2_mul(n0, n2));
+    const F2 nn = add(f2_mul(n0, A), f2_mul_xi(add(f2_mul(n2, B), f2_mul(n1, C))));
+    // 1 / nn in Fq2: conj(nn) / (nn0^2 + nn1^2)
+    const Fq32 d = inv_gcd(add(sqr(nn.c0), sqr(nn.c1)));
+    const F2 ni{mul(nn.c0, d), neg(mul(nn.c1, d))};
+    const F2 iA = f2_mul(A, ni), iB = f2_mul(B, ni), iC = f2_mul(C, ni);   // N^-1 = iA + iB v + iC v^2 = iA + iB w^2 + iC w^4
+    // views of N^-1 as an Fq12 (odd coefficients zero), then a^-1 = conj(a) * N^-1
+    const F2 z = F2::zero();
+    const F2 c = w.i == 0 ? iA : w.i == 2 ? iB : w.i == 4 ? iC : z;
+    const Fq32 nv = w.s == 0 ? c.c0 : w.s == 1 ? c.c1 : add(c.c0, c.c1);
+    return w3_mul(w, ac, nv);
+}
+ZK_DI Fq32 w3_exp_x(const W3& w, const Fq32& a) {   // f12_exp_x
+    Fq32 t = a;
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
-        t = wide_cyc_sqr(w, t);
-        if ((ZK_BLS_X_ABS >> b) & 1ull) t = wide_mul(w, t, a);
+        t = w3_cyc_sqr(w, t);
+        if ((ZK_BLS_X_ABS >> b) & 1ull) t = w3_mul(w, t, a);
     }
-    return wide_conj(w, t);
+    return w3_conj(w, t);
 }
 
-// k_miller_loop with six lanes per (item, pair).  Every pair reads PREPARED line coefficients: prep0 [n][68][72] words =
-// the triples of the items' own G2 points (k_g2_prepare over the decoded B of the batch), prep1 / prep2 the key's.
-// Grid (ceil(n / 10), 3 pairs), 64 threads.  f_out[pair * n + i] as k_miller_loop.
-static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+// ---- k_g2_prepare with THREE lanes per point (r5): the same views, one level down.  The line preparation of a batch's B
+// points is a chain of 63 doubling and 5 addition steps of Fq2 arithmetic per point (4.0 ms for any batch up to ~2000 points:
+// the second-longest stage of a verification); an Fq2 product or square is ONE Fq product per lane here, the three
+// partials meet in LDS, and the independent products of a step share one exchange: 11 Fq products in a row per doubling
+// step instead of 25.  21 points per wave; the exchange area is double-buffered, one barrier per batch of products.
+constexpr uint32_t TL_POINTS = 21, TL_BATCH = 5;
+struct TlLds {
+    Fq32 ex[2][TL_POINTS + 1][TL_BATCH][3];
+    uint32_t flag[TL_POINTS + 1];
+};
+struct Tl {
+    TlLds* l;
+    uint32_t g, s, par;
+};
+// the partial product of slot k of the current batch: this lane's views of the two factors
+ZK_DI void tl_put(const Tl& t, int k, const Fq32& a, const Fq32& b) { t.l->ex[t.par][t.g][k][t.s] = mul(a, b); }
+// ... and this lane's view of that product, once the barrier behind the batch has been taken
+ZK_DI Fq32 tl_get(const Tl& t, int k) {
+    const Fq32(&p)[3] = t.l->ex[t.par][t.g][k];
+    const uint32_t s = t.s;
+    Fq32 r = sub(p[s == 0 ? 0 : 2], p[s == 1 ? 0 : 1]);        // view 0: p0 - p1, view 1: p2 - p0 - p1, view 2: p2 - 2 p1
+    return sub(r, fq_sel(s == 0, Fq32::zero(), p[1]));
+}
+#define TL_SYNC(t) do { __syncthreads(); } while (0)
+#define TL_NEXT(t) do { (t).par ^= 1u; } while (0)
+static __global__ void __launch_bounds__(64, 1)
+k_g2_prepare_tri(const uint32_t* __restrict__ q, uint32_t* __restrict__ out, uint32_t n, uint32_t* st) {
+    ZK_SHARED TlLds lds;
+    const uint32_t tid = threadIdx.x;
+    Tl t{&lds, tid / 3 < TL_POINTS ? tid / 3 : TL_POINTS, tid % 3, 0u};
+    const uint32_t item = blockIdx.x * TL_POINTS + tid / 3;
+    const bool real = tid < 3 * TL_POINTS && item < n && !(st && st[item] != 0);   // nothing was decoded: the lanes run along on point 0
+    const uint32_t it = real ? item : 0;
+    const uint32_t s = t.s;
+    const Fq32 qx = w3_ld(q + (size_t)it * 48, s), qy = w3_ld(q + (size_t)it * 48 + 24, s);
+    Fq32 X = qx, Y = qy, Z = fq_sel(s != 1, Fq32::one(), Fq32::zero());
+    uint32_t* o = out + (size_t)it * PAIRING_NCOEF * 72;
+    int idx = 0;
+    auto store = [&](const Fq32& a, const Fq32& b, const Fq32& c) {   // coef_st: a | b | c, 24 words each (c0 | c1)
+        if (real && s < 2) {
+            uint32_t* p = o + (size_t)idx * 72 + 12 * s;
+            fq_st(p, a);
+            fq_st(p + 24, b);
+            fq_st(p + 48, c);
+        }
+        idx++;
+    };
+    // g2_double_step in views
+    auto dbl_step = [&]() {
+        tl_put(t, 0, X, X);                                  // A = X^2
+        tl_put(t, 1, Y, Y);                                  // B = Y^2
+        tl_put(t, 2, Z, Z);                                  // zz
+        const Fq32 yz = add(Y, Z);
+        tl_put(t, 3, yz, yz);                                // (Y + Z)^2
+        TL_SYNC(t);
+        const Fq32 A = tl_get(t, 0), B = tl_get(t, 1), zz = tl_get(t, 2), yz2 = tl_get(t, 3);
+        TL_NEXT(t);
+        const Fq32 E = add(dbl(A), A), z3 = sub(sub(yz2, B), zz), xb = add(X, B), xe = add(X, E);
+        tl_put(t, 0, B, B);                                  // C = B^2
+        tl_put(t, 1, xb, xb);                                // (X + B)^2
+        tl_put(t, 2, E, E);                                  // G = E^2
+        tl_put(t, 3, xe, xe);                                // (X + E)^2
+        tl_put(t, 4, z3, zz);                                // z3 zz
+        TL_SYNC(t);
+        const Fq32 Cc = tl_get(t, 0), xb2 = tl_get(t, 1), G = tl_get(t, 2), xe2 = tl_get(t, 3), z3zz = tl_get(t, 4);
+        TL_NEXT(t);
+        const Fq32 D = dbl(sub(sub(xb2, A), Cc));           // 4 X Y^2
+        const Fq32 x3 = sub(G, dbl(D));
+        tl_put(t, 0, sub(D, x3), E);
+        tl_put(t, 1, E, zz);
+        TL_SYNC(t);
+        const Fq32 m = tl_get(t, 0), ezz = tl_get(t, 1);
+        TL_NEXT(t);
+        const Fq32 y3 = sub(m, dbl(dbl(dbl(Cc))));
+        store(dbl(z3zz), neg(dbl(ezz)), sub(sub(sub(xe2, A), G), dbl(dbl(B))));
+        X = x3;
+        Y = y3;
+        Z = z3;
+    };
+    // qy^2, used by every addition step
+    tl_put(t, 0, qy, qy);
+    TL_SYNC(t);
+    const Fq32 yy = tl_get(t, 0);
+    TL_NEXT(t);
+    // g2_add_step in views
+    auto add_step = [&]() {
+        const Fq32 qz = add(qy, Z);
+        tl_put(t, 0, Z, Z);                                  // zz
+        tl_put(t, 1, qz, qz);                                // (qy + Z)^2
+        TL_SYNC(t);
+        const Fq32 zz = tl_get(t, 0), qz2 = tl_get(t, 1);
+        TL_NEXT(t);
+        tl_put(t, 0, zz, qx);                                // u2
+        tl_put(t, 1, sub(sub(qz2, yy), zz), zz);             // 2 y_Q Z^3
+        TL_SYNC(t);
+        const Fq32 u2 = tl_get(t, 0), s2x2 = tl_get(t, 1);
+        TL_NEXT(t);
+        const Fq32 H = sub(u2, X), r2 = sub(s2x2, dbl(Y)), zh = add(Z, H);
+        tl_put(t, 0, H, H);                                  // HH
+        tl_put(t, 1, r2, qx);                                // rq
+        tl_put(t, 2, r2, r2);
+        tl_put(t, 3, zh, zh);                                // (Z + H)^2
+        TL_SYNC(t);
+        const Fq32 HH = tl_get(t, 0), rq = tl_get(t, 1), r22 = tl_get(t, 2), zh2 = tl_get(t, 3);
+        TL_NEXT(t);
+        const Fq32 H4 = dbl(dbl(HH)), z3 = sub(sub(zh2, zz), HH), qz3 = add(qy, z3);
+        tl_put(t, 0, H4, H);                                 // 4 H^3
+        tl_put(t, 1, H4, X);                                 // V
+        tl_put(t, 2, qz3, qz3);                              // (qy + z3)^2
+        tl_put(t, 3, z3, z3);
+        TL_SYNC(t);
+        const Fq32 H3x4 = tl_get(t, 0), V = tl_get(t, 1), qz32 = tl_get(t, 2), z32 = tl_get(t, 3);
+        TL_NEXT(t);
+        const Fq32 x3 = sub(sub(r22, H3x4), dbl(V));
+        tl_put(t, 0, sub(V, x3), r2);
+        tl_put(t, 1, Y, H3x4);
+        TL_SYNC(t);
+        const Fq32 m = tl_get(t, 0), yh = tl_get(t, 1);
+        TL_NEXT(t);
+        const Fq32 y3 = sub(m, dbl(yh));
+        const Fq32 yz2 = sub(sub(qz32, yy), z32);            // 2 y_Q Z3
+        store(dbl(z3), neg(dbl(r2)), sub(dbl(rq), yz2));
+        X = x3;
+        Y = y3;
+        Z = z3;
+    };
+#pragma unroll 1
+    for (int b = 61; b >= 0; b--) {
+        dbl_step();
+        if ((PAIRING_LOOP >> b) & 1ull) add_step();
+    }
+    dbl_step();
+    if (st) {
+        // psi(Q) == [x] Q = -[|x|] Q on the last running point (g2_in_subgroup): X == px Z^2, Y == -py Z^3, Z != 0
+        const uint32_t cx1[12] = ZK_G2_PSI_CX1_MONT_32, cy0[12] = ZK_G2_PSI_CY0_MONT_32, cy1[12] = ZK_G2_PSI_CY1_MONT_32;
+        // views of the constants (0 + cx1 u) and (cy0 + cy1 u), and of the conjugates of qx, qy: (x0, -x1, x0 - x1)
+        const Fq32 kx = s == 0 ? Fq32::zero() : fq32_const(cx1);
+        const Fq32 ky = s == 0 ? fq32_const(cy0) : s == 1 ? fq32_const(cy1) : add(fq32_const(cy0), fq32_const(cy1));
+        t.l->ex[t.par][t.g][0][s] = qx;
+        t.l->ex[t.par][t.g][1][s] = qy;
+        TL_SYNC(t);
+        const Fq32(&vx)[3] = t.l->ex[t.par][t.g][0];
+        const Fq32(&vy)[3] = t.l->ex[t.par][t.g][1];
+        const Fq32 cqx = s == 0 ? vx[0] : s == 1 ? neg(vx[1]) : sub(vx[0], vx[1]);
+        const Fq32 cqy = s == 0 ? vy[0] : s == 1 ? neg(vy[1]) : sub(vy[0], vy[1]);
+        TL_NEXT(t);
+        tl_put(t, 0, kx, cqx);                               // px
+        tl_put(t, 1, ky, cqy);                               // py
+        tl_put(t, 2, Z, Z);                                  // zz
+        TL_SYNC(t);
+        const Fq32 px = tl_get(t, 0), py = tl_get(t, 1), zz = tl_get(t, 2);
+        TL_NEXT(t);
+        tl_put(t, 0, px, zz);
+        tl_put(t, 1, zz, Z);
+        TL_SYNC(t);
+        const Fq32 pxzz = tl_get(t, 0), zzz = tl_get(t, 1);
+        TL_NEXT(t);
+        tl_put(t, 0, py, zzz);
+        if (tid % 3 == 0) t.l->flag[t.g] = 1u;
+        TL_SYNC(t);
+        const Fq32 pyzzz = tl_get(t, 0);
+        TL_NEXT(t);
+        // every lane looks at its view; Z != 0 <=> view 0 or view 1 is not zero
+        if (!(X == pxzz) || !(Y == neg(pyzzz))) t.l->flag[t.g] = 0u;
+        t.l->ex[t.par][t.g][0][s] = Z;
+        TL_SYNC(t);
+        const bool z_zero = t.l->ex[t.par][t.g][0][0].is_zero() && t.l->ex[t.par][t.g][0][1].is_zero();
+        if (real && s == 0 && (z_zero || !t.l->flag[t.g])) st[item] = 2;
+    }
+}
+#undef TL_SYNC
+#undef TL_NEXT
+
+// k_miller_loop with eighteen lanes per (item, pair).  Every pair reads PREPARED line coefficients: prep0 [n][68][72] words
+// = the triples of the items' own G2 points (k_g2_prepare over the decoded B of the batch), prep1 / prep2 the key's.
+// Grid (ceil(n / 3), 3 pairs), 64 threads.  f_out[pair * n + i] as k_miller_loop.
+static __global__ void __launch_bounds__(W3_THREADS, 1)
 k_miller_loop_wide(const uint32_t* __restrict__ p0, const uint32_t* __restrict__ prep0, const uint32_t* __restrict__ p1,
                    const uint32_t* __restrict__ prep1, const uint32_t* __restrict__ p2, const uint32_t* __restrict__ prep2,
                    const uint32_t* __restrict__ skip, F12* __restrict__ f_out, uint32_t n) {
-    ZK_SHARED WideLds lds;
+    ZK_SHARED W3Lds lds;
     const uint32_t tid = threadIdx.x, pair = blockIdx.y;
-    const Wide w = wide_of(lds, tid);
-    const uint32_t item = blockIdx.x * WIDE_GROUPS + tid / WIDE_LANES;
-    const bool real = tid < WIDE_GROUPS * WIDE_LANES && item < n;
+    const W3 w = w3_of(lds, tid);
+    const uint32_t item = blockIdx.x * W3_GROUPS + tid / W3_LANES;
+    const bool real = tid < W3_GROUPS * W3_LANES && item < n;
     const uint32_t it = real ? item : 0;
     const uint32_t* pp = pair == 0 ? p0 : pair == 1 ? p1 : p2;
     const uint32_t* prep = pair == 0 ? (prep0 ? prep0 + (size_t)it * PAIRING_NCOEF * 72 : nullptr) : pair == 1 ? prep1 : prep2;
@@ -665,56 +905,55 @@ k_miller_loop_wide(const uint32_t* __restrict__ p0, const uint32_t* __restrict__
     if (!coef) coef = prep2;
     const uint32_t* pq = pp ? pp : (p0 ? p0 : p1);
     const Fq32 px = fq_ld(pq + (size_t)it * 24), py = fq_ld(pq + (size_t)it * 24 + 12);
-    F2 f = f2_sel(w.i == 0, F2::one(), F2::zero());
+    Fq32 f = w3_one(w);
     int idx = 0;
+    // one line: f <- f * (c + b x_P w^2 + a y_P w^3), the coefficient triple (a, b, c) at coef + 72 idx
+    auto line = [&](Fq32 v) {
+        const uint32_t* l = coef + (size_t)(idx++) * 72;
+        return w3_mul_line(w, v, w3_ld(l + 48, w.s), mul(w3_ld(l + 24, w.s), px), mul(w3_ld(l, w.s), py));
+    };
 #pragma unroll 1
     for (int b = 61; b >= -1; b--) {
-        {
-            const LineCoef l = coef_ld(coef + (idx++) * 72);
-            f = wide_mul_line(w, f, l.c, f2_mul_fq(l.b, px), f2_mul_fq(l.a, py));
-        }
+        f = line(f);
         if (b < 0) break;
-        if ((PAIRING_LOOP >> b) & 1ull) {
-            const LineCoef l = coef_ld(coef + (idx++) * 72);
-            f = wide_mul_line(w, f, l.c, f2_mul_fq(l.b, px), f2_mul_fq(l.a, py));
-        }
-        f = wide_sqr(w, f);
+        if ((PAIRING_LOOP >> b) & 1ull) f = line(f);
+        f = w3_sqr(w, f);
     }
-    f = wide_conj(w, f);   // the curve parameter is negative
-    if (!on) f = f2_sel(w.i == 0, F2::one(), F2::zero());
-    if (real) *f12_coef(&f_out[(size_t)pair * n + item], w.i) = f;
+    f = w3_conj(w, f);   // the curve parameter is negative
+    if (!on) f = w3_one(w);
+    if (real) w3_st12(w, &f_out[(size_t)pair * n + item], f);
 }
 
-// k_final_exp with six lanes per item; same arguments, grid ceil(n / 10), 64 threads
-static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+// k_final_exp with eighteen lanes per item; same arguments, grid ceil(n / 3), 64 threads
+static __global__ void __launch_bounds__(W3_THREADS, 1)
 k_final_exp_wide(const F12* __restrict__ f_in, const uint32_t* __restrict__ gam, const F12* __restrict__ want,
                  const uint32_t* __restrict__ valid, uint32_t* __restrict__ ok, F12* value_out, uint32_t n) {
-    ZK_SHARED WideLds lds;
+    ZK_SHARED W3Lds lds;
     const uint32_t tid = threadIdx.x;
-    const Wide w = wide_of(lds, tid);
-    const uint32_t item = blockIdx.x * WIDE_GROUPS + tid / WIDE_LANES;
-    const bool real = tid < WIDE_GROUPS * WIDE_LANES && item < n;
+    const W3 w = w3_of(lds, tid);
+    const uint32_t item = blockIdx.x * W3_GROUPS + tid / W3_LANES;
+    const bool real = tid < W3_GROUPS * W3_LANES && item < n;
     const uint32_t it = real ? item : 0;
-    F2 f = *f12_coef(&f_in[it], w.i);
-    f = wide_mul(w, f, *f12_coef(&f_in[(size_t)n + it], w.i));
-    f = wide_mul(w, f, *f12_coef(&f_in[(size_t)2 * n + it], w.i));
+    Fq32 f = w3_ld12(w, &f_in[it]);
+    f = w3_mul(w, f, w3_ld12(w, &f_in[(size_t)n + it]));
+    f = w3_mul(w, f, w3_ld12(w, &f_in[(size_t)2 * n + it]));
     // easy part: f^((q^6 - 1)(q^2 + 1))
-    F2 t = wide_mul(w, wide_conj(w, f), wide_inv(w, f));
-    f = wide_mul(w, wide_frob(w, t, 2, gam), t);
+    Fq32 t = w3_mul(w, w3_conj(w, f), w3_inv(w, f));
+    f = w3_mul(w, w3_frob(w, t, 2, gam), t);
     // hard part (k_final_exp): a = f^((x-1)^2), b = a^(x+q), c = b^(x^2+q^2-1), c * f^3
-    F2 a = wide_mul(w, wide_exp_x(w, f), wide_conj(w, f));
-    a = wide_mul(w, wide_exp_x(w, a), wide_conj(w, a));
-    const F2 b = wide_mul(w, wide_exp_x(w, a), wide_frob(w, a, 1, gam));
-    F2 c = wide_mul(w, wide_exp_x(w, wide_exp_x(w, b)), wide_frob(w, b, 2, gam));
-    c = wide_mul(w, c, wide_conj(w, b));
-    c = wide_mul(w, c, wide_mul(w, wide_sqr(w, f), f));
-    if (real && value_out) *f12_coef(&value_out[item], w.i) = c;
-    // the comparison: every lane looks at its coefficient
-    if (w.i == 0) *w.flag = 1u;
+    Fq32 a = w3_mul(w, w3_exp_x(w, f), w3_conj(w, f));
+    a = w3_mul(w, w3_exp_x(w, a), w3_conj(w, a));
+    const Fq32 b = w3_mul(w, w3_exp_x(w, a), w3_frob(w, a, 1, gam));
+    Fq32 c = w3_mul(w, w3_exp_x(w, w3_exp_x(w, b)), w3_frob(w, b, 2, gam));
+    c = w3_mul(w, c, w3_conj(w, b));
+    c = w3_mul(w, c, w3_mul(w, w3_sqr(w, f), f));
+    if (real && value_out) w3_st12(w, &value_out[item], c);
+    // the comparison: every lane looks at its view
+    if (w.i == 0 && w.s == 0) *w.flag = 1u;
     __syncthreads();
-    if (want && !(c == *f12_coef(want, w.i))) *w.flag = 0u;
+    if (want && !(c == w3_ld12(w, want))) *w.flag = 0u;
     __syncthreads();
-    if (real && ok && w.i == 0) ok[item] = (valid && !valid[item]) ? 0u : *w.flag;
+    if (real && ok && w.i == 0 && w.s == 0) ok[item] = (valid && !valid[item]) ? 0u : *w.flag;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -856,30 +1095,44 @@ k_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags,
 // multiplication is the sum of the table entries at the set bits: one thread per (proof, input), ~127
 // mixed additions each, then one thread per proof sums the n_ic - 1 products, adds ic[0] and normalises.
 // ---------------------------------------------------------------------------------------------
+// (r5: four threads per (proof, input), one per 64-bit quarter of the scalar - 32 mixed additions in a row on average instead
+//  of 127 - and eight threads per proof for the sum, with the Euclidean inversion at the end: once the Miller loops and the
+//  line preparation had been shortened this branch, 3.9 ms beside them, was what a verification waited for.)
 static __global__ void __launch_bounds__(64, 2)
 k_inputs_mul(const Affine<Fq>* __restrict__ table, const uint32_t* __restrict__ scalars, XYZZ<Fq>* __restrict__ part,
              uint32_t n_ic, uint32_t n_proofs) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ni = n_ic - 1;
-    if (t >= ni * n_proofs) return;
-    const uint32_t p = t / ni, j = t % ni + 1;
+    if (t >= 4 * ni * n_proofs) return;
+    const uint32_t qd = t & 3u, u = t >> 2, p = u / ni, j = u % ni + 1;
     const uint32_t* s = scalars + ((size_t)p * ni + (j - 1)) * 8;
     XYZZ<Fq> acc = XYZZ<Fq>::inf();
-    for (uint32_t k = 0; k < 255; k++)
+    for (uint32_t k = 64 * qd; k < 64 * qd + 64 && k < 255; k++)
         if ((s[k >> 5] >> (k & 31)) & 1u) madd(acc, table[(size_t)k * n_ic + j], false);
     part[t] = acc;
 }
-// out: [n][24] words affine (x, y) in the Fq32 layout; inf[i] = 1 if the accumulator is the point at infinity
+// out: [n][24] words affine (x, y) in the Fq32 layout; inf[i] = 1 if the accumulator is the point at infinity.
+// Eight threads per proof (eight proofs per workgroup): each sums every eighth of the proof's 4 (n_ic - 1) partial products,
+// a tree in LDS adds the eight.
 static __global__ void __launch_bounds__(64, 2)
 k_inputs_sum(const Affine<Fq>* __restrict__ table, const XYZZ<Fq>* __restrict__ part, uint32_t* __restrict__ out,
              uint32_t* __restrict__ inf, uint32_t n_ic, uint32_t n_proofs) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n_proofs) return;
-    const uint32_t ni = n_ic - 1;
-    XYZZ<Fq> acc = XYZZ<Fq>::from_affine(table[0]);
-    for (uint32_t j = 0; j < ni; j++) acc = xadd(acc, part[(size_t)p * ni + j]);
+    ZK_SHARED XYZZ<Fq> sm[64];
+    const uint32_t tid = threadIdx.x, r = tid & 7u, p = blockIdx.x * 8 + (tid >> 3);
+    const uint32_t np = 4 * (n_ic - 1);
+    XYZZ<Fq> acc = XYZZ<Fq>::inf();
+    if (p < n_proofs)
+        for (uint32_t k = r; k < np; k += 8) acc = xadd(acc, part[(size_t)p * np + k]);
+    sm[tid] = acc;
+    __syncthreads();
+    for (uint32_t st = 4; st >= 1; st >>= 1) {
+        if (r < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
+        __syncthreads();
+    }
+    if (r != 0 || p >= n_proofs) return;
+    acc = xadd(XYZZ<Fq>::from_affine(table[0]), sm[tid]);
     inf[p] = acc.is_inf() ? 1u : 0u;
-    const Affine<Fq> a = to_affine(acc);
+    const Affine<Fq> a = to_affine<Fq, true>(acc);
     fld_export(a.x, out + (size_t)p * 24);
     fld_export(a.y, out + (size_t)p * 24 + 12);
 }
@@ -1023,58 +1276,58 @@ k_rlc_flags(const uint32_t* __restrict__ st_g1, const uint32_t* __restrict__ st_
         skip[i] = inf[i - n];   // an accumulator / a C sum at infinity drops out of the product (mod.rs:50-54)
     }
 }
-// out[g] = product of in[g], in[g + groups], ... (g < groups <= gridDim.x * WIDE_GROUPS), six lanes per element
-static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+// out[g] = product of in[g], in[g + groups], ... (g < groups <= gridDim.x * W3_GROUPS), eighteen lanes per element
+static __global__ void __launch_bounds__(W3_THREADS, 1)
 k_f12_prod_wide(const F12* __restrict__ in, uint32_t m, F12* __restrict__ out, uint32_t groups) {
-    ZK_SHARED WideLds lds;
+    ZK_SHARED W3Lds lds;
     const uint32_t tid = threadIdx.x;
-    const Wide w = wide_of(lds, tid);
-    const uint32_t gid = blockIdx.x * WIDE_GROUPS + tid / WIDE_LANES;
-    const bool real = tid < WIDE_GROUPS * WIDE_LANES && gid < groups;
-    const F2 one = f2_sel(w.i == 0, F2::one(), F2::zero());
-    F2 acc = one;
+    const W3 w = w3_of(lds, tid);
+    const uint32_t gid = blockIdx.x * W3_GROUPS + tid / W3_LANES;
+    const bool real = tid < W3_GROUPS * W3_LANES && gid < groups;
+    const Fq32 one = w3_one(w);
+    Fq32 acc = one;
     const uint32_t trips = (m + groups - 1) / groups;
 #pragma unroll 1
     for (uint32_t k = 0; k < trips; k++) {
         const uint32_t idx = gid + k * groups;
         const bool have = real && idx < m;
-        const F2 v = have ? *f12_coef(&in[idx], w.i) : one;
-        acc = wide_mul(w, acc, v);
+        const Fq32 v = have ? w3_ld12(w, &in[idx]) : one;
+        acc = w3_mul(w, acc, v);
     }
-    if (real) *f12_coef(&out[gid], w.i) = acc;
+    if (real) w3_st12(w, &out[gid], acc);
 }
-// out = base^e for base in the cyclotomic subgroup (e(alpha, beta)), e: nbits bits in little-endian words; one group
-static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+// out = base^e for base in the cyclotomic subgroup (e(alpha, beta)), e: nbits bits in little-endian words; one element
+static __global__ void __launch_bounds__(W3_THREADS, 1)
 k_f12_pow_wide(const F12* __restrict__ base, const uint32_t* __restrict__ e, uint32_t nbits, F12* __restrict__ out) {
-    ZK_SHARED WideLds lds;
+    ZK_SHARED W3Lds lds;
     const uint32_t tid = threadIdx.x;
-    const Wide w = wide_of(lds, tid);
-    const F2 a = *f12_coef(base, w.i);
-    F2 t = f2_sel(w.i == 0, F2::one(), F2::zero());
+    const W3 w = w3_of(lds, tid);
+    const Fq32 a = w3_ld12(w, base);
+    Fq32 t = w3_one(w);
 #pragma unroll 1
     for (int b = (int)nbits - 1; b >= 0; b--) {
-        t = wide_cyc_sqr(w, t);
-        if ((e[b >> 5] >> (b & 31)) & 1u) t = wide_mul(w, t, a);
+        t = w3_cyc_sqr(w, t);
+        if ((e[b >> 5] >> (b & 31)) & 1u) t = w3_mul(w, t, a);
     }
-    if (tid < WIDE_LANES) *f12_coef(out, w.i) = t;
+    if (tid < W3_LANES) w3_st12(w, out, t);
 }
 // out = base0^e0 * base1^e1 in one chain (both bases in the cyclotomic subgroup; e0 | e1: 4 words each, nbits <= 128)
-static __global__ void __launch_bounds__(WIDE_THREADS, 1)
+static __global__ void __launch_bounds__(W3_THREADS, 1)
 k_f12_pow2_wide(const F12* __restrict__ base0, const F12* __restrict__ base1, const uint32_t* __restrict__ e, uint32_t nbits,
                 F12* __restrict__ out) {
-    ZK_SHARED WideLds lds;
+    ZK_SHARED W3Lds lds;
     const uint32_t tid = threadIdx.x;
-    const Wide w = wide_of(lds, tid);
-    const F2 a0 = *f12_coef(base0, w.i), a1 = *f12_coef(base1, w.i);
-    const F2 a01 = wide_mul(w, a0, a1);
-    F2 t = f2_sel(w.i == 0, F2::one(), F2::zero());
+    const W3 w = w3_of(lds, tid);
+    const Fq32 a0 = w3_ld12(w, base0), a1 = w3_ld12(w, base1);
+    const Fq32 a01 = w3_mul(w, a0, a1);
+    Fq32 t = w3_one(w);
 #pragma unroll 1
     for (int b = (int)nbits - 1; b >= 0; b--) {
-        t = wide_cyc_sqr(w, t);
+        t = w3_cyc_sqr(w, t);
         const uint32_t b0 = (e[b >> 5] >> (b & 31)) & 1u, b1 = (e[4 + (b >> 5)] >> (b & 31)) & 1u;   // uniform over the block
-        if (b0 | b1) t = wide_mul(w, t, (b0 & b1) ? a01 : b0 ? a0 : a1);
+        if (b0 | b1) t = w3_mul(w, t, (b0 & b1) ? a01 : b0 ? a0 : a1);
     }
-    if (tid < WIDE_LANES) *f12_coef(out, w.i) = t;
+    if (tid < W3_LANES) w3_st12(w, out, t);
 }
 
 }  // namespace zkdev

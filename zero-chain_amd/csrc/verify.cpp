@@ -417,7 +417,7 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     ZK_TRY(V->aff_g2.ensure(n * 192));
     ZK_TRY(V->st_g1.ensure(2 * n * 4));
     ZK_TRY(V->st_g2.ensure(n * 4));
-    ZK_TRY(V->part.ensure((size_t)n * (ni ? ni : 1) * sizeof(DG1)));
+    ZK_TRY(V->part.ensure((size_t)n * (ni ? 4 * ni : 1) * sizeof(DG1)));
     ZK_TRY(V->acc.ensure(n * 96));
     ZK_TRY(V->acc_inf.ensure(n * 4));
     ZK_TRY(V->skip.ensure(n * 4));
@@ -432,8 +432,9 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
     HIP_TRY(hipStreamWaitEvent(g_stream2, g_ev_fork, 0));
     HIP_TRY(hipStreamWaitEvent(g_copy_stream, g_ev_fork, 0));
-    // six lanes per (proof, pair) and per final exponentiation (pairing.h "Lane-parallel Fq12"): the chains are 3-4x
-    // shorter; ZKAMD_VERIFY_WIDE=0 keeps one thread per pair / per proof (A/B; the key's e(alpha, beta) always takes it)
+    // eighteen lanes per (proof, pair) and per final exponentiation (pairing.h "Lane-parallel Fq12"; six in round 3): the chains
+    // are ~9x shorter than one thread's; ZKAMD_VERIFY_WIDE=0 keeps one thread per pair / per proof (A/B; the key's e(alpha,
+    // beta) always takes it)
     const char* wide_env = getenv("ZKAMD_VERIFY_WIDE");
     const bool wide = !(wide_env && atoi(wide_env) == 0);
     {
@@ -447,8 +448,9 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     if (wide) {
         ZK_TRY(V->prep_b.ensure(n * COEF_WORDS * 4));
         ProfScope ps("verify_prepare");
-        ZK_LAUNCH(zkdev::k_g2_prepare, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g2.as<uint32_t>(),
-                  V->prep_b.as<uint32_t>(), (uint32_t)n, own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>());
+        ZK_LAUNCH_SYNC(zkdev::k_g2_prepare_tri, dim3((unsigned)((n + zkdev::TL_POINTS - 1) / zkdev::TL_POINTS)), dim3(64), 0, g_stream,
+                       (const uint32_t*)V->aff_g2.as<uint32_t>(), V->prep_b.as<uint32_t>(), (uint32_t)n,
+                       own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>());
     }
     {
         ProfScope ps("verify_decode_g1", g_stream2);
@@ -460,10 +462,10 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     {
         ProfScope ps("verify_inputs", g_copy_stream);
         if (ni)
-            ZK_LAUNCH(zkdev::k_inputs_mul, dim3((unsigned)((n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
+            ZK_LAUNCH(zkdev::k_inputs_mul, dim3((unsigned)((4 * n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
                       (const DG1A*)V->ic_table.as<DG1A>(), (const uint32_t*)V->scal.as<uint32_t>(), V->part.as<DG1>(), V->n_ic,
                       (uint32_t)n);
-        ZK_LAUNCH(zkdev::k_inputs_sum, dim3(b64), dim3(64), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
+        ZK_LAUNCH_SYNC(zkdev::k_inputs_sum, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
                   (const DG1*)V->part.as<DG1>(), V->acc.as<uint32_t>(), V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n);
     }
     HIP_TRY(hipEventRecord(V->ev_join[1], g_copy_stream));
@@ -475,17 +477,17 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     const uint32_t* prep_gamma = V->gamma_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[0].as<uint32_t>();
     const uint32_t* prep_delta = V->delta_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[1].as<uint32_t>();
     if (wide) {
-        const unsigned bw = (unsigned)((n + zkdev::WIDE_GROUPS - 1) / zkdev::WIDE_GROUPS);
+        const unsigned bw = (unsigned)((n + zkdev::W3_GROUPS - 1) / zkdev::W3_GROUPS);
         {
             ProfScope ps("verify_miller");
-            ZK_LAUNCH_SYNC(zkdev::k_miller_loop_wide, dim3(bw, 3), dim3(zkdev::WIDE_THREADS), 0, g_stream,
+            ZK_LAUNCH_SYNC(zkdev::k_miller_loop_wide, dim3(bw, 3), dim3(zkdev::W3_THREADS), 0, g_stream,
                            (const uint32_t*)V->aff_g1.as<uint32_t>(), (const uint32_t*)V->prep_b.as<uint32_t>(),
                            (const uint32_t*)V->acc.as<uint32_t>(), prep_gamma, (const uint32_t*)(V->aff_g1.as<uint32_t>() + n * 24),
                            prep_delta, (const uint32_t*)V->skip.as<uint32_t>(), V->f.as<F12>(), (uint32_t)n);
         }
         {
             ProfScope ps("verify_final");
-            ZK_LAUNCH_SYNC(zkdev::k_final_exp_wide, dim3(bw), dim3(zkdev::WIDE_THREADS), 0, g_stream, (const F12*)V->f.as<F12>(),
+            ZK_LAUNCH_SYNC(zkdev::k_final_exp_wide, dim3(bw), dim3(zkdev::W3_THREADS), 0, g_stream, (const F12*)V->f.as<F12>(),
                            (const uint32_t*)V->gam.as<uint32_t>(), (const F12*)V->alpha_beta.as<F12>(),
                            (const uint32_t*)V->valid.as<uint32_t>(), V->ok.as<uint32_t>(), (F12*)nullptr, (uint32_t)n);
         }
@@ -685,8 +687,9 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
     }
     {
         ProfScope ps("verify_prepare");
-        ZK_LAUNCH(zkdev::k_g2_prepare, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->aff_g2.as<uint32_t>(),
-                  V->prep_b.as<uint32_t>(), (uint32_t)n, own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>());
+        ZK_LAUNCH_SYNC(zkdev::k_g2_prepare_tri, dim3((unsigned)((n + zkdev::TL_POINTS - 1) / zkdev::TL_POINTS)), dim3(64), 0, g_stream,
+                       (const uint32_t*)V->aff_g2.as<uint32_t>(), V->prep_b.as<uint32_t>(), (uint32_t)n,
+                       own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>());
     }
     {   // side stream: A and C decoded, scaled by rho_i, the C's summed
         ProfScope ps("verify_decode_g1", g_stream2);
@@ -716,13 +719,13 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
             ZK_TRY(dl.ensure(32));
             HIP_TRY(hipMemcpy(dl.p, lam, 32, hipMemcpyHostToDevice));
             ZK_TRY(V->rlc_ab_lambda.ensure(sizeof(F12)));
-            ZK_LAUNCH_SYNC(zkdev::k_f12_pow_wide, dim3(1), dim3(zkdev::WIDE_THREADS), 0, g_copy_stream, (const F12*)V->alpha_beta.as<F12>(),
+            ZK_LAUNCH_SYNC(zkdev::k_f12_pow_wide, dim3(1), dim3(zkdev::W3_THREADS), 0, g_copy_stream, (const F12*)V->alpha_beta.as<F12>(),
                            (const uint32_t*)dl.as<uint32_t>(), 255u, V->rlc_ab_lambda.as<F12>());
             HIP_TRY(hipStreamSynchronize(g_copy_stream));
         }
         uint32_t nbits = 128;
         while (nbits > 1 && !(((ev[(nbits - 1) >> 5] | ev[4 + ((nbits - 1) >> 5)]) >> ((nbits - 1) & 31)) & 1u)) nbits--;
-        ZK_LAUNCH_SYNC(zkdev::k_f12_pow2_wide, dim3(1), dim3(zkdev::WIDE_THREADS), 0, g_copy_stream, (const F12*)V->alpha_beta.as<F12>(),
+        ZK_LAUNCH_SYNC(zkdev::k_f12_pow2_wide, dim3(1), dim3(zkdev::W3_THREADS), 0, g_copy_stream, (const F12*)V->alpha_beta.as<F12>(),
                        (const F12*)V->rlc_ab_lambda.as<F12>(), (const uint32_t*)V->rlc_exp.as<uint32_t>(), nbits, V->rlc_want.as<F12>());
     }
     HIP_TRY(hipEventRecord(V->ev_join[1], g_copy_stream));
@@ -739,7 +742,7 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
     HIP_TRY(hipMemcpyAsync(V->prep_b.as<uint32_t>() + (n + 1) * COEF_WORDS, V->prep[1].p, COEF_WORDS * 4, hipMemcpyDeviceToDevice, g_stream));
     {
         ProfScope ps("verify_miller");
-        ZK_LAUNCH_SYNC(zkdev::k_miller_loop_wide, dim3((unsigned)((m + zkdev::WIDE_GROUPS - 1) / zkdev::WIDE_GROUPS), 1), dim3(zkdev::WIDE_THREADS), 0,
+        ZK_LAUNCH_SYNC(zkdev::k_miller_loop_wide, dim3((unsigned)((m + zkdev::W3_GROUPS - 1) / zkdev::W3_GROUPS), 1), dim3(zkdev::W3_THREADS), 0,
                        g_stream, (const uint32_t*)V->rlc_pts.as<uint32_t>(), (const uint32_t*)V->prep_b.as<uint32_t>(), (const uint32_t*)nullptr,
                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)V->skip.as<uint32_t>(),
                        V->f.as<F12>(), (uint32_t)m);
@@ -754,13 +757,13 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
         while (cnt > 1) {
             const uint32_t groups = (cnt + 11) / 12;
             F12* dst = groups == 1 ? V->rlc_fe.as<F12>() : bufs[which];
-            ZK_LAUNCH_SYNC(zkdev::k_f12_prod_wide, dim3((groups + zkdev::WIDE_GROUPS - 1) / zkdev::WIDE_GROUPS), dim3(zkdev::WIDE_THREADS), 0, g_stream,
+            ZK_LAUNCH_SYNC(zkdev::k_f12_prod_wide, dim3((groups + zkdev::W3_GROUPS - 1) / zkdev::W3_GROUPS), dim3(zkdev::W3_THREADS), 0, g_stream,
                            src, cnt, dst, groups);
             src = dst;
             cnt = groups;
             which ^= 1;
         }
-        ZK_LAUNCH_SYNC(zkdev::k_final_exp_wide, dim3(1), dim3(zkdev::WIDE_THREADS), 0, g_stream, (const F12*)V->rlc_fe.as<F12>(),
+        ZK_LAUNCH_SYNC(zkdev::k_final_exp_wide, dim3(1), dim3(zkdev::W3_THREADS), 0, g_stream, (const F12*)V->rlc_fe.as<F12>(),
                        (const uint32_t*)V->gam.as<uint32_t>(), (const F12*)V->rlc_want.as<F12>(), (const uint32_t*)nullptr, V->ok.as<uint32_t>(),
                        (F12*)nullptr, 1u);
     }
@@ -906,8 +909,8 @@ zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_
                   wide ? 0u : 1u);
         if (wide) {
             ZK_TRY(vk->prep_b.ensure(np * COEF_WORDS * 4));
-            ZK_LAUNCH(zkdev::k_g2_prepare, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, (const uint32_t*)vk->aff_g2.as<uint32_t>(),
-                      vk->prep_b.as<uint32_t>(), (uint32_t)np, vk->st_g2.as<uint32_t>());
+            ZK_LAUNCH_SYNC(zkdev::k_g2_prepare_tri, dim3((unsigned)((np + zkdev::TL_POINTS - 1) / zkdev::TL_POINTS)), dim3(64), 0, g_stream,
+                           (const uint32_t*)vk->aff_g2.as<uint32_t>(), vk->prep_b.as<uint32_t>(), (uint32_t)np, vk->st_g2.as<uint32_t>());
         }
         ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * np + 63) / 64)), dim3(64), 0, g_stream,
                   (const uint32_t*)vk->in_g1.as<uint32_t>(), (const uint32_t*)vk->fl_g1.as<uint32_t>(), vk->aff_g1.as<uint32_t>(),

@@ -452,6 +452,15 @@ struct MsmGroup {
         *n_inf = v[1];
         return ZK_OK;
     }
+    // the table of doublings over a slice 0 that is in place, enqueued on st (the caller waits and then frees `scratch`)
+    zk_status table_enqueue(DevBuf& scratch, hipStream_t st) {
+        if (!n_points) return ZK_OK;
+        ZK_TRY(scratch.ensure((size_t)zkdev::MSM_TABLE_CHUNK * 5 * sizeof(DF) * n_points));
+        ZK_LAUNCH(zkdev::k_msm_build_table<DF>, dim3((unsigned)((n_points + 127) / 128)), dim3(128), 0, st, table.as<DAffine>(),
+                  (uint32_t)n_points, zkdev::MSM_NPOS, scratch.as<DF>());
+        HIP_TRY(hipGetLastError());
+        return ZK_OK;
+    }
     // the table of doublings over a slice 0 that is already in place; checked: curve + subgroup test of every base first
     zk_status finish_build(bool checked, const char* what, bool with_table) {
         if (!n_points) return ZK_OK;
@@ -970,8 +979,8 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     } guard{P};
     P->device = device;
     Reader r{pk, len};
-    HG1A alpha_g1, beta_g1, delta_g1, tmp1;
-    HG2A beta_g2, gamma_g2, delta_g2, tmp2;
+    HG1A alpha_g1, beta_g1, delta_g1;
+    HG2A beta_g2, gamma_g2, delta_g2;
     ZK_TRY(read_g1(r, &alpha_g1, "vk.alpha_g1", true));
     ZK_TRY(read_g1(r, &beta_g1, "vk.beta_g1", true));
     ZK_TRY(read_g2(r, &beta_g2, "vk.beta_g2", true));
@@ -989,35 +998,65 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     for (uint32_t i = 0; i < P->n_ic; i++) ZK_TRY(read_g1(r, &ic[i], "vk.ic"));
 
     P->vk_bytes.assign(pk, pk + (len - r.left));
-    std::vector<HG1A> pts1;
-    auto read_vec1 = [&](uint32_t* n, uint32_t* off, const char* what) -> zk_status {
+    // The query vectors are only LOCATED here; their 10 MB of encodings are gathered in table order and decoded on the
+    // device (msm.h k_decode_uncompressed: round 5 - the host loop it replaces was a quarter of the load).
+    // G1 table order: h | l | a | alpha_g1 | delta_g1 | b_g1 | beta_g1   (the tails carry the scalars 1, r / 1)
+    // G2 table order: b_g2 | beta_g2 | delta_g2                            (scalars 1, s)
+    struct Section {
+        const uint8_t* at;
+        uint32_t n;
+        const char* what;
+        bool inf_ok;   // alpha, beta, delta may be the point at infinity (bellman reads them with a plain into_affine())
+    };
+    auto locate = [&](uint32_t* n, size_t size, const char* what, const uint8_t** at) -> zk_status {
         if (!r.u32be(n)) return fail(ZK_ERR_IO, std::string("unexpected end of parameters (length of ") + what + ")");
-        if ((size_t)*n * 96 > r.left) return fail(ZK_ERR_IO, std::string("unexpected end of parameters in ") + what);
-        *off = (uint32_t)pts1.size();
-        pts1.reserve(pts1.size() + *n + 4);
-        for (uint32_t i = 0; i < *n; i++) {
-            ZK_TRY(read_g1(r, &tmp1, what));
-            pts1.push_back(tmp1);
-        }
+        if ((size_t)*n * size > r.left) return fail(ZK_ERR_IO, std::string("unexpected end of parameters in ") + what);
+        (void)r.take((size_t)*n * size, at);
         return ZK_OK;
     };
-    ZK_TRY(read_vec1(&P->n_h, &P->off_h, "h"));
-    ZK_TRY(read_vec1(&P->n_l, &P->off_l, "l"));
-    ZK_TRY(read_vec1(&P->n_a, &P->off_a, "a"));
-    pts1.push_back(alpha_g1);   // a-slice tail: [alpha_g1, delta_g1]  (scalars 1, r)
-    pts1.push_back(delta_g1);
-    ZK_TRY(read_vec1(&P->n_b1, &P->off_b1, "b_g1"));
-    pts1.push_back(beta_g1);    // b_g1-slice tail: [beta_g1]           (scalar 1)
-    std::vector<HG2A> pts2;
-    if (!r.u32be(&P->n_b2)) return fail(ZK_ERR_IO, "unexpected end of parameters (length of b_g2)");
-    if ((size_t)P->n_b2 * 192 > r.left) return fail(ZK_ERR_IO, "unexpected end of parameters in b_g2");
-    pts2.reserve(P->n_b2 + 2);
-    for (uint32_t i = 0; i < P->n_b2; i++) {
-        ZK_TRY(read_g2(r, &tmp2, "b_g2"));
-        pts2.push_back(tmp2);
-    }
-    pts2.push_back(beta_g2);    // tail: [beta_g2, delta_g2]            (scalars 1, s)
-    pts2.push_back(delta_g2);
+    const uint8_t *at_h, *at_l, *at_a, *at_b1, *at_b2;
+    ZK_TRY(locate(&P->n_h, 96, "h", &at_h));
+    ZK_TRY(locate(&P->n_l, 96, "l", &at_l));
+    ZK_TRY(locate(&P->n_a, 96, "a", &at_a));
+    ZK_TRY(locate(&P->n_b1, 96, "b_g1", &at_b1));
+    ZK_TRY(locate(&P->n_b2, 192, "b_g2", &at_b2));
+    const Section sec1[7] = {{at_h, P->n_h, "h", false},       {at_l, P->n_l, "l", false},          {at_a, P->n_a, "a", false},
+                             {pk, 1, "vk.alpha_g1", true},     {pk + 576, 1, "vk.delta_g1", true},  {at_b1, P->n_b1, "b_g1", false},
+                             {pk + 96, 1, "vk.beta_g1", true}};
+    const Section sec2[3] = {{at_b2, P->n_b2, "b_g2", false}, {pk + 192, 1, "vk.beta_g2", true}, {pk + 672, 1, "vk.delta_g2", true}};
+    P->off_h = 0;
+    P->off_l = P->n_h;
+    P->off_a = P->off_l + P->n_l;
+    P->off_b1 = P->off_a + P->n_a + 2;
+    auto gather = [](const Section* sec, int k, size_t size, std::vector<uint8_t>& out) {
+        size_t total = 0;
+        for (int i = 0; i < k; i++) total += sec[i].n;
+        out.resize(total * size);
+        size_t at = 0;
+        for (int i = 0; i < k; i++) {
+            memcpy(out.data() + at, sec[i].at, (size_t)sec[i].n * size);
+            at += (size_t)sec[i].n * size;
+        }
+        return total;
+    };
+    std::vector<uint8_t> enc1, enc2;
+    const size_t n1 = gather(sec1, 7, 96, enc1), n2 = gather(sec2, 3, 192, enc2);
+    // a refused encoding / an unexpected point at infinity is named by the query it sits in
+    auto name_of = [](const Section* sec, int k, size_t idx) -> const Section& {
+        for (int i = 0; i < k; i++) {
+            if (idx < sec[i].n) return sec[i];
+            idx -= sec[i].n;
+        }
+        return sec[k - 1];
+    };
+    auto infinity_check = [&](const Section* sec, int k, size_t size, const std::vector<uint8_t>& enc, uint32_t n_inf) -> zk_status {
+        if (!n_inf) return ZK_OK;
+        size_t idx = 0;
+        for (int i = 0; i < k; i++)
+            for (uint32_t j = 0; j < sec[i].n; j++, idx++)
+                if ((enc[idx * size] & 0x40) && !sec[i].inf_ok) return fail(ZK_ERR_IO, std::string("point at infinity in ") + sec[i].what);
+        return ZK_OK;
+    };
 
     // the evaluation domain: bellman writes h with m - 1 entries
     size_t m = (size_t)P->n_h + 1;
@@ -1040,10 +1079,38 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     P->split_g1 = !(getenv("ZKAMD_SPLIT_G1") && atoi(getenv("ZKAMD_SPLIT_G1")) == 0);
     const uint32_t c1 = P->split_g1 ? pick_window((size_t)P->n_h + P->n_l + P->n_b1, 1) : c_avg;
     const uint32_t c2 = pick_window(P->n_b2, 2);
-    ZK_TRY(P->g1.build(pts1, c1, checked != 0, "parameters (G1)"));
+    {
+        // both groups decoded side by side, then both tables of doublings built side by side (each is one thread per base
+        // walking 254 doublings: latency, not work - 19 + 23 ms one after the other)
+        DevBuf raw1, raw2, map1, map2, scratch1, scratch2;
+        ZK_TRY(P->g1.decode_enqueue(enc1.data(), n1, c1, true, raw1, map1, g_stream));
+        ZK_TRY(P->g2.decode_enqueue(enc2.data(), n2, c2, true, raw2, map2, g_stream2));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream2));
+        uint32_t inf1 = 0, inf2 = 0;
+        zk_status d1 = P->g1.decode_finish("", &inf1);
+        if (d1 != ZK_OK) {
+            const size_t idx = (size_t)atol(g_err.c_str() + g_err.rfind(' ') + 1);
+            return fail(ZK_ERR_IO, std::string("invalid G1 encoding in ") + name_of(sec1, 7, idx).what);
+        }
+        zk_status d2 = P->g2.decode_finish("", &inf2);
+        if (d2 != ZK_OK) {
+            const size_t idx = (size_t)atol(g_err.c_str() + g_err.rfind(' ') + 1);
+            return fail(ZK_ERR_IO, std::string("invalid G2 encoding in ") + name_of(sec2, 3, idx).what);
+        }
+        ZK_TRY(infinity_check(sec1, 7, 96, enc1, inf1));
+        ZK_TRY(infinity_check(sec2, 3, 192, enc2, inf2));
+        if (checked) {
+            ZK_TRY((check_points_dev<zkhost::Fq, zkdev::Fq>(P->g1.table.as<zkdev::Affine<zkdev::Fq>>(), n1, "parameters (G1)")));
+            ZK_TRY((check_points_dev<zkhost::Fq2, DevFq2>(P->g2.table.as<zkdev::Affine<DevFq2>>(), n2, "parameters (G2)")));
+        }
+        ZK_TRY(P->g1.table_enqueue(scratch1, g_stream));
+        ZK_TRY(P->g2.table_enqueue(scratch2, g_stream2));
+        HIP_TRY(hipStreamSynchronize(g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream2));
+    }
     P->g1a.alias(P->g1, pick_window(P->n_a, 3));
     P->g1_lone.alias(P->g1, c_avg);
-    ZK_TRY(P->g2.build(pts2, c2, checked != 0, "parameters (G2)"));
     P->g2_lone.alias(P->g2, getenv("ZKAMD_WINDOW_BITS_G2") || c2 <= 10 ? c2 : 10u);
     ZK_TRY(P->ntt.init(P->log_m));
     ZK_TRY(calibrate_kernel_forms(P));
