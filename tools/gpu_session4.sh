@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 GPU session: parity suite, bench line (statement -> proof), self-spawned 2-rank check, optional profiles.
-# usage (from the repo root on the GPU box):  bash tools/gpu_session3.sh <tag> [bench args...]
+# usage (from the repo root on the GPU box):  bash tools/sessions/gpu_session3.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true
 OUT=gpurun_out/$TAG

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_traffic.json from the rocprofv3 passes of one GPU session (tools/gpu_session3.sh):
+"""profiles/<tag>_traffic.json from the rocprofv3 passes of one GPU session (tools/sessions/gpu_session3.sh):
 
   python tools/make_roofline.py <session dir> <out.json> <batch>
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic.json from the three PMC passes of tools/gpu_session2.sh (DO_PMC=1): per kernel and launch the
+"""profiles/r02_traffic.json from the three PMC passes of tools/sessions/gpu_session2.sh (DO_PMC=1): per kernel and launch the
 HBM bytes (FETCH_SIZE, WRITE_SIZE: KiB units, separate passes) and the VALU wave-instructions (SQ_INSTS_VALU).
 usage: python tools/make_traffic.py gpurun_out/<tag> <batch> [out.json]"""
 import collections, csv, glob, json, os, sys

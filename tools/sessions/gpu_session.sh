@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box session: parity suite, bench line, rocprofv3 kernel-trace summary.
-# usage (from the repo root on the GPU box):  bash tools/gpu_session.sh <tag> [bench args...]
+# usage (from the repo root on the GPU box):  bash tools/sessions/gpu_session.sh <tag> [bench args...]
 set -u
 TAG=${1:-run}; shift || true
 OUT=gpurun_out/$TAG
