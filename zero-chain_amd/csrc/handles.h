@@ -61,6 +61,12 @@ zk_status witness_anon_gpu_finish(zk_r1cs* R, size_t np, int slot, size_t index_
 // Groth16 verification of a batch (verify.cpp; zk_verify_batch is this with own_proofs = false).  own_proofs: the
 // proofs are this library's own fresh results (gen_proof's self-check) - decoded without the r-torsion test.
 namespace zkrt {
+// what wallet.cpp (gen_proof, the Jubjub host side) needs of zkamd.cpp: one chunk of proofs from the assignment the witness
+// kernels left in R->z[slot]; proofs per launch set; the key's device and evaluation domain
+zk_status lib_prove_from_z(zk_params* P, zk_r1cs* R, size_t np, int slot, const uint8_t* rs, uint8_t* proofs_out);
+size_t lib_batch_chunk();
+int lib_params_device(const zk_params* P);
+size_t lib_params_domain(const zk_params* P);
 zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,
                        bool own_proofs, bool rlc = false);
 }

@@ -9,6 +9,8 @@
 #include <map>
 #include <thread>
 #include <mutex>
+#include <system_error>
+#include <functional>
 #if defined(__linux__)
 #include <sched.h>
 #endif
@@ -109,6 +111,33 @@ inline unsigned host_threads(size_t work_items, unsigned cap) {
     if ((unsigned long)n > cap) n = cap;
     if ((size_t)n > work_items) n = (long)work_items;
     return n > 0 ? (unsigned)n : 1u;
+}
+
+// work(t) for t = 0 .. nthreads - 1 on host threads
+template <class Fn>
+inline void run_threads(unsigned nthreads, Fn& work) {
+    if (nthreads <= 1) {
+        work(0);
+        return;
+    }
+    // a thread that cannot be started (std::system_error must not cross the C ABI) leaves its share to this thread
+    std::vector<std::thread> ths;
+    unsigned started = 0;
+    try {
+        for (; started < nthreads; started++) ths.emplace_back(std::ref(work), started);
+    } catch (const std::system_error&) {
+    }
+    for (unsigned t = started; t < nthreads; t++) work(t);
+    for (auto& th : ths) th.join();
+}
+
+// 32 little-endian bytes -> four 64-bit limbs
+inline void load_scalar_le(const uint8_t* b, uint64_t out[4]) {
+    for (int i = 0; i < 4; i++) {
+        uint64_t w = 0;
+        for (int j = 7; j >= 0; j--) w = (w << 8) | b[i * 8 + j];
+        out[i] = w;
+    }
 }
 
 struct DevBuf {
