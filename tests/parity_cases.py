@@ -236,7 +236,7 @@ def _bad_uncompressed(group):
     return bad, checked_only
 
 
-def msm_decoder_refusals(lib):
+def msm_decoder_refusals(lib, oneshot_every=1):
     """The device decoder of the bases (msm.h k_decode_uncompressed) behind zk_msm_create / zk_msm_create_variable and the
     one-shot entries zk_msm_g1 / zk_msm_g2: every malformed encoding of the reference's tests is refused with IoError and
     the index of the offending base; what only `into_affine` (checked) refuses passes unchecked and fails checked."""
@@ -253,6 +253,8 @@ def msm_decoder_refusals(lib):
                 with pytest.raises(zk.ZkError) as e:
                     zk.MultiexpContext(group, bases, lib=lib, variable_base=variable)
                 assert e.value.variant == "IoError" and "base %d" % at in str(e.value), (why, str(e.value))
+            if k % oneshot_every:    # (the one-shot entry names the base after the whole multiexp has run: the emulation takes a sample)
+                continue
             with pytest.raises(zk.ZkError) as e:
                 zk.multiexp(group, bases, [1] * (len(good) + 1), lib=lib)
             assert e.value.variant == "IoError" and "base %d" % at in str(e.value), (why, str(e.value))

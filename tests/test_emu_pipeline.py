@@ -53,7 +53,7 @@ def test_msm_edges(emu_lib):
 
 
 def test_msm_decoder_refusals(emu_lib):
-    pc.msm_decoder_refusals(emu_lib)
+    pc.msm_decoder_refusals(emu_lib, oneshot_every=16)
 
 
 def test_msm_oneshot_entries(emu_lib):
