@@ -28,6 +28,9 @@
  *     single-threaded); different handles - on the same or on different GPUs - may be used from
  *     different threads: streams live in a per-device context, the current device is selected on
  *     every entry.
+ *   - no C++ exception leaves the library: every entry that returns a zk_status is an exception barrier
+ *     (a failed host allocation is ZK_ERR_OUT_OF_MEMORY, anything else ZK_ERR_DEVICE with the text in
+ *     zk_last_error()), also for work the library does on its own threads.
  */
 #ifndef ZKAMD_H
 #define ZKAMD_H

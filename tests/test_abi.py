@@ -121,6 +121,26 @@ def test_every_declared_entry_point_has_a_caller_in_the_tests():
     assert not unreached, "entry points no test calls: %s" % unreached
 
 
+def test_every_status_entry_is_an_exception_barrier():
+    """No C++ exception may unwind into the Rust / C host: every definition of an exported entry that returns a zk_status
+    is a function-try-block closed by ZK_ABI_CATCH (zero-chain_amd/csrc/host_common.h); behaviour:
+    tests/test_gen_proof.py test_no_exception_crosses_the_c_abi."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "zkamd.h")).read(), flags=re.S)
+    status_entries = set(re.findall(r"\bzk_status\s+(zk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(status_entries) >= 45
+    cdir = os.path.join(ROOT, "zero-chain_amd", "csrc")
+    src = "".join(open(os.path.join(cdir, f)).read() for f in sorted(os.listdir(cdir)) if f.endswith(".cpp"))
+    for name in sorted(status_entries):
+        m = re.search(r'^(?:extern "C" )?zk_status %s\([^;{]*?\)\s*(try\s*)?\{' % name, src, flags=re.M | re.S)
+        assert m, "no definition of %s found" % name
+        assert m.group(1), "%s is not a function-try-block" % name
+        rest = src[m.end():]
+        first_line = rest.split("\n", 1)[0]
+        # a one-line definition closes on its own line; any other body closes at the next "}" in column 0
+        closing = first_line if first_line.rstrip().endswith("ZK_ABI_CATCH") else rest[rest.index("\n}") + 1:].split("\n", 1)[0]
+        assert closing.rstrip().endswith("} ZK_ABI_CATCH"), "%s does not end in ZK_ABI_CATCH" % name
+
+
 def test_c_program_proves_on_several_devices_from_one_process(tmp_path, emu_lib):
     """tests/abi_multi.c: the multi-device pattern for a single-process host (the reference's zface / core/proofs): N
     pthreads, each binds to its device's NUMA node, loads the key on its device and proves its contiguous block straight

@@ -149,6 +149,22 @@ def test_jubjub_entries_match_oracle():
         zk.jubjub_base_mul([jj.FS_MOD], lib=lib)                      # not a canonical Fs scalar
 
 
+def test_no_exception_crosses_the_c_abi(monkeypatch):
+    """The host on the other side of include/zkamd.h is Rust or C: a C++ exception must come back as a status (every exported
+    entry is a function-try-block, host_common.h ZK_ABI_CATCH), also when it is thrown on a worker thread (run_threads hands
+    it to the joining thread).  ZKAMD_INJECT_THROW makes the last worker of zk_jubjub_base_mul fail an allocation."""
+    import zero_chain_amd as zk
+    lib = _lib()
+    monkeypatch.setenv("ZKAMD_INJECT_THROW", "1")
+    for n in (1, 40):   # the calling thread itself / a spawned worker
+        with pytest.raises(zk.ZkError) as e:
+            zk.jubjub_base_mul(list(range(1, n + 1)), lib=lib)
+        assert e.value.variant == "OutOfMemory" and "host allocation failed" in str(e.value)
+    monkeypatch.delenv("ZKAMD_INJECT_THROW")
+    g = jj.note_commitment_randomness_generator()
+    assert zk.jubjub_base_mul([5], lib=lib) == [jj.write_point(jj.mul(g, 5))]   # and the library goes on working
+
+
 def test_points_outside_the_prime_order_subgroup_are_refused():
     """The reference's typed inputs pass through as_prime_order (EncryptionKey::read keys.rs:269-276, Ciphertext::read
     elgamal.rs:117-133): P + (0, -1) = (-x, -y) decodes, lies on the curve and has order 2 s - the wallet-level entries

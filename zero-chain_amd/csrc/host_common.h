@@ -10,6 +10,9 @@
 #include <thread>
 #include <mutex>
 #include <system_error>
+#include <stdexcept>
+#include <exception>
+#include <new>
 #include <functional>
 #if defined(__linux__)
 #include <sched.h>
@@ -113,23 +116,96 @@ inline unsigned host_threads(size_t work_items, unsigned cap) {
     return n > 0 ? (unsigned)n : 1u;
 }
 
-// work(t) for t = 0 .. nthreads - 1 on host threads
+// No C++ exception crosses the C ABI (the host on the other side is Rust or C: unwinding into it is undefined): every
+// exported entry that returns a zk_status is a function-try-block ending in ZK_ABI_CATCH, and work done on other threads
+// hands its exception to the thread that joins it (run_threads, SideThread) or turns it into a status on the spot (guarded).
+inline zk_status status_of_exception() noexcept {   // inside a catch block
+    zk_status st = ZK_ERR_DEVICE;
+    try {
+        try {
+            throw;
+        } catch (const std::bad_alloc&) {
+            st = ZK_ERR_OUT_OF_MEMORY;
+            g_err = "host allocation failed";
+        } catch (const std::length_error&) {
+            st = ZK_ERR_OUT_OF_MEMORY;
+            g_err = "host allocation failed (size)";
+        } catch (const std::exception& e) {
+            g_err = std::string("internal: ") + e.what();
+        } catch (...) {
+            g_err = "internal: unknown exception";
+        }
+    } catch (...) {
+    }
+    return st;
+}
+#define ZK_ABI_CATCH \
+    catch (...) { return zkrt::status_of_exception(); }
+template <class Fn>
+inline zk_status guarded(Fn&& fn) noexcept {
+    try {
+        return fn();
+    } catch (...) {
+        return status_of_exception();
+    }
+}
+
+// work(t) for t = 0 .. nthreads - 1 on host threads; the first exception of a worker is rethrown here after all have joined
 template <class Fn>
 inline void run_threads(unsigned nthreads, Fn& work) {
     if (nthreads <= 1) {
         work(0);
         return;
     }
-    // a thread that cannot be started (std::system_error must not cross the C ABI) leaves its share to this thread
+    std::exception_ptr first;
+    std::mutex first_mu;
+    auto body = [&](unsigned t) {
+        try {
+            work(t);
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(first_mu);
+            if (!first) first = std::current_exception();
+        }
+    };
+    // a thread that cannot be started leaves its share to this thread
     std::vector<std::thread> ths;
     unsigned started = 0;
     try {
-        for (; started < nthreads; started++) ths.emplace_back(std::ref(work), started);
-    } catch (const std::system_error&) {
+        ths.reserve(nthreads);
+        for (; started < nthreads; started++) ths.emplace_back(std::ref(body), started);
+    } catch (...) {
     }
-    for (unsigned t = started; t < nthreads; t++) work(t);
+    for (unsigned t = started; t < nthreads; t++) body(t);
     for (auto& th : ths) th.join();
+    if (first) std::rethrow_exception(first);
 }
+
+// one helper thread beside the caller (the staging of the next block of a batch); joined on every path out of the scope
+struct SideThread {
+    std::thread t;
+    std::exception_ptr err;
+    template <class Fn>
+    void start(Fn fn) {
+        t = std::thread([this, fn]() mutable {
+            try {
+                fn();
+            } catch (...) {
+                err = std::current_exception();
+            }
+        });
+    }
+    void join() {
+        if (t.joinable()) t.join();
+        if (err) {
+            std::exception_ptr e = err;
+            err = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+    ~SideThread() {
+        if (t.joinable()) t.join();
+    }
+};
 
 // 32 little-endian bytes -> four 64-bit limbs
 inline void load_scalar_le(const uint8_t* b, uint64_t out[4]) {

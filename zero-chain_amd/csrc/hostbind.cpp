@@ -53,7 +53,7 @@ bool read_line(const std::string& path, char* buf, size_t cap) {
 
 }  // namespace
 
-extern "C" zk_status zk_bind_host_to_device(int device, int* numa_node_out, int* n_cpus_out) {
+extern "C" zk_status zk_bind_host_to_device(int device, int* numa_node_out, int* n_cpus_out) try {
     if (numa_node_out) *numa_node_out = -1;
     if (n_cpus_out) *n_cpus_out = 0;
 #if defined(__linux__) && !defined(ZK_EMU)
@@ -83,4 +83,4 @@ extern "C" zk_status zk_bind_host_to_device(int device, int* numa_node_out, int*
     (void)device;
 #endif
     return ZK_OK;
-}
+} ZK_ABI_CATCH

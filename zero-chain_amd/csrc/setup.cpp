@@ -76,7 +76,7 @@ void put_u32be(std::vector<uint8_t>& o, uint32_t v) {
 
 extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[96], const uint8_t g2_bytes[192], const uint8_t alpha_b[32],
                                             const uint8_t beta_b[32], const uint8_t gamma_b[32], const uint8_t delta_b[32],
-                                            const uint8_t tau_b[32], uint8_t* out, size_t cap, size_t* len) {
+                                            const uint8_t tau_b[32], uint8_t* out, size_t cap, size_t* len) try {
     if (!R || !g1_bytes || !g2_bytes || !alpha_b || !beta_b || !gamma_b || !delta_b || !tau_b || !len)
         return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     ZK_TRY(use_device(R->device));
@@ -262,4 +262,4 @@ extern "C" zk_status zk_generate_parameters(zk_r1cs* R, const uint8_t g1_bytes[9
     if (cap < o.size()) return fail(ZK_ERR_INVALID_ARGUMENT, "output buffer too small");
     memcpy(out, o.data(), o.size());
     return ZK_OK;   // dev_wipe / host_wipe: the toxic waste does not outlive the call, on the device or on the host
-}
+} ZK_ABI_CATCH

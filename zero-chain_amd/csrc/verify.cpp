@@ -564,10 +564,7 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
                 h.finish(&dig[l * 32]);
             }
         };
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nth; t++) th.emplace_back(leaf_work, t);
-        leaf_work(0);
-        for (auto& x : th) x.join();
+        run_threads(nth, leaf_work);
         zkhash::Blake2s h(pers);
         h.update_u64be(n);
         h.update(dig.data(), dig.size());
@@ -620,12 +617,7 @@ zk_status verify_chunk_rlc(zk_vk* V, size_t n, const uint8_t* proofs, const uint
             }
         }
     };
-    {
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < nth; t++) th.emplace_back(work, t);
-        work(0);
-        for (auto& x : th) x.join();
-    }
+    run_threads(nth, work);
     std::vector<uint32_t> sv((size_t)(ni + 1) * 8), ev(8, 0);
     unsigned __int128 sa = 0, sb = 0;
     for (unsigned t = 0; t < nth; t++) {
@@ -808,17 +800,17 @@ zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t
 
 extern "C" {
 
-zk_status zk_vk_prepare(const uint8_t* vk_bytes, size_t len, int device, zk_vk** out) {
+zk_status zk_vk_prepare(const uint8_t* vk_bytes, size_t len, int device, zk_vk** out) try {
     if (!vk_bytes || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     return vk_prepare(vk_bytes, len, device, out);
-}
-zk_status zk_vk_read(const uint8_t* pvk_bytes, size_t len, int device, zk_vk** out) {
+} ZK_ABI_CATCH
+zk_status zk_vk_read(const uint8_t* pvk_bytes, size_t len, int device, zk_vk** out) try {
     if (!pvk_bytes || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     return vk_read_prepared(pvk_bytes, len, device, out);
-}
-zk_status zk_vk_write(const zk_vk* vk, uint8_t* out, size_t cap, size_t* len) {
+} ZK_ABI_CATCH
+zk_status zk_vk_write(const zk_vk* vk, uint8_t* out, size_t cap, size_t* len) try {
     if (!vk || !len) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     std::vector<uint8_t> o;
     zkhost::Fq2 c;
@@ -848,23 +840,23 @@ zk_status zk_vk_write(const zk_vk* vk, uint8_t* out, size_t cap, size_t* len) {
         memcpy(out, o.data(), o.size());
     }
     return ZK_OK;
-}
-zk_status zk_vk_num_inputs(const zk_vk* vk, uint32_t* n_inputs) {
+} ZK_ABI_CATCH
+zk_status zk_vk_num_inputs(const zk_vk* vk, uint32_t* n_inputs) try {
     if (!vk || !n_inputs) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *n_inputs = vk->n_ic ? vk->n_ic - 1 : 0;
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 void zk_vk_free(zk_vk* vk) { delete vk; }
 
 zk_status zk_verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
-                          uint8_t* ok_out) {
+                          uint8_t* ok_out) try {
     return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false, false);
-}
+} ZK_ABI_CATCH
 zk_status zk_verify_batch_rlc(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
-                              uint8_t* ok_out) {
+                              uint8_t* ok_out) try {
     return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false, true);
-}
-zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_t* status_out) {
+} ZK_ABI_CATCH
+zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_t* status_out) try {
     if (!vk || (n && (!proofs || !status_out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     ZK_TRY(use_device(vk->device));
     for (size_t first = 0; first < n; first += VERIFY_CHUNK) {
@@ -935,13 +927,13 @@ zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_
         }
     }
     return ZK_OK;
-}
-zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* public_inputs, size_t n_inputs, int* ok) {
+} ZK_ABI_CATCH
+zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* public_inputs, size_t n_inputs, int* ok) try {
     if (!ok) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     uint8_t v = 0;
     zk_status st = zk_verify_batch(vk, 1, proof, public_inputs, n_inputs, &v);
     *ok = v;
     return st;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"

@@ -227,7 +227,7 @@ zk_status transfer_derive(const zk_transfer_request* rq, size_t n, zk_transfer_s
 
 extern "C" {
 
-zk_status zk_spending_key_from_seed(const uint8_t* seed, size_t len, uint8_t spending_key_out[32]) {
+zk_status zk_spending_key_from_seed(const uint8_t* seed, size_t len, uint8_t spending_key_out[32]) try {
     if ((!seed && len) || !spending_key_out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     // keys.rs:45-58: Blake2b-512 personalised "zech_ExpandSeed_", then Fs::to_uniform
     static const uint8_t person[16] = {'z', 'e', 'c', 'h', '_', 'E', 'x', 'p', 'a', 'n', 'd', 'S', 'e', 'e', 'd', '_'};
@@ -239,16 +239,20 @@ zk_status zk_spending_key_from_seed(const uint8_t* seed, size_t len, uint8_t spe
     fs_to_uniform(d, 64, v);
     memcpy(spending_key_out, v, 32);
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
-zk_status zk_jubjub_base_mul(const uint8_t* scalars, size_t n, uint8_t* points_out) {
+zk_status zk_jubjub_base_mul(const uint8_t* scalars, size_t n, uint8_t* points_out) try {
     if (n && (!scalars || !points_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return ZK_OK;
     (void)zkwit::tables();
     const unsigned nthreads = host_threads(n, 64);
     std::vector<zk_status> sts(nthreads, ZK_OK);
     std::vector<std::string> msgs(nthreads);
+    // test hook (tests/test_gen_proof.py): the LAST worker thread fails an allocation - the exception must reach the caller as
+    // a status, through run_threads and the barrier of this entry, not unwind into it
+    const bool inject = getenv("ZKAMD_INJECT_THROW") != nullptr;
     auto work = [&](unsigned t) {
+        if (inject && t + 1 == nthreads) throw std::bad_alloc();
         for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
             uint64_t k[4];
             load_scalar_le(scalars + 32 * i, k);
@@ -265,10 +269,10 @@ zk_status zk_jubjub_base_mul(const uint8_t* scalars, size_t n, uint8_t* points_o
     for (unsigned t = 0; t < nthreads; t++)
         if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 zk_status zk_elgamal_encrypt(const uint32_t* values, const uint8_t* randomness, const uint8_t* enc_keys, size_t n, uint8_t* left_out,
-                             uint8_t* right_out) {
+                             uint8_t* right_out) try {
     if (n && (!values || !randomness || !enc_keys || !left_out || !right_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return ZK_OK;
     (void)zkwit::tables();
@@ -300,18 +304,18 @@ zk_status zk_elgamal_encrypt(const uint32_t* values, const uint8_t* randomness, 
     for (unsigned t = 0; t < nthreads; t++)
         if (sts[t] != ZK_OK) return fail(sts[t], msgs[t]);
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
-zk_status zk_transfer_derive(const zk_transfer_request* req, size_t n, zk_transfer_statement* statements_out, uint8_t* rsk_out) {
+zk_status zk_transfer_derive(const zk_transfer_request* req, size_t n, zk_transfer_statement* statements_out, uint8_t* rsk_out) try {
     if (n && (!req || !statements_out || !rsk_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     return transfer_derive(req, n, statements_out, rsk_out, true);
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"
 extern "C" {
 
 zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk, size_t n, const zk_transfer_request* req,
-                                      const uint8_t* rs, zk_confidential_xt* out) {
+                                      const uint8_t* rs, zk_confidential_xt* out) try {
     if (!p || !circuit || !vk || (n && (!req || !rs || !out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
         return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the transfer circuit's");
@@ -381,7 +385,7 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
     for (size_t i = 0; i < n; i++)
         if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------
 // gen_proof of the anonymous transfer (core/proofs/src/anonymous.rs:97-183, 267-352): the same derivations, the
@@ -509,13 +513,13 @@ zk_status anonymous_derive(const zk_anonymous_request* rq, size_t n, zk_anonymou
 
 extern "C" {
 
-zk_status zk_anonymous_derive(const zk_anonymous_request* req, size_t n, zk_anonymous_statement* statements_out, uint8_t* rsk_out) {
+zk_status zk_anonymous_derive(const zk_anonymous_request* req, size_t n, zk_anonymous_statement* statements_out, uint8_t* rsk_out) try {
     if (n && (!req || !statements_out || !rsk_out)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     return anonymous_derive(req, n, statements_out, rsk_out, nullptr);
-}
+} ZK_ABI_CATCH
 
 zk_status zk_anonymous_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk, size_t n, const zk_anonymous_request* req,
-                                       const uint8_t* rs, zk_anonymous_xt* out) {
+                                       const uint8_t* rs, zk_anonymous_xt* out) try {
     if (!p || !circuit || !vk || (n && (!req || !rs || !out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return ZK_OK;
     const size_t n_pts = 4 * ZK_ANONYMOUS_SIZE + 4, n_pub = 2 * n_pts;
@@ -547,6 +551,6 @@ zk_status zk_anonymous_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk
     for (size_t i = 0; i < n; i++)
         if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"

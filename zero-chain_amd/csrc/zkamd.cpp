@@ -969,8 +969,8 @@ zk_status params_load(const uint8_t* pk, size_t len, int checked, int device, zk
     P->delta_g1_inf = delta_g1.is_inf();
     P->delta_g2_inf = delta_g2.is_inf();
     if (!r.u32be(&P->n_ic)) return fail(ZK_ERR_IO, "unexpected end of parameters (ic length)");
+    if ((size_t)P->n_ic * 96 > r.left) return fail(ZK_ERR_IO, "unexpected end of parameters in vk.ic");   // (before the allocation)
     std::vector<HG1A> ic(P->n_ic);
-    if ((size_t)P->n_ic * 96 > r.left) return fail(ZK_ERR_IO, "unexpected end of parameters in vk.ic");
     for (uint32_t i = 0; i < P->n_ic; i++) ZK_TRY(read_g1(r, &ic[i], "vk.ic"));
 
     P->vk_bytes.assign(pk, pk + (len - r.left));
@@ -1576,9 +1576,9 @@ zk_status prove_batch_host(zk_params* P, size_t n, const zk_assignment* asgs, co
         const size_t np = std::min(hc, n - first), next = first + hc;
         zk_status next_rc = ZK_OK;
         std::string next_err;
-        std::thread copier;
+        SideThread copier;
         if (next < n)
-            copier = std::thread([&, next] {
+            copier.start([&, next] {
                 next_rc = stage(cur ^ 1, next, std::min(hc, n - next));
                 if (next_rc != ZK_OK) next_err = g_err;   // g_err is thread-local
             });
@@ -1595,7 +1595,7 @@ zk_status prove_batch_host(zk_params* P, size_t n, const zk_assignment* asgs, co
         bt.b_input_density = z.b_input_density;
         bt.b_aux_density = z.b_aux_density;
         zk_status rc = prove_batch_dev(P, np, &bt, rs + first * 64, proofs_out + first * 192);
-        if (copier.joinable()) copier.join();
+        copier.join();
         if (rc != ZK_OK) return rc;
         if (next_rc != ZK_OK) return fail(next_rc, next_err);
         cur ^= 1;
@@ -2220,20 +2220,20 @@ const char* zk_strerror(zk_status st) {
 const char* zk_last_error(void) { return g_err.c_str(); }
 void zk_set_host_threads(int n) { g_host_threads = n > 0 ? n : 0; }
 
-zk_status zk_device_count(int* count) {
+zk_status zk_device_count(int* count) try {
     if (!count) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
     *count = n;
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
-zk_status zk_params_load(const uint8_t* pk_bytes, size_t len, int checked, int device, zk_params** out) {
+zk_status zk_params_load(const uint8_t* pk_bytes, size_t len, int checked, int device, zk_params** out) try {
     if (!pk_bytes || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     return params_load(pk_bytes, len, checked, device, out);
-}
-zk_status zk_params_get_info(const zk_params* p, zk_params_info* info) {
+} ZK_ABI_CATCH
+zk_status zk_params_get_info(const zk_params* p, zk_params_info* info) try {
     if (!p || !info) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     info->n_ic = p->n_ic;
     info->n_h = p->n_h;
@@ -2247,17 +2247,17 @@ zk_status zk_params_get_info(const zk_params* p, zk_params_info* info) {
     info->device = (uint32_t)p->device;
     info->device_bytes = p->g1.bytes + p->g2.bytes + p->ntt.bytes;
     return ZK_OK;
-}
-zk_status zk_params_get_windows(const zk_params* p, uint32_t out[4]) {
+} ZK_ABI_CATCH
+zk_status zk_params_get_windows(const zk_params* p, uint32_t out[4]) try {
     if (!p || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     out[0] = p->g1.c;
     out[1] = p->split_g1 ? p->g1a.c : p->g1.c;
     out[2] = p->g1_lone.c;
     out[3] = p->g2.c;
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 void zk_params_free(zk_params* p) { delete p; }
-zk_status zk_params_write_vk(const zk_params* p, uint8_t* out, size_t cap, size_t* len) {
+zk_status zk_params_write_vk(const zk_params* p, uint8_t* out, size_t cap, size_t* len) try {
     if (!p || !len) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *len = p->vk_bytes.size();
     if (out) {
@@ -2265,29 +2265,29 @@ zk_status zk_params_write_vk(const zk_params* p, uint8_t* out, size_t cap, size_
         memcpy(out, p->vk_bytes.data(), p->vk_bytes.size());
     }
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
-zk_status zk_prove(zk_params* p, const zk_assignment* asg, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[192]) {
+zk_status zk_prove(zk_params* p, const zk_assignment* asg, const uint8_t r[32], const uint8_t s[32], uint8_t proof_out[192]) try {
     if (!r || !s) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     uint8_t rs[64];
     memcpy(rs, r, 32);
     memcpy(rs + 32, s, 32);
     return prove_batch_host(p, 1, asg, rs, proof_out);
-}
-zk_status zk_prove_batch(zk_params* p, size_t n, const zk_assignment* asgs, const uint8_t* rs, uint8_t* proofs_out) {
+} ZK_ABI_CATCH
+zk_status zk_prove_batch(zk_params* p, size_t n, const zk_assignment* asgs, const uint8_t* rs, uint8_t* proofs_out) try {
     return prove_batch_host(p, n, asgs, rs, proofs_out);
-}
-zk_status zk_prove_batch_dev(zk_params* p, size_t n, const zk_batch_dev* batch, const uint8_t* rs, uint8_t* proofs_out) {
+} ZK_ABI_CATCH
+zk_status zk_prove_batch_dev(zk_params* p, size_t n, const zk_batch_dev* batch, const uint8_t* rs, uint8_t* proofs_out) try {
     return prove_batch_dev(p, n, batch, rs, proofs_out);
-}
+} ZK_ABI_CATCH
 
 zk_status zk_r1cs_load(uint32_t n_inputs, uint32_t n_aux, uint32_t n_constraints, const zk_csr* a, const zk_csr* b,
-                       const zk_csr* c, int device, zk_r1cs** out) {
+                       const zk_csr* c, int device, zk_r1cs** out) try {
     if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     const zk_csr* mats[3] = {a, b, c};
     return r1cs_load(n_inputs, n_aux, n_constraints, mats, device, out);
-}
+} ZK_ABI_CATCH
 void zk_r1cs_free(zk_r1cs* r) { delete r; }
 
 // the natively emitted constraint system of the transfer circuit (transfer_r1cs.h), built once per process
@@ -2295,14 +2295,14 @@ static const zkr1cs::System& transfer_system_cached() {
     static const zkr1cs::System sys = zkr1cs::transfer_system();
     return sys;
 }
-zk_status zk_transfer_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs, uint32_t* n_aux, uint32_t* n_constraints) {
+zk_status zk_transfer_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs, uint32_t* n_aux, uint32_t* n_constraints) try {
     const zkr1cs::System& sys = transfer_system_cached();
     if (hash_out) sys.fingerprint(hash_out);
     if (n_inputs) *n_inputs = sys.n_inputs;
     if (n_aux) *n_aux = sys.n_aux;
     if (n_constraints) *n_constraints = sys.n_constraints;
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 static zk_status system_load(const zkr1cs::System& sys, int device, zk_r1cs** out) {
     std::vector<uint8_t> coeff[3];
     zk_csr mats[3];
@@ -2320,48 +2320,48 @@ static zk_status system_load(const zkr1cs::System& sys, int device, zk_r1cs** ou
     const zk_csr* ptrs[3] = {&mats[0], &mats[1], &mats[2]};
     return r1cs_load(sys.n_inputs, sys.n_aux, sys.n_constraints, ptrs, device, out);
 }
-zk_status zk_transfer_r1cs_load(int device, zk_r1cs** out) {
+zk_status zk_transfer_r1cs_load(int device, zk_r1cs** out) try {
     if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     const zkr1cs::System& sys = transfer_system_cached();
     if (sys.n_inputs != ZK_TRANSFER_N_INPUTS || sys.n_aux != ZK_TRANSFER_N_AUX)
         return fail(ZK_ERR_INVALID_ARGUMENT, "internal: emitted system has the wrong shape");
     return system_load(sys, device, out);
-}
+} ZK_ABI_CATCH
 // the anonymous-transfer circuit, emitted the same way
 static const zkr1cs::System& anonymous_system_cached() {
     static const zkr1cs::System sys = zkr1cs::anonymous_system();
     return sys;
 }
-zk_status zk_anonymous_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs, uint32_t* n_aux, uint32_t* n_constraints) {
+zk_status zk_anonymous_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs, uint32_t* n_aux, uint32_t* n_constraints) try {
     const zkr1cs::System& sys = anonymous_system_cached();
     if (hash_out) sys.fingerprint(hash_out);
     if (n_inputs) *n_inputs = sys.n_inputs;
     if (n_aux) *n_aux = sys.n_aux;
     if (n_constraints) *n_constraints = sys.n_constraints;
     return ZK_OK;
-}
-zk_status zk_anonymous_r1cs_load(int device, zk_r1cs** out) {
+} ZK_ABI_CATCH
+zk_status zk_anonymous_r1cs_load(int device, zk_r1cs** out) try {
     if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     const zkr1cs::System& sys = anonymous_system_cached();
     if (sys.n_inputs != ZK_ANONYMOUS_N_INPUTS || sys.n_aux != ZK_ANONYMOUS_N_AUX)
         return fail(ZK_ERR_INVALID_ARGUMENT, "internal: emitted system has the wrong shape");
     return system_load(sys, device, out);
-}
+} ZK_ABI_CATCH
 zk_status zk_prove_batch_witness(zk_params* p, zk_r1cs* circuit, size_t n, const uint8_t* witness, uint32_t flags,
-                                 const uint8_t* rs, uint8_t* proofs_out) {
+                                 const uint8_t* rs, uint8_t* proofs_out) try {
     return prove_batch_witness(p, circuit, n, witness, flags, rs, proofs_out);
-}
+} ZK_ABI_CATCH
 
-zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
+zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) try {
     return transfer_witness(st, n, flags, witness_out);
-}
-zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
+} ZK_ABI_CATCH
+zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) try {
     return anonymous_witness(st, n, flags, witness_out);
-}
+} ZK_ABI_CATCH
 zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
-                                  const uint8_t* rs, uint8_t* proofs_out) {
+                                  const uint8_t* rs, uint8_t* proofs_out) try {
     if (!p || !circuit || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
         return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the transfer circuit's");
@@ -2401,20 +2401,20 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
         const size_t next = first + chunk;
         zk_status next_rc = ZK_OK;
         std::string next_err;
-        std::thread producer;
+        SideThread producer;
         if (next < n)
-            producer = std::thread([&, next] {
+            producer.start([&, next] {
                 next_rc = transfer_witness(st + next, std::min(chunk, n - next), ZK_FR_MONTGOMERY, buf[cur ^ 1], next);
                 if (next_rc != ZK_OK) next_err = g_err;   // g_err is thread-local
             });
         rc = prove_batch_witness(p, circuit, np, buf[cur], ZK_FR_MONTGOMERY, rs + first * 64, proofs_out + first * 192);
-        if (producer.joinable()) producer.join();
+        producer.join();
         if (rc != ZK_OK) return rc;
         if (next_rc != ZK_OK) return fail(next_rc, next_err);
         cur ^= 1;
     }
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 // Statement -> proof for the anonymous-transfer circuit (core/proofs/src/anonymous.rs:165: create_random_proof of
 // AnonymousTransfer): witness generation on the GPU (witness_anon_gpu.h, round 4), the kernels of chunk k + 1 beside the
@@ -2422,7 +2422,7 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
 // the host cores.  Both paths prove every chunk before the first malformed statement's and report that statement in the
 // same words.
 zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_anonymous_statement* st, const uint8_t* rs,
-                                   uint8_t* proofs_out) {
+                                   uint8_t* proofs_out) try {
     if (!p || !circuit || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (circuit->n_in != ZK_ANONYMOUS_N_INPUTS || circuit->n_aux != ZK_ANONYMOUS_N_AUX)
         return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the anonymous-transfer circuit's");
@@ -2466,9 +2466,9 @@ zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, con
         const size_t np = std::min(chunk, n - first), next = first + chunk;
         zk_status next_rc = ZK_OK;
         std::string next_err;
-        std::thread producer;
+        SideThread producer;
         if (next < n)
-            producer = std::thread([&, next] {
+            producer.start([&, next] {
                 next_rc = witness(next, std::min(chunk, n - next), buf[cur ^ 1]);
                 if (next_rc != ZK_OK) next_err = g_err;
             });
@@ -2477,17 +2477,17 @@ zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, con
         for (size_t off = 0; off < np && rc == ZK_OK; off += chunk)
             rc = prove_batch_witness(p, circuit, std::min(chunk, np - off), buf[cur] + off * nv * 32, ZK_FR_MONTGOMERY,
                                      rs + (first + off) * 64, proofs_out + (first + off) * 192);
-        if (producer.joinable()) producer.join();
+        producer.join();
         if (rc != ZK_OK) return rc;
         if (next_rc != ZK_OK) return fail(next_rc, next_err);
         cur ^= 1;
     }
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 // The witness vectors the GPU generator of the anonymous circuit produces, copied back to the host (tests: element by
 // element against zk_anonymous_witness).  witness_out: n x (105 + 50429) x 32 bytes.
-zk_status zk_anonymous_witness_gpu(zk_r1cs* circuit, const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
+zk_status zk_anonymous_witness_gpu(zk_r1cs* circuit, const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) try {
     if (!circuit || (n && (!st || !witness_out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (circuit->n_in != ZK_ANONYMOUS_N_INPUTS || circuit->n_aux != ZK_ANONYMOUS_N_AUX)
         return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the anonymous-transfer circuit's");
@@ -2507,11 +2507,11 @@ zk_status zk_anonymous_witness_gpu(zk_r1cs* circuit, const zk_anonymous_statemen
         HIP_TRY(hipMemcpy(witness_out + first * nv * 32, circuit->z[0].p, np * nv * 32, hipMemcpyDeviceToHost));
     }
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 // The witness vectors the GPU generator produces, copied back to the host: lets the tests compare it with the
 // host calculator (zk_transfer_witness) element by element.  witness_out: n x (23 + 19955) x 32 bytes.
-zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) {
+zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement* st, size_t n, uint32_t flags, uint8_t* witness_out) try {
     if (!circuit || (n && (!st || !witness_out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
         return fail(ZK_ERR_INVALID_ARGUMENT, "the loaded constraint matrices are not the transfer circuit's");
@@ -2531,7 +2531,7 @@ zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement*
         HIP_TRY(hipMemcpy(witness_out + first * nv * 32, circuit->z[0].p, np * nv * 32, hipMemcpyDeviceToHost));
     }
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 // ------------------------------------------------------------------------------------------
 // zk_pipeline: a stream of statement batches.  zk_transfer_prove_batch overlaps the witnesses of
@@ -2596,7 +2596,7 @@ struct zk_pipeline {
                     continue;
                 }
             }
-            zk_status rc = transfer_witness(j.st, j.n, ZK_FR_MONTGOMERY, buf[j.slot].as<uint8_t>(), j.index_base);
+            zk_status rc = guarded([&] { return transfer_witness(j.st, j.n, ZK_FR_MONTGOMERY, buf[j.slot].as<uint8_t>(), j.index_base); });
             std::lock_guard<std::mutex> lk(mu);
             if (rc != ZK_OK) fail_with(rc, g_err);
             q_gpu.push_back(j);
@@ -2628,7 +2628,7 @@ struct zk_pipeline {
         const hipStream_t wstream = g_copy_stream;
         auto start = [&](Job& j, int s) -> zk_status {
             j.slot = s;
-            return witness_gpu_enqueue(R, j.st, j.n, s, wstream);
+            return guarded([&] { return witness_gpu_enqueue(R, j.st, j.n, s, wstream); });
         };
         for (;;) {
             zk_status rc = ZK_OK;
@@ -2662,8 +2662,8 @@ struct zk_pipeline {
             }
             zk_status rc_next = ZK_OK;
             if (have_nxt && !skip && rc == ZK_OK) rc_next = start(nxt, cur.slot ^ 1);
-            if (!skip && rc == ZK_OK) rc = witness_gpu_finish(R, cur.n, cur.slot, cur.index_base);
-            if (!skip && rc == ZK_OK) rc = prove_from_z(P, R, cur.n, cur.slot, cur.rs, cur.out);
+            if (!skip && rc == ZK_OK) rc = guarded([&] { return witness_gpu_finish(R, cur.n, cur.slot, cur.index_base); });
+            if (!skip && rc == ZK_OK) rc = guarded([&] { return prove_from_z(P, R, cur.n, cur.slot, cur.rs, cur.out); });
             // nothing of a failed job stays in flight when wait() returns: drain the device BEFORE the job is counted done
             if (rc != ZK_OK || rc_next != ZK_OK) (void)hipDeviceSynchronize();
             if (lane > 0 && (rc == ZK_ERR_OUT_OF_MEMORY || rc_next == ZK_ERR_OUT_OF_MEMORY)) {
@@ -2720,7 +2720,7 @@ struct zk_pipeline {
                 skip = err != ZK_OK;
             }
             zk_status rc = ZK_OK;
-            if (!skip) rc = prove_batch_witness(P, R, j.n, buf[j.slot].as<uint8_t>(), ZK_FR_MONTGOMERY, j.rs, j.out);
+            if (!skip) rc = guarded([&] { return prove_batch_witness(P, R, j.n, buf[j.slot].as<uint8_t>(), ZK_FR_MONTGOMERY, j.rs, j.out); });
             std::lock_guard<std::mutex> lk(mu);
             if (rc != ZK_OK) fail_with(rc, g_err);
             slot_free[j.slot] = true;
@@ -2732,7 +2732,7 @@ struct zk_pipeline {
 
 extern "C" {
 
-zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) {
+zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) try {
     if (!p || !circuit || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (circuit->n_in != ZK_TRANSFER_N_INPUTS || circuit->n_aux != ZK_TRANSFER_N_AUX)
@@ -2817,7 +2817,7 @@ zk_status zk_pipeline_create(zk_params* p, zk_r1cs* circuit, zk_pipeline** out) 
     }
     *out = L;
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 int zk_pipeline_lanes(const zk_pipeline* L) {
     if (!L) return 0;
@@ -2825,7 +2825,7 @@ int zk_pipeline_lanes(const zk_pipeline* L) {
     return L->live_lanes;
 }
 
-zk_status zk_pipeline_submit(zk_pipeline* L, size_t n, const zk_transfer_statement* st, const uint8_t* rs, uint8_t* proofs_out) {
+zk_status zk_pipeline_submit(zk_pipeline* L, size_t n, const zk_transfer_statement* st, const uint8_t* rs, uint8_t* proofs_out) try {
     if (!L || !rs || !proofs_out || (!st && n)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     std::lock_guard<std::mutex> lk(L->mu);
     for (size_t first = 0; first < n; first += L->chunk) {
@@ -2835,9 +2835,9 @@ zk_status zk_pipeline_submit(zk_pipeline* L, size_t n, const zk_transfer_stateme
     }
     L->cv.notify_all();
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
-zk_status zk_pipeline_wait(zk_pipeline* L) {
+zk_status zk_pipeline_wait(zk_pipeline* L) try {
     if (!L) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     std::unique_lock<std::mutex> lk(L->mu);
     L->cv.wait(lk, [&] { return L->in_flight == 0; });
@@ -2846,7 +2846,7 @@ zk_status zk_pipeline_wait(zk_pipeline* L) {
     L->err = ZK_OK;   // the stream is usable again after the failure has been reported
     L->err_msg.clear();
     return rc;
-}
+} ZK_ABI_CATCH
 
 void zk_pipeline_free(zk_pipeline* L) {
     if (!L) return;
@@ -2866,29 +2866,29 @@ void zk_pipeline_free(zk_pipeline* L) {
     delete L;
 }
 
-zk_status zk_msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
+zk_status zk_msm_create(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) try {
     if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     return msm_create(group, bases, n, window_bits, checked, device, out);
-}
-zk_status zk_msm_create_variable(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) {
+} ZK_ABI_CATCH
+zk_status zk_msm_create_variable(int group, const uint8_t* bases, size_t n, int window_bits, int checked, int device, zk_msm** out) try {
     if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     return msm_create(group, bases, n, window_bits, checked, device, out, true);
-}
-zk_status zk_msm_run(zk_msm* m, const uint8_t* scalars, uint32_t flags, uint8_t* out) { return msm_run(m, scalars, flags, out); }
-zk_status zk_msm_run_dev(zk_msm* m, const void* d_scalars, uint32_t flags, uint8_t* out) { return msm_run_dev(m, d_scalars, flags, out); }
+} ZK_ABI_CATCH
+zk_status zk_msm_run(zk_msm* m, const uint8_t* scalars, uint32_t flags, uint8_t* out) try { return msm_run(m, scalars, flags, out); } ZK_ABI_CATCH
+zk_status zk_msm_run_dev(zk_msm* m, const void* d_scalars, uint32_t flags, uint8_t* out) try { return msm_run_dev(m, d_scalars, flags, out); } ZK_ABI_CATCH
 void zk_msm_free(zk_msm* m) { delete m; }
 
 // (the device this host thread selected last through any other entry, else device 0)
-zk_status zk_msm_g1(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+zk_status zk_msm_g1(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) try {
     return msm_oneshot(1, bases, scalars, n, out);
-}
-zk_status zk_msm_g2(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) {
+} ZK_ABI_CATCH
+zk_status zk_msm_g2(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]) try {
     return msm_oneshot(2, bases, scalars, n, out);
-}
+} ZK_ABI_CATCH
 
-zk_status zk_ntt_create(uint32_t log_n, int device, zk_ntt** out) {
+zk_status zk_ntt_create(uint32_t log_n, int device, zk_ntt** out) try {
     if (!out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     zk_status st = use_device(device);
@@ -2903,11 +2903,11 @@ zk_status zk_ntt_create(uint32_t log_n, int device, zk_ntt** out) {
     }
     *out = t;
     return ZK_OK;
-}
-zk_status zk_ntt_run_dev(zk_ntt* t, void* d_data, uint32_t batch, uint32_t flags) { return ntt_run_dev(t, d_data, batch, flags); }
+} ZK_ABI_CATCH
+zk_status zk_ntt_run_dev(zk_ntt* t, void* d_data, uint32_t batch, uint32_t flags) try { return ntt_run_dev(t, d_data, batch, flags); } ZK_ABI_CATCH
 void zk_ntt_free(zk_ntt* t) { delete t; }
 
-zk_status zk_ntt_fr(uint8_t* data, uint32_t log_n, int inverse, int coset) {
+zk_status zk_ntt_fr(uint8_t* data, uint32_t log_n, int inverse, int coset) try {
     if (!data) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     size_t n = (size_t)1 << log_n;
     zk_status st = check_scalars(data, n, 0);
@@ -2932,9 +2932,9 @@ zk_status zk_ntt_fr(uint8_t* data, uint32_t log_n, int inverse, int coset) {
     }
     zk_ntt_free(t);
     return st;
-}
+} ZK_ABI_CATCH
 
-zk_status zk_debug_field_mul(int field, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) {
+zk_status zk_debug_field_mul(int field, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t n) try {
     if (!a || !b || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     if (field != 0 && field != 1) return fail(ZK_ERR_INVALID_ARGUMENT, "field must be 0 (Fr) or 1 (Fq)");
     zk_status st = use_device(g_device >= 0 ? g_device : 0);
@@ -2957,7 +2957,7 @@ zk_status zk_debug_field_mul(int field, const uint8_t* a, const uint8_t* b, uint
     HIP_TRY(hipStreamSynchronize(g_stream));
     HIP_TRY(hipMemcpy(out, dc.p, n * sz, hipMemcpyDeviceToHost));
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 void zk_profile_begin(void) {
     zk_profile_end();
@@ -2990,7 +2990,7 @@ void zk_profile_end(void) {
     g_recs.clear();
     g_prof = false;
 }
-zk_status zk_kernel_forms(int device, uint32_t forms_out[2], float ms_out[4]) {
+zk_status zk_kernel_forms(int device, uint32_t forms_out[2], float ms_out[4]) try {
     if (device < 0 || device >= 64) return fail(ZK_ERR_INVALID_ARGUMENT, "device index out of range");
     std::lock_guard<std::mutex> lock(g_forms_mu);
     const KernelForms& F = g_forms[device];
@@ -3001,12 +3001,12 @@ zk_status zk_kernel_forms(int device, uint32_t forms_out[2], float ms_out[4]) {
     for (int i = 0; i < 4; i++)
         if (ms_out) ms_out[i] = F.ms[i];
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 void* zk_stream(void) { return (void*)g_stream; }
-zk_status zk_synchronize(void) {
+zk_status zk_synchronize(void) try {
     if (g_stream) HIP_TRY(hipStreamSynchronize(g_stream));
     if (g_stream2) HIP_TRY(hipStreamSynchronize(g_stream2));
     return ZK_OK;
-}
+} ZK_ABI_CATCH
 
 }  // extern "C"
