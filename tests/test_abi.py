@@ -121,6 +121,59 @@ def test_every_declared_entry_point_has_a_caller_in_the_tests():
     assert not unreached, "entry points no test calls: %s" % unreached
 
 
+def _rust_sizeof(ty, structs, consts):
+    """size and alignment of a type of include/zkamd_sys.rs under #[repr(C)] on x86-64"""
+    ty = ty.strip()
+    prim = {"u8": (1, 1), "u32": (4, 4), "u64": (8, 8), "i32": (4, 4), "f32": (4, 4), "f64": (8, 8), "usize": (8, 8), "c_int": (4, 4)}
+    if ty in prim:
+        return prim[ty]
+    if ty.startswith("*"):
+        return (8, 8)
+    if ty.startswith("["):
+        inner, bound = ty[1:-1].rsplit(";", 1)
+        bound = bound.strip().strip("{} ")
+        for k, v in consts.items():
+            bound = re.sub(r"\b%s\b" % k, str(v), bound)
+        size, align = _rust_sizeof(inner, structs, consts)
+        return (size * int(eval(bound, {"__builtins__": {}})), align)
+    off, amax = 0, 1
+    for fty in structs[ty]:
+        size, align = _rust_sizeof(fty, structs, consts)
+        off = (off + align - 1) // align * align + size
+        amax = max(amax, align)
+    return ((off + amax - 1) // amax * amax, amax)
+
+
+def test_rust_binding_file_matches_the_header(tmp_path):
+    """include/zkamd_sys.rs - the `extern "C"` block the reference's maintainer would add - is generated from
+    include/zkamd.h: regenerating gives the committed bytes, every entry point is declared, and every #[repr(C)] struct has
+    the size the C compiler gives the header's (there is no rustc in this image to compile the file itself)."""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("gen_rust", os.path.join(ROOT, "tools", "gen_rust_bindings.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    text, names = gen.generate()
+    assert open(os.path.join(ROOT, "include", "zkamd_sys.rs")).read() == text, "run python tools/gen_rust_bindings.py"
+    assert sorted(names) == declared_symbols()
+    for s in declared_symbols():
+        assert re.search(r"pub fn %s\(" % s, text)
+    consts = {k: int(v) for k, v in re.findall(r"pub const (ZK_[A-Z_0-9]+): \w+ = (\d+);", text)}
+    structs = {}
+    for name, body in re.findall(r"pub struct (zk_\w+) \{(.*?)\n\}", text, flags=re.S):
+        structs[name] = [f.split(":", 1)[1].strip().rstrip(",") for f in body.strip().split("\n") if ":" in f]
+    plain = [n for n, f in structs.items() if f != ["[u8; 0]"]]
+    assert len(plain) >= 10
+    prog = tmp_path / "sizes.c"
+    prog.write_text('#include <stdio.h>\n#include "zkamd.h"\nint main(void) {\n' +
+                    "".join('    printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in plain) + "    return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    c_sizes = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for n in plain:
+        assert _rust_sizeof(n, structs, consts)[0] == int(c_sizes[n]), n
+
+
 def test_every_status_entry_is_an_exception_barrier():
     """No C++ exception may unwind into the Rust / C host: every definition of an exported entry that returns a zk_status
     is a function-try-block closed by ZK_ABI_CATCH (zero-chain_amd/csrc/host_common.h); behaviour:
