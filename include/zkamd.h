@@ -31,6 +31,49 @@
  *   - no C++ exception leaves the library: every entry that returns a zk_status is an exception barrier
  *     (a failed host allocation is ZK_ERR_OUT_OF_MEMORY, anything else ZK_ERR_DEVICE with the text in
  *     zk_last_error()), also for work the library does on its own threads.
+ *
+ * Index: entry point -> the reference interface it replaces (paths under /root/reference; "bellman" = the un-vendored
+ * bellman 0.1.0 crate, Cargo.lock:210-212, whose surface as the reference uses it is SURVEY.md 8(b)); "-" = no
+ * counterpart in the reference (why it exists is said at the declaration).
+ *   zk_params_load, zk_params_free  Parameters::read(reader, checked)             core/proofs/src/confidential.rs:99
+ *   zk_params_get_info, zk_params_get_windows   - (fields of Parameters: lengths of the queries; the recoding widths chosen here)
+ *   zk_params_write_vk              Parameters.vk, the input of prepare_verifying_key   core/proofs/src/setup.rs:31, 62
+ *   zk_prove / zk_prove_batch       create_random_proof -> create_proof           confidential.rs:149, anonymous.rs:165
+ *   zk_prove_batch_dev              the same, assignments already in HBM          confidential.rs:149
+ *   zk_r1cs_load, zk_r1cs_free      the matrices a Circuit::synthesize enforces   circuit/confidential_transfer.rs:61-305
+ *   zk_prove_batch_witness          create_proof; bellman's ProvingAssignment row evaluation
+ *   zk_transfer_r1cs_load           structure half of ConfidentialTransfer::synthesize   circuit/confidential_transfer.rs:61-305
+ *   zk_transfer_r1cs_fingerprint    TestConstraintSystem::hash / the pinned values       circuit/test.rs:228-251, confidential_transfer.rs:383-386
+ *   zk_transfer_witness, zk_transfer_witness_gpu   value half of ConfidentialTransfer::synthesize       circuit/confidential_transfer.rs:29-41, 61-305
+ *   zk_transfer_prove_batch         synthesize + create_random_proof              confidential.rs:134-149
+ *   zk_pipeline_create, zk_pipeline_submit, zk_pipeline_wait, zk_pipeline_lanes, zk_pipeline_free
+ *                                   the same for a stream of batches; - (the reference proves one transaction per call)
+ *   zk_spending_key_from_seed       SpendingKey::from_seed                        core/proofs/src/no_std_aliases/keys.rs:45-58
+ *   zk_jubjub_base_mul              EncryptionKey::from_decryption_key            no_std_aliases/keys.rs:250-261
+ *   zk_elgamal_encrypt              elgamal::Ciphertext::encrypt                  no_std_aliases/elgamal.rs:46-63
+ *   zk_transfer_derive              the derivations at the head of gen_proof      confidential.rs:105-133
+ *   zk_transfer_gen_proof_batch     ProofBuilder::gen_proof (Confidential)        confidential.rs:105-172, check_proof :208-278
+ *   zk_anonymous_r1cs_load          structure half of AnonymousTransfer::synthesize      circuit/anonymous_transfer.rs:56-337
+ *   zk_anonymous_r1cs_fingerprint   TestConstraintSystem::hash (no pin in the reference) circuit/test.rs:228-251, anonymous_transfer.rs:446-451
+ *   zk_anonymous_witness, zk_anonymous_witness_gpu   value half of AnonymousTransfer::synthesize          circuit/anonymous_transfer.rs:40-54, 56-337
+ *   zk_anonymous_prove_batch        synthesize + create_random_proof              anonymous.rs:147-165
+ *   zk_anonymous_derive             the derivations at the head of gen_proof      anonymous.rs:97-146
+ *   zk_anonymous_gen_proof_batch    ProofBuilder::gen_proof (Anonymous)           anonymous.rs:97-183, check_proof :213-264
+ *   zk_generate_parameters          generate_random_parameters                    core/proofs/src/setup.rs:28-31, 59-62
+ *   zk_vk_prepare                   prepare_verifying_key                         core/bellman-verifier/src/verifier.rs:15-30
+ *   zk_vk_read, zk_vk_write, zk_vk_free   PreparedVerifyingKey::read / write            core/bellman-verifier/src/lib.rs:175-244
+ *   zk_vk_num_inputs                pvk.ic.len() - 1                              verifier.rs:38-40
+ *   zk_verify_proof / zk_verify_batch   verify_proof                              verifier.rs:32-63; callers confidential.rs:271, modules/zk-system/src/lib.rs:57-108
+ *   zk_verify_batch_rlc             - (bellman's batch verifier): the same verdicts, one final exponentiation
+ *   zk_proof_read_batch             Proof::read                                   core/bellman-verifier/src/lib.rs:67-110
+ *   zk_msm_create, zk_msm_create_variable, zk_msm_run, zk_msm_run_dev, zk_msm_free, zk_msm_g1, zk_msm_g2
+ *                                   bellman multiexp(FullDensity); group law core/pairing/src/bls12_381/ec.rs:296-526
+ *   zk_ntt_fr, zk_ntt_create, zk_ntt_run_dev, zk_ntt_free
+ *                                   bellman EvaluationDomain {fft, ifft, coset_fft, icoset_fft}; field core/pairing/src/bls12_381/fr.rs:341-571
+ *   zk_debug_field_mul              Fr / Fq mul_assign (for the literal KATs)     fr.rs:438-464, fq.rs:915-965
+ *   zk_strerror / zk_last_error     the variants of SynthesisError and their texts   core/bellman-verifier/src/lib.rs:359-383
+ *   zk_device_count, zk_set_host_threads, zk_bind_host_to_device, zk_stream, zk_synchronize, zk_kernel_forms,
+ *   zk_profile_begin, zk_profile_get, zk_profile_end   - (device selection, host threads, measurement; the reference runs on the CPU)
  */
 #ifndef ZKAMD_H
 #define ZKAMD_H
@@ -238,7 +281,7 @@ void zk_pipeline_free(zk_pipeline* pl);
  * (no_std_aliases/keys.rs:132-198), rvk = pgk + alpha G, nonce = dec_key * g_epoch, the proof, the ElGamal
  * ciphertexts of amount and fee under both keys (elgamal.rs:46-63), check_proof against the prepared verifying key
  * (confidential.rs:208-278; ZK_ERR_UNSATISFIABLE if a proof does not verify, as the reference) and the packing of
- * ConfidentialXt (:282-361), rsk = sk + alpha.  randomness / alpha are the two Fs::rand draws of gen_proof,
+ * ConfidentialXt (gen_xt :282-354, the struct :358-370), rsk = sk + alpha.  randomness / alpha are the two Fs::rand draws of gen_proof,
  * rs (n x 64 bytes) the two Fr::rand draws of create_random_proof; scalars 32 bytes little-endian, points in the
  * 32-byte Jubjub encoding.
  * zk_transfer_derive is the host half alone (request -> statement and rsk); zk_spending_key_from_seed is
@@ -253,7 +296,7 @@ typedef struct {
     uint8_t enc_key_recipient[32], enc_balance_left[32], enc_balance_right[32], g_epoch[32];
     uint8_t randomness[32], alpha[32];
 } zk_transfer_request;
-typedef struct {   /* ConfidentialXt, confidential.rs:349-361 */
+typedef struct {   /* ConfidentialXt, confidential.rs:358-370 */
     uint8_t proof[192];
     uint8_t enc_key_sender[32], enc_key_recipient[32], left_amount_sender[32], left_amount_recipient[32], left_fee[32],
         right_randomness[32], rsk[32], rvk[32], enc_balance[64], nonce[32];
@@ -310,8 +353,8 @@ zk_status zk_anonymous_r1cs_fingerprint(uint8_t hash_out[32], uint32_t* n_inputs
  * derivations of the confidential entry, the anonymity set assembled with the sender at s_index, the recipient at
  * t_index and the ten decoys in their order elsewhere (:117-126), MultiCiphertexts::<Anonymous>::encrypt
  * (crypto_components.rs:168-220: -amount under the sender's key, +amount under the recipient's, zero under every
- * decoy's, one randomness), the proof, check_proof over the 104 public coordinates (:200-262; ZK_ERR_UNSATISFIABLE if
- * it fails) and the packing of AnonymousXt (:277-352).  enc_balances_* are indexed by set member.
+ * decoy's, one randomness), the proof, check_proof over the 104 public coordinates (:213-264; ZK_ERR_UNSATISFIABLE if
+ * it fails) and the packing of AnonymousXt (gen_xt :278-348, the struct :351-359).  enc_balances_* are indexed by set member.
  * zk_anonymous_derive is the host half alone (request -> statement and rsk). */
 typedef struct {
     uint32_t amount, remaining_balance, s_index, t_index;
@@ -321,7 +364,7 @@ typedef struct {
     uint8_t g_epoch[32];
     uint8_t randomness[32], alpha[32];
 } zk_anonymous_request;
-typedef struct {   /* AnonymousXt, anonymous.rs:344-352 */
+typedef struct {   /* AnonymousXt, anonymous.rs:351-359 */
     uint8_t proof[192];
     uint8_t enc_keys[ZK_ANONYMOUS_SIZE][32], left_ciphertexts[ZK_ANONYMOUS_SIZE][32];
     uint8_t right_ciphertext[32], nonce[32], rsk[32], rvk[32];

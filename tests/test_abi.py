@@ -121,6 +121,16 @@ def test_every_declared_entry_point_has_a_caller_in_the_tests():
     assert not unreached, "entry points no test calls: %s" % unreached
 
 
+def test_header_index_names_what_every_entry_replaces():
+    """include/zkamd.h opens with an index: every entry point next to the reference interface (file:line) it replaces, or
+    "-" where the reference has no counterpart."""
+    src = open(os.path.join(ROOT, "include", "zkamd.h")).read()
+    head = src[src.index("Index: entry point"):src.index("#ifndef ZKAMD_H")]
+    missing = [s for s in declared_symbols() if not re.search(r"\b%s\b" % s, head)]
+    assert not missing, "entries the header's index does not name: %s" % missing
+    assert len(re.findall(r"\.rs:\d+", head)) >= 30
+
+
 def _rust_sizeof(ty, structs, consts):
     """size and alignment of a type of include/zkamd_sys.rs under #[repr(C)] on x86-64"""
     ty = ty.strip()

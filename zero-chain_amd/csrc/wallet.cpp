@@ -31,7 +31,7 @@ using zkhost::Fr;
 // gen_proof: the wallet-level entry of the reference (core/proofs/src/confidential.rs:105-172) for a batch of
 // transfers - key derivation (no_std_aliases/keys.rs:132-198), the statement, create_proof, the ElGamal
 // ciphertexts (elgamal.rs:46-63), the self-check (check_proof, confidential.rs:208-278) and the packing of
-// ConfidentialXt (:282-361).
+// ConfidentialXt (gen_xt :282-354, the struct :358-370).
 // ------------------------------------------------------------------------------------------
 
 
@@ -391,7 +391,7 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
 // gen_proof of the anonymous transfer (core/proofs/src/anonymous.rs:97-183, 267-352): the same derivations, the
 // anonymity set assembled around the sender and the recipient, MultiCiphertexts::<Anonymous>::encrypt
 // (crypto_components.rs:168-220: the sender's amount negated, the recipient's positive, zero under every decoy key,
-// one randomness), check_proof over the 104 public coordinates (:200-262) and the packing of AnonymousXt.
+// one randomness), check_proof over the 104 public coordinates (:213-264) and the packing of AnonymousXt.
 // ------------------------------------------------------------------------------------------
 }  // extern "C"
 
@@ -546,7 +546,7 @@ zk_status zk_anonymous_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk
         jubjub_encode(tail[3].x, tail[3].y, x.nonce);
         memcpy(x.rsk, &rsk[i * 32], 32);
     }
-    // check_proof (anonymous.rs:200-262)
+    // check_proof (anonymous.rs:213-264)
     ZK_TRY(verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data(), true));
     for (size_t i = 0; i < n; i++)
         if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");
