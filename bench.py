@@ -791,6 +791,43 @@ def main():
                                               "witness generation, proof, check_proof of every proof, ConfidentialXt" % (2 * B)}
         except Exception as exc:
             secondary["gen_proof"] = {"error": repr(exc)[:200]}
+        # (4b) ONE transaction at a time - the reference's call pattern (one gen_proof per transfer): statement -> proof and
+        # request -> ConfidentialXt for a single statement.  Its assignment is computed on a host core by default (the
+        # witness kernels are 8.4 ms of serial chains whatever the batch holds, the host calculator 1.4 ms per statement);
+        # ZKAMD_WITNESS=gpu beside it.
+        try:
+            one_st = zk.transfer_statements(items[:1])
+            one_rq = zk.transfer_requests(req_items[:1])
+            one_rs = zk.scalars_to_bytes([5, 7])
+            pvk4 = zk.prepare_verifying_key(params)
+            lone = {}
+            for engine in ("host", "gpu"):
+                os.environ["ZKAMD_WITNESS"] = engine
+                zk.transfer_prove_batch(mats, params, one_st, [(5, 7)])
+                zk.gen_proofs(params, mats, pvk4, one_rq, one_rs, raw=True)
+                t0 = time.perf_counter()
+                for i in range(5):
+                    pf1 = zk.transfer_prove_batch(mats, params, one_st, [(5, 7)])
+                t1 = time.perf_counter()
+                for i in range(5):
+                    zk.gen_proofs(params, mats, pvk4, one_rq, one_rs, raw=True)
+                t2 = time.perf_counter()
+                lone[engine] = (round((t1 - t0) / 5 * 1e3, 2), round((t2 - t1) / 5 * 1e3, 2), pf1[0].write())
+            del os.environ["ZKAMD_WITNESS"]
+            t0 = time.perf_counter()
+            pf0 = zk.transfer_prove_batch(mats, params, one_st, [(5, 7)])
+            dflt = round((time.perf_counter() - t0) * 1e3, 2)
+            pvk4.close()
+            assert lone["host"][2] == lone["gpu"][2] == pf0[0].write(), "the two witness engines disagree"
+            secondary["single_transaction"] = {
+                "statement_to_proof_ms": lone["host"][0], "gen_proof_ms": lone["host"][1], "default_engine_ms": dflt,
+                "with_gpu_witness": {"statement_to_proof_ms": lone["gpu"][0], "gen_proof_ms": lone["gpu"][1]},
+                "note": "zk_transfer_prove_batch / zk_transfer_gen_proof_batch with n = 1 (gen_proof: derivations, proof, "
+                        "check_proof, ConfidentialXt); the assignment of up to 2 x host-threads statements is computed on the host "
+                        "cores by default, create_proof is on the GPU either way; both engines give the same proof bytes"}
+        except Exception as exc:
+            os.environ.pop("ZKAMD_WITNESS", None)
+            secondary["single_transaction"] = {"error": repr(exc)[:200]}
         # (5) the verifier alone (row f-3: zk_verify_batch = n verify_proof calls, full decoding with the r-torsion
         # tests of Proof::read): the proofs of the last step, once as they are and eight times over
         try:

@@ -253,7 +253,9 @@ zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_
 zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
                                   const uint8_t* rs, uint8_t* proofs_out);
 /* zk_transfer_prove_batch and zk_pipeline compute the witnesses ON THE GPU (one thread per statement and gadget,
- * the assignment never leaves HBM; ZKAMD_WITNESS=host selects the host calculator instead).  This entry returns
+ * the assignment never leaves HBM) - except for a handful of statements (n <= 2 x host threads: one transaction at a time,
+ * the reference's call pattern), whose assignments the native host calculator computes faster than the kernels' 8.4 ms of
+ * serial chains; ZKAMD_WITNESS = host | gpu forces an engine, the proof bytes do not depend on it.  This entry returns
  * what that generator produces - same format as zk_transfer_witness - so that the two can be compared. */
 zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement* st, size_t n, uint32_t flags,
                                   uint8_t* witness_out);
@@ -338,7 +340,7 @@ zk_status zk_anonymous_witness(const zk_anonymous_statement* st, size_t n, uint3
 /* The same vectors from the GPU witness generator (csrc/witness_anon_gpu.h; tests compare the two element by element) */
 zk_status zk_anonymous_witness_gpu(zk_r1cs* circuit, const zk_anonymous_statement* st, size_t n, uint32_t flags, uint8_t* witness_out);
 /* statement -> proof for that circuit (create_random_proof of AnonymousTransfer, core/proofs/src/anonymous.rs:165):
- * witness generation on the GPU (round 4; ZKAMD_WITNESS=host: the host calculator on the host cores), the kernels of
+ * witness generation on the GPU (round 4; a handful of statements, or ZKAMD_WITNESS=host: the host calculator), the kernels of
  * chunk k + 1 beside row evaluations + create_proof of chunk k, over the matrices loaded with zk_anonymous_r1cs_load. */
 zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_anonymous_statement* st,
                                    const uint8_t* rs, uint8_t* proofs_out);

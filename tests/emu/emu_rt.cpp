@@ -31,6 +31,10 @@ void emu_barrier_wait() {
 }
 
 void emu_launch(emu_dim3 grid, emu_dim3 block, size_t shmem, bool needs_sync, const std::function<void()>& body) {
+    // one launch at a time: blockDim / gridDim, the dynamic shared area and the barrier state are process-wide (two host
+    // threads driving two handles - tests/abi_multi.c - launched into each other's grid: found by this very build, r5)
+    static std::mutex launch_mu;
+    std::lock_guard<std::mutex> launch_lock(launch_mu);
     blockDim = block;
     gridDim = grid;
     std::vector<unsigned char> dyn(shmem + 64);

@@ -170,8 +170,11 @@ def test_anonymous_circuit_from_witness(gpu_lib, monkeypatch):
         monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "2")
         ws = [ac.make_witness(1 + i, amount=10 + i, balance=100 + 3 * i) for i in range(2)]   # the statements of anonymous_case(2)
         sts = zk.anonymous_statements([ac.statement_dict(ws[i % 2]) for i in range(3)])
-        got = zk.anonymous_prove_batch(mats, params, sts, rs)
-        assert [p.write() for p in got] == [p.write() for p in proofs]
+        for engine in WITNESS_ENGINES:   # the witness kernels / the host calculator (the default for a handful of statements)
+            monkeypatch.setenv("ZKAMD_WITNESS", engine)
+            got = zk.anonymous_prove_batch(mats, params, sts, rs)
+            assert [p.write() for p in got] == [p.write() for p in proofs]
+        monkeypatch.delenv("ZKAMD_WITNESS")
         # the same over the natively emitted matrices (zk_anonymous_r1cs_load): no oracle on the product's path
         native = zk.ConstraintMatrices.anonymous_circuit(lib=gpu_lib)
         try:
@@ -184,12 +187,20 @@ def test_anonymous_circuit_from_witness(gpu_lib, monkeypatch):
         params.close()
 
 
-def test_transfer_prove_from_statements(gpu_lib, monkeypatch):
-    """zk_transfer_prove_batch: native witness calculator (host) -> A z, B z, C z (GPU) -> create_proof,
+# The assignment of a handful of statements is computed on the host cores by default (zkamd.cpp witness_on_host: a transaction
+# proved alone is 4.6 instead of 11.5 ms), of a batch by the witness kernels: the statement -> proof tests run under both.
+WITNESS_ENGINES = ("gpu", "host")
+
+
+@pytest.mark.parametrize("engine", WITNESS_ENGINES + ("default",))
+def test_transfer_prove_from_statements(gpu_lib, monkeypatch, engine):
+    """zk_transfer_prove_batch: the witness (GPU generator / native host calculator) -> A z, B z, C z (GPU) -> create_proof,
     from the ten private values of each statement; proofs equal the trapdoor proofs of the oracle's
     assignment of the same statement."""
     import zero_chain_amd as zk
     from oracle import transfer_circuit as tc
+    if engine != "default":
+        monkeypatch.setenv("ZKAMD_WITNESS", engine)
     monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "3")   # two chunks: the witness producer thread runs beside the GPU
     r1, asgs, P, pk = helpers.transfer_case(1)
     E = g.Bls12Engine()
@@ -481,7 +492,8 @@ def test_setup_transfer_circuit_byte_identical(gpu_lib):
         mats.close()
 
 
-def test_gen_proof_confidential_xt(gpu_lib, monkeypatch):
+@pytest.mark.parametrize("engine", WITNESS_ENGINES)
+def test_gen_proof_confidential_xt(gpu_lib, monkeypatch, engine):
     """zk_transfer_gen_proof_batch = the reference's gen_proof (core/proofs/src/confidential.rs:105-172): every field
     of ConfidentialXt against the oracle's restatement (oracle/gen_proof.py: keys, ElGamal, rvk, rsk, nonce) and the
     proof against the discrete-log proof of the same statement; an inconsistent request fails the self-check with
@@ -492,6 +504,7 @@ def test_gen_proof_confidential_xt(gpu_lib, monkeypatch):
     from oracle import jubjub as jj
     from oracle import transfer_circuit as tc
     import test_gen_proof as tg
+    monkeypatch.setenv("ZKAMD_WITNESS", engine)
     r1, asgs, P, pk = helpers.transfer_case(1)
     E = g.Bls12Engine()
     items, bals = [], []
@@ -543,7 +556,8 @@ def test_gen_proof_confidential_xt(gpu_lib, monkeypatch):
             with pytest.raises(zk.ZkError) as e:
                 zk.gen_proofs(params, mats, pvk, zk.transfer_requests([items[1], dict(items[0], **{field: torsion})]), rs[:2])
             assert e.value.variant == "InvalidArgument" and field in str(e.value) and "prime-order" in str(e.value)
-            assert "statement 1" in str(e.value)
+            # (the witness kernels of the chunk name the statement, the host derivation the request)
+            assert ("statement 1" if engine == "gpu" else "request 1") in str(e.value)
         # several chunks: check_proof of chunk k runs on its own lane while chunk k + 1 is proved
         monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "2")
         again = zk.gen_proofs(params, mats, pvk, zk.transfer_requests(items + items[:2]), rs + rs[:2])
@@ -560,7 +574,8 @@ def test_gen_proof_confidential_xt(gpu_lib, monkeypatch):
         params.close()
 
 
-def test_gen_proof_anonymous_xt(gpu_lib):
+@pytest.mark.parametrize("engine", WITNESS_ENGINES)
+def test_gen_proof_anonymous_xt(gpu_lib, monkeypatch, engine):
     """zk_anonymous_gen_proof_batch = the reference's anonymous gen_proof (core/proofs/src/anonymous.rs:97-183): every
     field of AnonymousXt against the oracle's restatement, the proof against the discrete-log proof of the derived
     statement, over the natively emitted matrices and a key made by the product's generate_parameters; an
@@ -568,6 +583,7 @@ def test_gen_proof_anonymous_xt(gpu_lib):
     import zero_chain_amd as zk
     from oracle import anonymous_circuit as ac
     import test_gen_proof as tg
+    monkeypatch.setenv("ZKAMD_WITNESS", engine)
     cases = [tg.anonymous_request(1), tg.anonymous_request(5, amount=77, balance=5000)]   # sender after / before the recipient
     E = g.Bls12Engine()
     mats = zk.ConstraintMatrices.anonymous_circuit(lib=gpu_lib)

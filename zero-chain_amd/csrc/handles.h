@@ -65,6 +65,7 @@ namespace zkrt {
 // kernels left in R->z[slot]; proofs per launch set; the key's device and evaluation domain
 zk_status lib_prove_from_z(zk_params* P, zk_r1cs* R, size_t np, int slot, const uint8_t* rs, uint8_t* proofs_out);
 size_t lib_batch_chunk();
+bool lib_witness_on_host(size_t n);   // a handful of statements: the assignment on the host cores (zkamd.cpp witness_on_host)
 int lib_params_device(const zk_params* P);
 size_t lib_params_domain(const zk_params* P);
 zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,

@@ -331,27 +331,50 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
     const bool timing = getenv("ZKAMD_DEBUG_TIMING") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
-    ZK_TRY(transfer_derive(req, n, st.data(), rsk.data(), false));   // the typed inputs are checked by the witness kernels
+    // A handful of requests (one transaction at a time is the reference's call pattern): the assignment on the host cores,
+    // 1.4 ms per statement, instead of the witness kernels' 8.4 ms of serial chains (zkamd.cpp witness_on_host); the typed
+    // inputs are then checked here, otherwise by the witness kernels of the chunk.
+    const bool host_wit = lib_witness_on_host(n);
+    ZK_TRY(transfer_derive(req, n, st.data(), rsk.data(), host_wit));
     if (timing) fprintf(stderr, "[gen_proof] derive done %.1f ms\n", since());
     const size_t chunk = lib_batch_chunk(), nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX, n_pub = ZK_TRANSFER_N_INPUTS - 1;
     PinBuf pin_in;
-    ZK_TRY(pin_in.ensure(std::min(chunk, n) * ZK_TRANSFER_N_INPUTS * 32));
-    std::vector<uint8_t> inputs(n * n_pub * 32);
+    std::vector<uint8_t> inputs(n * n_pub * 32), host_w;
+    WipeOnExit wipe_w{nullptr, 0};   // (the assignment holds the bits of the keys)
     int slot = 0;
-    ZK_TRY(witness_gpu_enqueue(circuit, st.data(), std::min(chunk, n), slot, g_copy_stream, true));
+    if (host_wit) {
+        host_w.resize(n * nv * 32);
+        wipe_w.p = host_w.data();
+        wipe_w.n = host_w.size();
+        ZK_TRY(zk_transfer_witness(st.data(), n, ZK_FR_MONTGOMERY, host_w.data()));
+    } else {
+        ZK_TRY(pin_in.ensure(std::min(chunk, n) * ZK_TRANSFER_N_INPUTS * 32));
+        ZK_TRY(witness_gpu_enqueue(circuit, st.data(), std::min(chunk, n), slot, g_copy_stream, true));
+    }
     for (size_t first = 0; first < n; first += chunk) {
         const size_t np = std::min(chunk, n - first), next = first + chunk;
-        ZK_TRY(witness_gpu_finish(circuit, np, slot, first));
-        if (next < n) ZK_TRY(witness_gpu_enqueue(circuit, st.data() + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream, true));
         // the 23 public inputs of every statement (the head of its assignment), for check_proof and the packing
-        HIP_TRY(hipMemcpy2DAsync(pin_in.p, ZK_TRANSFER_N_INPUTS * 32, circuit->z[slot].p, nv * 32, ZK_TRANSFER_N_INPUTS * 32, np,
-                                 hipMemcpyDeviceToHost, g_stream));
-        if (timing) fprintf(stderr, "[gen_proof] chunk %zu witness ready %.1f ms\n", first / chunk, since());
-        ZK_TRY(lib_prove_from_z(p, circuit, np, slot, rs + first * 64, proofs.data() + first * 192));
-        HIP_TRY(hipStreamSynchronize(g_stream));
+        const uint8_t* heads = nullptr;
+        size_t head_stride = 0;
+        if (host_wit) {
+            ZK_TRY(zk_prove_batch_witness(p, circuit, np, host_w.data() + first * nv * 32, ZK_FR_MONTGOMERY, rs + first * 64,
+                                          proofs.data() + first * 192));
+            heads = host_w.data() + first * nv * 32;
+            head_stride = nv * 32;
+        } else {
+            ZK_TRY(witness_gpu_finish(circuit, np, slot, first));
+            if (next < n) ZK_TRY(witness_gpu_enqueue(circuit, st.data() + next, std::min(chunk, n - next), slot ^ 1, g_copy_stream, true));
+            HIP_TRY(hipMemcpy2DAsync(pin_in.p, ZK_TRANSFER_N_INPUTS * 32, circuit->z[slot].p, nv * 32, ZK_TRANSFER_N_INPUTS * 32, np,
+                                     hipMemcpyDeviceToHost, g_stream));
+            if (timing) fprintf(stderr, "[gen_proof] chunk %zu witness ready %.1f ms\n", first / chunk, since());
+            ZK_TRY(lib_prove_from_z(p, circuit, np, slot, rs + first * 64, proofs.data() + first * 192));
+            HIP_TRY(hipStreamSynchronize(g_stream));
+            heads = pin_in.as<uint8_t>();
+            head_stride = ZK_TRANSFER_N_INPUTS * 32;
+        }
         if (timing) fprintf(stderr, "[gen_proof] chunk %zu proved %.1f ms\n", first / chunk, since());
         for (size_t i = 0; i < np; i++) {
-            const zkhost::Fr* z = reinterpret_cast<const zkhost::Fr*>(pin_in.as<uint8_t>() + i * ZK_TRANSFER_N_INPUTS * 32);
+            const zkhost::Fr* z = reinterpret_cast<const zkhost::Fr*>(heads + i * head_stride);
             zk_confidential_xt& x = out[first + i];
             memset(&x, 0, sizeof(x));
             for (size_t k = 0; k < n_pub; k++) {

@@ -1825,9 +1825,19 @@ zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t f
         [](const zkwit::Statement& s, zkwit::Wit& w) { zkwit::synthesize(s, w); });
 }
 
-bool witness_on_host() {
-    const char* env = getenv("ZKAMD_WITNESS");
-    return env && !strcmp(env, "host");
+// Which engine computes the variable assignment of n statements.  ZKAMD_WITNESS = host | gpu forces one.  Default: the GPU
+// generator (witness_gpu.h) - except for a handful of statements: its kernels are serial chains (point decompression 2.0 ms,
+// the 252-bit in-circuit multiplications 5.1 + 0.7 ms, the rest 0.7) that take 8.4 ms whatever the batch holds, while the
+// native host calculator (transfer_witness.h) needs 1.4 ms per statement and host thread.  A transaction proved ALONE - the
+// reference's call pattern, one gen_proof per transfer - is 11.5 ms through the kernels and 4.6 ms with its assignment
+// computed on a host core, as the reference's own synthesize is (profiles/r05_experiments.txt r05k / r05l).  The proof itself
+// (create_proof) is on the GPU either way.  n = SIZE_MAX: a stream of batches (zk_pipeline) - the GPU generator.
+bool witness_on_host(size_t n = (size_t)-1) {
+    if (const char* env = getenv("ZKAMD_WITNESS")) {
+        if (!strcmp(env, "host")) return true;
+        if (!strcmp(env, "gpu")) return false;
+    }
+    return n != (size_t)-1 && n <= 2 * (size_t)host_threads(n, 64);
 }
 
 zk_status decode_fs(const uint8_t* b, uint64_t (&v)[4], size_t index, const char* what) {
@@ -2190,6 +2200,7 @@ zk_status lib_prove_from_z(zk_params* P, zk_r1cs* R, size_t np, int slot, const 
     return prove_from_z(P, R, np, slot, rs, proofs_out);
 }
 size_t lib_batch_chunk() { return batch_chunk(); }
+bool lib_witness_on_host(size_t n) { return witness_on_host(n); }
 int lib_params_device(const zk_params* P) { return P->device; }
 size_t lib_params_domain(const zk_params* P) { return P->m; }
 }  // namespace zkrt
@@ -2373,7 +2384,7 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
     if (rc != ZK_OK) return rc;
     if ((size_t)circuit->n_con + circuit->n_in > p->m)
         return fail(ZK_ERR_POLYNOMIAL_DEGREE_TOO_LARGE, "more rows than the key's evaluation domain");
-    if (!witness_on_host()) {
+    if (!witness_on_host(n)) {
         // witnesses on the GPU (witness_gpu.h), on the side stream of the copy engine: the kernels of chunk k + 1
         // are latency-bound chains for a few hundred waves and run beside the multiexps of chunk k
         int slot = 0;
@@ -2387,8 +2398,8 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
         }
         return ZK_OK;
     }
-    // ZKAMD_WITNESS=host: the host calculator (transfer_witness.h) on the host cores; two pinned buffers, the
-    // witnesses of chunk k + 1 are computed while the GPU proves chunk k
+    // a handful of statements, or ZKAMD_WITNESS=host: the host calculator (transfer_witness.h) on the host cores; two pinned
+    // buffers, the witnesses of chunk k + 1 are computed while the GPU proves chunk k
     const size_t cap = std::min(chunk, n) * nv * 32;
     rc = circuit->host_ensure(2 * cap);
     if (rc != ZK_OK) return rc;
@@ -2431,7 +2442,7 @@ zk_status zk_anonymous_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, con
     const size_t nv = ZK_ANONYMOUS_N_INPUTS + ZK_ANONYMOUS_N_AUX;
     size_t chunk = batch_chunk();
     if (chunk > 512) chunk = 512;   // domain 2^16: half the proofs of a transfer chunk fill the same workspaces
-    if (!witness_on_host()) {
+    if (!witness_on_host(n)) {
         // witness generation on the GPU (witness_anon_gpu.h), statement in: 1.7 KB instead of 1.6 MB of witness vector; the
         // kernels of chunk k + 1 run beside the multiexps of chunk k (as zk_transfer_prove_batch)
         if (circuit->device != p->device) return fail(ZK_ERR_INVALID_ARGUMENT, "parameters and circuit live on different devices");
