@@ -397,8 +397,8 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
         slot ^= 1;
     }
     // check_proof of every proof of the call, in ONE set of launches at the end: a verification is a bundle of serial
-    // chains (a few dozen waves on the whole GPU) whose duration hardly depends on how many proofs it holds - 45 ms for
-    // 1024, about the same for 8192.  Run beside the proving of the next chunk, as rounds 2 and 3 first did, it is
+    // chains (a few hundred waves on the whole GPU) whose duration hardly depends on how many proofs it holds - 8.0 ms for
+    // 1024, 9.2 for 2048 (round 2: 45 ms).  Run beside the proving of the next chunk, as rounds 2 and 3 first did, it is
     // starved by the persistent accumulation launches (its one-wave-per-SIMD kernels wait for a whole SIMD's
     // registers): chunk 0's check was still running 335 ms later and the call waited 40 ms for it
     // (profiles/r03_experiments.txt r03q).
