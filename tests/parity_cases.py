@@ -800,6 +800,78 @@ def verifier_pvk_fixtures(lib):
             pvk.close()
 
 
+def parsers_survive_mutations(lib, rounds=24):
+    """The three parsers of caller bytes - Parameters::read, PreparedVerifyingKey::read, Proof::read - on damaged input: every
+    truncation point of the framing and seeded random byte flips, length fields included (a count that promises more than
+    the bytes that are left must be refused before anything is sized by it).  Whatever comes back is a status of the ABI -
+    IoError / MalformedVerifyingKey / a verdict - or a handle that works; under the sanitizer build any stray read is a failure."""
+    r1, asg, P, pk = helpers.small_case(4, 2, 6, 7)
+    rng = synth.SplitMix64(0xC0FFEE)
+    good = zk.Parameters.read(pk, checked=True, lib=lib)
+    pvk = zk.prepare_verifying_key(good)
+    pvk_bytes = pvk.write()
+    proof = helpers.expected_proof_trapdoor(P, asg, 3, 5)
+    inputs = list(asg.inputs[1:])
+    assert zk.verify_proofs(pvk, [proof], [inputs]) == [True]
+    n_ic_at = 864
+    counts = [n_ic_at]                                        # offsets of the u32 length fields of the key
+    at = n_ic_at + 4 + 96 * int.from_bytes(pk[n_ic_at:n_ic_at + 4], "big")
+    for size in (96, 96, 96, 96, 192):
+        counts.append(at)
+        at += 4 + size * int.from_bytes(pk[at:at + 4], "big")
+    assert at == len(pk)
+
+    def load(b):
+        try:
+            h = zk.Parameters.read(bytes(b), checked=True, lib=lib)
+        except zk.ZkError as e:
+            assert e.variant in ("IoError", "UnexpectedIdentity", "InvalidArgument"), e.variant
+            return False
+        h.close()
+        return True
+
+    for off in counts:                                        # every length field: huge, one more, one less, zero
+        for v in (0xffffffff, 0x7fffffff, None, -1, 0):
+            cur = int.from_bytes(pk[off:off + 4], "big")
+            val = cur + 1 if v is None else cur - 1 if v == -1 else v
+            b = bytearray(pk)
+            b[off:off + 4] = (val & 0xffffffff).to_bytes(4, "big")
+            # (a smaller count of the LAST query leaves unread bytes behind a well-formed key: accepted, as by bellman's
+            #  sequential reader - the proof-time density check refuses a witness that does not fit it)
+            assert not load(b) or (off == counts[-1] and val < cur), (off, val, cur)
+    for cut in [0, 1, 95, 96, 863, 864, 867] + [c + d for c in counts for d in (0, 3, 4, 5)] + [len(pk) - 1]:
+        assert not load(pk[:cut])
+    refused = 0
+    for _ in range(rounds):                                   # random damage anywhere
+        b = bytearray(pk)
+        for _ in range(1 + rng.next() % 3):
+            b[rng.next() % len(b)] ^= 1 << (rng.next() % 8)
+        refused += 0 if load(b) else 1
+    assert refused >= rounds // 2                             # (a flipped bit inside a coordinate leaves the curve)
+    # PreparedVerifyingKey::read
+    for cut in (0, 1, 100, len(pvk_bytes) // 2, len(pvk_bytes) - 1):
+        with pytest.raises(zk.ZkError):
+            zk.PreparedVerifyingKey.read(pvk_bytes[:cut], lib=lib)
+    for _ in range(rounds):
+        b = bytearray(pvk_bytes)
+        b[rng.next() % len(b)] ^= 1 << (rng.next() % 8)
+        try:
+            zk.PreparedVerifyingKey.read(bytes(b), lib=lib).close()
+        except zk.ZkError as e:
+            assert e.variant in ("IoError", "MalformedVerifyingKey"), e.variant
+    # Proof::read + verify_proof: a damaged proof is a verdict, never an error
+    batch, want = [], []
+    for k in range(rounds):
+        b = bytearray(proof)
+        b[rng.next() % 192] ^= 1 << (rng.next() % 8)
+        batch.append(bytes(b))
+    verdicts = zk.verify_proofs(pvk, batch + [proof], [inputs] * (rounds + 1))
+    assert verdicts[-1] is True and not any(verdicts[:-1])
+    assert zk.verify_proofs(pvk, batch + [proof], [inputs] * (rounds + 1), rlc=True) == verdicts
+    pvk.close()
+    good.close()
+
+
 def verifier_small_circuit(lib, seed=5, n_in=3, n_aux=12, n_con=14):
     """verify_proof on proofs of a small circuit: accepted exactly when the oracle's verifier accepts."""
     r1, asg, P, pk = helpers.small_case(seed, n_in, n_aux, n_con)

@@ -2,6 +2,7 @@
 csrc/gpu_rt.h) against the oracle.  Exercises the kernels' index math, the sort / accumulate /
 reduce pipeline, the H pipeline and the C-ABI host logic at small sizes.  The product library
 and the GPU itself are covered by the `-m gpu` suite."""
+import os
 import numpy as np
 
 import parity_cases as pc
@@ -103,6 +104,11 @@ def test_prover_batch_split_g1_launch_sets(emu_lib, monkeypatch):
 def test_prover_errors(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "4")
     pc.prover_errors(emu_lib)
+
+
+def test_parsers_survive_mutations(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "4")
+    pc.parsers_survive_mutations(emu_lib, rounds=16 if os.environ.get("ZKAMD_EMU_SANITIZED") else 64)
 
 
 def test_params_subgroup_refusal(emu_lib, monkeypatch):

@@ -330,6 +330,10 @@ def test_verifier_golden_multiples(gpu_lib):
     pc.verifier_golden_multiples(gpu_lib)
 
 
+def test_parsers_survive_mutations(gpu_lib):
+    pc.parsers_survive_mutations(gpu_lib, rounds=48)
+
+
 def test_verifier_reference_vectors(gpu_lib):
     pc.verifier_reference_vectors(gpu_lib)
 
