@@ -17,7 +17,7 @@ if "--trace" in sys.argv:
         else:
             cur.append(e)
     calls.append(cur)
-    lone = [c for c in calls if 60 <= len(c) <= 400 and (max(x[1] for x in c) - c[0][0]) < 8_000_000]
+    lone = [c for c in calls if 60 <= len(c) <= 400 and (max(x[1] for x in c) - c[0][0]) < 20_000_000]
     print("%d launch groups, %d that look like one proof" % (len(calls), len(lone)))
     for c in lone[-6:]:
         span = max(x[1] for x in c) - c[0][0]
