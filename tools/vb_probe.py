@@ -44,6 +44,9 @@ def run(label, env, window_bits=0):
 
 
 ref = run("default", {})
+if "segs" in sys.argv:   # task lengths given on the command line: python tools/vb_probe.py segs 40 44 48 ...
+    for seg in sys.argv[sys.argv.index("segs") + 1:]:
+        assert run("seg = %s" % seg, {"ZKAMD_MSM_SEG": seg}) == ref
 if "sweep" in sys.argv:
     for w in (13, 14, 15, 16):
         assert run("w = %d" % w, {}, window_bits=w) == ref
