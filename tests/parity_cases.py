@@ -800,6 +800,36 @@ def verifier_pvk_fixtures(lib):
             pvk.close()
 
 
+def empty_batches(lib):
+    """n = 0 through every batch entry of the boundary: nothing to do is not an error and touches no buffer."""
+    r1, asg, P, pk = helpers.small_case(2, 2, 6, 7)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    mats = zk.ConstraintMatrices(r1.n_in, r1.n_aux, r1.constraints, lib=lib)
+    pvk = zk.prepare_verifying_key(params)
+    try:
+        assert zk.create_proofs([], params, []) == []
+        assert zk.create_proofs_from_witness(mats, params, [], []) == []
+        assert zk.verify_proofs(pvk, [], []) == [] and zk.verify_proofs(pvk, [], [], rlc=True) == []
+        assert zk.read_proofs(pvk, []) == []
+        for group, size in ((1, 96), (2, 192)):
+            assert zk.multiexp(group, b"", [], lib=lib) == bytes([0x40]) + bytes(size - 1)
+        assert zk.transfer_witness(zk.transfer_statements([]), lib=lib).size == 0
+        assert zk.jubjub_base_mul([], lib=lib) == []
+        assert zk.elgamal_encrypt([], [], [], lib=lib) == ([], [])
+        assert zk.transfer_derive(zk.transfer_requests([]), lib=lib)[1] == []
+        # null pointers with n = 0 straight through the C entry points
+        for call in (lambda: lib.zk_verify_batch(pvk._h, 0, None, None, pvk.n_inputs, None),
+                     lambda: lib.zk_proof_read_batch(pvk._h, 0, None, None),
+                     lambda: lib.zk_transfer_witness(None, 0, 0, None),
+                     lambda: lib.zk_jubjub_base_mul(None, 0, None),
+                     lambda: lib.zk_transfer_derive(None, 0, None, None)):
+            assert call() == 0
+    finally:
+        pvk.close()
+        mats.close()
+        params.close()
+
+
 def parsers_survive_mutations(lib, rounds=24):
     """The three parsers of caller bytes - Parameters::read, PreparedVerifyingKey::read, Proof::read - on damaged input: every
     truncation point of the framing and seeded random byte flips, length fields included (a count that promises more than

@@ -106,6 +106,11 @@ def test_prover_errors(emu_lib, monkeypatch):
     pc.prover_errors(emu_lib)
 
 
+def test_empty_batches(emu_lib, monkeypatch):
+    monkeypatch.setenv("ZKAMD_WINDOW_BITS", "4")
+    pc.empty_batches(emu_lib)
+
+
 def test_parsers_survive_mutations(emu_lib, monkeypatch):
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "4")
     pc.parsers_survive_mutations(emu_lib, rounds=16 if os.environ.get("ZKAMD_EMU_SANITIZED") else 64)

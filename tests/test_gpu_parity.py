@@ -330,6 +330,10 @@ def test_verifier_golden_multiples(gpu_lib):
     pc.verifier_golden_multiples(gpu_lib)
 
 
+def test_empty_batches(gpu_lib):
+    pc.empty_batches(gpu_lib)
+
+
 def test_parsers_survive_mutations(gpu_lib):
     pc.parsers_survive_mutations(gpu_lib, rounds=48)
 
