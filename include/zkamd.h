@@ -260,8 +260,9 @@ zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, cons
 zk_status zk_transfer_witness_gpu(zk_r1cs* circuit, const zk_transfer_statement* st, size_t n, uint32_t flags,
                                   uint8_t* witness_out);
 
-/* A stream of statement batches: submit() queues a batch and returns at once; a producer thread computes
- * its witnesses on the host cores (zk_set_host_threads) while the GPU proves the batch submitted before it;
+/* A stream of statement batches: submit() queues a batch and returns at once; worker threads (one per lane, two lanes
+ * by default) enqueue the witness kernels of a chunk beside the proving of the chunk before it, so two chunks are in flight
+ * (ZKAMD_WITNESS=host: a producer thread computes the witnesses on the host cores, zk_set_host_threads, instead);
  * wait() blocks until everything submitted so far is proved and returns the first failure, if any (the
  * statement index in its message is relative to the failing submit).  The caller's buffers (statements, rs,
  * proofs_out) must stay valid until wait() returns, and `p` / `circuit` must not be used by other calls

@@ -824,7 +824,8 @@ def anonymous_gen_proofs(params, matrices, pvk, requests, rs):
 
 
 def transfer_prove_batch(matrices, params, statements, rs):
-    """zk_transfer_prove_batch: statements -> witnesses (host) -> row evaluations + create_proof (GPU)."""
+    """zk_transfer_prove_batch: statements -> witnesses (the GPU generator; the native host calculator for a handful of
+    statements, ZKAMD_WITNESS = gpu | host forces one) -> row evaluations + create_proof (GPU)."""
     lib = params._lib
     n = len(statements)
     rsb = scalars_to_bytes([x for pair in rs for x in pair])
@@ -835,8 +836,9 @@ def transfer_prove_batch(matrices, params, statements, rs):
 
 
 class TransferPipeline:
-    """zk_pipeline: a stream of statement batches; the witnesses of batch k + 1 are computed on the host cores
-    while the GPU proves batch k.  submit() returns at once, wait() returns the proofs of everything submitted
+    """zk_pipeline: a stream of statement batches; the witness kernels of batch k + 1 run beside the proving of
+    batch k, two batches in flight on two lanes (ZKAMD_WITNESS=host: the host calculator on the host cores instead).
+    submit() returns at once, wait() returns the proofs of everything submitted
     since the last wait, in submission order."""
 
     def __init__(self, matrices, params):
