@@ -403,7 +403,7 @@ zk_status zk_generate_parameters(zk_r1cs* circuit, const uint8_t g1[96], const u
  *   zk_vk_prepare       VerifyingKey bytes -> prepare_verifying_key (pairing and G2 preparation on the GPU)
  *   zk_vk_read / write  PreparedVerifyingKey::read / write (core/bellman-verifier/src/lib.rs:175-244; the
  *                       reference's zface/params/conf_vk.dat is such a file)
- *   zk_verify_batch     n independent verify_proof calls, one GPU thread per proof: proofs n x 192 bytes
+ *   zk_verify_batch     n independent verify_proof calls (eighteen lanes per Fq12 element, csrc/pairing.h): proofs n x 192 bytes
  *                       (Proof::read: compressed points, curve and subgroup checks), public inputs
  *                       n x n_inputs x 32 bytes (plain little-endian, WITHOUT the leading ONE).
  *                       ok_out[i] = 1 iff proof i verifies; a malformed proof or input is 0, not an error.
