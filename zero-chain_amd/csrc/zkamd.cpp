@@ -2621,9 +2621,9 @@ struct zk_pipeline {
         bool have_cur = false;
         int slot = 0;
         g_lane = lane;
-        zk_params* P = lane ? this->Pl[lane] : this->P;
-        zk_r1cs* R = lane ? this->Rl[lane] : this->R;
-        if (use_device(P->device) != ZK_OK) {
+        zk_params* Pw = lane ? Pl[lane] : P;   // this lane's handles: its own workspaces over the shared tables
+        zk_r1cs* Rw = lane ? Rl[lane] : R;
+        if (use_device(Pw->device) != ZK_OK) {
             // no context on this lane (stream creation / out of memory): report it and keep DRAINING the queue, so
             // that wait() and free() never block on jobs nobody will take
             std::unique_lock<std::mutex> lk(mu);
@@ -2639,7 +2639,7 @@ struct zk_pipeline {
         const hipStream_t wstream = g_copy_stream;
         auto start = [&](Job& j, int s) -> zk_status {
             j.slot = s;
-            return guarded([&] { return witness_gpu_enqueue(R, j.st, j.n, s, wstream); });
+            return guarded([&] { return witness_gpu_enqueue(Rw, j.st, j.n, s, wstream); });
         };
         for (;;) {
             zk_status rc = ZK_OK;
@@ -2673,8 +2673,8 @@ struct zk_pipeline {
             }
             zk_status rc_next = ZK_OK;
             if (have_nxt && !skip && rc == ZK_OK) rc_next = start(nxt, cur.slot ^ 1);
-            if (!skip && rc == ZK_OK) rc = guarded([&] { return witness_gpu_finish(R, cur.n, cur.slot, cur.index_base); });
-            if (!skip && rc == ZK_OK) rc = guarded([&] { return prove_from_z(P, R, cur.n, cur.slot, cur.rs, cur.out); });
+            if (!skip && rc == ZK_OK) rc = guarded([&] { return witness_gpu_finish(Rw, cur.n, cur.slot, cur.index_base); });
+            if (!skip && rc == ZK_OK) rc = guarded([&] { return prove_from_z(Pw, Rw, cur.n, cur.slot, cur.rs, cur.out); });
             // nothing of a failed job stays in flight when wait() returns: drain the device BEFORE the job is counted done
             if (rc != ZK_OK || rc_next != ZK_OK) (void)hipDeviceSynchronize();
             if (lane > 0 && (rc == ZK_ERR_OUT_OF_MEMORY || rc_next == ZK_ERR_OUT_OF_MEMORY)) {
