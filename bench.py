@@ -823,7 +823,7 @@ def main():
                 "statement_to_proof_ms": lone["host"][0], "gen_proof_ms": lone["host"][1], "default_engine_ms": dflt,
                 "with_gpu_witness": {"statement_to_proof_ms": lone["gpu"][0], "gen_proof_ms": lone["gpu"][1]},
                 "note": "zk_transfer_prove_batch / zk_transfer_gen_proof_batch with n = 1 (gen_proof: derivations, proof, "
-                        "check_proof, ConfidentialXt); the assignment of up to 2 x host-threads statements is computed on the host "
+                        "check_proof, ConfidentialXt); the assignment of up to 8 x host-threads statements is computed on the host "
                         "cores by default, create_proof is on the GPU either way; both engines give the same proof bytes"}
         except Exception as exc:
             os.environ.pop("ZKAMD_WITNESS", None)

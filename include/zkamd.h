@@ -253,7 +253,7 @@ zk_status zk_transfer_witness(const zk_transfer_statement* st, size_t n, uint32_
 zk_status zk_transfer_prove_batch(zk_params* p, zk_r1cs* circuit, size_t n, const zk_transfer_statement* st,
                                   const uint8_t* rs, uint8_t* proofs_out);
 /* zk_transfer_prove_batch and zk_pipeline compute the witnesses ON THE GPU (one thread per statement and gadget,
- * the assignment never leaves HBM) - except for a handful of statements (n <= 2 x host threads: one transaction at a time,
+ * the assignment never leaves HBM) - except for a handful of statements (n <= 8 x host threads: one transaction at a time,
  * the reference's call pattern), whose assignments the native host calculator computes faster than the kernels' 8.4 ms of
  * serial chains; ZKAMD_WITNESS = host | gpu forces an engine, the proof bytes do not depend on it.  This entry returns
  * what that generator produces - same format as zk_transfer_witness - so that the two can be compared. */

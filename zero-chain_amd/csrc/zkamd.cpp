@@ -1837,7 +1837,9 @@ bool witness_on_host(size_t n = (size_t)-1) {
         if (!strcmp(env, "host")) return true;
         if (!strcmp(env, "gpu")) return false;
     }
-    return n != (size_t)-1 && n <= 2 * (size_t)host_threads(n, 64);
+    // (the crossover, measured with 16 host threads: 64 statements 34.0 against 39.3 ms per call, 128: 51.9 / 53.9, 192: 68.2 / 69.3,
+    //  256: 87.6 / 85.3 - tools/witness_engine_probe.py, profiles/r05end_witness_engine_probe.txt)
+    return n != (size_t)-1 && n <= 8 * (size_t)host_threads(n, 64);
 }
 
 zk_status decode_fs(const uint8_t* b, uint64_t (&v)[4], size_t index, const char* what) {
