@@ -198,7 +198,16 @@ struct NttPlan {
 // ------------------------------------------------------------------------------------------
 // MSM group: window tables of a set of bases + the bucket pipeline over a list of jobs
 // ------------------------------------------------------------------------------------------
-constexpr size_t MSM_FEW_JOBS = 8;      // at most this many jobs per launch: latency-optimised reduction tail
+// At most this many jobs per launch set: the latency-optimised form (many-workgroup sort, bit-plane tail of the bucket
+// reduction).  8 until round 5; a kernel trace of a 32-proof call then showed the many-jobs form's eleven k_msm_segsum<Fq2x>
+// launches - 0.8 ms each whether for 32 jobs or 1024: 8.9 of the call's 16.8 ms - and the sweep of tools/few_jobs_probe.py
+// (profiles/r05end_few_jobs_probe.txt, same proof bytes under every setting): 8 proofs per call 10.5 -> 7.8 ms, 16: 14.9 -> 10.9,
+// 32: 19.9 -> 17.6, 64: 35.1 -> 30.1, 128: 51.6 -> 49.7; from 256 jobs on the many-jobs form wins (86.1 against 90.2).
+constexpr size_t MSM_FEW_JOBS = 128;
+inline size_t few_jobs_max() {           // ZKAMD_FEW_JOBS: measurement override
+    static const size_t v = getenv("ZKAMD_FEW_JOBS") && atoll(getenv("ZKAMD_FEW_JOBS")) > 0 ? (size_t)atoll(getenv("ZKAMD_FEW_JOBS")) : MSM_FEW_JOBS;
+    return v;
+}
 constexpr uint32_t MSM_RED_FAN = 16;   // buckets per level-1 node and children per upper node (bucket reduction)
 
 // Width of the NAF recoding for jobs of about n scalars: minimise, in units of one mixed addition,
@@ -532,7 +541,7 @@ struct MsmGroup {
         // the latency-optimised form of the launch set (many-workgroup sort, bit-plane tail of the bucket reduction: msm.h,
         // passes 1-3, 5c and 6): one or a few jobs - and the digit positions of ONE variable-base multiexp, a dozen or two
         // jobs over the same large scalar vector, which are as far from filling the machine per job as a lone job is
-        const bool few = nj <= MSM_FEW_JOBS || jobs[0].vb_digit != 0;
+        const bool few = nj <= few_jobs_max() || jobs[0].vb_digit != 0;
         const uint32_t merge_inline = nj >= 64 || few ? 8u : 2u;
         const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
         ZK_TRY(heavy.ensure(heavy_cap * 4));
