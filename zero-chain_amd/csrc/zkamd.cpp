@@ -1382,7 +1382,8 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     hipStream_t side = getenv("ZKAMD_NO_OVERLAP") ? g_stream : g_stream2;
     HIP_TRY(hipEventRecord(g_ev_fork, g_stream));
     HIP_TRY(hipStreamWaitEvent(side, g_ev_fork, 0));
-    MsmG2& G2 = np <= 2 ? P->g2_lone : P->g2;
+    static const size_t g2_lone_max = getenv("ZKAMD_G2_LONE_MAX") ? (size_t)atoll(getenv("ZKAMD_G2_LONE_MAX")) : 2;   // (measurement override)
+    MsmG2& G2 = np <= g2_lone_max ? P->g2_lone : P->g2;
     ZK_TRY(G2.enqueue(P->jobs2, P->res2, side, false));
     ZK_TRY(P->pin_g2.ensure(np * sizeof(HG2)));
     ZK_TRY(P->pin_g1.ensure(2 * np * sizeof(HG1)));
