@@ -3,6 +3,7 @@ csrc/gpu_rt.h) against the oracle.  Exercises the kernels' index math, the sort 
 reduce pipeline, the H pipeline and the C-ABI host logic at small sizes.  The product library
 and the GPU itself are covered by the `-m gpu` suite."""
 import os
+import pytest
 import numpy as np
 
 import parity_cases as pc
@@ -81,7 +82,16 @@ def test_prover_montgomery_inputs_two_pass_ntt(emu_lib, monkeypatch):
     pc.prover_small(emu_lib, 7, 4, 300, 330, checked=False, montgomery=True)   # m = 512: two NTT passes
 
 
-def test_prover_batch(emu_lib, monkeypatch):
+# A launch set takes the latency-optimised form up to 128 jobs (zkamd.cpp MSM_FEW_JOBS) - every batch the emulation can afford.
+# ZKAMD_FEW_JOBS=1 sends the same batches through the throughput form (one workgroup per job in the LDS sort, light / heavy
+# merges, the tree of reduction levels): what a 1024-proof chunk runs on the GPU.
+LAUNCH_SET_FORMS = ("latency", "throughput")
+
+
+@pytest.mark.parametrize("form", LAUNCH_SET_FORMS)
+def test_prover_batch(emu_lib, monkeypatch, form):
+    if form == "throughput":
+        monkeypatch.setenv("ZKAMD_FEW_JOBS", "1")
     monkeypatch.setenv("ZKAMD_WINDOW_BITS", "5")
     monkeypatch.setenv("ZKAMD_BATCH_CHUNK", "2")
     pc.prover_batch(emu_lib, 4, 3, 12, 3)       # two device chunks: block 2 is staged beside block 1
@@ -90,8 +100,11 @@ def test_prover_batch(emu_lib, monkeypatch):
     pc.prover_batch(emu_lib, 5, 3, 12, 3)       # one device chunk staged in three blocks
 
 
-def test_prover_batch_split_g1_launch_sets(emu_lib, monkeypatch):
+@pytest.mark.parametrize("form", LAUNCH_SET_FORMS)
+def test_prover_batch_split_g1_launch_sets(emu_lib, monkeypatch, form):
     """the A jobs and the C' jobs of a batch as two launch sets with their own recoding widths (zkamd.cpp prove_chunk)"""
+    if form == "throughput":
+        monkeypatch.setenv("ZKAMD_FEW_JOBS", "1")
     monkeypatch.setenv("ZKAMD_WINDOW_BITS_G1", "6")
     monkeypatch.setenv("ZKAMD_WINDOW_BITS_G1A", "4")
     monkeypatch.setenv("ZKAMD_WINDOW_BITS_G2", "5")
@@ -137,7 +150,10 @@ def test_msm_two_level_sort_path(emu_lib, monkeypatch):
     pc.prover_small(emu_lib, 5, 3, 10, 12)
 
 
-def test_prover_from_witness(emu_lib):
+@pytest.mark.parametrize("form", LAUNCH_SET_FORMS)
+def test_prover_from_witness(emu_lib, monkeypatch, form):
+    if form == "throughput":
+        monkeypatch.setenv("ZKAMD_FEW_JOBS", "1")
     pc.prover_from_witness(emu_lib, 3, 3, 14, 3)
     pc.prover_from_witness(emu_lib, 4, 2, 9, 2, montgomery=True)
 

@@ -204,9 +204,9 @@ struct NttPlan {
 // (profiles/r05end_few_jobs_probe.txt, same proof bytes under every setting): 8 proofs per call 10.5 -> 7.8 ms, 16: 14.9 -> 10.9,
 // 32: 19.9 -> 17.6, 64: 35.1 -> 30.1, 128: 51.6 -> 49.7; from 256 jobs on the many-jobs form wins (86.1 against 90.2).
 constexpr size_t MSM_FEW_JOBS = 128;
-inline size_t few_jobs_max() {           // ZKAMD_FEW_JOBS: measurement override
-    static const size_t v = getenv("ZKAMD_FEW_JOBS") && atoll(getenv("ZKAMD_FEW_JOBS")) > 0 ? (size_t)atoll(getenv("ZKAMD_FEW_JOBS")) : MSM_FEW_JOBS;
-    return v;
+inline size_t few_jobs_max() {           // ZKAMD_FEW_JOBS: override for measurements and for the tests (read at every launch set:
+    const char* env = getenv("ZKAMD_FEW_JOBS");   // the emulation suite runs its batches under both forms)
+    return env && atoll(env) > 0 ? (size_t)atoll(env) : MSM_FEW_JOBS;
 }
 constexpr uint32_t MSM_RED_FAN = 16;   // buckets per level-1 node and children per upper node (bucket reduction)
 
