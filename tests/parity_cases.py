@@ -201,6 +201,41 @@ def msm_edge_cases(lib):
     assert e.value.variant == "IoError"
 
 
+def msm_noncanonical_scalars(lib, sizes=(20, 200), groups=(1, 2)):
+    """a scalar >= r must be refused WITHOUT the recoders having indexed anything with it.  s = r + 1 (even:
+    the regular recoding's r - s wrapped to ~2^256), 2^255 (the width-w NAF would emit a digit past the table's last slice) and
+    2^256 - 1, at sizes whose automatic window divides 255 (w = 3 at ~20 scalars, 5 at ~200; 15 at 2^20: the GPU suite), through
+    the table handle, the variable-base handle and the one-shot entry; every refusal names the scalar, and the same handle then
+    still gives the right sum."""
+    for group in groups:
+        pts = helpers.golden_points("g1_uncompressed" if group == 1 else "g2_uncompressed")
+        for n in sizes:
+            rng = synth.SplitMix64(1000 + n)
+            ks = [1 + rng.below(len(pts) - 1) for _ in range(n)]
+            bases = b"".join(pts[k] for k in ks)
+            good = [rng.field(bls.R_MOD) for _ in range(n)]
+            want = sum(a * b for a, b in zip(ks, good)) % bls.R_MOD
+            want = helpers.g1_of(want) if group == 1 else helpers.g2_of(want)
+            for variable in (False, True):
+                ctx = zk.MultiexpContext(group, bases, lib=lib, variable_base=variable)
+                try:
+                    for bad in (bls.R_MOD + 1, 1 << 255, (1 << 256) - 1, bls.R_MOD + (1 << 254)):
+                        for at in (0, n // 2, n - 1):
+                            sc = list(good)
+                            sc[at] = bad
+                            raw = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in sc), dtype=np.uint8)
+                            with pytest.raises(zk.ZkError) as e:
+                                ctx.run(raw)
+                            assert e.value.variant == "InvalidArgument", (group, n, variable, hex(bad))
+                            if not variable and at == 0:
+                                with pytest.raises(zk.ZkError) as e:
+                                    zk.multiexp(group, bases, raw, lib=lib)
+                                assert e.value.variant == "InvalidArgument" and "scalar %d" % at in str(e.value)
+                    assert ctx.run(good) == want, (group, n, variable)
+                finally:
+                    ctx.close()
+
+
 def _bad_uncompressed(group):
     """The malformed uncompressed encodings of the reference's decoder tests (core/pairing/src/bls12_381/tests/mod.rs:
     101-214 G1, :216-340 G2): [(encoding, what `into_affine_unchecked` says)], then [(encoding, what only the CHECKED

@@ -54,6 +54,11 @@ def test_msm_edges(emu_lib):
     pc.msm_edge_cases(emu_lib)
 
 
+def test_msm_noncanonical_scalars(emu_lib):
+    pc.msm_noncanonical_scalars(emu_lib, sizes=(20, 200), groups=(1,))
+    pc.msm_noncanonical_scalars(emu_lib, sizes=(20,), groups=(2,))
+
+
 def test_msm_decoder_refusals(emu_lib):
     pc.msm_decoder_refusals(emu_lib, oneshot_every=16)
 

@@ -82,6 +82,13 @@ def test_msm_edges(gpu_lib):
     pc.msm_edge_cases(gpu_lib)
 
 
+def test_msm_noncanonical_scalars(gpu_lib):
+    """scalars >= r at the sizes whose automatic window divides 255 (w = 3, 5 and - 2^20 scalars - 15), both handle modes
+    and the one-shot entry: refused, nothing indexed with them."""
+    pc.msm_noncanonical_scalars(gpu_lib, sizes=(20, 200))
+    pc.msm_noncanonical_scalars(gpu_lib, sizes=(1 << 20,), groups=(1,))
+
+
 def test_msm_g1_2p20_identity(gpu_lib):
     """BASELINE config 2 size.  Bases cycle through the reference's golden multiples, so
     sum_i s_i (k_i G) must equal (sum_i s_i k_i) G; the heavy base repetition also drives the

@@ -19,6 +19,12 @@ if "--trace" in sys.argv:
     calls.append(cur)
     lone = [c for c in calls if 60 <= len(c) <= 400 and (max(x[1] for x in c) - c[0][0]) < 20_000_000]
     print("%d launch groups, %d that look like one proof" % (len(calls), len(lone)))
+    if "--list" in sys.argv:   # the launches of the last call: start offset, duration, kernel
+        c = lone[-1]
+        print("the LAST call (%d launches, %.3f ms from the first launch to the end of the last; start offset, duration, kernel)" %
+              (len(c), (max(x[1] for x in c) - c[0][0]) / 1e6))
+        for s_, e_, k_ in c:
+            print("%9.1f us + %8.1f us  %s" % ((s_ - c[0][0]) / 1e3, (e_ - s_) / 1e3, k_[:90]))
     for c in lone[-6:]:
         span = max(x[1] for x in c) - c[0][0]
         busy, last = 0, c[0][0]
@@ -40,7 +46,13 @@ mats = zk.ConstraintMatrices.transfer_circuit(lib=lib)
 params = zk.Parameters.read(zk.generate_parameters(mats, *helpers.TOXIC), checked=False, lib=lib)
 items = bench.make_statements_native(zk, lib, 0, 4)
 one = zk.transfer_statements(items[:1])
-for name, fn in (("zk_transfer_prove_batch, n = 1", lambda i: zk.transfer_prove_batch(mats, params, one, [(3 + i, 5 + i)])),):
+# r and s as create_random_proof draws them: uniform 255-bit scalars (--tiny-rs: the 3 + i, 5 + i of round 5's probe, under which
+# the fold s * A is four windows instead of sixty-four)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from oracle import bls12_381 as bls, synth
+rng = synth.SplitMix64(77)
+rs = [(3 + i, 5 + i) if "--tiny-rs" in sys.argv else (rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for i in range(16)]
+for name, fn in (("zk_transfer_prove_batch, n = 1", lambda i: zk.transfer_prove_batch(mats, params, one, [rs[i]])),):
     fn(0); fn(1)
     ts = []
     for i in range(10):

@@ -115,7 +115,13 @@ ZK_DI void msm_wnaf(const uint32_t* __restrict__ sp, uint32_t c, Fn&& f) {
     uint32_t zero_or = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) zero_or |= s[i];
-    if (!zero_or) return;
+    // s = 0 has no digits; neither has a NON-CANONICAL scalar (s >= r: r - s borrowed, or is zero).  The caller's canonical
+    // test (k_fr_first_noncanonical, k_build_scalars) runs beside these launches and fails the call at its end; until then
+    // the recoding must be total: a value >= 2^255 would put a digit at a position past the table's last slice.
+    uint32_t t_or = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t_or |= t[i];
+    if (!zero_or || bo || !t_or) return;
     const bool neg = lt != 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = neg ? t[i] : s[i];
@@ -183,12 +189,20 @@ ZK_DI bool msm_vb_digit(const uint32_t* __restrict__ sp, uint32_t c, uint32_t di
     for (int i = 0; i < 8; i++) any |= s[i];
     if (!any) return false;
     const bool flip = (s[0] & 1u) == 0;
-    if (flip) {   // r - s
-        uint32_t bo = 0, co;
+    {   // r - s: taken for an even scalar; its borrow / zero result names a NON-CANONICAL scalar (s >= r), which has no digits
+        // here (the call fails at its end on the canonical test that runs beside these launches: until then every digit must
+        // stay below the 2^w the buckets were sized for - an even s >= r wrapped to ~2^256 and indexed past them)
+        uint32_t d[8], bo = 0, co, d_or = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            s[i] = __builtin_subc(MsmConsts::R[i], s[i], bo, &co);
+            d[i] = __builtin_subc(MsmConsts::R[i], s[i], bo, &co);
             bo = co;
+            d_or |= d[i];
+        }
+        if (bo || !d_or) return false;
+        if (flip) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = d[i];
         }
     }
     const uint32_t w = c - 1, bit = w * digit, word = bit >> 5, sh = bit & 31;

@@ -319,16 +319,20 @@ k_r1cs_eval(R1csMat ma, R1csMat mb, R1csMat mc, const uint32_t* __restrict__ z, 
 //   wit_out[p] = [ wit[p][0..nv) | 1 | r | s ]                          (A and B2 multiexps)
 //   cvec[p]    = [ h (m, written later) | aux (n_aux) | r * z (nv) | r ]  (merged C multiexp:
 //                C' = H + L + r * (B1 + beta_1), one bucket set instead of three)
+//                fold != 0 appends [ s * z (nv) | s | r * s ] over the bases of the A query, alpha_1 and delta_1: the job is
+//                then C = s * A + C' itself (A = alpha_1 + sum z_i A_i + r delta_1) - for a few proofs made alone, whose
+//                final fold would otherwise be a 255-bit double-and-add chain on the critical path (zkamd.cpp prove_chunk)
 // tail[p] = (1, r, s).  Witness scalars are converted out of Montgomery form when `mont` is set.
 static __global__ void __launch_bounds__(256)
 k_build_scalars(uint32_t* wit_out, uint32_t* cvec, const uint32_t* __restrict__ wit, const uint32_t* __restrict__ tail,
-                uint32_t nv, uint32_t n_in, uint32_t m, uint32_t cstride, uint32_t mont, uint32_t* bad) {
+                uint32_t nv, uint32_t n_in, uint32_t m, uint32_t cstride, uint32_t mont, uint32_t* bad, uint32_t fold) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nv + 3) return;
     const size_t p = blockIdx.y;
     uint32_t* cv = cvec + p * (size_t)cstride * 8;
     const uint32_t n_aux = nv - n_in;
     Fr r = ld_fr(tail + (p * 3 + 1) * 8);   // plain
+    Fr sR = fold ? mul(ld_fr(tail + (p * 3 + 2) * 8), Fr::r2()) : Fr::zero();   // s in Montgomery form
     Fr v;
     if (i < nv) {
         Fr raw = ld_fr(wit + (p * nv + i) * 8);
@@ -348,9 +352,12 @@ k_build_scalars(uint32_t* wit_out, uint32_t* cvec, const uint32_t* __restrict__ 
         }
         if (i >= n_in) st_fr(cv + (size_t)(m + (i - n_in)) * 8, v);
         st_fr(cv + (size_t)(m + n_aux + i) * 8, rz);
+        if (fold) st_fr(cv + (size_t)(m + n_aux + nv + 1 + i) * 8, mul(v, sR));   // (z)(s R) / R = z s
     } else {
         v = ld_fr(tail + (p * 3 + (i - nv)) * 8);
         if (i == nv) st_fr(cv + (size_t)(m + n_aux + nv) * 8, r);   // r * 1 for beta_1
+        if (fold && i == nv + 1) st_fr(cv + (size_t)(m + n_aux + 2 * nv + 2) * 8, mul(r, sR));   // r s for delta_1
+        if (fold && i == nv + 2) st_fr(cv + (size_t)(m + n_aux + 2 * nv + 1) * 8, v);            // s for alpha_1
     }
     st_fr(wit_out + (p * (nv + 3) + i) * 8, v);
 }

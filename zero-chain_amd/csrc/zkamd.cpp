@@ -933,7 +933,7 @@ struct zk_params {
     NttPlan ntt;
     // cached per-circuit index maps (keyed by the density bytes)
     std::vector<uint8_t> dens_key;
-    DevBuf map_a, map_b2, map_c;
+    DevBuf map_a, map_b2, map_c, map_cf;   // (map_cf: the C job with the fold s * A inside, for a few proofs made alone)
     uint32_t map_nv = 0;
     // workspaces
     DevBuf abc, wit, cvec, tail, stage_a, stage_b, stage_c, stage_w, fold_tbl, fold_c, fold_a1, fold_c1, fold_b2;
@@ -1316,6 +1316,11 @@ zk_status ensure_maps(zk_params* P, uint32_t n_in, uint32_t n_aux, const uint8_t
     for (uint32_t j = 0; j < n_aux; j++) mc.push_back((int32_t)(P->off_l + j));
     for (uint32_t i = 0; i < nv; i++) mc.push_back(mb1[i] < 0 ? -1 : (int32_t)(P->off_b1 + mb1[i]));
     mc.push_back(P->beta_g1_inf ? -1 : (int32_t)(P->off_b1 + P->n_b1));   // r * beta_g1
+    // the folded form of the job (ntt.h k_build_scalars, fold): + [s z (nv) | s | r s] over the A query, alpha_1, delta_1
+    std::vector<int32_t> mcf(mc);
+    for (uint32_t i = 0; i < nv + 2; i++) mcf.push_back(ma[i] < 0 ? -1 : (int32_t)(P->off_a + ma[i]));
+    ZK_TRY(P->map_cf.ensure(mcf.size() * 4));
+    HIP_TRY(hipMemcpy(P->map_cf.p, mcf.data(), mcf.size() * 4, hipMemcpyHostToDevice));
     ZK_TRY(P->map_a.ensure(ma.size() * 4));
     ZK_TRY(P->map_b2.ensure(mb2.size() * 4));
     ZK_TRY(P->map_c.ensure(mc.size() * 4));
@@ -1362,12 +1367,19 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     ZK_TRY(P->pin_bad.ensure(8));
     uint32_t* bad = P->bad.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(bad, 0, 4, g_stream));
-    const uint32_t cstride = (uint32_t)(m + n_aux + nv + 1);
+    // A few proofs made alone carry the final fold C = s * A + C' INSIDE the C multiexp: s * A = s alpha_1 + sum (s z_i) A_i +
+    // (r s) delta_1 is 15.6 k more terms over bases whose doublings are in the table (+19 % pairs in a launch whose duration is
+    // the length of its longest task, not their number), where k_xyzz_scale_add is a chain of 252 doublings and ~75 additions
+    // of ONE point: 4.7 ms of a 7.4 ms proof under a 255-bit s (profiles/r06c_lone_baseline_random_rs_launch_list.txt).
+    // A batch keeps the chain: one lane per proof, hidden behind the other pipeline lane, no extra pairs.
+    static const size_t fold_max = getenv("ZKAMD_FOLD_IN_MSM_MAX") ? (size_t)atoll(getenv("ZKAMD_FOLD_IN_MSM_MAX")) : 8;
+    const bool fold_in_msm = np <= fold_max;
+    const uint32_t cstride = (uint32_t)(m + n_aux + nv + 1 + (fold_in_msm ? nv + 2 : 0));
     ZK_TRY(P->cvec.ensure(np * (size_t)cstride * 32));
     uint32_t* cvec = P->cvec.as<uint32_t>();
     ZK_LAUNCH(zkdev::k_build_scalars, dim3((nv + 3 + 255) / 256, (unsigned)np), dim3(256), 0, g_stream, wit, cvec,
               (const uint32_t*)bt->d_wit + first * (size_t)nv * 8, P->tail.as<uint32_t>(), nv, n_in, (uint32_t)m, cstride,
-              mont ? 1u : 0u, bad);
+              mont ? 1u : 0u, bad, fold_in_msm ? 1u : 0u);
     // ---- multiexps (create_proof step 4).  The G2 job only needs the witness scalars: it is
     // enqueued first, on the side stream, and runs beside the H pipeline and the G1 multiexps (its
     // reduction tree is latency-bound with one job per proof; the G1 work fills the machine).
@@ -1424,7 +1436,7 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     const bool split = P->split_g1 && np >= split_min;
     MsmG1& G1C = split ? P->g1 : P->g1_lone;
     for (size_t p = 0; p < np; p++) {
-        MsmJob jc = {cvec + p * (size_t)cstride * 8, P->map_c.as<int32_t>(), cstride, 0, npts1, 0, 0, 0};
+        MsmJob jc = {cvec + p * (size_t)cstride * 8, (fold_in_msm ? P->map_cf : P->map_c).as<int32_t>(), cstride, 0, npts1, 0, 0, 0};
         P->jobs1.push_back(jc);
     }
     P->jobs1a.clear();
@@ -1454,14 +1466,17 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     // only encodes.  (On the host the fold was 0.47 ms per proof with the GPU idle: 8 % of the step.)
     {
         ProfScope ps("proof_fold", g_stream);
-        ZK_TRY(P->fold_tbl.ensure(np * 15 * sizeof(DP1)));
-        ZK_TRY(P->fold_c.ensure(np * sizeof(DP1)));
         const DP1* cprime = G1C.res_dev;
         const DP1* a = a_dev;
-        ZK_LAUNCH(zkdev::k_xyzz_scale_add<zkdev::Fq>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, a, cprime,
-                  (const uint32_t*)P->tail.as<uint32_t>() + 16, 24u, P->fold_tbl.as<DP1>(), P->fold_c.as<DP1>(), (uint32_t)np);
-        ZK_TRY(G1C.normalize2_to_host(a, P->fold_c.as<DP1>(), np, P->pin_g1.as<HG1>() + np, P->pin_g1.as<HG1>(), P->fold_a1, P->fold_c1,
-                                      g_stream));
+        const DP1* cfin = cprime;   // the C job was s * A + C' already
+        if (!fold_in_msm) {
+            ZK_TRY(P->fold_tbl.ensure(np * 15 * sizeof(DP1)));
+            ZK_TRY(P->fold_c.ensure(np * sizeof(DP1)));
+            ZK_LAUNCH(zkdev::k_xyzz_scale_add<zkdev::Fq>, dim3((unsigned)((np + 63) / 64)), dim3(64), 0, g_stream, a, cprime,
+                      (const uint32_t*)P->tail.as<uint32_t>() + 16, 24u, P->fold_tbl.as<DP1>(), P->fold_c.as<DP1>(), (uint32_t)np);
+            cfin = P->fold_c.as<DP1>();
+        }
+        ZK_TRY(G1C.normalize2_to_host(a, cfin, np, P->pin_g1.as<HG1>() + np, P->pin_g1.as<HG1>(), P->fold_a1, P->fold_c1, g_stream));
     }
     HIP_TRY(hipMemcpyAsync(P->pin_bad.p, bad, 8, hipMemcpyDeviceToHost, g_stream));
     const bool trace_host = getenv("ZKAMD_TRACE_HOST") != nullptr;
