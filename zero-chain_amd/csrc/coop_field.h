@@ -52,6 +52,14 @@ ZK_DI uint32_t coop_row_in_block() { return threadIdx.x; }
 ZK_DI uint32_t coop_rows_per_block() { return blockDim.x; }
 #endif
 
+// The products are inlined on the GPU (the compiler interleaves the independent products of a curve formula) and real
+// functions in the emulation (a point addition inlines fourteen of them, each 14 rounds of 16-lane loops).
+#ifndef ZK_EMU
+#define ZK_CDI ZK_DI
+#else
+#define ZK_CDI inline __attribute__((noinline))
+#endif
+
 // DPP controls (gfx90a+ encodings)
 constexpr int COOP_DPP_SHL1 = 0x101, COOP_DPP_SHR1 = 0x111, COOP_DPP_BCAST = 0x150;
 
@@ -84,6 +92,11 @@ ZK_DI CLanes coop_from_lower(const CLanes& a) {
     CLanes r;
 #ifndef ZK_EMU
     r.v[0] = coop_dpp<COOP_DPP_SHR1>(a.v[0]);
+    // The result is made opaque to the optimiser: hipcc (ROCm 7.2) folds this move into the additions and subtractions
+    // around it (v_subrev_u32_dpp against a value that an in-place v_mov_b32_dpp of the same register has just shifted)
+    // and the G1 doubling came out with limbs off by one and two on the GPU while the emulation was right
+    // (tools/ubench/coop_curve.hip found it; profiles/r06h_coop_curve.txt).  One v_mov_b32_dpp per carry pass is the price.
+    asm volatile("" : "+v"(r.v[0]));
 #else
     for (int j = 0; j < 16; j++) r.v[j] = j > 0 ? a.v[j - 1] : 0u;
 #endif
@@ -175,10 +188,12 @@ ZK_DI bool CFq::is_zero_norm() const {
     return coop_ballot(nz) == 0u || coop_ballot(np) == 0u;
 }
 
-// ---- Montgomery products.  K accumulators, accumulator k = sum over its NT terms of x[k][t] * y[k][t]; the y enter by
-// broadcast (limbs <= 2^28 + 8), the x limb-wise (< 2^30.4: un-normalised differences are allowed there).  All K chains
-// advance round by round, so their instructions interleave.
-template <int I, int K, int NT> struct CoopRounds {
+// ---- Montgomery products.  K accumulators, accumulator k = sum over its terms t of x[k][t] * y[k][t] (the terms whose bit
+// k * NT + t of MASK is set); the y enter by broadcast (limbs <= 2^28 + 8), the x limb-wise (< 2^30.4: un-normalised
+// differences are allowed there).  All K chains advance round by round, so their instructions interleave: hipcc leaves
+// independent products written one after the other one after the other (the ISA of a point addition shows the broadcasts
+// 0, 0, 1, 0, 2, 0 ... of ONE product at a time), so the curve formulas of coop_curve.h hand over whole groups.
+template <int I, int K, int NT, uint64_t MASK> struct CoopRounds {
     static ZK_DI void run(const CLanes& pc, const CLanes (&x)[K][NT], const CLanes (&y)[K][NT], CLanes (&T)[K]) {
         uint64_t D[K][COOP_L];
         CLanes q[K];
@@ -187,6 +202,7 @@ template <int I, int K, int NT> struct CoopRounds {
             ZK_COOP_EACH(j) D[k][j] = T[k].v[j];
 #pragma unroll
             for (int t = 0; t < NT; t++) {
+                if (!((MASK >> (k * NT + t)) & 1u)) continue;
                 const CLanes yi = coop_bcast<I>(y[k][t]);
                 ZK_COOP_EACH(j) D[k][j] += (uint64_t)x[k][t].v[j] * yi.v[j];
             }
@@ -204,16 +220,17 @@ template <int I, int K, int NT> struct CoopRounds {
             const CLanes ru = coop_from_upper(r);
             ZK_COOP_EACH(j) T[k].v[j] = c.v[j] + ru.v[j];
         }
-        if constexpr (I < 13) CoopRounds<I + 1, K, NT>::run(pc, x, y, T);
+        if constexpr (I < 13) CoopRounds<I + 1, K, NT, MASK>::run(pc, x, y, T);
     }
 };
-template <int K, int NT>
-ZK_DI void coop_products(const CLanes (&x)[K][NT], const CLanes (&y)[K][NT], CFq (&out)[K]) {
+template <int K, int NT, uint64_t MASK = ~0ull>
+ZK_CDI void coop_products(const CLanes (&x)[K][NT], const CLanes (&y)[K][NT], CFq (&out)[K]) {
+    static_assert(K * NT <= 64, "term mask too narrow");
     const CLanes pc = coop_const(Fq28Consts::P);
     CLanes T[K];
 #pragma unroll
     for (int k = 0; k < K; k++) ZK_COOP_EACH(j) T[k].v[j] = 0u;
-    CoopRounds<0, K, NT>::run(pc, x, y, T);
+    CoopRounds<0, K, NT, MASK>::run(pc, x, y, T);
 #pragma unroll
     for (int k = 0; k < K; k++) out[k] = coop_wnorm(CFq{T[k]});
 }

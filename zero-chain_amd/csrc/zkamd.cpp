@@ -30,6 +30,7 @@
 #include "host_math.h"
 #include "ntt.h"
 #include "msm.h"
+#include "coop_tail.h"
 #include "transfer_witness.h"
 #include "handles.h"
 #include "transfer_r1cs.h"
@@ -378,6 +379,16 @@ void launch_asm_loop<zkdev::Fq2x>(const zkdev::Affine<zkdev::Fq2x>* table, const
 }
 #endif
 
+// The few-jobs tail of the bucket reduction on the wave-cooperative field (coop_tail.h): the two fields the multiexps run
+// on have it; ZKAMD_COOP_TAIL=0 keeps the one-lane kernels (A/B switch, read at every launch set).
+template <class DF> struct HasCoopTail { static constexpr bool value = false; };
+template <> struct HasCoopTail<zkdev::Fq28> { static constexpr bool value = true; };
+template <> struct HasCoopTail<zkdev::Fq2x> { static constexpr bool value = true; };
+inline bool coop_tail_on() {
+    const char* e = getenv("ZKAMD_COOP_TAIL");
+    return !(e && atoi(e) == 0);
+}
+
 template <class HF, class DF>
 struct MsmGroup {
     typedef zkhost::Affine<HF> HAffine;
@@ -542,7 +553,16 @@ struct MsmGroup {
         // passes 1-3, 5c and 6): one or a few jobs - and the digit positions of ONE variable-base multiexp, a dozen or two
         // jobs over the same large scalar vector, which are as far from filling the machine per job as a lone job is
         const bool few = nj <= few_jobs_max() || jobs[0].vb_digit != 0;
-        const uint32_t merge_inline = nj >= 64 || few ? 8u : 2u;
+        const bool coop = few && HasCoopTail<DF>::value && coop_tail_on();
+        // rows per bucket of the cooperative merge: a power of two near a quarter of the average number of partials
+        uint32_t coop_rb = 1;
+        if (coop) {
+            uint64_t est_tasks = (uint64_t)nj * nb;
+            for (size_t k = 0; k < nj; k++) est_tasks += (uint64_t)jobs[k].n * maxd / seg;
+            const uint64_t avg = est_tasks / ((uint64_t)nj * nb);
+            while (coop_rb < 16 && coop_rb * 4 < avg) coop_rb <<= 1;
+        }
+        const uint32_t merge_inline = coop ? 8u * coop_rb : (nj >= 64 || few ? 8u : 2u);
         const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
         ZK_TRY(heavy.ensure(heavy_cap * 4));
         // buckets with 2 .. merge_inline task partials (each holds more than seg pairs): listed for k_msm_merge_light
@@ -566,7 +586,7 @@ struct MsmGroup {
         const bool big_launch = total >= (min_env ? (uint64_t)atoll(min_env) : 4000000ull);
         // level 1 of the reduction in assembly: many-jobs launches only (the few-jobs tail folds level 1 differently)
         const bool red_asm = asm_reduce<DF>() && big_launch && !few;
-        uint32_t L = pick_fan((uint64_t)nj * nb);
+        uint32_t L = coop ? zkcoop::LEVEL1_FAN : pick_fan((uint64_t)nj * nb);
         if (red_asm) {
             // buckets per node of the assembly loop (a power of two): 32 - half the nodes for the compiled levels above
             // it, still eight generations of waves per launch (16 / 32 / 64 measured within noise, r04g)
@@ -578,7 +598,13 @@ struct MsmGroup {
         const uint32_t T = nb / L;
         ZK_TRY(red_r.ensure(nj * ((size_t)nb + 2 * (size_t)T) * sizeof(DPoint)));   // suffix sums: level 1 | two upper-level areas
         ZK_TRY(red_w.ensure(2 * nj * (size_t)T * sizeof(DPoint)));  // W of the nodes (ping-pong halves)
-        ZK_TRY(red_t.ensure(nj * (size_t)T * sizeof(DPoint)));      // 2M * sum R' of the level being built
+        size_t red_t_points = (size_t)T;                            // 2M * sum R' of the level being built
+        if (coop) {   // the cooperative tail keeps the parts of its planes and their sums Y here (coop_tail.h planes)
+            uint32_t nb_ = 0;
+            while ((1u << nb_) < T) nb_++;
+            red_t_points = std::max(red_t_points, (size_t)(nb_ + 1) * (zkcoop::planes_split(T) + 1));
+        }
+        ZK_TRY(red_t.ensure(nj * red_t_points * sizeof(DPoint)));
         // job descriptors through page-locked staging (collect() separates consecutive launch sets)
         ZK_TRY(pin_jobs.ensure(nj * (sizeof(MsmJob) + 4)));
         memcpy(pin_jobs.p, jobs.data(), nj * sizeof(MsmJob));
@@ -704,6 +730,28 @@ struct MsmGroup {
             auto grid = [&](uint32_t threads) { return dim3((threads + 63) / 64, (unsigned)nj); };
             const uint32_t heavy_blocks = (uint32_t)std::min<size_t>(heavy_cap, few ? 512 : 4096);
             const uint32_t light_buckets = few ? (uint32_t)n_buckets : 0u;
+            if constexpr (HasCoopTail<DF>::value) {
+                if (coop) {
+                    // the whole tail on rows of 16 lanes: merge, level 1 (S, W per node of L buckets), bit planes over the T
+                    // nodes, their weighted sum - four launches, ~55 dependent additions of 2 - 3 us (coop_tail.cpp)
+                    uint32_t nbits = 0, log2_2l = 1;
+                    while ((1u << nbits) < T) nbits++;
+                    while ((1u << (log2_2l - 1)) < L) log2_2l++;
+                    DPoint* Sn = R;                        // [nj T]
+                    const uint32_t nsplit = zkcoop::planes_split(T);
+                    DPoint* parts = red_t.as<DPoint>();    // [nj (nbits + 1) nsplit] when a plane takes several workgroups
+                    DPoint* Y = nsplit > 1 ? parts + nj * (size_t)(nbits + 1) * nsplit : parts;   // [nj (nbits + 1)]
+                    DPoint* outp = Wb;
+                    zkcoop::merge<DF>(heavy.as<uint32_t>(), d_nheavy, cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(),
+                                      tsums.as<DPoint>(), nb, seg, n_buckets, heavy_blocks, merge_inline, coop_rb, st);
+                    zkcoop::level1<DF>(tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(), Sn, Wa, nb, L,
+                                       (uint32_t)nj, st);
+                    zkcoop::planes<DF>(Sn, Wa, Y, parts, T, nbits, (uint32_t)nj, st);
+                    zkcoop::combine<DF>(Y, outp, nbits, log2_2l, (uint32_t)nj, st);
+                    in = outp;
+                }
+            }
+            if (!coop) {
             ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>,
                            dim3(heavy_blocks + (light_buckets + zkdev::MSM_MERGE_THREADS - 1) / zkdev::MSM_MERGE_THREADS),
                            dim3(zkdev::MSM_MERGE_THREADS), 0, st, (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy,
@@ -793,6 +841,7 @@ struct MsmGroup {
                 m *= fan;
                 n = n_out;
             }
+            }   // (!coop)
         }
         res_dev = in;   // one XYZZ per job, valid until the next enqueue on this group
         if (!to_host) {
@@ -819,6 +868,17 @@ struct MsmGroup {
             ZK_LAUNCH((zkdev::k_xyzz_normalize_export<DF, false>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, src,
                       stage.as<uint32_t>(), (uint32_t)n);
         }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, stage.p, n * sizeof(HPoint), hipMemcpyDeviceToHost, st));
+        return ZK_OK;
+    }
+    // out[i] = src[i] as it is (host layout, zz and zzz NOT normalised: zkhost::to_affine inverts), enqueued on st.  For a
+    // handful of proofs made alone: three inversions on a host core are 0.1 ms, the two normalisation kernels 0.3 - 0.37 ms
+    // each on the critical path of a 2.4 ms proof (profiles/r06e_*).
+    zk_status export_to_host(const DPoint* src, size_t n, HPoint* out, DevBuf& stage, hipStream_t st) {
+        if (!n) return ZK_OK;
+        ZK_TRY(stage.ensure(n * sizeof(HPoint)));
+        ZK_LAUNCH(zkdev::k_export_xyzz<DF>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, src, stage.as<uint32_t>(), (uint32_t)n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out, stage.p, n * sizeof(HPoint), hipMemcpyDeviceToHost, st));
         return ZK_OK;
@@ -1399,7 +1459,11 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     ZK_TRY(G2.enqueue(P->jobs2, P->res2, side, false));
     ZK_TRY(P->pin_g2.ensure(np * sizeof(HG2)));
     ZK_TRY(P->pin_g1.ensure(2 * np * sizeof(HG1)));
-    ZK_TRY(G2.normalize_to_host(G2.res_dev, np, P->pin_g2.as<HG2>(), P->fold_b2, side));   // B in affine form
+    // into_affine of a handful of proofs: on the host (the encoder's to_affine), the kernels only export
+    static const size_t host_norm_max = getenv("ZKAMD_HOST_NORMALIZE_MAX") ? (size_t)atoll(getenv("ZKAMD_HOST_NORMALIZE_MAX")) : 16;
+    const bool host_norm = np <= host_norm_max;
+    if (host_norm) ZK_TRY(G2.export_to_host(G2.res_dev, np, P->pin_g2.as<HG2>(), P->fold_b2, side));
+    else ZK_TRY(G2.normalize_to_host(G2.res_dev, np, P->pin_g2.as<HG2>(), P->fold_b2, side));   // B in affine form
     // ---- H pipeline (create_proof step 3)
     ZK_TRY(P->abc.ensure(3 * np * m * 32));
     uint32_t* A = P->abc.as<uint32_t>();
@@ -1476,7 +1540,12 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
                       (const uint32_t*)P->tail.as<uint32_t>() + 16, 24u, P->fold_tbl.as<DP1>(), P->fold_c.as<DP1>(), (uint32_t)np);
             cfin = P->fold_c.as<DP1>();
         }
-        ZK_TRY(G1C.normalize2_to_host(a, cfin, np, P->pin_g1.as<HG1>() + np, P->pin_g1.as<HG1>(), P->fold_a1, P->fold_c1, g_stream));
+        if (host_norm) {
+            ZK_TRY(G1C.export_to_host(a, np, P->pin_g1.as<HG1>() + np, P->fold_a1, g_stream));
+            ZK_TRY(G1C.export_to_host(cfin, np, P->pin_g1.as<HG1>(), P->fold_c1, g_stream));
+        } else {
+            ZK_TRY(G1C.normalize2_to_host(a, cfin, np, P->pin_g1.as<HG1>() + np, P->pin_g1.as<HG1>(), P->fold_a1, P->fold_c1, g_stream));
+        }
     }
     HIP_TRY(hipMemcpyAsync(P->pin_bad.p, bad, 8, hipMemcpyDeviceToHost, g_stream));
     const bool trace_host = getenv("ZKAMD_TRACE_HOST") != nullptr;
