@@ -22,7 +22,7 @@ template <class F> ZK_DI void coop_store(XYZZ<F>& d, const XYZZ<CoopT<F>>& p) {
     coop_store(d.zzz, p.zzz);
 }
 
-constexpr uint32_t CT_ROWS = 32;   // rows per workgroup of the kernels that sum across rows (512 threads)
+constexpr uint32_t CT_ROWS = 16;   // rows per workgroup of the kernels that sum across rows: 256 threads = ONE wave per SIMD of a CU (an addition is issue-bound for its wave: two waves of a workgroup on one SIMD take twice as long each)
 constexpr uint32_t CT_THIN = 4;    // rows per workgroup of the kernels that do not (one wave)
 
 // sum over groups of g consecutive rows (g a power of two <= CT_ROWS), valid in the first row of a group.  Called by all
