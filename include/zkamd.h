@@ -66,13 +66,13 @@
  *   zk_verify_proof / zk_verify_batch   verify_proof                              verifier.rs:32-63; callers confidential.rs:271, modules/zk-system/src/lib.rs:57-108
  *   zk_verify_batch_rlc             - (bellman's batch verifier): the same verdicts, one final exponentiation
  *   zk_proof_read_batch             Proof::read                                   core/bellman-verifier/src/lib.rs:67-110
- *   zk_msm_create, zk_msm_create_variable, zk_msm_run, zk_msm_run_dev, zk_msm_free, zk_msm_g1, zk_msm_g2
+ *   zk_msm_create, zk_msm_create_variable, zk_msm_run, zk_msm_run_dev, zk_msm_free, zk_msm_g1, zk_msm_g2, zk_msm_cache_release
  *                                   bellman multiexp(FullDensity); group law core/pairing/src/bls12_381/ec.rs:296-526
  *   zk_ntt_fr, zk_ntt_create, zk_ntt_run_dev, zk_ntt_free
  *                                   bellman EvaluationDomain {fft, ifft, coset_fft, icoset_fft}; field core/pairing/src/bls12_381/fr.rs:341-571
  *   zk_debug_field_mul              Fr / Fq mul_assign (for the literal KATs)     fr.rs:438-464, fq.rs:915-965
  *   zk_strerror / zk_last_error     the variants of SynthesisError and their texts   core/bellman-verifier/src/lib.rs:359-383
- *   zk_device_count, zk_set_host_threads, zk_bind_host_to_device, zk_stream, zk_synchronize, zk_kernel_forms,
+ *   zk_device_count, zk_set_host_threads, zk_bind_host_to_device, zk_stream, zk_synchronize, zk_kernel_forms, zk_memory_stats,
  *   zk_profile_begin, zk_profile_get, zk_profile_end   - (device selection, host threads, measurement; the reference runs on the CPU)
  */
 #ifndef ZKAMD_H
@@ -408,6 +408,9 @@ zk_status zk_generate_parameters(zk_r1cs* circuit, const uint8_t g1[96], const u
  *                       n x n_inputs x 32 bytes (plain little-endian, WITHOUT the leading ONE).
  *                       ok_out[i] = 1 iff proof i verifies; a malformed proof or input is 0, not an error.
  *                       ZK_ERR_MALFORMED_VERIFYING_KEY if n_inputs + 1 != ic length (verifier.rs:38-40).
+ *                       The entry picks the faster of the two forms per chunk itself (round 6): the per-proof check below 4096
+ *                       proofs, the combined check of zk_verify_batch_rlc from there on (measured crossover, verify.cpp
+ *                       VERIFY_RLC_AUTO_MIN) - the verdicts are the same either way.
  * ------------------------------------------------------------------------------------------ */
 typedef struct zk_vk zk_vk;
 zk_status zk_params_write_vk(const zk_params* p, uint8_t* out, size_t cap, size_t* len);
@@ -456,6 +459,9 @@ zk_status zk_msm_run_dev(zk_msm* m, const void* d_scalars, uint32_t flags, uint8
 void zk_msm_free(zk_msm* m);
 zk_status zk_msm_g1(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]);
 zk_status zk_msm_g2(const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[192]);
+/* The one-shot entries keep a handle per (device, group) - decoded bases, sort and reduction workspaces, ~1.1 KB per base -
+ * for the next call; a call over more than 2^21 bases releases it again by itself.  This releases all of them now. */
+void zk_msm_cache_release(void);
 
 /* EvaluationDomain transforms over Fr, n = 2^log_n.
  * zk_ntt_fr: in-place on a HOST buffer of plain LE scalars, natural order in and out, the four
@@ -494,6 +500,13 @@ void zk_profile_end(void);
  * free); ms_out = the comparison [G2 first, G2 scratch-free, reduction first, reduction scratch-free], zeros before any key
  * was loaded on the device.  No reference counterpart. */
 zk_status zk_kernel_forms(int device, uint32_t forms_out[2], float ms_out[4]);
+/* What the library holds on the device and in page-locked host memory, and what it wiped: every buffer that can hold
+ * key-derived data (assignments, scalar vectors, the witness kernels' scratch, the digits and bucket sums of a multiexp,
+ * staging areas) is zeroed before it goes back to the runtime; only the tables of a key (CRS points, twiddles) are not.
+ * out = [device bytes held, device bytes of such buffers released so far, device bytes zeroed before release,
+ *        page-locked bytes held, page-locked bytes released, page-locked bytes zeroed before release].
+ * out[1] == out[2] and out[4] == out[5] always.  No reference counterpart (the reference leaves its heap to the OS). */
+void zk_memory_stats(uint64_t out[6]);
 /* the HIP stream (hipStream_t) all work of this library is enqueued on */
 void* zk_stream(void);
 zk_status zk_synchronize(void);

@@ -39,3 +39,11 @@ def gpu_lib():
     lib.check(lib.zk_device_count(ctypes.byref(n)))
     assert n.value > 0, "no HIP device visible: -m gpu tests must run on the GPU box"
     return lib
+
+
+@pytest.fixture(scope="session")
+def gpu_hooks_lib(gpu_lib):
+    """libzkamd_hooks.so: the product sources with -DZK_TEST_HOOKS (fault injection, debug prints), for the GPU tests that
+    inject a failure or read a debug line.  A second library in the process, with its own global state."""
+    from zero_chain_amd import _lib
+    return _lib.ZkLib(_lib.HOOKS_LIB_PATH)

@@ -48,7 +48,7 @@ def build_emu(force=False, sanitize=False):
         deps = sorted(_deps(src))
         if not force and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps):
             continue
-        cmd = [cxx] + flags + ["-std=c++17", "-fPIC", "-DZK_EMU=1", "-Wno-psabi", "-x", "c++", "-c", src, "-o", obj]
+        cmd = [cxx] + flags + ["-std=c++17", "-fPIC", "-DZK_EMU=1", "-DZK_TEST_HOOKS=1", "-Wno-psabi", "-x", "c++", "-c", src, "-o", obj]
         print("+", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd), obj, time.time()))
     for cmd, p, obj, t0 in procs:

@@ -201,6 +201,30 @@ def msm_edge_cases(lib):
     assert e.value.variant == "IoError"
 
 
+def memory_hygiene(lib):
+    """VERDICT r5 missing 5: the workspaces that hold key-derived data are zeroed before they go back to the runtime.
+    zk_memory_stats counts what the library holds, what it released and what it wiped before the release: after a key was
+    loaded, a proof made, a one-shot multiexp run and everything closed again, the library holds what it held before,
+    every released byte of a non-public buffer was wiped (device and page-locked), and something WAS released."""
+    before = zk.memory_stats(lib)
+    r1, asg, P, pk = helpers.small_case(1, 3, 40, 44)
+    params = zk.Parameters.read(pk, checked=True, lib=lib)
+    proof = zk.create_proof(helpers.to_assignment(zk, asg), params, 0xabcdef0123456789, 0x9876543210fedcba).write()
+    assert proof == helpers.expected_proof_trapdoor(P, asg, 0xabcdef0123456789, 0x9876543210fedcba)
+    pts = helpers.golden_points("g1_uncompressed")
+    assert zk.multiexp(1, pts[3] + pts[5], [2, 7], lib=lib) == helpers.g1_of(3 * 2 + 5 * 7)
+    mid = zk.memory_stats(lib)
+    assert mid["device_held"] > before["device_held"] and mid["pinned_held"] >= before["pinned_held"]
+    params.close()
+    zk.multiexp_cache_release(lib)
+    after = zk.memory_stats(lib)
+    assert after["device_held"] == before["device_held"], (before, mid, after)
+    d_rel, d_wiped = after["device_released"] - before["device_released"], after["device_wiped"] - before["device_wiped"]
+    p_rel, p_wiped = after["pinned_released"] - before["pinned_released"], after["pinned_wiped"] - before["pinned_wiped"]
+    assert d_rel > 0 and d_rel == d_wiped, (before, after)
+    assert p_rel > 0 and p_rel == p_wiped, (before, after)
+
+
 def msm_noncanonical_scalars(lib, sizes=(20, 200), groups=(1, 2)):
     """a scalar >= r must be refused WITHOUT the recoders having indexed anything with it.  s = r + 1 (even:
     the regular recoding's r - s wrapped to ~2^256), 2^255 (the width-w NAF would emit a digit past the table's last slice) and

@@ -217,3 +217,44 @@ def test_c_program_proves_on_several_devices_from_one_process(tmp_path, emu_lib)
     for threads, n in ((2, 7), (3, 2), (1, 0)):
         out = subprocess.check_output([exe, emu_lib.path, "small", str(threads), str(n)], timeout=600).decode()
         assert "abi_multi ok: %d small-circuit proofs from %d threads" % (n, threads) in out, out
+
+
+def _env_names_in_sources():
+    import re
+    names = set()
+    csrc = os.path.join(ROOT, "zero-chain_amd", "csrc")
+    for f in os.listdir(csrc):
+        names |= set(re.findall(r'"(ZKAMD_[A-Z0-9_]+)"', open(os.path.join(csrc, f)).read()))
+    return names
+
+
+def test_readme_lists_every_environment_variable_the_library_reads():
+    """one table of the variables the product build reads, and it is the truth - every "ZKAMD_..." string
+    literal of the sources is in README.md (first table: the shipped library; second: the -DZK_TEST_HOOKS build only), and the
+    README names nothing the sources do not read."""
+    import re
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    sec = readme[readme.index("## Environment variables the library reads"):]
+    first, second = sec.split("Compiled in only under `-DZK_TEST_HOOKS`")
+    listed = set(re.findall(r"^\| `(ZKAMD_[A-Z0-9_]+)` \|", first, flags=re.M))
+    hooks = set(re.findall(r"^\| `(ZKAMD_[A-Z0-9_]+)` \|", second, flags=re.M))
+    in_src = _env_names_in_sources()
+    assert hooks and all(n.startswith(("ZKAMD_INJECT_", "ZKAMD_DEBUG_")) for n in hooks)
+    assert listed | hooks == in_src, (sorted(in_src - listed - hooks), sorted((listed | hooks) - in_src))
+    assert not (listed & hooks)
+    # ... and the hook variables are read through hook_env() only (host_common.h: nullptr without -DZK_TEST_HOOKS)
+    csrc = os.path.join(ROOT, "zero-chain_amd", "csrc")
+    for f in os.listdir(csrc):
+        text = open(os.path.join(csrc, f)).read()
+        assert not re.search(r'getenv\("ZKAMD_(INJECT|DEBUG)_', text), f
+
+
+def test_shipped_library_carries_no_test_hook():
+    """... and the built artefact agrees: no hook variable's name is in libzkamd.so; the hooks library has them."""
+    from zero_chain_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(_lib.HOOKS_LIB_PATH):
+        pytest.skip("product libraries not built here")
+    shipped, hooks = open(_lib.LIB_PATH, "rb").read(), open(_lib.HOOKS_LIB_PATH, "rb").read()
+    for name in (b"ZKAMD_INJECT_THROW", b"ZKAMD_INJECT_LANE_OOM", b"ZKAMD_INJECT_SCRATCH_SLOW", b"ZKAMD_DEBUG_RLC", b"ZKAMD_DEBUG_TIMING"):
+        assert name not in shipped, name
+        assert name in hooks, name

@@ -54,6 +54,10 @@ def test_msm_edges(emu_lib):
     pc.msm_edge_cases(emu_lib)
 
 
+def test_secret_workspaces_are_wiped_before_release(emu_lib):
+    pc.memory_hygiene(emu_lib)
+
+
 def test_msm_noncanonical_scalars(emu_lib):
     pc.msm_noncanonical_scalars(emu_lib, sizes=(20, 200), groups=(1,))
     pc.msm_noncanonical_scalars(emu_lib, sizes=(20,), groups=(2,))

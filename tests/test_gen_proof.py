@@ -154,7 +154,8 @@ def test_no_exception_crosses_the_c_abi(monkeypatch):
     entry is a function-try-block, host_common.h ZK_ABI_CATCH), also when it is thrown on a worker thread (run_threads hands
     it to the joining thread).  ZKAMD_INJECT_THROW makes the last worker of zk_jubjub_base_mul fail an allocation."""
     import zero_chain_amd as zk
-    lib = _lib()
+    from zero_chain_amd import _lib as loader
+    lib = loader.ZkLib(loader.HOOKS_LIB_PATH)   # the injection is compiled into the hooks library only (host_common.h hook_env)
     monkeypatch.setenv("ZKAMD_INJECT_THROW", "1")
     for n in (1, 40):   # the calling thread itself / a spawned worker
         with pytest.raises(zk.ZkError) as e:

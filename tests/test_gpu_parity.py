@@ -82,6 +82,10 @@ def test_msm_edges(gpu_lib):
     pc.msm_edge_cases(gpu_lib)
 
 
+def test_secret_workspaces_are_wiped_before_release(gpu_lib):
+    pc.memory_hygiene(gpu_lib)
+
+
 def test_msm_noncanonical_scalars(gpu_lib):
     """scalars >= r at the sizes whose automatic window divides 255 (w = 3, 5 and - 2^20 scalars - 15), both handle modes
     and the one-shot entry: refused, nothing indexed with them."""
@@ -430,7 +434,7 @@ def test_pipeline_two_lanes_full_chunks_every_proof_checked(gpu_lib, monkeypatch
         params.close()
 
 
-def test_pipeline_lane_retires_when_its_workspaces_do_not_fit(gpu_lib, monkeypatch):
+def test_pipeline_lane_retires_when_its_workspaces_do_not_fit(gpu_hooks_lib, monkeypatch):
     """the free-memory estimate of zk_pipeline_create is only a hint.  A lane beyond the first whose
     allocation fails (injected here) hands its jobs back and retires; the stream of proofs is the one a single call
     makes, nothing is lost or duplicated, and the pipeline reports the lanes that are left."""
@@ -446,8 +450,8 @@ def test_pipeline_lane_retires_when_its_workspaces_do_not_fit(gpu_lib, monkeypat
     sts = zk.transfer_statements([tc.statement_dict(ws[i % 4]) for i in range(n)])
     rng = synth.SplitMix64(4242)
     rs = [(rng.field(bls.R_MOD), rng.field(bls.R_MOD)) for _ in range(n)]
-    params = zk.Parameters.read(pk, checked=False, lib=gpu_lib)
-    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_lib)
+    params = zk.Parameters.read(pk, checked=False, lib=gpu_hooks_lib)
+    mats = zk.ConstraintMatrices.transfer_circuit(lib=gpu_hooks_lib)
     pipe = zk.TransferPipeline(mats, params)
     try:
         assert pipe.lanes == 3
@@ -733,7 +737,10 @@ def test_kernel_form_selection(gpu_lib):
     ms = base["forms"]["ms"]
     assert base["verified"] == 1024 and all(x > 0 for x in ms), base
     assert base["forms"]["g2_accumulate"] == int(ms[0] > 1.4 * ms[1]) and base["forms"]["reduce_level1"] == int(ms[2] > 1.4 * ms[3])
-    slow = run({"ZKAMD_INJECT_SCRATCH_SLOW": "1"})
+    # (the injection exists in the hooks library only; the shipped one ignores the variable: same choice as `base`)
+    ignored = run({"ZKAMD_INJECT_SCRATCH_SLOW": "1"})
+    assert (ignored["forms"]["g2_accumulate"], ignored["forms"]["reduce_level1"]) == (base["forms"]["g2_accumulate"], base["forms"]["reduce_level1"])
+    slow = run({"ZKAMD_INJECT_SCRATCH_SLOW": "1", "ZK_LIB_FLAVOR": "hooks"})
     assert (slow["forms"]["g2_accumulate"], slow["forms"]["reduce_level1"]) == (1, 1), slow
     assert slow["verified"] == 1024 and slow["sha256"] == base["sha256"]
     forced = run({"ZKAMD_KERNEL_FORM": "free", "ZKAMD_NO_CALIBRATE": "1"})
@@ -761,9 +768,9 @@ def test_c_program_proves_on_several_devices_from_one_process(gpu_lib, tmp_path)
     assert out.returncode == 0 and "abi_multi ok: 10 small-circuit proofs from 3 threads" in out.stdout, out.stdout + out.stderr
 
 
-def test_verifier_rlc(gpu_lib, monkeypatch, capfd):
-    monkeypatch.setenv("ZKAMD_DEBUG_RLC", "1")
-    pc.verifier_rlc(gpu_lib, n=40, capfd=capfd)
+def test_verifier_rlc(gpu_hooks_lib, monkeypatch, capfd):
+    monkeypatch.setenv("ZKAMD_DEBUG_RLC", "1")   # (a debug line of the hooks build says which form decided)
+    pc.verifier_rlc(gpu_hooks_lib, n=40, capfd=capfd)
 
 
 def test_verifier_rlc_full_chunk(gpu_lib):

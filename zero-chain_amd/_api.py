@@ -25,7 +25,7 @@ from ._lib import (ZkError, ZkLib, ZK_FR_MONTGOMERY, ZK_NTT_INVERSE, ZK_NTT_COSE
 
 __all__ = ["Parameters", "Proof", "generate_parameters", "generate_random_parameters", "PreparedVerifyingKey", "prepare_verifying_key", "verify_proof", "verify_proofs", "read_proofs",
            "verify_transfer_batch", "ProvingAssignment", "create_proof", "create_random_proof", "create_proofs", "create_proofs_dev", "stream", "bind_host_to_device", "KernelTimer", "kernel_forms",
-           "multiexp", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "xt_fields", "gen_proof", "XT_FIELDS",
+           "multiexp", "multiexp_cache_release", "memory_stats", "MultiexpContext", "ConstraintMatrices", "create_proofs_from_witness", "fs_rand", "spending_key_from_seed", "jubjub_base_mul", "elgamal_encrypt", "transfer_requests", "transfer_derive", "gen_proofs", "xt_fields", "gen_proof", "XT_FIELDS",
            "FS_MODULUS", "transfer_statements", "transfer_witness", "transfer_witness_gpu", "transfer_r1cs_fingerprint", "anonymous_r1cs_fingerprint", "ANONYMOUS_N_INPUTS", "ANONYMOUS_N_AUX", "anonymous_statements", "anonymous_requests", "anonymous_derive", "anonymous_gen_proofs", "anonymous_witness", "anonymous_witness_gpu", "anonymous_prove_batch",
            "transfer_prove_batch", "TransferPipeline", "set_host_threads", "TRANSFER_N_INPUTS", "TRANSFER_N_AUX", "EvaluationDomain", "XorShiftRng", "fr_rand", "ZkError", "FR_MODULUS",
            "scalars_to_bytes", "bytes_to_scalars", "load_library", "ZK_FR_MONTGOMERY", "ZK_NTT_INVERSE",
@@ -925,6 +925,18 @@ class MultiexpContext:
             self.close()
         except Exception:
             pass
+
+
+def multiexp_cache_release(lib=None):
+    """zk_msm_cache_release: drop the handles the one-shot entries keep per (device, group)."""
+    (lib or load_library()).zk_msm_cache_release()
+
+
+def memory_stats(lib=None):
+    """zk_memory_stats as a dict: bytes held on the device / page-locked, released so far, zeroed before release."""
+    out = (C.c_uint64 * 6)()
+    (lib or load_library()).zk_memory_stats(out)
+    return dict(zip(("device_held", "device_released", "device_wiped", "pinned_held", "pinned_released", "pinned_wiped"), [int(v) for v in out]))
 
 
 def multiexp(group, bases, scalars, lib=None):

@@ -9,6 +9,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libzkamd.so")
+# the same sources with the test hooks compiled in (fault injection, debug prints): opened by the tests that need them, or
+# through ZK_LIB_FLAVOR=hooks in a test's subprocess - never by default
+HOOKS_LIB_PATH = os.path.join(HERE, "libzkamd_hooks.so")
 
 ZK_OK = 0
 ZK_FR_MONTGOMERY = 1
@@ -150,6 +153,8 @@ _PROTOS = {
     "zk_msm_free": (None, [C.c_void_p]),
     "zk_msm_g1": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "zk_msm_g2": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "zk_msm_cache_release": (None, []),
+    "zk_memory_stats": (None, [C.POINTER(C.c_uint64)]),
     "zk_ntt_fr": (C.c_int32, [C.c_void_p, C.c_uint32, C.c_int, C.c_int]),
     "zk_ntt_create": (C.c_int32, [C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]),
     "zk_ntt_run_dev": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
@@ -205,5 +210,5 @@ def load():
             import torch  # noqa: F401
         except ImportError:
             pass
-        _lib = ZkLib(LIB_PATH)
+        _lib = ZkLib(HOOKS_LIB_PATH if os.environ.get("ZK_LIB_FLAVOR") == "hooks" else LIB_PATH)
     return _lib

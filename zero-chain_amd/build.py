@@ -1,7 +1,8 @@
 """Build the product library in-tree:
 
-  libzkamd.so   gfx950 (hipcc --offload-arch=gfx950), the C ABI of include/zkamd.h.
-                Cross-compiles without a GPU.
+  libzkamd.so         gfx950 (hipcc --offload-arch=gfx950), the C ABI of include/zkamd.h.  Cross-compiles without a GPU.
+  libzkamd_hooks.so   the same sources with -DZK_TEST_HOOKS: fault injection and debug prints (host_common.h hook_env) for the
+                      three GPU tests that need them.  The shipped library reads none of those variables.
 """
 import os
 import subprocess
@@ -15,6 +16,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 LIB = os.path.join(HERE, "libzkamd.so")
+LIB_HOOKS = os.path.join(HERE, "libzkamd_hooks.so")
 
 
 def _sources():
@@ -53,29 +55,42 @@ def _deps(path, seen=None):
     return seen
 
 
-def build_lib(force=False):
-    if not force and not _stale(LIB, _sources()):
-        return LIB
+def _uses_hooks(tu):
+    return any("hook_env(" in open(d).read() for d in _deps(os.path.join(CSRC, tu)) if not d.endswith("host_common.h"))
+
+
+def build_lib(force=False, hooks=False):
+    lib = LIB_HOOKS if hooks else LIB
+    if not force and not _stale(lib, _sources()):
+        return lib
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     extra = (os.environ.get("ZKAMD_HIPCC_FLAGS") or "").split()
     procs, objs = [], []
     for tu in TRANSLATION_UNITS:
-        obj = os.path.join(objdir, tu.replace(".cpp", ".o"))
+        # the hooks library differs only in the units that call hook_env(): the others are the shipped objects
+        variant = hooks and _uses_hooks(tu)
+        obj = os.path.join(objdir, tu.replace(".cpp", ".hooks.o" if variant else ".o"))
         objs.append(obj)
         if not force and not extra and not _stale(obj, sorted(_deps(os.path.join(CSRC, tu)))):
             continue
-        cmd = [HIPCC] + extra + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-x", "hip",
-                                 os.path.join(CSRC, tu), "-o", obj]
+        cmd = [HIPCC] + extra + (["-DZK_TEST_HOOKS=1"] if variant else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-x", "hip",
+                                                                            os.path.join(CSRC, tu), "-o", obj]
         print("+", " ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd), obj, time.time()))
     for cmd, p, obj, t0 in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
         os.utime(obj, (t0, t0))   # an edit made WHILE the unit compiled must make it stale again
-    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-lpthread"])
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib, "-lpthread"])
+    return lib
+
+
+def build_all(force=False):
+    build_lib(force)
+    build_lib(force, hooks=True)
     return LIB
 
 
 if __name__ == "__main__":
-    build_lib("--force" in sys.argv)
+    build_all("--force" in sys.argv)

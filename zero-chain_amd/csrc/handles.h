@@ -28,13 +28,19 @@ struct zk_r1cs {
     void* host_z = nullptr;
     size_t host_z_cap = 0;
     ~zk_r1cs() {
-        if (host_z) (void)hipHostFree(host_z);
+        if (host_z) {
+            explicit_bzero(host_z, host_z_cap);   // witness vectors: the bits of the keys
+            (void)hipHostFree(host_z);
+        }
         for (int k = 0; k < 2; k++)
             if (wit_done[k]) (void)hipEventDestroy(wit_done[k]);
     }
     zk_status host_ensure(size_t bytes) {
         if (bytes <= host_z_cap) return ZK_OK;
-        if (host_z) (void)hipHostFree(host_z);
+        if (host_z) {
+            explicit_bzero(host_z, host_z_cap);
+            (void)hipHostFree(host_z);
+        }
         host_z = nullptr;
         host_z_cap = 0;
         if (hipHostMalloc(&host_z, bytes) != hipSuccess) {
@@ -69,5 +75,5 @@ bool lib_witness_on_host(size_t n);   // a handful of statements: the assignment
 int lib_params_device(const zk_params* P);
 size_t lib_params_domain(const zk_params* P);
 zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,
-                       bool own_proofs, bool rlc = false);
+                       bool own_proofs, int form = VERIFY_AUTO);
 }

@@ -202,11 +202,14 @@ struct MsmGroup {
     // infinity.  Everything is enqueued on st; decode_finish() reads the verdict once the stream has been waited for.
     zk_status decode_enqueue(const uint8_t* bases, size_t n, uint32_t c_, bool with_table, DevBuf& raw, DevBuf& map, hipStream_t st);
     // after the stream was waited for: ZK_ERR_IO naming the first refused encoding, else *n_inf = points at infinity
-    zk_status decode_finish(const char* what, uint32_t* n_inf) {
+    // (*bad_index = the refused encoding's index when the status is ZK_ERR_IO for that reason; a device error leaves it alone)
+    zk_status decode_finish(const char* what, uint32_t* n_inf, size_t* bad_index = nullptr) {
         uint32_t v[2] = {0xffffffffu, 0};
         HIP_TRY(hipMemcpy(v, dstat.p, 8, hipMemcpyDeviceToHost));
-        if (v[0] != 0xffffffffu)
+        if (v[0] != 0xffffffffu) {
+            if (bad_index) *bad_index = v[0];
             return fail(ZK_ERR_IO, std::string("invalid ") + (sizeof(HAffine) == 96 ? "G1" : "G2") + " encoding at " + what + " " + std::to_string(v[0]));
+        }
         *n_inf = v[1];
         return ZK_OK;
     }

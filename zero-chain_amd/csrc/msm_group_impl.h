@@ -14,6 +14,7 @@ zk_status MsmGroup<HF, DF>::decode_enqueue(const uint8_t* bases, size_t n, uint3
     const uint32_t npos = with_table ? zkdev::MSM_NPOS : 1u;
     if ((uint64_t)n_points * npos >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "doubling table too large");
     const size_t tb = sizeof(DAffine) * n_points * npos;
+    table.is_public = true;   // bases of a key or of a multiexp: public points, 4.2 GB for the transfer key - freed without the wipe
     ZK_TRY(table.ensure(tb ? tb : 1));
     bytes = tb;
     ZK_TRY(dstat.ensure(8));
@@ -64,6 +65,7 @@ zk_status MsmGroup<HF, DF>::build(const std::vector<typename MsmGroup<HF, DF>::H
     const uint32_t npos = with_table ? zkdev::MSM_NPOS : 1u;
     if ((uint64_t)n_points * npos >= (1ull << 31)) return fail(ZK_ERR_INVALID_ARGUMENT, "doubling table too large");
     size_t tb = sizeof(DAffine) * n_points * npos;
+    table.is_public = true;   // bases of a key or of a multiexp: public points, 4.2 GB for the transfer key - freed without the wipe
     ZK_TRY(table.ensure(tb ? tb : 1));
     bytes = tb;
     if (!n_points) return ZK_OK;
@@ -207,7 +209,7 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
         ProfScope ps("msm_sort_lds", st);
         ZK_LAUNCH_SYNC(zkdev::k_msm_sort_lds, dim3((unsigned)nj), dim3(zkdev::MSM_SORT_THREADS), (size_t)nb * 4, st, dj, c,
                        cnt.as<uint32_t>(), off.as<uint32_t>(), toff.as<uint32_t>(), ntasks.as<uint32_t>(),
-                       pairs.as<uint32_t>(), seg, getenv("ZKAMD_DEBUG_SORT") ? (uint32_t)atoi(getenv("ZKAMD_DEBUG_SORT")) : 0u);
+                       pairs.as<uint32_t>(), seg, hook_env("ZKAMD_DEBUG_SORT") ? (uint32_t)atoi(hook_env("ZKAMD_DEBUG_SORT")) : 0u);
     } else {
         // two-level counting sort, every per-digit atomic in LDS (msm.h)
         uint32_t fine_log = 7;
@@ -268,7 +270,7 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
             ZK_TRY(redo.ensure(std::max((size_t)total_tasks, (size_t)nj * T) * 4));   // (level 1 of the reduction may list its nodes here later)
             launch_asm_loop(table.as<DAffine>(), pairs.as<uint32_t>(), sorted.as<uint4>(), d_total, tsums.as<DPoint>(), d_nredo,
                             redo.as<uint32_t>(), (unsigned)((total_tasks + 127) / 128), st);
-            if (getenv("ZKAMD_DEBUG_REDO")) {   // diagnostics: how many tasks went to the second pass, and what they look like
+            if (hook_env("ZKAMD_DEBUG_REDO")) {   // diagnostics: how many tasks went to the second pass, and what they look like
                 (void)hipStreamSynchronize(st);
                 uint32_t nr = 0, tot = 0;
                 (void)hipMemcpy(&nr, d_nredo, 4, hipMemcpyDeviceToHost);
@@ -352,7 +354,7 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
             ZK_TRY(redo.ensure(std::max((size_t)total_tasks, (size_t)nj * T) * 4));   // (the accumulation's second pass is done with its list by now)
             launch_red_asm<DF>(tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(), R, Wa, nb, L,
                                grid(T), st, d_nfallback, redo.as<uint32_t>());
-            if (getenv("ZKAMD_DEBUG_REDO")) {   // diagnostics: nodes of level 1 the assembly loop handed to the compiled addition
+            if (hook_env("ZKAMD_DEBUG_REDO")) {   // diagnostics: nodes of level 1 the assembly loop handed to the compiled addition
                 (void)hipStreamSynchronize(st);
                 uint32_t v[2] = {0, 0};
                 (void)hipMemcpy(v, d_nlight, 8, hipMemcpyDeviceToHost);

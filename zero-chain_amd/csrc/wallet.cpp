@@ -250,7 +250,7 @@ zk_status zk_jubjub_base_mul(const uint8_t* scalars, size_t n, uint8_t* points_o
     std::vector<std::string> msgs(nthreads);
     // test hook (tests/test_gen_proof.py): the LAST worker thread fails an allocation - the exception must reach the caller as
     // a status, through run_threads and the barrier of this entry, not unwind into it
-    const bool inject = getenv("ZKAMD_INJECT_THROW") != nullptr;
+    const bool inject = hook_env("ZKAMD_INJECT_THROW") != nullptr;
     auto work = [&](unsigned t) {
         if (inject && t + 1 == nthreads) throw std::bad_alloc();
         for (size_t i = n * t / nthreads; i < n * (t + 1) / nthreads; i++) {
@@ -328,7 +328,7 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
     std::vector<uint8_t> rsk(n * 32), proofs(n * 192), ok(n);
     WipeOnExit wipe_st{st.data(), n * sizeof(zk_transfer_statement)}, wipe_rsk{rsk.data(), rsk.size()};
     // ZKAMD_DEBUG_TIMING=1: where the wall time of the call goes (stderr)
-    const bool timing = getenv("ZKAMD_DEBUG_TIMING") != nullptr;
+    const bool timing = hook_env("ZKAMD_DEBUG_TIMING") != nullptr;
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     // A handful of requests (one transaction at a time is the reference's call pattern): the assignment on the host cores,
@@ -429,7 +429,8 @@ zk_status anonymous_derive_one(const zk_anonymous_request& rq, size_t index, zk_
     const std::string who = "request " + std::to_string(index) + ": ";
     if (rq.s_index >= ZK_ANONYMOUS_SIZE || rq.t_index >= ZK_ANONYMOUS_SIZE || rq.s_index == rq.t_index)
         return fail(ZK_ERR_INVALID_ARGUMENT, who + "s_index and t_index must be two different members of the set");
-    uint64_t sk[4], alpha[4], rnd[4];
+    uint64_t sk[4], alpha[4], rnd[4], dk[4] = {0, 0, 0, 0};
+    WipeOnExit wipe_sk{sk, sizeof(sk)}, wipe_alpha{alpha, sizeof(alpha)}, wipe_rnd{rnd, sizeof(rnd)}, wipe_dk{dk, sizeof(dk)};   // every exit path
     load_scalar_le(rq.spending_key, sk);
     load_scalar_le(rq.alpha, alpha);
     load_scalar_le(rq.randomness, rnd);
@@ -451,7 +452,6 @@ zk_status anonymous_derive_one(const zk_anonymous_request& rq, size_t index, zk_
     h.update(st->proof_generation_key, 32);
     h.finish(st->dec_key);
     st->dec_key[31] &= 0x07;
-    uint64_t dk[4];
     load_scalar_le(st->dec_key, dk);
     // the set: sender at s_index, recipient at t_index, the decoys in their order everywhere else
     zkwit::JPoint keys[ZK_ANONYMOUS_SIZE];
@@ -491,6 +491,7 @@ zk_status anonymous_derive_one(const zk_anonymous_request& rq, size_t index, zk_
         memcpy(st->enc_balances_right[i], rq.enc_balances_right[i], 32);
     }
     uint64_t r[4];
+    WipeOnExit wipe_r{r, sizeof(r)};
     fs_add(sk, alpha, r);   // SpendingKey::into_rsk
     memcpy(rsk, r, 32);
     if (der) {
