@@ -50,10 +50,11 @@ def main():
     import zero_chain_amd as zk
     from zero_chain_amd import _lib
     mark("imports")
-    lib = zk.load_library()
+    lib = _lib.ZkLib(_lib.LIB_PATH)                   # (not load_library(): that imports torch first - 1-2 s a wallet does not pay)
+    mark("library_dlopen")
     n = C.c_int(0)
     lib.check(lib.zk_device_count(C.byref(n)))        # the first HIP call: runtime and device initialisation
-    mark("library_and_hip_init")
+    mark("hip_init")
     pk = open(os.path.join(d, "proving.params"), "rb").read()
     mark("read_key_file")
     params = zk.Parameters.read(pk, checked=checked, lib=lib)

@@ -119,20 +119,22 @@ k_ct_level1(const XYZZ<F>* __restrict__ tsums, const uint32_t* __restrict__ cnt,
 // takes the z-th part of its list and writes out[(job (nbits + 1) + i) nsplit + z]: with nsplit > 1 k_ct_fold adds the parts.
 template <class F>
 static __global__ void __launch_bounds__(CT_ROWS * COOP_W)
-k_ct_planes(const XYZZ<F>* __restrict__ S, const XYZZ<F>* __restrict__ W, XYZZ<F>* __restrict__ out, uint32_t T, uint32_t nbits) {
+k_ct_planes(const XYZZ<F>* __restrict__ S, uint32_t s_stride, const XYZZ<F>* __restrict__ W, XYZZ<F>* __restrict__ out, uint32_t T,
+            uint32_t nbits) {
     typedef CoopT<F> C;
     ZK_SHARED XYZZ<C> sm[CT_ROWS * COOP_W];
     const uint32_t r = coop_row_in_block(), i = blockIdx.x, job = blockIdx.y, nsplit = gridDim.z;
-    const XYZZ<F>* src = (i == nbits ? W : S) + (size_t)job * T;
+    const XYZZ<F>* src = i == nbits ? W + (size_t)job * T : S + (size_t)job * T * s_stride;
+    const uint32_t stride = i == nbits ? 1u : s_stride;
     const uint32_t count = i == nbits ? T : T >> 1, low = (1u << i) - 1u;
     const uint32_t per = (count + nsplit - 1) / nsplit, k0 = blockIdx.z * per, k1 = k0 + per < count ? k0 + per : count;
     auto index = [&](uint32_t k) { return i == nbits ? k : (((k & ~low) << 1) | (1u << i) | (k & low)); };
     XYZZ<C> acc = XYZZ<C>::inf();
     if (k0 + r < k1) {
-        XYZZ<C> nxt = coop_load(src[index(k0 + r)]);
+        XYZZ<C> nxt = coop_load(src[(size_t)index(k0 + r) * stride]);
         for (uint32_t k = k0 + r; k < k1; k += CT_ROWS) {
             const XYZZ<C> cur = nxt;
-            if (k + CT_ROWS < k1) nxt = coop_load(src[index(k + CT_ROWS)]);
+            if (k + CT_ROWS < k1) nxt = coop_load(src[(size_t)index(k + CT_ROWS) * stride]);
             acc = xadd(acc, cur);
         }
     }
@@ -201,9 +203,11 @@ uint32_t planes_split(uint32_t T) {
     return n;
 }
 template <class F>
-void planes(const XYZZ<F>* S, const XYZZ<F>* W, XYZZ<F>* Y, XYZZ<F>* parts, uint32_t T, uint32_t nbits, uint32_t nj, hipStream_t st) {
+void planes(const XYZZ<F>* S, uint32_t s_stride, const XYZZ<F>* W, XYZZ<F>* Y, XYZZ<F>* parts, uint32_t T, uint32_t nbits, uint32_t nj,
+            hipStream_t st) {
     const uint32_t nsplit = planes_split(T);
-    ZK_LAUNCH_SYNC(zkdev::k_ct_planes<F>, dim3(nbits + 1, nj, nsplit), dim3(CT_ROWS * COOP_W), 0, st, S, W, nsplit > 1 ? parts : Y, T, nbits);
+    ZK_LAUNCH_SYNC(zkdev::k_ct_planes<F>, dim3(nbits + 1, nj, nsplit), dim3(CT_ROWS * COOP_W), 0, st, S, s_stride, W, nsplit > 1 ? parts : Y, T,
+                   nbits);
     if (nsplit > 1)
         ZK_LAUNCH_SYNC(zkdev::k_ct_fold<F>, dim3((nbits + 1) * nj), dim3(CT_ROWS * COOP_W), 0, st, (const XYZZ<F>*)parts, Y, nsplit);
 }
@@ -217,7 +221,7 @@ void combine(const XYZZ<F>* Y, XYZZ<F>* out, uint32_t nbits, uint32_t log2_2l, u
                            uint32_t, size_t, uint32_t, uint32_t, uint32_t, hipStream_t);                                              \
     template void level1<F>(const XYZZ<F>*, const uint32_t*, const uint32_t*, const uint32_t*, XYZZ<F>*, XYZZ<F>*, uint32_t, uint32_t, \
                             uint32_t, hipStream_t);                                                                                   \
-    template void planes<F>(const XYZZ<F>*, const XYZZ<F>*, XYZZ<F>*, XYZZ<F>*, uint32_t, uint32_t, uint32_t, hipStream_t);                    \
+    template void planes<F>(const XYZZ<F>*, uint32_t, const XYZZ<F>*, XYZZ<F>*, XYZZ<F>*, uint32_t, uint32_t, uint32_t, hipStream_t);                    \
     template void combine<F>(const XYZZ<F>*, XYZZ<F>*, uint32_t, uint32_t, uint32_t, hipStream_t);
 ZK_COOP_TAIL_INSTANTIATE(zkdev::Fq28)
 ZK_COOP_TAIL_INSTANTIATE(zkdev::Fq2x)

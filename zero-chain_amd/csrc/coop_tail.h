@@ -25,12 +25,14 @@ template <class F>
 void level1(const zkdev::XYZZ<F>* tsums, const uint32_t* cnt, const uint32_t* toff, const uint32_t* task_base, zkdev::XYZZ<F>* S,
             zkdev::XYZZ<F>* W, uint32_t nb, uint32_t L, uint32_t nj, hipStream_t st);
 
-// Y[j (nbits + 1) + i] = sum of S over the nodes whose index has bit i set (i < nbits), = sum of W (i = nbits).  A plane of
-// many nodes is summed by planes_split(T) workgroups into `parts` (nj (nbits + 1) planes_split(T) points) and folded.
+// Y[j (nbits + 1) + i] = sum of S over the nodes whose index has bit i set (i < nbits), = sum of W (i = nbits); node t of job
+// j has its S at S[(j T + t) s_stride] (1 after level1() above; L after the one-lane level 1, whose S is the first suffix sum
+// of a node) and its W at W[j T + t].  A plane of many nodes is summed by planes_split(T) workgroups into `parts`
+// (nj (nbits + 1) planes_split(T) points) and folded.
 uint32_t planes_split(uint32_t T);
 template <class F>
-void planes(const zkdev::XYZZ<F>* S, const zkdev::XYZZ<F>* W, zkdev::XYZZ<F>* Y, zkdev::XYZZ<F>* parts, uint32_t T, uint32_t nbits,
-            uint32_t nj, hipStream_t st);
+void planes(const zkdev::XYZZ<F>* S, uint32_t s_stride, const zkdev::XYZZ<F>* W, zkdev::XYZZ<F>* Y, zkdev::XYZZ<F>* parts, uint32_t T,
+            uint32_t nbits, uint32_t nj, hipStream_t st);
 
 // out[j] = 2 L * sum_i 2^i Y_i + Y_nbits   (log2_2l = log2(2 L))
 template <class F>

@@ -133,15 +133,20 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
     // jobs over the same large scalar vector, which are as far from filling the machine per job as a lone job is
     const bool few = nj <= few_jobs_max() || jobs[0].vb_digit != 0;
     const bool coop = few && HasCoopTail<DF>::value && coop_tail_on();
+    // ... merge and level 1 too while the buckets of the set are few enough for rows to be the right grain: a row-addition is
+    // 4 - 5 x shorter than a lane's but a wave holds four rows instead of sixty-four lanes, so a set of 278 528 buckets (the
+    // seventeen digit positions of a 2^20-point variable-base multiexp) keeps the one-lane kernels for these two steps and
+    // goes onto rows where the tree gets narrow (msm_reduce_g1 1.33 ms one-lane, 1.23 all on rows, profiles/r06m_*)
+    const bool coop_l1 = coop && (uint64_t)nj * nb <= 131072;
     // rows per bucket of the cooperative merge: a power of two near a quarter of the average number of partials
     uint32_t coop_rb = 1;
-    if (coop) {
+    if (coop_l1) {
         uint64_t est_tasks = (uint64_t)nj * nb;
         for (size_t k = 0; k < nj; k++) est_tasks += (uint64_t)jobs[k].n * maxd / seg;
         const uint64_t avg = est_tasks / ((uint64_t)nj * nb);
         while (coop_rb < 16 && coop_rb * 4 < avg) coop_rb <<= 1;
     }
-    const uint32_t merge_inline = coop ? 8u * coop_rb : (nj >= 64 || few ? 8u : 2u);
+    const uint32_t merge_inline = coop_l1 ? 8u * coop_rb : (nj >= 64 || few ? 8u : 2u);
     const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;
     ZK_TRY(heavy.ensure(heavy_cap * 4));
     // buckets with 2 .. merge_inline task partials (each holds more than seg pairs): listed for k_msm_merge_light
@@ -165,7 +170,7 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
     const bool big_launch = total >= (min_env ? (uint64_t)atoll(min_env) : 4000000ull);
     // level 1 of the reduction in assembly: many-jobs launches only (the few-jobs tail folds level 1 differently)
     const bool red_asm = asm_reduce<DF>() && big_launch && !few;
-    uint32_t L = coop ? zkcoop::LEVEL1_FAN : pick_fan((uint64_t)nj * nb);
+    uint32_t L = coop_l1 ? zkcoop::LEVEL1_FAN : pick_fan((uint64_t)nj * nb);
     if (red_asm) {
         // buckets per node of the assembly loop (a power of two): 32 - half the nodes for the compiled levels above
         // it, still eight generations of waves per launch (16 / 32 / 64 measured within noise, r04g)
@@ -310,27 +315,15 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
         const uint32_t heavy_blocks = (uint32_t)std::min<size_t>(heavy_cap, few ? 512 : 4096);
         const uint32_t light_buckets = few ? (uint32_t)n_buckets : 0u;
         if constexpr (HasCoopTail<DF>::value) {
-            if (coop) {
-                // the whole tail on rows of 16 lanes: merge, level 1 (S, W per node of L buckets), bit planes over the T
-                // nodes, their weighted sum - four launches, ~55 dependent additions of 2 - 3 us (coop_tail.cpp)
-                uint32_t nbits = 0, log2_2l = 1;
-                while ((1u << nbits) < T) nbits++;
-                while ((1u << (log2_2l - 1)) < L) log2_2l++;
-                DPoint* Sn = R;                        // [nj T]
-                const uint32_t nsplit = zkcoop::planes_split(T);
-                DPoint* parts = red_t.as<DPoint>();    // [nj (nbits + 1) nsplit] when a plane takes several workgroups
-                DPoint* Y = nsplit > 1 ? parts + nj * (size_t)(nbits + 1) * nsplit : parts;   // [nj (nbits + 1)]
-                DPoint* outp = Wb;
+            if (coop_l1) {
+                // merge and level 1 (S, W per node of L buckets) on rows of 16 lanes (coop_tail.cpp)
                 zkcoop::merge<DF>(heavy.as<uint32_t>(), d_nheavy, cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(),
                                   tsums.as<DPoint>(), nb, seg, n_buckets, heavy_blocks, merge_inline, coop_rb, st);
-                zkcoop::level1<DF>(tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(), Sn, Wa, nb, L,
+                zkcoop::level1<DF>(tsums.as<DPoint>(), cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(), R, Wa, nb, L,
                                    (uint32_t)nj, st);
-                zkcoop::planes<DF>(Sn, Wa, Y, parts, T, nbits, (uint32_t)nj, st);
-                zkcoop::combine<DF>(Y, outp, nbits, log2_2l, (uint32_t)nj, st);
-                in = outp;
             }
         }
-        if (!coop) {
+        if (!coop_l1) {
         ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>,
                        dim3(heavy_blocks + (light_buckets + zkdev::MSM_MERGE_THREADS - 1) / zkdev::MSM_MERGE_THREADS),
                        dim3(zkdev::MSM_MERGE_THREADS), 0, st, (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy,
@@ -343,6 +336,7 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
             ZK_LAUNCH_SYNC(zkdev::k_msm_merge_light<DF>, dim3((unsigned)std::min<size_t>((light_cap + 63) / 64, 2048)), dim3(64), 0, st,
                            (const uint32_t*)light.as<uint32_t>(), (const uint32_t*)d_nlight, (const uint32_t*)cnt.as<uint32_t>(),
                            (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg);
+        }
         uint32_t n = T, m = L, stride = L;   // n nodes per job of m buckets each; S(node k) = R[k * stride]
         DPoint* Rcur = R;
         DPoint* Rnext = R + nj * (size_t)nb;       // upper levels ping-pong between two areas behind level 1
@@ -375,14 +369,29 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
             stride = fan;
             m *= fan;
             n = n_out;
-        } else {
+        } else if (!coop_l1) {
             // level 1: R = suffix sums over the buckets of a node; S = R_0; W = 2 * sum_{k>=1} R_k + R_0
             ZK_LAUNCH(zkdev::k_msm_suffix_buckets<DF>, grid(T), dim3(64), 0, st, tsums.as<DPoint>(), cnt.as<uint32_t>(),
                       toff.as<uint32_t>(), tbase.as<uint32_t>(), R, nb, L, few ? 0u : 1u /* merged by now */, seg);
             ZK_LAUNCH(zkdev::k_msm_segsum<DF>, grid(T), dim3(64), 0, st, (const DPoint*)R, (const DPoint*)nullptr, Wa, nb, L,
                       1u, 1u, 1u);
         }
-        if (few && T >= 2 && !getenv("ZKAMD_NO_BITSUM")) {
+        if (coop) {
+            if constexpr (HasCoopTail<DF>::value) {
+                // the T nodes of level 1 (S at R[t * s_stride], W compact) folded at once on rows of 16 lanes: bit planes, then
+                // their weighted sum - chains of ~15 and ~20 dependent additions of 2 - 4 us (coop_tail.cpp)
+                uint32_t nbits = 0, log2_2l = 1;
+                while ((1u << nbits) < T) nbits++;
+                while ((1u << (log2_2l - 1)) < L) log2_2l++;
+                const uint32_t nsplit = zkcoop::planes_split(T);
+                DPoint* parts = red_t.as<DPoint>();    // [nj (nbits + 1) nsplit] when a plane takes several workgroups
+                DPoint* Y = nsplit > 1 ? parts + nj * (size_t)(nbits + 1) * nsplit : parts;   // [nj (nbits + 1)]
+                zkcoop::planes<DF>(R, coop_l1 ? 1u : L, Wa, Y, parts, T, nbits, (uint32_t)nj, st);
+                zkcoop::combine<DF>(Y, Wb, nbits, log2_2l, (uint32_t)nj, st);
+                in = Wb;
+                n = 1;
+            }
+        } else if (few && T >= 2 && !getenv("ZKAMD_NO_BITSUM")) {
             // few large jobs: fold the T nodes of level 1 at once (msm.h, k_msm_bitsum)
             uint32_t nbits = 0, log2_2l = 1;
             while ((1u << nbits) < T) nbits++;
@@ -420,7 +429,6 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
             m *= fan;
             n = n_out;
         }
-        }   // (!coop)
     }
     res_dev = in;   // one XYZZ per job, valid until the next enqueue on this group
     if (!to_host) {
