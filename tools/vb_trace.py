@@ -13,7 +13,7 @@ if sys.argv[1] == "read":
         if e[0] - max(x[1] for x in cur) > 300_000: calls.append(cur); cur = [e]
         else: cur.append(e)
     calls.append(cur)
-    c = calls[-1]; t0 = c[0][0]
+    c = [x for x in calls if any('k_msm_accumulate' in e[2] for e in x)][-1]; t0 = c[0][0]   # (the last groups of a run are the wipes of the handle's buffers)
     print("%d launches, %.3f ms" % (len(c), (max(x[1] for x in c) - t0) / 1e6))
     import collections
     agg = collections.OrderedDict()
@@ -30,12 +30,13 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 from oracle import bls12_381 as bls, cport
 lib = zk.load_library()
-n = 1 << 20
-if len(sys.argv) > 2: os.environ["ZKAMD_MSM_SEG"] = sys.argv[2]
-bases = cport.fixed_base_mul(1, bench.fields_to_u8(bench.splitmix_fields(1, n, bls.R_MOD)).tobytes(), min(64, bench.usable_cores()))
+group = 2 if "g2" in sys.argv else 1   # `run g2`: the 2^17-point G2 multiexp of micro.msm_g2_2p17 instead
+n = 1 << (17 if group == 2 else 20)
+if len(sys.argv) > 2 and sys.argv[2].isdigit(): os.environ["ZKAMD_MSM_SEG"] = sys.argv[2]
+bases = cport.fixed_base_mul(group, bench.fields_to_u8(bench.splitmix_fields(1, n, bls.R_MOD)).tobytes(), min(64, bench.usable_cores()))
 sc = bench.fields_to_u8(bench.splitmix_fields(2, n, bls.R_MOD))
 d_sc = torch.from_numpy(sc.copy()).to("cuda:0")
-ctx = zk.MultiexpContext(1, bases, window_bits=0, lib=lib, variable_base=True)
+ctx = zk.MultiexpContext(group, bases, window_bits=0, lib=lib, variable_base=True)
 for _ in range(3):
     ctx.run_dev(d_sc.data_ptr()); time.sleep(0.01)
 t0 = time.perf_counter(); ctx.run_dev(d_sc.data_ptr()); print("run %.3f ms" % ((time.perf_counter() - t0) * 1e3))

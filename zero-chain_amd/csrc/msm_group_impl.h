@@ -145,6 +145,10 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
         for (size_t k = 0; k < nj; k++) est_tasks += (uint64_t)jobs[k].n * maxd / seg;
         const uint64_t avg = est_tasks / ((uint64_t)nj * nb);
         while (coop_rb < 16 && coop_rb * 4 < avg) coop_rb <<= 1;
+        // ... as long as the rows of the launch stay within ~2 waves per SIMD: beyond that the rows wait for each other's issue
+        // slots and one row per bucket is the faster merge (the 2^17-point G2 multiexp, 19 456 buckets of ~8 partials: 1.47 ms
+        // with four rows per bucket, profiles/r06o_vb_g2_launch_list.txt)
+        while (coop_rb > 1 && (uint64_t)nj * nb * coop_rb > 16384) coop_rb >>= 1;
     }
     const uint32_t merge_inline = coop_l1 ? 8u * coop_rb : (nj >= 64 || few ? 8u : 2u);
     const size_t heavy_cap = (size_t)(total / ((size_t)seg * merge_inline)) + 1;

@@ -1110,7 +1110,12 @@ zk_status transfer_witness(const zk_transfer_statement* st, size_t n, uint32_t f
     return witness_batch<zkwit::Statement>(
         n, ZK_TRANSFER_N_INPUTS, ZK_TRANSFER_N_AUX, flags, out,
         [&](size_t i, zkwit::Statement* s) { return transfer_decode(st[i], index_base + i, s); },
-        [](const zkwit::Statement& s, zkwit::Wit& w) { zkwit::synthesize(s, w); });
+        [n](const zkwit::Statement& s, zkwit::Wit& w) {
+            // fewer statements than a fifth of the host threads: each statement's five 252-bit multiplications side by side
+            // (transfer_witness.h synthesize_parallel) - one transaction 1.2 -> 0.35 ms; a batch keeps one thread per statement
+            if (n * 5 <= (size_t)host_threads(64, 64)) zkwit::synthesize_parallel(s, w);
+            else zkwit::synthesize(s, w);
+        });
 }
 
 // Which engine computes the variable assignment of n statements.  ZKAMD_WITNESS = host | gpu forces one.  Default: the GPU
