@@ -17,7 +17,8 @@ if "--trace" in sys.argv:
         else:
             cur.append(e)
     calls.append(cur)
-    lone = [c for c in calls if 60 <= len(c) <= 400 and (max(x[1] for x in c) - c[0][0]) < 20_000_000]
+    # (a call = a launch group with a bucket accumulation in it: the last groups of a run are the wipes of the freed workspaces)
+    lone = [c for c in calls if 50 <= len(c) <= 400 and (max(x[1] for x in c) - c[0][0]) < 20_000_000 and any("k_msm_accumulate" in x[2] for x in c)]
     print("%d launch groups, %d that look like one proof" % (len(calls), len(lone)))
     if "--list" in sys.argv:   # the launches of the last call: start offset, duration, kernel
         c = lone[-1]

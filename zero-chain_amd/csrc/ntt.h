@@ -25,7 +25,8 @@ constexpr int NTT_TILE_LOG = 10;   // 2^10 elements = 32 KiB of LDS per workgrou
 constexpr int NTT_THREADS = 256;
 // Large transforms (k >= NTT_BIG_LOG): 2^12-element tiles (128 KiB of LDS, one workgroup of 1024 threads = 4 waves
 // per SIMD on a CU) hold 10 stages, so 2^20 takes 2 passes instead of 3 (0.327 -> 0.315 ms per pair).
-// ZKAMD_NTT_SMALL_TILES keeps the small tiles at every size (A/B).  Also measured and dropped: per-stage twiddle
+// (ZKAMD_NTT_TILES = mid | big | small selects the tile form of these sizes: zkamd.cpp NttPlan::tile_form; round 6 made the
+// 2^11-element "mid" tiles - two workgroups per CU - the default.)  Also measured and dropped: per-stage twiddle
 // tables laid out so that lanes of consecutive columns read consecutive entries (twice the table memory; 0.327 ms
 // and 21.1 ms per chunk, i.e. no change: the strided twiddle gathers are not what the kernel waits for).
 constexpr int NTT_BIG_LOG = 17, NTT_BIG_MAX_G = 10, NTT_BIG_TILE_LOG = 12, NTT_BIG_THREADS = 1024;

@@ -69,22 +69,62 @@ struct NttPlan {
     DevBuf scratch;                  // permutation scratch for the stand-alone entry
     size_t bytes = 0;
 
-    static bool big(uint32_t k) {
-        static const bool off = getenv("ZKAMD_NTT_SMALL_TILES") != nullptr;
-        return !off && k >= (uint32_t)zkdev::NTT_BIG_LOG;
+    // Tile form of the transforms of 2^17 and more (ZKAMD_NTT_TILES = mid | big | small; A/B):
+    //   mid (default, round 6)   2^11-element tiles (64 KiB of LDS, 512 threads), two workgroups per CU; the pass whose tile is
+    //                            contiguous takes 11 stages, the strided ones up to 9 (four columns = 128-byte segments): 2^20 in
+    //                            two passes.  Pair of transforms, ms: 2^17 0.228 -> 0.140, 2^18 0.245 -> 0.155, 2^20 0.288 -> 0.279,
+    //                            2^22 1.349 -> 1.166 against `big` (profiles/r06q_ntt_tiles.txt; VERDICT r5 item 4 asked <= 0.27)
+    //   big (rounds 2-5)         2^12-element tiles (128 KiB, 1024 threads), one workgroup per CU, 10 stages per pass
+    //   small                    the 2^10-element tiles of the in-step transforms at every size
+    static int tile_form() {
+        static const int f = [] {
+            const char* e = getenv("ZKAMD_NTT_TILES");
+            return !e ? 1 : !strcmp(e, "big") ? 2 : !strcmp(e, "small") ? 0 : 1;
+        }();
+        return f;
     }
-    static std::vector<NttPass> passes(uint32_t k, bool dif, uint32_t stride) {
+    static bool big(uint32_t k) { return tile_form() == 2 && k >= (uint32_t)zkdev::NTT_BIG_LOG; }
+    static bool mid(uint32_t k) { return tile_form() == 1 && k >= (uint32_t)zkdev::NTT_BIG_LOG; }
+    static uint32_t threads_for(uint32_t k) { return mid(k) ? 512u : big(k) ? (uint32_t)zkdev::NTT_BIG_THREADS : (uint32_t)zkdev::NTT_THREADS; }
+    // A handful of small transforms (the H pipeline of a proof made alone: 2^15 elements, 32 workgroups of 2^10-element tiles,
+    // every thread four butterflies per stage one after the other - 25 us per pass on a machine that is otherwise idle):
+    // the latency form cuts the tiles to 2^8 elements, one butterfly per thread and stage, four times the workgroups
+    // (~10 us per pass; the 32-byte segments of its strided pass come out of L2).  Chosen per chain by the batch's size.
+    static bool latency_form(uint32_t k, uint32_t batch) { return k >= 9 && k < (uint32_t)zkdev::NTT_BIG_LOG && ((uint64_t)batch << k) <= (1u << 17); }
+    static std::vector<NttPass> passes(uint32_t k, bool dif, uint32_t stride, bool latency = false) {
         std::vector<NttPass> out;
         if (k == 0) return out;
-        const uint32_t max_g = big(k) ? zkdev::NTT_BIG_MAX_G : zkdev::NTT_MAX_G;
-        const uint32_t tile_log = big(k) ? zkdev::NTT_BIG_TILE_LOG : zkdev::NTT_TILE_LOG;
-        uint32_t np = (k + max_g - 1) / max_g;
-        uint32_t base = k / np, extra = k % np, t0 = 0;
-        for (uint32_t i = 0; i < np; i++) {
+        std::vector<uint32_t> gs;   // stages per pass, in the order of the global stages t0 = 0, g0, g0 + g1 ...
+        uint32_t tile_log;
+        if (latency) {
+            tile_log = 8;
+            const uint32_t np = (k + 7) / 8;
+            for (uint32_t i = 0; i < np; i++) gs.push_back(k / np + (i < k % np ? 1 : 0));
+        } else if (mid(k)) {
+            tile_log = 11;
+            const uint32_t g0 = 11, rest = k - g0, np = (rest + 8) / 9;
+            std::vector<uint32_t> strided;
+            for (uint32_t i = 0; i < np; i++) strided.push_back(rest / np + (i < rest % np ? 1 : 0));
+            // DIF: stage t0 = 0 has the LARGEST distance, the contiguous pass comes last; DIT: first
+            if (dif) {
+                gs = strided;
+                gs.push_back(g0);
+            } else {
+                gs.push_back(g0);
+                gs.insert(gs.end(), strided.begin(), strided.end());
+            }
+        } else {
+            const uint32_t max_g = big(k) ? zkdev::NTT_BIG_MAX_G : zkdev::NTT_MAX_G;
+            tile_log = big(k) ? zkdev::NTT_BIG_TILE_LOG : zkdev::NTT_TILE_LOG;
+            const uint32_t np = (k + max_g - 1) / max_g;
+            for (uint32_t i = 0; i < np; i++) gs.push_back(k / np + (i < k % np ? 1 : 0));
+        }
+        uint32_t t0 = 0;
+        for (uint32_t g : gs) {
             NttPass p;
             p.log_n = k;
             p.t0 = t0;
-            p.g = base + (i < extra ? 1 : 0);
+            p.g = g;
             uint32_t lcw = tile_log - p.g;
             if (lcw > k - p.g) lcw = k - p.g;
             p.log_cw = lcw;
@@ -157,7 +197,8 @@ struct NttPlan {
                     const uint32_t* pre, const uint32_t* post, const uint32_t* src = nullptr,
                     uint32_t src_stride = 0, uint32_t src_valid = 0, uint32_t* bad = nullptr,
                     const uint32_t* sub = nullptr, uint32_t sub_stride = 0) {
-        std::vector<NttPass> ps = passes(log_n, dif, stride);
+        const bool latency = latency_form(log_n, batch);
+        std::vector<NttPass> ps = passes(log_n, dif, stride, latency);
         const uint32_t* tw = inverse ? tw_inv.as<uint32_t>() : tw_fwd.as<uint32_t>();
         for (size_t i = 0; i < ps.size(); i++) {
             NttPass p = ps[i];
@@ -184,7 +225,7 @@ struct NttPlan {
                 }
             }
 #endif
-            ZK_LAUNCH_SYNC(zkdev::k_ntt_pass, grid, dim3(big(log_n) ? zkdev::NTT_BIG_THREADS : zkdev::NTT_THREADS), shmem, g_stream, data, s, tw,
+            ZK_LAUNCH_SYNC(zkdev::k_ntt_pass, grid, dim3(latency ? (1u << (p.g + p.log_cw - 1)) : threads_for(log_n)), shmem, g_stream, data, s, tw,
                            i == 0 ? pre : (const uint32_t*)nullptr,
                            i + 1 == ps.size() ? post : (const uint32_t*)nullptr, p, i == 0 && s ? bad : (uint32_t*)nullptr,
                            i + 1 == ps.size() ? sub : (const uint32_t*)nullptr, sub_stride);
