@@ -75,5 +75,5 @@ bool lib_witness_on_host(size_t n);   // a handful of statements: the assignment
 int lib_params_device(const zk_params* P);
 size_t lib_params_domain(const zk_params* P);
 zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,
-                       bool own_proofs, int form = VERIFY_AUTO);
+                       bool own_proofs, int form = VERIFY_AUTO, const uint8_t* own_affine = nullptr);
 }

@@ -217,6 +217,18 @@ inline void load_scalar_le(const uint8_t* b, uint64_t out[4]) {
     }
 }
 
+// gen_proof's self-check verifies the proofs this library made a moment ago: the prover hands their AFFINE coordinates over
+// (A.x A.y | B.x.c0 B.x.c1 B.y.c0 B.y.c1 | C.x C.y: 96 words = 384 bytes per proof, the host's Montgomery layout, which is
+// the verifier kernels' own) and the check skips the two decoders - 1.7 ms of square roots at the head of a 6.9 ms
+// verification (profiles/r06s_verify_one_launch_list.txt).  prove_chunk (zkamd.cpp) fills what this points at, if anything.
+// A cursor: every chunk the prover finishes on this thread appends its proofs' coordinates and advances it.
+constexpr size_t OWN_AFFINE_BYTES = 384;
+inline thread_local uint8_t* g_own_affine_sink = nullptr;
+struct OwnAffineSink {   // set for the duration of a gen_proof call, cleared on every way out
+    explicit OwnAffineSink(uint8_t* p) { g_own_affine_sink = p; }
+    ~OwnAffineSink() { g_own_affine_sink = nullptr; }
+};
+
 enum VerifyForm { VERIFY_PER_PROOF = 0, VERIFY_COMBINED = 1, VERIFY_AUTO = 2 };   // verify.cpp verify_batch (declared in handles.h)
 
 // Test hooks (fault injection) and debug prints are compiled in only under -DZK_TEST_HOOKS: the emulation build and

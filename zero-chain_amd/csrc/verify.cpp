@@ -395,14 +395,30 @@ bool parse_g2_compressed(const uint8_t* b, uint32_t* x, uint32_t* flags) {
 // own_proofs: A, B, C were computed by this library's prover a moment ago (the self-check of gen_proof): group elements
 // by construction, as the in-memory Proof the reference hands to verify_proof in check_proof (confidential.rs:208-278,
 // no deserialisation there) - the decoders then skip the r-torsion test, which only a foreign byte string needs.
-zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t* inputs, uint8_t* ok_out, bool own_proofs) {
+// own_affine (with own_proofs): the affine coordinates of A, B, C as the prover had them (host_common.h OWN_AFFINE_BYTES per
+// proof) - uploaded where the decoders would have left them, the decoders skipped.
+zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t* inputs, uint8_t* ok_out, bool own_proofs,
+                       const uint8_t* own_affine = nullptr) {
     const uint32_t ni = V->n_ic - 1;
+    if (!own_proofs) own_affine = nullptr;
     std::vector<uint32_t> g1((size_t)2 * n * 12), g2((size_t)n * 24), f1(2 * n), f2(n), bad(n, 0), sc((size_t)n * ni * 8);
     static const uint64_t RMOD[4] = ZK_FR_P_64;
     for (size_t i = 0; i < n; i++) {
         const uint8_t* p = proofs + i * 192;
-        bool good = parse_g1_compressed(p, &g1[i * 12], &f1[i]) && parse_g2_compressed(p + 48, &g2[i * 24], &f2[i]) &&
-                    parse_g1_compressed(p + 144, &g1[(n + i) * 12], &f1[n + i]);
+        bool good;
+        if (own_affine) {
+            // a point at infinity in A, B or C is what Proof::read refuses (x = y = 0 stands for it in the host's affine form)
+            const uint8_t* a = own_affine + i * OWN_AFFINE_BYTES;
+            auto zero = [](const uint8_t* q, size_t len) {
+                for (size_t k = 0; k < len; k++)
+                    if (q[k]) return false;
+                return true;
+            };
+            good = !zero(a, 96) && !zero(a + 96, 192) && !zero(a + 288, 96);
+        } else {
+            good = parse_g1_compressed(p, &g1[i * 12], &f1[i]) && parse_g2_compressed(p + 48, &g2[i * 24], &f2[i]) &&
+                   parse_g1_compressed(p + 144, &g1[(n + i) * 12], &f1[n + i]);
+        }
         for (uint32_t j = 0; j < ni && good; j++) {
             const uint8_t* s = inputs + (i * ni + j) * 32;
             uint64_t v[4];
@@ -438,6 +454,23 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     ZK_TRY(V->aff_g2.ensure(n * 192));
     ZK_TRY(V->st_g1.ensure(2 * n * 4));
     ZK_TRY(V->st_g2.ensure(n * 4));
+    if (own_affine) {
+        // [A | C] and B where the decoders write them, "decoded" in every state word
+        std::vector<uint8_t> a1((size_t)2 * n * 96), a2(n * 192);
+        for (size_t i = 0; i < n; i++) {
+            const uint8_t* a = own_affine + i * OWN_AFFINE_BYTES;
+            memcpy(&a1[i * 96], a, 96);
+            memcpy(&a1[(n + i) * 96], a + 288, 96);
+            memcpy(&a2[i * 192], a + 96, 192);
+        }
+        ZK_TRY(upload(V->in_g1, a1.data(), a1.size()));   // (staged through the buffers the encodings would have used)
+        ZK_TRY(upload(V->in_g2, a2.data(), a2.size()));
+        HIP_TRY(hipMemcpyAsync(V->aff_g1.p, V->in_g1.p, a1.size(), hipMemcpyDeviceToDevice, g_stream));
+        HIP_TRY(hipMemcpyAsync(V->aff_g2.p, V->in_g2.p, a2.size(), hipMemcpyDeviceToDevice, g_stream));
+        HIP_TRY(hipMemsetAsync(V->st_g1.p, 0, 2 * n * 4, g_stream));
+        HIP_TRY(hipMemsetAsync(V->st_g2.p, 0, n * 4, g_stream));
+        HIP_TRY(hipStreamSynchronize(g_stream));   // (a1 / a2 are about to go out of scope: pageable sources of asynchronous copies)
+    }
     ZK_TRY(V->part.ensure((size_t)n * (ni ? 4 * ni : 1) * sizeof(DG1)));
     ZK_TRY(V->acc.ensure(n * 96));
     ZK_TRY(V->acc_inf.ensure(n * 4));
@@ -462,6 +495,7 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
         // the lane-parallel Miller loop reads the lines of B prepared, and the preparation's last point settles B's r-torsion
         // test (k_g2_prepare): the decoder leaves it out there
         ProfScope ps("verify_decode");
+        if (!own_affine)
         ZK_LAUNCH(zkdev::k_decode_g2, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->in_g2.as<uint32_t>(),
                   (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n,
                   (own_proofs || wide) ? 0u : 1u);
@@ -475,6 +509,7 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     }
     {
         ProfScope ps("verify_decode_g1", g_stream2);
+        if (!own_affine)
         ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, g_stream2,
                   (const uint32_t*)V->in_g1.as<uint32_t>(), (const uint32_t*)V->fl_g1.as<uint32_t>(), V->aff_g1.as<uint32_t>(),
                   V->st_g1.as<uint32_t>(), (uint32_t)(2 * n), own_proofs ? 0u : 1u);
@@ -804,7 +839,7 @@ namespace zkrt {
 // 13.1, 8192: 22.5 / 16.0 (profiles/r05final_verify_probe.txt) - the two meet near 4000.
 constexpr size_t VERIFY_RLC_AUTO_MIN = 4096;
 zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs, uint8_t* ok_out,
-                       bool own_proofs, int form) {
+                       bool own_proofs, int form, const uint8_t* own_affine) {
     static const size_t auto_min = getenv("ZKAMD_VERIFY_RLC_MIN") ? (size_t)atoll(getenv("ZKAMD_VERIFY_RLC_MIN")) : VERIFY_RLC_AUTO_MIN;
     if (!vk || (n && (!proofs || !ok_out)) || (n && n_inputs && !public_inputs)) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
     // verifier.rs:38-40
@@ -821,7 +856,8 @@ zk_status verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t
                 continue;
             }
         }
-        ZK_TRY(verify_chunk(vk, np, proofs + first * 192, public_inputs + first * n_inputs * 32, ok_out + first, own_proofs));
+        ZK_TRY(verify_chunk(vk, np, proofs + first * 192, public_inputs + first * n_inputs * 32, ok_out + first, own_proofs,
+                            own_affine ? own_affine + first * OWN_AFFINE_BYTES : nullptr));
     }
     return ZK_OK;
 }
@@ -879,11 +915,11 @@ void zk_vk_free(zk_vk* vk) { delete vk; }
 
 zk_status zk_verify_batch(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
                           uint8_t* ok_out) try {
-    return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false, zkrt::VERIFY_AUTO);
+    return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false, zkrt::VERIFY_AUTO, nullptr);
 } ZK_ABI_CATCH
 zk_status zk_verify_batch_rlc(zk_vk* vk, size_t n, const uint8_t* proofs, const uint8_t* public_inputs, size_t n_inputs,
                               uint8_t* ok_out) try {
-    return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false, zkrt::VERIFY_COMBINED);
+    return zkrt::verify_batch(vk, n, proofs, public_inputs, n_inputs, ok_out, false, zkrt::VERIFY_COMBINED, nullptr);
 } ZK_ABI_CATCH
 zk_status zk_proof_read_batch(zk_vk* vk, size_t n, const uint8_t* proofs, uint8_t* status_out) try {
     if (!vk || (n && (!proofs || !status_out))) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");

@@ -340,6 +340,9 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
     const size_t chunk = lib_batch_chunk(), nv = ZK_TRANSFER_N_INPUTS + ZK_TRANSFER_N_AUX, n_pub = ZK_TRANSFER_N_INPUTS - 1;
     PinBuf pin_in;
     std::vector<uint8_t> inputs(n * n_pub * 32), host_w;
+    // the prover leaves the affine A, B, C of every proof here for the self-check below (host_common.h g_own_affine_sink)
+    std::vector<uint8_t> own_aff(n * OWN_AFFINE_BYTES);
+    OwnAffineSink sink(own_aff.data());
     WipeOnExit wipe_w{nullptr, 0};   // (the assignment holds the bits of the keys)
     int slot = 0;
     if (host_wit) {
@@ -403,7 +406,7 @@ zk_status zk_transfer_gen_proof_batch(zk_params* p, zk_r1cs* circuit, zk_vk* vk,
     // registers): chunk 0's check was still running 335 ms later and the call waited 40 ms for it
     // (profiles/r03_experiments.txt r03q).
     if (timing) fprintf(stderr, "[gen_proof] packed %.1f ms\n", since());
-    ZK_TRY(verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data(), true));
+    ZK_TRY(verify_batch(vk, n, proofs.data(), inputs.data(), n_pub, ok.data(), true, VERIFY_AUTO, own_aff.data()));
     if (timing) fprintf(stderr, "[gen_proof] done %.1f ms\n", since());
     for (size_t i = 0; i < n; i++)
         if (!ok[i]) return fail(ZK_ERR_UNSATISFIABLE, "request " + std::to_string(i) + ": the proof does not verify (inconsistent statement)");

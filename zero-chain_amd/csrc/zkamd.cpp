@@ -798,17 +798,30 @@ zk_status prove_chunk(zk_params* P, size_t np, const zk_batch_dev* bt, size_t fi
     const auto t_enc = std::chrono::steady_clock::now();
     // ---- encoding (host, one thread per slice of the chunk): pin_g1[p] = C, pin_g1[np + p] = A, pin_g2[p] = B
     const unsigned nthreads = host_threads(np, 32);
+    uint8_t* const own_affine = g_own_affine_sink;   // (read on the calling thread: the workers below are other threads)
     auto work = [&](size_t lo, size_t hi) {
         for (size_t p = lo; p < hi; p++)
         {
             uint8_t* out = proofs_out + (first + p) * 192;
-            zkhost::g1_to_compressed(zkhost::to_affine(P->pin_g1.as<HG1>()[np + p]), out);
-            zkhost::g2_to_compressed(zkhost::to_affine(P->pin_g2.as<HG2>()[p]), out + 48);
-            zkhost::g1_to_compressed(zkhost::to_affine(P->pin_g1.as<HG1>()[p]), out + 144);
+            const HG1A pa = zkhost::to_affine(P->pin_g1.as<HG1>()[np + p]), pc = zkhost::to_affine(P->pin_g1.as<HG1>()[p]);
+            const HG2A pb = zkhost::to_affine(P->pin_g2.as<HG2>()[p]);
+            zkhost::g1_to_compressed(pa, out);
+            zkhost::g2_to_compressed(pb, out + 48);
+            zkhost::g1_to_compressed(pc, out + 144);
+            if (own_affine) {   // for the self-check of gen_proof (host_common.h g_own_affine_sink)
+                uint8_t* o = own_affine + p * OWN_AFFINE_BYTES;   // (a cursor: the chunks of a call arrive in order)
+                memcpy(o, &pa.x, 48);
+                memcpy(o + 48, &pa.y, 48);
+                memcpy(o + 96, &pb.x, 96);
+                memcpy(o + 192, &pb.y, 96);
+                memcpy(o + 288, &pc.x, 48);
+                memcpy(o + 336, &pc.y, 48);
+            }
         }
     };
     auto part = [&](unsigned t) { work(np * t / nthreads, np * (t + 1) / nthreads); };
     run_threads(nthreads, part);
+    if (g_own_affine_sink) g_own_affine_sink += np * OWN_AFFINE_BYTES;
     if (trace_host) {
         const auto t_end = std::chrono::steady_clock::now();
         fprintf(stderr, "[zkamd] chunk of %zu: enqueue %.2f ms, wait for the GPU %.2f ms, host encoding %.2f ms\n", np,
