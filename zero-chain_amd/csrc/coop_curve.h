@@ -105,6 +105,46 @@ ZK_DI XYZZ<CFq> xadd(const XYZZ<CFq>& a, const XYZZ<CFq>& b) {
     return XYZZ<CFq>{x3, g4[0], zz3, g4[1]};
 }
 
+// acc + p, p affine and not infinity (EFD madd-2008-s), all special cases handled
+ZK_DI void madd(XYZZ<CFq>& acc, const Affine<CFq>& p) {
+    constexpr int MO = CFq::MO, BX = XYZZ<CFq>::BX, BY = XYZZ<CFq>::BY;
+    if (acc.is_inf()) {
+        acc = XYZZ<CFq>{p.x, p.y, CFq::one(), CFq::one()};
+        return;
+    }
+    CFq g1[2], g2[2], g3[3], g4[2];
+    {   // u2 = x2 zz1, s2 = y2 zzz1
+        const CLanes x[2][1] = {{p.x.l}, {p.y.l}}, y[2][1] = {{acc.zz.l}, {acc.zzz.l}};
+        coop_products<2, 1>(x, y, g1);
+    }
+    const CFq pp_ = sub_b<BX>(g1[0], acc.x);   // < MO + BX + 1
+    const CFq r = sub_b<BY>(g1[1], acc.y);     // < MO + BY + 1
+    {   // pp = p^2, r^2
+        const CLanes x[2][1] = {{pp_.l}, {r.l}}, y[2][1] = {{pp_.l}, {r.l}};
+        coop_products<2, 1>(x, y, g2);
+    }
+    const CFq pp = g2[0];
+    {   // ppp = p pp, q = x1 pp, zz3 = zz1 pp
+        const CLanes x[3][1] = {{pp_.l}, {acc.x.l}, {acc.zz.l}}, y[3][1] = {{pp.l}, {pp.l}, {pp.l}};
+        coop_products<3, 1>(x, y, g3);
+    }
+    const CFq ppp = g3[0], q = g3[1], zz3 = g3[2];
+    if (zz3.is_zero_norm()) {
+        // p.x == acc.x: the same point (double it) or its negative (infinity)
+        if (is_zero_full(r)) acc = xdbl(XYZZ<CFq>{p.x, p.y, CFq::one(), CFq::one()});
+        else acc = XYZZ<CFq>::inf();
+        return;
+    }
+    const CFq x3 = sub_sub2<MO, MO>(g2[1], ppp, q);
+    const CFq t = sub_raw<BX>(q, x3);
+    {   // y3 = r t - y1 ppp (one reduction), zzz3 = zzz1 ppp
+        const CFq ny = neg_raw<BY>(acc.y);
+        const CLanes x[2][2] = {{t.l, ny.l}, {acc.zzz.l, acc.zzz.l}}, y[2][2] = {{r.l, ppp.l}, {ppp.l, ppp.l}};
+        coop_products<2, 2, 0b0111>(x, y, g4);
+    }
+    acc = XYZZ<CFq>{x3, g4[0], zz3, g4[1]};
+}
+
 // ============================================================================================= G2: CFq2
 ZK_DI XYZZ<CFq2> xdbl(const XYZZ<CFq2>& a) {
     constexpr int MO = CFq2::MO, BX = XYZZ<CFq2>::BX, BY = XYZZ<CFq2>::BY;
@@ -191,6 +231,56 @@ ZK_DI XYZZ<CFq2> xadd(const XYZZ<CFq2>& a, const XYZZ<CFq2>& b) {
     }
     const CFq2 y3 = sub_b<MO>(CFq2{g4[0], g4[1]}, CFq2{g4[2], g4[3]});
     return XYZZ<CFq2>{x3, y3, zz3, CFq2{g4[4], g4[5]}};
+}
+
+// ---- the host's Montgomery words (12 x 32 bits, radix 2^384: fq.rs:700-701) <-> a row
+ZK_DI CFq coop_import(const uint32_t* h) {
+    CFq t;
+#ifndef ZK_EMU
+    const uint32_t j = coop_lane(), bit = 28u * (j < 14 ? j : 0u), q = bit >> 5, sh = bit & 31u;
+    const uint64_t two = (uint64_t)h[q] | ((uint64_t)(q + 1 < 12 ? h[q + 1] : 0u) << 32);
+    t.l.v[0] = j < 14 ? (uint32_t)(two >> sh) & FQ28_MASK : 0u;
+#else
+    for (int j = 0; j < 16; j++) {
+        const uint32_t bit = 28u * j, q = bit >> 5, sh = bit & 31u;
+        const uint64_t two = j < 14 ? ((uint64_t)h[q] | ((uint64_t)(q + 1 < 12 ? h[q + 1] : 0u) << 32)) : 0;
+        t.l.v[j] = (uint32_t)(two >> sh) & FQ28_MASK;
+    }
+#endif
+    return mul(t, CFq::from_const(Fq28Consts::KIN));
+}
+// canonical words of the row's element, written by lane 0 (every lane computes them: the row's value is gathered)
+ZK_DI void coop_export(const CFq& a, uint32_t* h) {
+    const Fq28 t = coop_gather(coop_exact(mul(a, CFq::from_const(Fq28Consts::KOUT))));
+    uint32_t w[12];
+    fq28_export_tail(t, w);
+#ifndef ZK_EMU
+    if (coop_lane() == 0)
+#endif
+    {
+#pragma unroll
+        for (int i = 0; i < 12; i++) h[i] = w[i];
+    }
+}
+// a^(q - 2): 380 squarings and ~190 products in a row - 0.19 ms for a lone row, where the one-lane Euclidean inversion
+// (divergent word loops) takes ~0.3 ms
+ZK_DI CFq inv(const CFq& a) {
+    const uint32_t e[12] = ZK_FQ_EXP_QM2_32;
+    CFq r = a;
+    bool started = false;
+#pragma unroll 1
+    for (int i = 11; i >= 0; i--) {
+        const uint32_t w = e[i];
+#pragma unroll 1
+        for (int b = 31; b >= 0; b--) {
+            if (started) r = mul(r, r);
+            if ((w >> b) & 1u) {
+                if (started) r = mul(r, a);
+                started = true;
+            }
+        }
+    }
+    return r;
 }
 
 }  // namespace zkdev

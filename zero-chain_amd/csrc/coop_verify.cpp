@@ -1,0 +1,325 @@
+// The head of a verification on the wave-cooperative field (round 6): the public-input accumulator and the line
+// preparation of B for a HANDFUL of proofs - the check_proof of a lone gen_proof, zk_verify_proof, a small zk_verify_batch.
+//
+// A verification is decode -> [inputs | lines of B] -> Miller loops -> final exponentiation, every stage a bundle of serial
+// chains; for one proof the one-lane kernels take 0.71 + 0.59 ms for the accumulator (22 x 4 chains of ~32 mixed additions,
+// a tree, an inversion) and 1.59 ms for the 68 line-coefficient triples (63 doubling and 5 addition steps of Fq2 arithmetic,
+// three lanes per point) - profiles/r06s_verify_one_launch_list.txt.  Here an Fq / Fq2 value is a ROW (coop_field.h), a
+// mixed addition 2.7 us instead of 17, a doubling step of the line preparation four product groups deep.  The results are
+// the one-lane kernels' to the bit (canonical words out of the same group elements / field elements): the accumulator in
+// V->acc, the coefficient tables in V->prep_b, consumed by the unchanged Miller loop.  Rows are the wrong grain for a
+// thousand proofs (18 k rows would be work-bound): verify.cpp takes this path up to COOP_VERIFY_MAX proofs.
+//
+// Reference: core/bellman-verifier/src/verifier.rs:32-63 (the accumulator), core/pairing/src/bls12_381/mod.rs:335-359,
+// :98-160 (G2Prepared::from_affine: the doubling / addition steps and their coefficient scaling), ec.rs:296-526.
+#include "gpu_rt.h"
+#include "coop_curve.h"
+#include "coop_verify.h"
+
+namespace zkdev {
+
+// (the loop constants of pairing.h, restated here so that this unit does not compile the pairing kernels; verify.cpp asserts
+//  that they are the same)
+constexpr int PAIRING_NCOEF = zkcoop::VERIFY_NCOEF;
+constexpr uint64_t PAIRING_LOOP = ZK_BLS_X_ABS >> 1;
+constexpr uint32_t CV_THIN = 4;     // rows per workgroup of the chain kernels (one wave)
+constexpr uint32_t CV_ROWS = 16;    // rows per workgroup of the kernels that sum across rows (one wave per SIMD)
+
+ZK_DI XYZZ<CFq> cv_load(const XYZZ<Fq28>& p) { return XYZZ<CFq>{coop_load(p.x), coop_load(p.y), coop_load(p.zz), coop_load(p.zzz)}; }
+ZK_DI void cv_store(XYZZ<Fq28>& d, const XYZZ<CFq>& p) {
+    coop_store(d.x, p.x);
+    coop_store(d.y, p.y);
+    coop_store(d.zz, p.zz);
+    coop_store(d.zzz, p.zzz);
+}
+ZK_DI Affine<CFq> cv_load(const Affine<Fq28>& p) { return Affine<CFq>{coop_load(p.x), coop_load(p.y)}; }
+
+// ---- the input accumulator: part[(p ni + (j - 1)) 4 + qd] = sum over the set bits k of quarter qd of x_pj of 2^k ic_j
+// (the doubling table of ic: table[k n_ic + j]); one row per chain, the next table entry in flight during an addition
+static __global__ void __launch_bounds__(CV_THIN * COOP_W)
+k_cv_inputs_mul(const Affine<Fq28>* __restrict__ table, const uint32_t* __restrict__ scalars, XYZZ<Fq28>* __restrict__ part, uint32_t n_ic,
+                uint32_t n_proofs) {
+    const uint32_t t = coop_row(), ni = n_ic - 1;
+    if (t >= 4 * ni * n_proofs) return;
+    const uint32_t qd = t & 3u, u = t >> 2, p = u / ni, j = u % ni + 1;
+    const uint32_t* s = scalars + ((size_t)p * ni + (j - 1)) * 8;
+    uint64_t bits = (uint64_t)s[2 * qd] | ((uint64_t)s[2 * qd + 1] << 32);
+    if (qd == 3) bits &= ~(1ull << 63);   // (bit 255 does not exist: the scalars are canonical)
+    XYZZ<CFq> acc = XYZZ<CFq>::inf();
+    auto take = [&](uint64_t& b) {   // the lowest set bit's table entry
+        const uint32_t k = 64 * qd + (uint32_t)__builtin_ctzll(b);
+        b &= b - 1;
+        return cv_load(table[(size_t)k * n_ic + j]);
+    };
+    if (bits) {
+        Affine<CFq> nxt = take(bits);
+        for (;;) {
+            const Affine<CFq> cur = nxt;
+            const bool more = bits != 0;
+            if (more) nxt = take(bits);
+            madd(acc, cur);
+            if (!more) break;
+        }
+    }
+    cv_store(part[t], acc);
+}
+// out: [n][24] words affine (x, y) in the host's layout; inf[i] = 1 if the accumulator is the point at infinity.  One
+// workgroup of 16 rows per proof: each row sums every sixteenth of the 4 (n_ic - 1) partial products, a tree in LDS adds
+// the sixteen and ic_0; row 0 inverts (a^(q - 2) on the row) and exports.
+static __global__ void __launch_bounds__(CV_ROWS * COOP_W)
+k_cv_inputs_sum(const Affine<Fq28>* __restrict__ table, const XYZZ<Fq28>* __restrict__ part, uint32_t* __restrict__ out,
+                uint32_t* __restrict__ inf, uint32_t n_ic) {
+    ZK_SHARED XYZZ<CFq> sm[CV_ROWS * COOP_W];
+    const uint32_t r = coop_row_in_block(), tid = threadIdx.x, p = blockIdx.x, np = 4 * (n_ic - 1);
+    XYZZ<CFq> acc = XYZZ<CFq>::inf();
+    if (r < np) {
+        XYZZ<CFq> nxt = cv_load(part[(size_t)p * np + r]);
+        for (uint32_t k = r; k < np; k += CV_ROWS) {
+            const XYZZ<CFq> cur = nxt;
+            if (k + CV_ROWS < np) nxt = cv_load(part[(size_t)p * np + k + CV_ROWS]);
+            acc = xadd(acc, cur);
+        }
+    }
+    for (uint32_t st = CV_ROWS >> 1; st >= 1; st >>= 1) {
+        sm[tid] = acc;
+        __syncthreads();
+        if (r < st) acc = xadd(acc, sm[tid + st * COOP_W]);
+        __syncthreads();
+    }
+    if (r != 0) return;
+    const Affine<CFq> ic0 = cv_load(table[0]);
+    if (!ic0.is_inf()) madd(acc, ic0);
+    const bool is_inf = acc.is_inf();
+#ifndef ZK_EMU
+    if (coop_lane() == 0)
+#endif
+        inf[p] = is_inf ? 1u : 0u;
+    CFq ax = CFq::zero(), ay = CFq::zero();
+    if (!is_inf) {
+        const CFq izzz = inv(acc.zzz);
+        CFq sq[2];
+        mul2(acc.zz, acc.zz, izzz, izzz, sq[0], sq[1]);
+        const CFq izz = mul(sq[0], sq[1]);   // zz^2 / zzz^2 = 1 / zz
+        mul2(acc.x, izz, acc.y, izzz, ax, ay);
+    }
+    coop_export(ax, out + (size_t)p * 24);
+    coop_export(ay, out + (size_t)p * 24 + 12);
+}
+
+// ---- G2Prepared::from_affine on rows.  The running point (X, Y, Z) is Jacobian, every step's results are brought back
+// below 2p by a product with one (the differences of a step reach 35 p; the Fq2 square wants its operand below 30 p):
+// doubling = 4 squares | 4 squares | 3 products | 3 products with one; the formulas are pairing.h's g2_double_step /
+// g2_add_step, bound of each intermediate (in units of p) in the comments.
+struct CvLine {
+    CFq2 a, b, c;
+};
+// N squares: operand i has components below B[i] p (compile-time list)
+template <int B0, int B1, int B2, int B3>
+ZK_DI void cv_sqr4(const CFq2& a0, const CFq2& a1, const CFq2& a2, const CFq2& a3, CFq2& r0, CFq2& r1, CFq2& r2, CFq2& r3) {
+    CLanes x[8][1], y[8][1];
+    coop_slot_sqr<B0>(x, y, 0, a0);
+    coop_slot_sqr<B1>(x, y, 2, a1);
+    coop_slot_sqr<B2>(x, y, 4, a2);
+    coop_slot_sqr<B3>(x, y, 6, a3);
+    CFq g[8];
+    coop_products<8, 1>(x, y, g);
+    r0 = CFq2{g[0], g[1]};
+    r1 = CFq2{g[2], g[3]};
+    r2 = CFq2{g[4], g[5]};
+    r3 = CFq2{g[6], g[7]};
+}
+template <int B0, int B1, int B2>
+ZK_DI void cv_sqr3(const CFq2& a0, const CFq2& a1, const CFq2& a2, CFq2& r0, CFq2& r1, CFq2& r2) {
+    CLanes x[6][1], y[6][1];
+    coop_slot_sqr<B0>(x, y, 0, a0);
+    coop_slot_sqr<B1>(x, y, 2, a1);
+    coop_slot_sqr<B2>(x, y, 4, a2);
+    CFq g[6];
+    coop_products<6, 1>(x, y, g);
+    r0 = CFq2{g[0], g[1]};
+    r1 = CFq2{g[2], g[3]};
+    r2 = CFq2{g[4], g[5]};
+}
+template <int B0, int B1>
+ZK_DI void cv_sqr2(const CFq2& a0, const CFq2& a1, CFq2& r0, CFq2& r1) {
+    CLanes x[4][1], y[4][1];
+    coop_slot_sqr<B0>(x, y, 0, a0);
+    coop_slot_sqr<B1>(x, y, 2, a1);
+    CFq g[4];
+    coop_products<4, 1>(x, y, g);
+    r0 = CFq2{g[0], g[1]};
+    r1 = CFq2{g[2], g[3]};
+}
+// products a_i b_i (the first operand's c1 below 15 p)
+ZK_DI void cv_mul3(const CFq2& a0, const CFq2& b0, const CFq2& a1, const CFq2& b1, const CFq2& a2, const CFq2& b2, CFq2& r0, CFq2& r1, CFq2& r2) {
+    CLanes x[6][2], y[6][2];
+    coop_slot_mul(x, y, 0, a0, b0);
+    coop_slot_mul(x, y, 2, a1, b1);
+    coop_slot_mul(x, y, 4, a2, b2);
+    CFq g[6];
+    coop_products<6, 2>(x, y, g);
+    r0 = CFq2{g[0], g[1]};
+    r1 = CFq2{g[2], g[3]};
+    r2 = CFq2{g[4], g[5]};
+}
+ZK_DI void cv_mul2(const CFq2& a0, const CFq2& b0, const CFq2& a1, const CFq2& b1, CFq2& r0, CFq2& r1) {
+    CLanes x[4][2], y[4][2];
+    coop_slot_mul(x, y, 0, a0, b0);
+    coop_slot_mul(x, y, 2, a1, b1);
+    CFq g[4];
+    coop_products<4, 2>(x, y, g);
+    r0 = CFq2{g[0], g[1]};
+    r1 = CFq2{g[2], g[3]};
+}
+// three values (any magnitude a product allows) back below 2p: six products with one
+ZK_DI void cv_reduce3(CFq2& a, CFq2& b, CFq2& c) {
+    const CLanes one = CFq::one().l;
+    const CLanes x[6][1] = {{a.c0.l}, {a.c1.l}, {b.c0.l}, {b.c1.l}, {c.c0.l}, {c.c1.l}}, y[6][1] = {{one}, {one}, {one}, {one}, {one}, {one}};
+    CFq g[6];
+    coop_products<6, 1>(x, y, g);
+    a = CFq2{g[0], g[1]};
+    b = CFq2{g[2], g[3]};
+    c = CFq2{g[4], g[5]};
+}
+
+// R <- 2 R; tangent at R.  In: X, Y, Z < 2.
+ZK_DI void cv_double_step(CFq2& X, CFq2& Y, CFq2& Z, CvLine& l) {
+    CFq2 A, B, zz, t2, C, t1, G, t3;
+    cv_sqr4<2, 2, 2, 4>(X, Y, Z, add(Y, Z), A, B, zz, t2);                 // X^2, Y^2, Z^2, (Y + Z)^2
+    const CFq2 E = add(dbl(A), A);                                         // 3 A            < 6
+    cv_sqr4<2, 4, 6, 8>(B, add(X, B), E, add(X, E), C, t1, G, t3);         // B^2, (X + B)^2, E^2, (X + E)^2
+    const CFq2 D = dbl(sub_b<2>(sub_b<2>(t1, A), C));                      // 4 X Y^2        < 16
+    const CFq2 x3 = sub_b<32>(G, dbl(D));                                  //                < 35
+    const CFq2 z3 = sub_b<2>(sub_b<2>(t2, B), zz);                         // 2 Y Z          < 8
+    const CFq2 c8 = dbl(dbl(dbl(C)));                                      //                < 16
+    CFq2 p0, p1, p2;
+    cv_mul3(E, sub_b<35>(D, x3), z3, zz, E, zz, p0, p1, p2);               // E (D - x3), z3 zz, E zz
+    CFq2 y3 = sub_b<16>(p0, c8);                                           //                < 19
+    l.a = dbl(p1);
+    l.b = neg_b<4>(dbl(p2));
+    l.c = sub_b<8>(sub_b<2>(sub_b<2>(t3, A), G), dbl(dbl(B)));
+    X = x3;
+    Y = y3;
+    Z = z3;
+    cv_reduce3(X, Y, Z);
+}
+// R <- R + Q (Q affine, < 2; yy = y_Q^2); chord through R and Q.  In: X, Y, Z < 2.
+ZK_DI void cv_add_step(CFq2& X, CFq2& Y, CFq2& Z, const CFq2& qx, const CFq2& qy, const CFq2& yy, CvLine& l) {
+    CFq2 zz, t1, dummy;
+    cv_sqr2<2, 4>(Z, add(qy, Z), zz, t1);                                  // Z^2, (y_Q + Z)^2
+    CFq2 u2, s2x2;
+    cv_mul2(zz, qx, sub_b<2>(sub_b<2>(t1, yy), zz), zz, u2, s2x2);         // x_Q Z^2, 2 y_Q Z^3     (first operands < 2, < 8)
+    const CFq2 H = sub_b<2>(u2, X);                                        //                < 5
+    const CFq2 r2 = sub_b<4>(s2x2, dbl(Y));                                //                < 7
+    CFq2 HH, r2sq, zh;
+    cv_sqr3<5, 7, 7>(H, r2, add(Z, H), HH, r2sq, zh);                      // H^2, r2^2, (Z + H)^2
+    const CFq2 H4 = dbl(dbl(HH));                                          //                < 8
+    CFq2 H3x4, V, rq;
+    cv_mul3(H4, H, H4, X, r2, qx, H3x4, V, rq);                            // 4 H^3, 4 X H^2, r2 x_Q
+    const CFq2 x3 = sub_sub2<2, 2>(r2sq, H3x4, V);                         // r2^2 - 4 H^3 - 8 X H^2  < 9
+    const CFq2 z3 = sub_b<2>(sub_b<2>(zh, zz), HH);                        // 2 Z H          < 8
+    CFq2 y3a, yh;
+    cv_mul2(r2, sub_b<9>(V, x3), Y, H3x4, y3a, yh);                        // r2 (V - x3), Y 4 H^3
+    const CFq2 y3 = sub_b<4>(y3a, dbl(yh));                                //                < 7
+    CFq2 t4, z3sq;
+    cv_sqr2<10, 8>(add(qy, z3), z3, t4, z3sq);                             // (y_Q + Z3)^2, Z3^2
+    const CFq2 yz2 = sub_b<2>(sub_b<2>(t4, yy), z3sq);                     // 2 y_Q Z3       < 8
+    l.a = dbl(z3);
+    l.b = neg_b<14>(dbl(r2));
+    l.c = sub_b<8>(dbl(rq), yz2);
+    X = x3;
+    Y = y3;
+    Z = z3;
+    cv_reduce3(X, Y, Z);
+    (void)dummy;
+}
+
+ZK_DI CFq2 cv_import2(const uint32_t* h) { return CFq2{coop_import(h), coop_import(h + 12)}; }
+ZK_DI void cv_put(Fq28* stage, const CvLine& l) {   // [a.c0 a.c1 b.c0 b.c1 c.c0 c.c1] as they are (k_cv_export_coefs reduces)
+    coop_store(stage[0], l.a.c0);
+    coop_store(stage[1], l.a.c1);
+    coop_store(stage[2], l.b.c0);
+    coop_store(stage[3], l.b.c1);
+    coop_store(stage[4], l.c.c0);
+    coop_store(stage[5], l.c.c1);
+}
+// q: [n][48] words (x.c0, x.c1, y.c0, y.c1; the host's Montgomery words), stage: [n][68][6] field elements in the multiexps'
+// representation, st as k_g2_prepare's: the last running point IS [|x|] Q, so psi(Q) == [x] Q settles the r-torsion test.
+static __global__ void __launch_bounds__(CV_THIN * COOP_W)
+k_cv_g2_prepare(const uint32_t* __restrict__ q, Fq28* __restrict__ stage, uint32_t n, uint32_t* st) {
+    const uint32_t i = coop_row();
+    if (i >= n) return;
+    if (st && st[i] != 0) return;   // nothing was decoded
+    const CFq2 qx = cv_import2(q + (size_t)i * 48), qy = cv_import2(q + (size_t)i * 48 + 24);
+    CFq2 yy, unused;
+    cv_sqr2<2, 2>(qy, qy, yy, unused);
+    CFq2 X = qx, Y = qy, Z = CFq2::one();
+    Fq28* o = stage + (size_t)i * PAIRING_NCOEF * 6;
+    CvLine l;
+    int idx = 0;
+#pragma unroll 1
+    for (int b = 61; b >= 0; b--) {
+        cv_double_step(X, Y, Z, l);
+        cv_put(o + (idx++) * 6, l);
+        if ((PAIRING_LOOP >> b) & 1ull) {
+            cv_add_step(X, Y, Z, qx, qy, yy, l);
+            cv_put(o + (idx++) * 6, l);
+        }
+    }
+    cv_double_step(X, Y, Z, l);
+    cv_put(o + idx * 6, l);
+    if (st) {
+        const uint32_t cx1[12] = ZK_G2_PSI_CX1_MONT_32, cy0[12] = ZK_G2_PSI_CY0_MONT_32, cy1[12] = ZK_G2_PSI_CY1_MONT_32;
+        // (the constants are uniform words: every lane unpacks its own limb of them)
+        const CFq2 kx{CFq::zero(), coop_import(cx1)}, ky{coop_import(cy0), coop_import(cy1)};
+        const CFq2 cqx{qx.c0, neg_b<2>(qx.c1)}, cqy{qy.c0, neg_b<2>(qy.c1)};   // conjugates (c1 < 4)
+        CFq2 px, py, zz, unused2;
+        cv_mul2(kx, cqx, ky, cqy, px, py);
+        cv_sqr2<2, 2>(Z, Z, zz, unused2);
+        CFq2 pz, zzz;
+        cv_mul2(px, zz, zz, Z, pz, zzz);
+        const CFq2 pyz = mul(py, zzz);
+        // X == psi(Q).x Z^2 and Y == -psi(Q).y Z^3, Z != 0
+        const bool in = !is_zero_full(Z) && is_zero_full(sub_b<2>(X, pz)) && is_zero_full(add(Y, pyz));
+#ifndef ZK_EMU
+        if (coop_lane() == 0)
+#endif
+            if (!in) st[i] = 2;
+    }
+}
+// stage -> the tables the Miller loop reads: out[(item 68 + step) 72 + which 24 + comp 12 ...], canonical words.  One lane
+// per field element: 408 per point, all side by side.
+static __global__ void __launch_bounds__(64)
+k_cv_export_coefs(const Fq28* __restrict__ stage, uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ st) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * (uint32_t)PAIRING_NCOEF * 6) return;
+    const uint32_t item = t / (PAIRING_NCOEF * 6);
+    if (st && st[item] != 0) return;
+    fq28_export(stage[t], out + (size_t)t * 12);   // (step, which, comp) is the word order of coef_st: 6 x 12 words per triple
+}
+
+}  // namespace zkdev
+
+namespace zkcoop {
+using zkdev::COOP_W;
+
+void verify_inputs(const void* ic_table, const uint32_t* scalars, void* part, uint32_t* acc_out, uint32_t* inf_out, uint32_t n_ic,
+                   uint32_t n_proofs, hipStream_t st) {
+    typedef zkdev::Affine<zkdev::Fq28> A;
+    typedef zkdev::XYZZ<zkdev::Fq28> P;
+    const uint32_t ni = n_ic - 1, rows = 4 * ni * n_proofs;
+    if (rows)
+        ZK_LAUNCH(zkdev::k_cv_inputs_mul, dim3((rows + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, (const A*)ic_table,
+                  scalars, (P*)part, n_ic, n_proofs);
+    ZK_LAUNCH_SYNC(zkdev::k_cv_inputs_sum, dim3(n_proofs), dim3(zkdev::CV_ROWS * COOP_W), 0, st, (const A*)ic_table, (const P*)part, acc_out,
+                   inf_out, n_ic);
+}
+size_t g2_prepare_stage_bytes(uint32_t n) { return (size_t)n * zkdev::PAIRING_NCOEF * 6 * sizeof(zkdev::Fq28); }
+void verify_g2_prepare(const uint32_t* q, void* stage, uint32_t* out, uint32_t n, uint32_t* st_flags, hipStream_t st) {
+    ZK_LAUNCH(zkdev::k_cv_g2_prepare, dim3((n + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, q, (zkdev::Fq28*)stage,
+              n, st_flags);
+    const uint32_t cnt = n * (uint32_t)zkdev::PAIRING_NCOEF * 6;
+    ZK_LAUNCH(zkdev::k_cv_export_coefs, dim3((cnt + 63) / 64), dim3(64), 0, st, (const zkdev::Fq28*)stage, out, n, (const uint32_t*)st_flags);
+}
+
+}  // namespace zkcoop

@@ -761,9 +761,8 @@ ZK_DI Fq28 fq28_unpack(const uint32_t* h) {
     return t;
 }
 ZK_DI Fq28 fq28_import(const uint32_t* h) { return mul(fq28_unpack(h), Fq28::from_const(Fq28Consts::KIN)); }
-ZK_DI void fq28_export(const Fq28& a, uint32_t* h) {
-    Fq28 t = mul(a, Fq28::from_const(Fq28Consts::KOUT));
-    // canonical: subtract p once if needed (t < 2p, exact limbs)
+// t = a * KOUT (exact limbs, < 2p) -> the canonical 12 words: subtract p once if needed, repack 14 x 28 -> 12 x 32 bits
+ZK_DI void fq28_export_tail(const Fq28& t, uint32_t* h) {
     int32_t d[14], bo = 0;
 #pragma unroll
     for (int i = 0; i < 14; i++) {
@@ -785,6 +784,7 @@ ZK_DI void fq28_export(const Fq28& a, uint32_t* h) {
         h[q] = v;
     }
 }
+ZK_DI void fq28_export(const Fq28& a, uint32_t* h) { fq28_export_tail(mul(a, Fq28::from_const(Fq28Consts::KOUT)), h); }
 
 // Weak reduction: any stored value (< 64 p) -> the same residue, EXACTLY normalised, < 3 p.
 // q = floor(top limb / (p_top + 1)) never exceeds floor(x / p) and misses it by at most 2

@@ -14,6 +14,7 @@
 #include "host_math.h"
 #include "blake2s.h"
 #include "pairing.h"
+#include "coop_verify.h"
 
 using namespace zkrt;
 using zkdev::F12;
@@ -119,6 +120,7 @@ struct zk_vk {
     DevBuf ic_table, prep[2], gam, alpha_beta;
     // per-batch workspaces
     DevBuf in_g1, in_g2, fl_g1, fl_g2, aff_g1, aff_g2, st_g1, st_g2, scal, part, acc, acc_inf, host_bad, skip, valid, f, ok;
+    DevBuf coop_stage;   // the cooperative line preparation's un-reduced coefficients (coop_verify.cpp)
     DevBuf prep_b;   // line coefficients of the batch's own B points (the lane-parallel Miller loop reads every pair prepared)
     // the random-linear-combination check (verify_chunk_rlc): rho_i, the n_ic input scalars, rho_i A_i | acc | C sum, rho_i C_i and
     // its partial sums, the accumulator, flags, the exponent and e(alpha, beta)^S, the product tree, two Fq12 ones
@@ -500,7 +502,17 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
                   (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n,
                   (own_proofs || wide) ? 0u : 1u);
     }
-    if (wide) {
+    static_assert(zkcoop::VERIFY_NCOEF == zkdev::PAIRING_NCOEF, "coop_verify.cpp restates the loop constants");
+    // a handful of proofs: the line preparation and the input accumulator on rows of 16 lanes (coop_verify.cpp) - the same
+    // tables and the same accumulator, 1.6 + 1.3 ms of one-lane chains shorter; ZKAMD_COOP_VERIFY=0 keeps the one-lane kernels
+    const bool coop_head = wide && n <= zkcoop::VERIFY_MAX && !(getenv("ZKAMD_COOP_VERIFY") && atoi(getenv("ZKAMD_COOP_VERIFY")) == 0);
+    if (coop_head) {
+        ZK_TRY(V->prep_b.ensure(n * COEF_WORDS * 4));
+        ZK_TRY(V->coop_stage.ensure(zkcoop::g2_prepare_stage_bytes((uint32_t)n)));
+        ProfScope ps("verify_prepare");
+        zkcoop::verify_g2_prepare((const uint32_t*)V->aff_g2.as<uint32_t>(), V->coop_stage.p, V->prep_b.as<uint32_t>(), (uint32_t)n,
+                                  own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>(), g_stream);
+    } else if (wide) {
         ZK_TRY(V->prep_b.ensure(n * COEF_WORDS * 4));
         ProfScope ps("verify_prepare");
         ZK_LAUNCH_SYNC(zkdev::k_g2_prepare_tri, dim3((unsigned)((n + zkdev::TL_POINTS - 1) / zkdev::TL_POINTS)), dim3(64), 0, g_stream,
@@ -517,12 +529,17 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     HIP_TRY(hipEventRecord(V->ev_join[0], g_stream2));
     {
         ProfScope ps("verify_inputs", g_copy_stream);
+        if (coop_head)
+            zkcoop::verify_inputs(V->ic_table.p, (const uint32_t*)V->scal.as<uint32_t>(), V->part.p, V->acc.as<uint32_t>(),
+                                  V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n, g_copy_stream);
+        else {
         if (ni)
             ZK_LAUNCH(zkdev::k_inputs_mul, dim3((unsigned)((4 * n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
                       (const DG1A*)V->ic_table.as<DG1A>(), (const uint32_t*)V->scal.as<uint32_t>(), V->part.as<DG1>(), V->n_ic,
                       (uint32_t)n);
         ZK_LAUNCH_SYNC(zkdev::k_inputs_sum, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
                   (const DG1*)V->part.as<DG1>(), V->acc.as<uint32_t>(), V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n);
+        }
     }
     HIP_TRY(hipEventRecord(V->ev_join[1], g_copy_stream));
     HIP_TRY(hipStreamWaitEvent(g_stream, V->ev_join[0], 0));
