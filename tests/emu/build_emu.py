@@ -37,7 +37,7 @@ def build_emu(force=False, sanitize=False):
     # one object per translation unit, compiled in parallel; a unit is recompiled only when something it reads changed
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    units = [os.path.join(CSRC, f) for f in ("zkamd.cpp", "verify.cpp", "witness.cpp", "setup.cpp", "hostbind.cpp", "wallet.cpp", "coop_tail.cpp", "msm_g1.cpp", "msm_g2.cpp", "coop_verify.cpp")] + [os.path.join(HERE, "emu_rt.cpp")]
+    units = [os.path.join(CSRC, f) for f in ("zkamd.cpp", "verify.cpp", "witness.cpp", "setup.cpp", "hostbind.cpp", "wallet.cpp", "coop_tail.cpp", "msm_g1.cpp", "msm_g2.cpp", "coop_verify.cpp", "coop_pairing.cpp")] + [os.path.join(HERE, "emu_rt.cpp")]
     # (-O0: at -O1 the instrumented field arithmetic of zkamd.cpp takes the better part of an hour to compile)
     flags = ["-O0", "-g1", "-DZK_EMU_NO_FIBERS=1", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize=vptr,function",
              "-fno-sanitize-recover=undefined"] if sanitize else ["-O2"]

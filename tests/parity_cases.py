@@ -1028,6 +1028,41 @@ def verifier_small_circuit(lib, seed=5, n_in=3, n_aux=12, n_con=14):
         params.close()
 
 
+def verifier_forms_agree(lib, seed=6, n_in=4, n_aux=10, n_con=13):
+    """A handful of proofs is verified on rows (coop_verify.cpp: the accumulator and the lines of B; coop_pairing.cpp: the
+    Miller loops and the final exponentiation with an Fq12 value on six rows): the verdicts are those of the eighteen-lane
+    kernels and of the one-lane head on the same batch - accepted proofs included, i.e. the 12 x 381-bit comparison with
+    e(alpha, beta) comes out equal on every form."""
+    r1, asg, P, pk = helpers.small_case(seed, n_in, n_aux, n_con)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    pvk = zk.prepare_verifying_key(params)
+    keys = ("ZKAMD_COOP_PAIRING", "ZKAMD_COOP_VERIFY")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        good = [helpers.expected_proof_trapdoor(P, asg, r, s) for r, s in ((1, 2), (bls.R_MOD - 2, 0), (99, 2 ** 200 + 1))]
+        inputs = list(asg.inputs[1:])
+        bad_in = inputs[:-1] + [(inputs[-1] + 5) % bls.R_MOD]
+        mixed = good[0][:144] + good[1][144:]
+        other_b = good[0][:48] + good[2][48:144] + good[0][144:]
+        batch = [good[0], mixed, good[1], other_b, good[2], good[1], good[0]]
+        ins = [inputs, inputs, inputs, inputs, inputs, bad_in, inputs]
+        want = [True, False, True, False, True, False, True]
+        for form in ({}, {"ZKAMD_COOP_PAIRING": "0"}, {"ZKAMD_COOP_VERIFY": "0"}):
+            for k in keys:
+                os.environ.pop(k, None)
+            os.environ.update(form)
+            assert zk.verify_proofs(pvk, batch, ins) == want, form
+            assert zk.verify_proof(pvk, zk.Proof(good[2]), inputs) is True, form
+            assert zk.verify_proof(pvk, zk.Proof(mixed), inputs) is False, form
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        pvk.close()
+        params.close()
+
+
 def verifier_rlc(lib, n=20, seed=8, capfd=None):
     """zk_verify_batch_rlc (one combined check per chunk: rho_i-weighted Miller loops, ONE final exponentiation, the per-proof
     verifier behind it) gives EXACTLY zk_verify_batch's verdicts: a batch of proofs of different statements, all good; one /

@@ -199,6 +199,10 @@ def test_verifier_small_circuit(emu_lib):
     pc.verifier_small_circuit(emu_lib)
 
 
+def test_verifier_forms_agree(emu_lib):
+    pc.verifier_forms_agree(emu_lib)
+
+
 def test_verifier_rlc(emu_lib, monkeypatch, capfd):
     monkeypatch.setenv("ZKAMD_DEBUG_RLC", "1")
     pc.verifier_rlc(emu_lib, n=11, capfd=capfd)

@@ -337,6 +337,10 @@ def test_verifier_small_circuit(gpu_lib):
     pc.verifier_small_circuit(gpu_lib)
 
 
+def test_verifier_forms_agree(gpu_lib):
+    pc.verifier_forms_agree(gpu_lib)
+
+
 def test_verifier_golden_multiples(gpu_lib):
     pc.verifier_golden_multiples(gpu_lib)
 

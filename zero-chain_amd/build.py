@@ -38,7 +38,7 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-TRANSLATION_UNITS = ("zkamd.cpp", "verify.cpp", "witness.cpp", "setup.cpp", "hostbind.cpp", "wallet.cpp", "coop_tail.cpp", "msm_g1.cpp", "msm_g2.cpp", "coop_verify.cpp")   # compiled in parallel, linked into one library
+TRANSLATION_UNITS = ("zkamd.cpp", "verify.cpp", "witness.cpp", "setup.cpp", "hostbind.cpp", "wallet.cpp", "coop_tail.cpp", "msm_g1.cpp", "msm_g2.cpp", "coop_verify.cpp", "coop_pairing.cpp")   # compiled in parallel, linked into one library
 
 
 def _deps(path, seen=None):

@@ -318,6 +318,7 @@ size_t g2_prepare_stage_bytes(uint32_t n) { return (size_t)n * zkdev::PAIRING_NC
 void verify_g2_prepare(const uint32_t* q, void* stage, uint32_t* out, uint32_t n, uint32_t* st_flags, hipStream_t st) {
     ZK_LAUNCH(zkdev::k_cv_g2_prepare, dim3((n + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, q, (zkdev::Fq28*)stage,
               n, st_flags);
+    if (!out) return;
     const uint32_t cnt = n * (uint32_t)zkdev::PAIRING_NCOEF * 6;
     ZK_LAUNCH(zkdev::k_cv_export_coefs, dim3((cnt + 63) / 64), dim3(64), 0, st, (const zkdev::Fq28*)stage, out, n, (const uint32_t*)st_flags);
 }

@@ -19,6 +19,18 @@ void verify_inputs(const void* ic_table, const uint32_t* scalars, void* part, ui
 // out[item][68][72 words] = the coefficient triples of the G2 points q[item][48 words] (G2Prepared::from_affine); st_flags as
 // k_g2_prepare's (may be null: no r-torsion test); stage: workspace of g2_prepare_stage_bytes(n).
 size_t g2_prepare_stage_bytes(uint32_t n);
+// (out may be null: the cooperative Miller loop reads the stage itself)
 void verify_g2_prepare(const uint32_t* q, void* stage, uint32_t* out, uint32_t n, uint32_t* st_flags, hipStream_t st);
+
+// ---- coop_pairing.cpp: the Miller loops and the final exponentiation with an Fq12 value on six rows; same arguments and
+// the same words out as pairing.h's k_miller_loop_wide / k_final_exp_wide, except that the line coefficients come in the
+// multiexps' representation: lines0 = the stage of verify_g2_prepare ([n][68][6] field elements), lines1 / lines2 = the
+// key's prepared -gamma / -delta converted once by verify_import_coefs ([68][6]; count = 408 field elements of 12 words).
+constexpr size_t LINE_TABLE_BYTES = (size_t)VERIFY_NCOEF * 6 * 14 * 4;
+void verify_import_coefs(const uint32_t* words, void* out, uint32_t count, hipStream_t st);
+void verify_miller(const uint32_t* p0, const void* lines0, const uint32_t* p1, const void* lines1, const uint32_t* p2, const void* lines2,
+                   const uint32_t* skip, void* f_out, uint32_t n, hipStream_t st);
+void verify_final_exp(const void* f_in, const uint32_t* gam, const void* want, const uint32_t* valid, uint32_t* ok, void* value_out, uint32_t n,
+                      hipStream_t st);
 
 }  // namespace zkcoop

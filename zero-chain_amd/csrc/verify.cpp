@@ -121,6 +121,7 @@ struct zk_vk {
     // per-batch workspaces
     DevBuf in_g1, in_g2, fl_g1, fl_g2, aff_g1, aff_g2, st_g1, st_g2, scal, part, acc, acc_inf, host_bad, skip, valid, f, ok;
     DevBuf coop_stage;   // the cooperative line preparation's un-reduced coefficients (coop_verify.cpp)
+    DevBuf lines28[2];   // prep[] in the multiexps' representation, for the Miller loop on rows (coop_pairing.cpp); built on first use
     DevBuf prep_b;   // line coefficients of the batch's own B points (the lane-parallel Miller loop reads every pair prepared)
     // the random-linear-combination check (verify_chunk_rlc): rho_i, the n_ic input scalars, rho_i A_i | acc | C sum, rho_i C_i and
     // its partial sums, the accumulator, flags, the exponent and e(alpha, beta)^S, the product tree, two Fq12 ones
@@ -506,12 +507,22 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     // a handful of proofs: the line preparation and the input accumulator on rows of 16 lanes (coop_verify.cpp) - the same
     // tables and the same accumulator, 1.6 + 1.3 ms of one-lane chains shorter; ZKAMD_COOP_VERIFY=0 keeps the one-lane kernels
     const bool coop_head = wide && n <= zkcoop::VERIFY_MAX && !(getenv("ZKAMD_COOP_VERIFY") && atoi(getenv("ZKAMD_COOP_VERIFY")) == 0);
+    // ... and the Miller loops and the final exponentiation with an Fq12 value on six rows (coop_pairing.cpp): the same words in
+    // V->f, the same verdicts; ZKAMD_COOP_PAIRING=0 keeps the eighteen-lane kernels behind the cooperative head
+    const bool coop_pairing = coop_head && !(getenv("ZKAMD_COOP_PAIRING") && atoi(getenv("ZKAMD_COOP_PAIRING")) == 0);
+    if (coop_pairing)
+        for (int k = 0; k < 2; k++) {
+            if ((k == 0 ? V->gamma_inf : V->delta_inf) || V->lines28[k].cap) continue;
+            V->lines28[k].is_public = true;
+            ZK_TRY(V->lines28[k].ensure(zkcoop::LINE_TABLE_BYTES));
+            zkcoop::verify_import_coefs((const uint32_t*)V->prep[k].as<uint32_t>(), V->lines28[k].p, (uint32_t)zkcoop::VERIFY_NCOEF * 6, g_stream);
+        }
     if (coop_head) {
-        ZK_TRY(V->prep_b.ensure(n * COEF_WORDS * 4));
+        if (!coop_pairing) ZK_TRY(V->prep_b.ensure(n * COEF_WORDS * 4));
         ZK_TRY(V->coop_stage.ensure(zkcoop::g2_prepare_stage_bytes((uint32_t)n)));
         ProfScope ps("verify_prepare");
-        zkcoop::verify_g2_prepare((const uint32_t*)V->aff_g2.as<uint32_t>(), V->coop_stage.p, V->prep_b.as<uint32_t>(), (uint32_t)n,
-                                  own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>(), g_stream);
+        zkcoop::verify_g2_prepare((const uint32_t*)V->aff_g2.as<uint32_t>(), V->coop_stage.p, coop_pairing ? (uint32_t*)nullptr : V->prep_b.as<uint32_t>(),
+                                  (uint32_t)n, own_proofs ? (uint32_t*)nullptr : V->st_g2.as<uint32_t>(), g_stream);
     } else if (wide) {
         ZK_TRY(V->prep_b.ensure(n * COEF_WORDS * 4));
         ProfScope ps("verify_prepare");
@@ -549,7 +560,19 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
               (const uint32_t*)V->host_bad.as<uint32_t>(), V->skip.as<uint32_t>(), V->valid.as<uint32_t>(), (uint32_t)n);
     const uint32_t* prep_gamma = V->gamma_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[0].as<uint32_t>();
     const uint32_t* prep_delta = V->delta_inf ? (const uint32_t*)nullptr : (const uint32_t*)V->prep[1].as<uint32_t>();
-    if (wide) {
+    if (coop_pairing) {
+        {
+            ProfScope ps("verify_miller");
+            zkcoop::verify_miller((const uint32_t*)V->aff_g1.as<uint32_t>(), V->coop_stage.p, (const uint32_t*)V->acc.as<uint32_t>(),
+                                  V->gamma_inf ? nullptr : V->lines28[0].p, (const uint32_t*)(V->aff_g1.as<uint32_t>() + n * 24),
+                                  V->delta_inf ? nullptr : V->lines28[1].p, (const uint32_t*)V->skip.as<uint32_t>(), V->f.p, (uint32_t)n, g_stream);
+        }
+        {
+            ProfScope ps("verify_final");
+            zkcoop::verify_final_exp(V->f.p, (const uint32_t*)V->gam.as<uint32_t>(), V->alpha_beta.p, (const uint32_t*)V->valid.as<uint32_t>(),
+                                     V->ok.as<uint32_t>(), nullptr, (uint32_t)n, g_stream);
+        }
+    } else if (wide) {
         const unsigned bw = (unsigned)((n + zkdev::W3_GROUPS - 1) / zkdev::W3_GROUPS);
         {
             ProfScope ps("verify_miller");
