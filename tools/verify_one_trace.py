@@ -11,7 +11,7 @@ if "--trace" in sys.argv:
         if e[0] - max(x[1] for x in cur) > 300_000: calls.append(cur); cur = [e]
         else: cur.append(e)
     calls.append(cur)
-    c = [x for x in calls if any("k_miller" in e[2] for e in x) and not any("k_msm_accumulate" in e[2] for e in x)][-1]
+    c = [x for x in calls if any("miller" in e[2] for e in x) and not any("k_msm_accumulate" in e[2] or "k_check_points" in e[2] for e in x)][-1]
     t0 = c[0][0]
     print("the LAST verification (%d launches, %.3f ms)" % (len(c), (max(x[1] for x in c) - t0) / 1e6))
     for s, e, k in c:

@@ -234,7 +234,8 @@ ZK_DI XYZZ<CFq2> xadd(const XYZZ<CFq2>& a, const XYZZ<CFq2>& b) {
 }
 
 // ---- the host's Montgomery words (12 x 32 bits, radix 2^384: fq.rs:700-701) <-> a row
-ZK_DI CFq coop_import(const uint32_t* h) {
+// 12 x 32-bit words -> the row's 14 limbs of 28 bits (no arithmetic: the same integer)
+ZK_DI CFq coop_unpack(const uint32_t* h) {
     CFq t;
 #ifndef ZK_EMU
     const uint32_t j = coop_lane(), bit = 28u * (j < 14 ? j : 0u), q = bit >> 5, sh = bit & 31u;
@@ -247,8 +248,11 @@ ZK_DI CFq coop_import(const uint32_t* h) {
         t.l.v[j] = (uint32_t)(two >> sh) & FQ28_MASK;
     }
 #endif
-    return mul(t, CFq::from_const(Fq28Consts::KIN));
+    return t;
 }
+ZK_DI CFq coop_import(const uint32_t* h) { return mul(coop_unpack(h), CFq::from_const(Fq28Consts::KIN)); }
+// the plain integer below q in 12 words (an encoding's x) -> the row's Montgomery form
+ZK_DI CFq coop_import_plain(const uint32_t* h) { return mul(coop_unpack(h), CFq::from_const(Fq28Consts::R2)); }
 // canonical words of the row's element, written by lane 0 (every lane computes them: the row's value is gathered)
 ZK_DI void coop_export(const CFq& a, uint32_t* h) {
     const Fq28 t = coop_gather(coop_exact(mul(a, CFq::from_const(Fq28Consts::KOUT))));
@@ -262,10 +266,8 @@ ZK_DI void coop_export(const CFq& a, uint32_t* h) {
         for (int i = 0; i < 12; i++) h[i] = w[i];
     }
 }
-// a^(q - 2): 380 squarings and ~190 products in a row - 0.19 ms for a lone row, where the one-lane Euclidean inversion
-// (divergent word loops) takes ~0.3 ms
-ZK_DI CFq inv(const CFq& a) {
-    const uint32_t e[12] = ZK_FQ_EXP_QM2_32;
+// a^e for a public 12-word exponent, MSB first: ~380 squarings and ~190 products in a row, 0.19 ms for a lone row
+ZK_DI CFq coop_pow(const CFq& a, const uint32_t (&e)[12]) {
     CFq r = a;
     bool started = false;
 #pragma unroll 1
@@ -281,6 +283,36 @@ ZK_DI CFq inv(const CFq& a) {
         }
     }
     return r;
+}
+// a^(q - 2) (the one-lane Euclidean inversion - divergent word loops - takes ~0.3 ms)
+ZK_DI CFq inv(const CFq& a) {
+    const uint32_t e[12] = ZK_FQ_EXP_QM2_32;
+    return coop_pow(a, e);
+}
+// is the PLAIN value of a (any stored magnitude) above (q - 1) / 2, i.e. y > -y in the reference's ordering (fq.rs:707-713)?
+// The Montgomery reduction of a x 1 leaves the plain residue below 2p; it is gathered, brought below p and compared.
+ZK_DI bool coop_lex_largest(const CFq& a) {
+    const uint32_t one[14] = {1u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const Fq28 t = coop_gather(coop_exact(mul(a, CFq::from_const(one))));
+    int32_t d[14], bo = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const int32_t v = (int32_t)t.l[i] - (int32_t)Fq28Consts::P[i] - bo;
+        bo = v < 0 ? 1 : 0;
+        d[i] = i < 13 ? (v & (int32_t)FQ28_MASK) : v;
+    }
+    bool gt = false, decided = false;
+#pragma unroll
+    for (int i = 13; i >= 0; i--) {
+        const uint32_t c = bo ? t.l[i] : (uint32_t)d[i];
+        // limb i of (p - 1) / 2: p is odd, so the shift drops exactly the bit that the subtraction of one clears
+        const uint32_t h = (Fq28Consts::P[i] >> 1) | (i < 13 ? (Fq28Consts::P[i + 1] & 1u) << 27 : 0u);
+        if (!decided && c != h) {
+            gt = c > h;
+            decided = true;
+        }
+    }
+    return gt;
 }
 
 }  // namespace zkdev

@@ -96,6 +96,49 @@ ZK_C12_FN CFq2 c12_line(C12Lds& lds, uint32_t k, const CFq2& f, const CFq2& L0, 
     __syncthreads();
     return CFq2{o[0], o[1]};
 }
+ZK_DI CLanes c12_sel(bool c, const CLanes& a, const CLanes& b) {
+    CLanes r;
+    ZK_COOP_EACH(j) r.v[j] = c ? a.v[j] : b.v[j];
+    return r;
+}
+ZK_DI CLanes c12_x3(const CLanes& a) {   // limb-wise, un-normalised (limbs below 2^29.6)
+    CLanes r;
+    ZK_COOP_EACH(j) r.v[j] = 3u * a.v[j];
+    return r;
+}
+// Row k's coefficient of z^2 for z in the cyclotomic subgroup (f12_cyc_sqr of pairing.h: Granger-Scott, eprint 2009/565
+// section 3.2).  Over Fq4 = Fq2[s] / (s^2 - xi) the element is the three pairs (z_A, z_(A+3)) of coefficients, A = 0, 1, 2;
+// with (a + b s)^2 = (a^2 + xi b^2) + (2 a b) s the new coefficients are
+//     w^0: 3 (a^2 + xi b^2) - 2 z   of pair 0        w^3: 3 (2 a b) + 2 z      of pair 0
+//     w^2: 3 (a^2 + xi b^2) - 2 z   of pair 1        w^5: 3 (2 a b) + 2 z      of pair 1
+//     w^4: 3 (a^2 + xi b^2) - 2 z   of pair 2        w^1: 3 (2 (xi a) b) + 2 z of pair 2
+// (z = the row's own coefficient): an even row computes a "square" form, an odd row a "product" form, BOTH as two
+// accumulators of four terms - three Fq products scaled by 3 limb-wise and +-2 z times one - so that the rows of a wave run
+// one instruction stream: 8 products and 5 broadcasts a round where the general product has 24 and 12.
+//     even: c0 = (a0 + a1)(a0 - a1) + (b0 + b1)(b0 - b1) - 2 b0 b1,   c1 = 2 a0 a1 + (b0 + b1)(b0 - b1) + 2 b0 b1
+//     odd:  c0 = 2 a0 b0 - 2 a1 b1,                                   c1 = 2 a1 b0 + 2 a0 b1
+// Magnitudes (units of p; z below 4 - a conjugate may come in -, a below 9 on row 1; the subtractions take the bound of the
+// worst row): at most 3 (8 x 14 + 8 x 9 + 19 x 4) + 9 = 789 p^2; columns 3 x 3 x 2^56 + 2 x 2^56 < 2^60.
+ZK_C12_FN CFq2 c12_cyc_sqr(C12Lds& lds, uint32_t k, const CFq2& z) {
+    c12_put(lds.f, k, z);
+    c12_put(lds.fx, k, c12_xi(z));
+    __syncthreads();
+    const uint32_t A = (k == 0 || k == 3) ? 0u : (k == 2 || k == 5) ? 1u : 2u;
+    const bool odd = (k & 1u) != 0;
+    const CFq2 a = c12_get(k == 1 ? lds.fx : lds.f, A), b = c12_get(lds.f, A + 3);
+    const CFq sa = add(a.c0, a.c1), da = sub_b<9>(a.c0, a.c1), sb = add(b.c0, b.c1), db = sub_b<4>(b.c0, b.c1);
+    const CFq a0x2 = dbl(a.c0), a1x2 = dbl(a.c1), b0x2 = dbl(b.c0), z0x2 = dbl(z.c0), z1x2 = dbl(z.c1);
+    const CFq ng = neg_b<18>(CFq{c12_sel(odd, a1x2.l, b0x2.l)});
+    const CLanes zero = CFq::zero().l, one = CFq::one().l;
+    const CLanes mid = c12_x3(c12_sel(odd, zero, sb.l));
+    const CLanes x[2][4] = {{c12_x3(c12_sel(odd, a0x2.l, sa.l)), mid, c12_x3(ng.l), c12_sel(odd, z0x2.l, neg_b<8>(z0x2).l)},
+                            {c12_x3(c12_sel(odd, a1x2.l, a0x2.l)), mid, c12_x3(c12_sel(odd, a0x2.l, b0x2.l)), c12_sel(odd, z1x2.l, neg_b<8>(z1x2).l)}};
+    const CLanes y[2][4] = {{c12_sel(odd, b.c0.l, da.l), db.l, b.c1.l, one}, {c12_sel(odd, b.c0.l, a.c1.l), db.l, b.c1.l, one}};
+    CFq o[2];
+    coop_products<2, 4>(x, y, o);
+    __syncthreads();
+    return CFq2{o[0], o[1]};
+}
 ZK_DI CFq2 c12_one(uint32_t k) { return k == 0 ? CFq2::one() : CFq2::zero(); }
 // a^(q^6): w -> -w  (below 3 p)
 ZK_DI CFq2 c12_conj(uint32_t k, const CFq2& a) { return (k & 1u) ? neg_b<2>(a) : a; }
@@ -171,12 +214,12 @@ ZK_DI CFq2 c12_frob(const CFq2& a, int j, const CFq2& g) {
     const CFq2 x = (j & 1) ? CFq2{a.c0, neg_b<4>(a.c1)} : a;
     return mul(x, g);
 }
-// f^|x| by square and multiply, then the conjugate (f12_exp_x)
+// f^|x| by square and multiply, then the conjugate (f12_exp_x); f in the cyclotomic subgroup
 ZK_C12_FN CFq2 c12_exp_x(C12Lds& lds, uint32_t k, const CFq2& a) {
     CFq2 t = a;
 #pragma unroll 1
     for (int b = 62; b >= 0; b--) {
-        t = c12_mul(lds, k, t, t);
+        t = c12_cyc_sqr(lds, k, t);
         if ((ZK_BLS_X_ABS >> b) & 1ull) t = c12_mul(lds, k, t, a);
     }
     return c12_conj(k, t);

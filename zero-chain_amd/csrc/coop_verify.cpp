@@ -298,6 +298,123 @@ k_cv_export_coefs(const Fq28* __restrict__ stage, uint32_t* __restrict__ out, ui
     fq28_export(stage[t], out + (size_t)t * 12);   // (step, which, comp) is the word order of coef_st: 6 x 12 words per triple
 }
 
+// ---- Proof decoding on rows: compressed G1 / G2 -> affine with the checks of into_affine() (ec.rs:776-868, :1480-1500;
+// pairing.h k_decode_g1 / k_decode_g2, the same statuses and the same words out).  One row per point; what a decoder costs
+// is two chains - the square root (an exponentiation: ~570 products in a row) and, for G1, the r-torsion test
+// phi(P) == -[x^2] P (two multiplications by |x|: 126 doublings, 10 additions) - 0.33 us per product and 2.5 us per doubling
+// on a row against 1.4 and 9 us on a lane.  in: the plain x below q (12 words per Fq), flags: bit 0 = refused by the parser,
+// bit 1 = the encoding's sign bit; st: 0 = decoded, 1 = no y on the curve, 2 = outside the subgroup, 3 = refused.
+ZK_DI XYZZ<CFq> cv_mul_x_abs(const Affine<CFq>& p) {   // [|x|] p, p affine and not infinity
+    XYZZ<CFq> acc{p.x, p.y, CFq::one(), CFq::one()};
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        acc = xdbl(acc);
+        if ((ZK_BLS_X_ABS >> b) & 1ull) madd(acc, p);
+    }
+    return acc;
+}
+ZK_DI XYZZ<CFq> cv_mul_x_abs(const XYZZ<CFq>& p) {
+    XYZZ<CFq> acc = p;
+#pragma unroll 1
+    for (int b = 62; b >= 0; b--) {
+        acc = xdbl(acc);
+        if ((ZK_BLS_X_ABS >> b) & 1ull) acc = xadd(acc, p);
+    }
+    return acc;
+}
+ZK_DI void cv_status(uint32_t* st, uint32_t i, uint32_t v) {
+#ifndef ZK_EMU
+    if (coop_lane() == 0)
+#endif
+        st[i] = v;
+}
+static __global__ void __launch_bounds__(CV_THIN * COOP_W)
+k_cv_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out, uint32_t* __restrict__ st,
+               uint32_t n, uint32_t check_subgroup) {
+    const uint32_t i = coop_row();
+    if (i >= n) return;
+    if (flags[i] & 1u) {
+        cv_status(st, i, 3);
+        return;
+    }
+    const uint32_t e[12] = ZK_FQ_EXP_QP1D4_32;
+    const CFq x = coop_import_plain(in + (size_t)i * 12);
+    const CFq rhs = add(mul(mul(x, x), x), CFq::from_const(Fq28Consts::B));   // < 3
+    CFq y = coop_pow(rhs, e);                                                 // q = 3 mod 4
+    if (!is_zero_full(sub_b<4>(mul(y, y), rhs))) {
+        cv_status(st, i, 1);
+        return;
+    }
+    if (coop_lex_largest(y) != ((flags[i] & 2u) != 0)) y = mul(neg_b<2>(y), CFq::one());
+    if (check_subgroup) {   // phi(P) == -[x^2] P (pairing.h g1_in_subgroup)
+        const uint32_t beta[12] = ZK_G1_BETA_MONT_32;
+        const XYZZ<CFq> t = cv_mul_x_abs(cv_mul_x_abs(Affine<CFq>{x, y}));
+        bool in = !t.is_inf();
+        if (in) {
+            const CFq bx = mul(coop_import(beta), x);
+            CFq l, r;
+            mul2(bx, t.zz, y, t.zzz, l, r);
+            in = is_zero_full(sub_b<2>(t.x, l)) && is_zero_full(add(t.y, r));
+        }
+        if (!in) {
+            cv_status(st, i, 2);
+            return;
+        }
+    }
+    coop_export(x, out + (size_t)i * 24);
+    coop_export(y, out + (size_t)i * 24 + 12);
+    cv_status(st, i, 0);
+}
+// some square root in Fq2 by the norm route of pairing.h f2_sqrt (two exponentiations in Fq); a below 4
+ZK_DI bool cv_f2_sqrt(const CFq2& a, CFq2& out) {
+    if (is_zero_full(a)) {
+        out = CFq2::zero();
+        return true;
+    }
+    const uint32_t e_s[12] = ZK_FQ_EXP_QP1D4_32, e_t[12] = ZK_FQ_EXP_QM3D4_32, half[12] = ZK_FQ_HALF_MONT_32;
+    const CFq h = coop_import(half);
+    const CLanes xs[1][2] = {{a.c0.l, a.c1.l}}, ys[1][2] = {{a.c0.l, a.c1.l}};
+    CFq nn[1];
+    coop_products<1, 2>(xs, ys, nn);                          // a0^2 + a1^2
+    const CFq s = coop_pow(nn[0], e_s);
+    const CFq delta = is_zero_full(a.c1) ? mul(a.c0, CFq::one()) : mul(add(a.c0, s), h);
+    const CFq t = coop_pow(delta, e_t);
+    CFq x0, a1h, tt;
+    mul2(t, delta, a.c1, h, x0, a1h);
+    CFq x0sq, w0;
+    mul2(x0, x0, t, t, x0sq, tt);
+    w0 = mul(a1h, x0);
+    const CFq w = mul(w0, tt);
+    out = is_zero_full(sub_b<2>(x0sq, delta)) ? CFq2{x0, w} : CFq2{w, x0};
+    return is_zero_full(sub_b<4>(sqr(out), a));
+}
+static __global__ void __launch_bounds__(CV_THIN * COOP_W)
+k_cv_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out, uint32_t* __restrict__ st,
+               uint32_t n) {
+    const uint32_t i = coop_row();
+    if (i >= n) return;
+    if (flags[i] & 1u) {
+        cv_status(st, i, 3);
+        return;
+    }
+    const CFq2 x{coop_import_plain(in + (size_t)i * 24), coop_import_plain(in + (size_t)i * 24 + 12)};
+    const CFq b = CFq::from_const(Fq28Consts::B);
+    const CFq2 rhs = add(mul(sqr(x), x), CFq2{b, b});          // 4 (u + 1), ec.rs:1567-1572
+    CFq2 y;
+    if (!cv_f2_sqrt(rhs, y)) {
+        cv_status(st, i, 1);
+        return;
+    }
+    // Fq2 ordering: c1 first, then c0 (fq2.rs:21-30)
+    const bool largest = is_zero_full(y.c1) ? coop_lex_largest(y.c0) : coop_lex_largest(y.c1);
+    if (largest != ((flags[i] & 2u) != 0)) mul2(neg_b<2>(y.c0), CFq::one(), neg_b<2>(y.c1), CFq::one(), y.c0, y.c1);
+    coop_export(x.c0, out + (size_t)i * 48);
+    coop_export(x.c1, out + (size_t)i * 48 + 12);
+    coop_export(y.c0, out + (size_t)i * 48 + 24);
+    coop_export(y.c1, out + (size_t)i * 48 + 36);
+    cv_status(st, i, 0);
+}
+
 }  // namespace zkdev
 
 namespace zkcoop {
@@ -313,6 +430,13 @@ void verify_inputs(const void* ic_table, const uint32_t* scalars, void* part, ui
                   scalars, (P*)part, n_ic, n_proofs);
     ZK_LAUNCH_SYNC(zkdev::k_cv_inputs_sum, dim3(n_proofs), dim3(zkdev::CV_ROWS * COOP_W), 0, st, (const A*)ic_table, (const P*)part, acc_out,
                    inf_out, n_ic);
+}
+void verify_decode_g1(const uint32_t* in, const uint32_t* flags, uint32_t* out, uint32_t* status, uint32_t n, uint32_t check_subgroup, hipStream_t st) {
+    ZK_LAUNCH(zkdev::k_cv_decode_g1, dim3((n + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, in, flags, out, status, n,
+              check_subgroup);
+}
+void verify_decode_g2(const uint32_t* in, const uint32_t* flags, uint32_t* out, uint32_t* status, uint32_t n, hipStream_t st) {
+    ZK_LAUNCH(zkdev::k_cv_decode_g2, dim3((n + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, in, flags, out, status, n);
 }
 size_t g2_prepare_stage_bytes(uint32_t n) { return (size_t)n * zkdev::PAIRING_NCOEF * 6 * sizeof(zkdev::Fq28); }
 void verify_g2_prepare(const uint32_t* q, void* stage, uint32_t* out, uint32_t n, uint32_t* st_flags, hipStream_t st) {

@@ -8,7 +8,8 @@
 
 namespace zkcoop {
 
-constexpr size_t VERIFY_MAX = 64;   // proofs per chunk up to which verify.cpp takes these kernels (88 + 1 rows per proof)
+constexpr size_t VERIFY_MAX = 64;   // proofs per chunk up to which verify.cpp takes the input accumulator on rows (88 rows per proof)
+constexpr size_t PAIRING_MAX = 2048;   // ... and the line preparation, Miller loops and final exponentiation on rows (coop_pairing.cpp)
 constexpr int VERIFY_NCOEF = 68;    // line-coefficient triples per G2 point (pairing.h PAIRING_NCOEF)
 
 // acc_out[p][24 words] = ic_0 + sum_j x_pj ic_j in affine form (the host's Montgomery words), inf_out[p] = 1 for the point
@@ -16,6 +17,10 @@ constexpr int VERIFY_NCOEF = 68;    // line-coefficient triples per G2 point (pa
 // part: workspace of 4 (n_ic - 1) n points (XYZZ<Fq28>).
 void verify_inputs(const void* ic_table, const uint32_t* scalars, void* part, uint32_t* acc_out, uint32_t* inf_out, uint32_t n_ic,
                    uint32_t n_proofs, hipStream_t st);
+// k_decode_g1 / k_decode_g2 of pairing.h on rows (same arguments, statuses and words; the G2 form leaves the r-torsion test to
+// verify_g2_prepare, whose last running point settles it)
+void verify_decode_g1(const uint32_t* in, const uint32_t* flags, uint32_t* out, uint32_t* status, uint32_t n, uint32_t check_subgroup, hipStream_t st);
+void verify_decode_g2(const uint32_t* in, const uint32_t* flags, uint32_t* out, uint32_t* status, uint32_t n, hipStream_t st);
 // out[item][68][72 words] = the coefficient triples of the G2 points q[item][48 words] (G2Prepared::from_affine); st_flags as
 // k_g2_prepare's (may be null: no r-torsion test); stage: workspace of g2_prepare_stage_bytes(n).
 size_t g2_prepare_stage_bytes(uint32_t n);

@@ -494,22 +494,34 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     // beta) always takes it)
     const char* wide_env = getenv("ZKAMD_VERIFY_WIDE");
     const bool wide = !(wide_env && atoi(wide_env) == 0);
+    // Rows of 16 lanes instead of one value per lane (coop_verify.cpp, coop_pairing.cpp) - the same tables, accumulators and
+    // Fq12 words, the same verdicts:
+    //  - the input accumulator for a handful of proofs (88 rows per proof: work-bound beyond COOP_INPUTS_MAX);
+    //  - the decoders, the line preparation of B, the Miller loops and the final exponentiation (3 + 1 + 18 + 6 rows per
+    //    proof) up to COOP_PAIRING_MAX proofs per chunk: shorter chains AND fewer instructions than the eighteen-lane form.
+    // ZKAMD_COOP_VERIFY=0 keeps the one-lane head, ZKAMD_COOP_PAIRING=0 the eighteen-lane pairing (A/B; *_MAX: the limits).
+    auto env_n = [](const char* name, size_t dflt) {
+        const char* e = getenv(name);
+        return e && *e ? (size_t)strtoull(e, nullptr, 10) : dflt;
+    };
+    const bool coop_on = wide && env_n("ZKAMD_COOP_VERIFY", 1) != 0;
+    const bool coop_inputs = coop_on && n <= env_n("ZKAMD_COOP_INPUTS_MAX", zkcoop::VERIFY_MAX);
+    const bool coop_head = coop_on && n <= std::max(env_n("ZKAMD_COOP_PAIRING_MAX", zkcoop::PAIRING_MAX), env_n("ZKAMD_COOP_INPUTS_MAX", zkcoop::VERIFY_MAX));
+    const bool coop_pairing = coop_head && n <= env_n("ZKAMD_COOP_PAIRING_MAX", zkcoop::PAIRING_MAX) && env_n("ZKAMD_COOP_PAIRING", 1) != 0;
     {
         // the lane-parallel Miller loop reads the lines of B prepared, and the preparation's last point settles B's r-torsion
         // test (k_g2_prepare): the decoder leaves it out there
         ProfScope ps("verify_decode");
-        if (!own_affine)
+        if (own_affine) {
+        } else if (coop_head)
+            zkcoop::verify_decode_g2((const uint32_t*)V->in_g2.as<uint32_t>(), (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(),
+                                     V->st_g2.as<uint32_t>(), (uint32_t)n, g_stream);
+        else
         ZK_LAUNCH(zkdev::k_decode_g2, dim3(b64), dim3(64), 0, g_stream, (const uint32_t*)V->in_g2.as<uint32_t>(),
                   (const uint32_t*)V->fl_g2.as<uint32_t>(), V->aff_g2.as<uint32_t>(), V->st_g2.as<uint32_t>(), (uint32_t)n,
                   (own_proofs || wide) ? 0u : 1u);
     }
     static_assert(zkcoop::VERIFY_NCOEF == zkdev::PAIRING_NCOEF, "coop_verify.cpp restates the loop constants");
-    // a handful of proofs: the line preparation and the input accumulator on rows of 16 lanes (coop_verify.cpp) - the same
-    // tables and the same accumulator, 1.6 + 1.3 ms of one-lane chains shorter; ZKAMD_COOP_VERIFY=0 keeps the one-lane kernels
-    const bool coop_head = wide && n <= zkcoop::VERIFY_MAX && !(getenv("ZKAMD_COOP_VERIFY") && atoi(getenv("ZKAMD_COOP_VERIFY")) == 0);
-    // ... and the Miller loops and the final exponentiation with an Fq12 value on six rows (coop_pairing.cpp): the same words in
-    // V->f, the same verdicts; ZKAMD_COOP_PAIRING=0 keeps the eighteen-lane kernels behind the cooperative head
-    const bool coop_pairing = coop_head && !(getenv("ZKAMD_COOP_PAIRING") && atoi(getenv("ZKAMD_COOP_PAIRING")) == 0);
     if (coop_pairing)
         for (int k = 0; k < 2; k++) {
             if ((k == 0 ? V->gamma_inf : V->delta_inf) || V->lines28[k].cap) continue;
@@ -532,7 +544,11 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     }
     {
         ProfScope ps("verify_decode_g1", g_stream2);
-        if (!own_affine)
+        if (own_affine) {
+        } else if (coop_head)
+            zkcoop::verify_decode_g1((const uint32_t*)V->in_g1.as<uint32_t>(), (const uint32_t*)V->fl_g1.as<uint32_t>(), V->aff_g1.as<uint32_t>(),
+                                     V->st_g1.as<uint32_t>(), (uint32_t)(2 * n), own_proofs ? 0u : 1u, g_stream2);
+        else
         ZK_LAUNCH(zkdev::k_decode_g1, dim3((unsigned)((2 * n + 63) / 64)), dim3(64), 0, g_stream2,
                   (const uint32_t*)V->in_g1.as<uint32_t>(), (const uint32_t*)V->fl_g1.as<uint32_t>(), V->aff_g1.as<uint32_t>(),
                   V->st_g1.as<uint32_t>(), (uint32_t)(2 * n), own_proofs ? 0u : 1u);
@@ -540,7 +556,7 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
     HIP_TRY(hipEventRecord(V->ev_join[0], g_stream2));
     {
         ProfScope ps("verify_inputs", g_copy_stream);
-        if (coop_head)
+        if (coop_inputs)
             zkcoop::verify_inputs(V->ic_table.p, (const uint32_t*)V->scal.as<uint32_t>(), V->part.p, V->acc.as<uint32_t>(),
                                   V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n, g_copy_stream);
         else {
