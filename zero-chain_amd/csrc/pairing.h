@@ -1098,34 +1098,41 @@ k_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags,
 // (r5: four threads per (proof, input), one per 64-bit quarter of the scalar - 32 mixed additions in a row on average instead
 //  of 127 - and eight threads per proof for the sum, with the Euclidean inversion at the end: once the Miller loops and the
 //  line preparation had been shortened this branch, 3.9 ms beside them, was what a verification waited for.)
+// (r6: PARTS pieces per scalar and TPP threads per proof for the sum are template parameters - 4 and 8 as above while the chunk
+//  is a few dozen waves, 16 and 64 from INPUTS_FINE_MIN proofs, where the 4 x 21 chains of 32 additions per proof left the
+//  machine at 1.4 waves per SIMD for 2.3 + 1.0 ms beside a pairing that rows had shortened to 2.9 ms.)
+constexpr size_t INPUTS_FINE_MIN = 256;
+template <uint32_t PARTS>
 static __global__ void __launch_bounds__(64, 2)
 k_inputs_mul(const Affine<Fq>* __restrict__ table, const uint32_t* __restrict__ scalars, XYZZ<Fq>* __restrict__ part,
              uint32_t n_ic, uint32_t n_proofs) {
+    constexpr uint32_t BITS = 256 / PARTS;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ni = n_ic - 1;
-    if (t >= 4 * ni * n_proofs) return;
-    const uint32_t qd = t & 3u, u = t >> 2, p = u / ni, j = u % ni + 1;
+    if (t >= PARTS * ni * n_proofs) return;
+    const uint32_t qd = t % PARTS, u = t / PARTS, p = u / ni, j = u % ni + 1;
     const uint32_t* s = scalars + ((size_t)p * ni + (j - 1)) * 8;
     XYZZ<Fq> acc = XYZZ<Fq>::inf();
-    for (uint32_t k = 64 * qd; k < 64 * qd + 64 && k < 255; k++)
+    for (uint32_t k = BITS * qd; k < BITS * qd + BITS && k < 255; k++)
         if ((s[k >> 5] >> (k & 31)) & 1u) madd(acc, table[(size_t)k * n_ic + j], false);
     part[t] = acc;
 }
 // out: [n][24] words affine (x, y) in the Fq32 layout; inf[i] = 1 if the accumulator is the point at infinity.
 // Eight threads per proof (eight proofs per workgroup): each sums every eighth of the proof's 4 (n_ic - 1) partial products,
 // a tree in LDS adds the eight.
+template <uint32_t PARTS, uint32_t TPP>
 static __global__ void __launch_bounds__(64, 2)
 k_inputs_sum(const Affine<Fq>* __restrict__ table, const XYZZ<Fq>* __restrict__ part, uint32_t* __restrict__ out,
              uint32_t* __restrict__ inf, uint32_t n_ic, uint32_t n_proofs) {
     ZK_SHARED XYZZ<Fq> sm[64];
-    const uint32_t tid = threadIdx.x, r = tid & 7u, p = blockIdx.x * 8 + (tid >> 3);
-    const uint32_t np = 4 * (n_ic - 1);
+    const uint32_t tid = threadIdx.x, r = tid % TPP, p = blockIdx.x * (64 / TPP) + tid / TPP;
+    const uint32_t np = PARTS * (n_ic - 1);
     XYZZ<Fq> acc = XYZZ<Fq>::inf();
     if (p < n_proofs)
-        for (uint32_t k = r; k < np; k += 8) acc = xadd(acc, part[(size_t)p * np + k]);
+        for (uint32_t k = r; k < np; k += TPP) acc = xadd(acc, part[(size_t)p * np + k]);
     sm[tid] = acc;
     __syncthreads();
-    for (uint32_t st = 4; st >= 1; st >>= 1) {
+    for (uint32_t st = TPP / 2; st >= 1; st >>= 1) {
         if (r < st) sm[tid] = xadd(sm[tid], sm[tid + st]);
         __syncthreads();
     }

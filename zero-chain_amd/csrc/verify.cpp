@@ -474,7 +474,7 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
         HIP_TRY(hipMemsetAsync(V->st_g2.p, 0, n * 4, g_stream));
         HIP_TRY(hipStreamSynchronize(g_stream));   // (a1 / a2 are about to go out of scope: pageable sources of asynchronous copies)
     }
-    ZK_TRY(V->part.ensure((size_t)n * (ni ? 4 * ni : 1) * sizeof(DG1)));
+    ZK_TRY(V->part.ensure((size_t)n * (ni ? 16 * ni : 1) * sizeof(DG1)));   // (sixteen pieces per scalar from INPUTS_FINE_MIN proofs)
     ZK_TRY(V->acc.ensure(n * 96));
     ZK_TRY(V->acc_inf.ensure(n * 4));
     ZK_TRY(V->skip.ensure(n * 4));
@@ -560,12 +560,20 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
             zkcoop::verify_inputs(V->ic_table.p, (const uint32_t*)V->scal.as<uint32_t>(), V->part.p, V->acc.as<uint32_t>(),
                                   V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n, g_copy_stream);
         else {
+        if (n >= env_n("ZKAMD_INPUTS_FINE_MIN", zkdev::INPUTS_FINE_MIN)) {   // sixteen pieces per scalar, a wave per proof for the sum
+            if (ni)
+                ZK_LAUNCH(zkdev::k_inputs_mul<16>, dim3((unsigned)((16 * n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
+                          (const DG1A*)V->ic_table.as<DG1A>(), (const uint32_t*)V->scal.as<uint32_t>(), V->part.as<DG1>(), V->n_ic, (uint32_t)n);
+            ZK_LAUNCH_SYNC((zkdev::k_inputs_sum<16, 64>), dim3((unsigned)n), dim3(64), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
+                           (const DG1*)V->part.as<DG1>(), V->acc.as<uint32_t>(), V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n);
+        } else {
         if (ni)
-            ZK_LAUNCH(zkdev::k_inputs_mul, dim3((unsigned)((4 * n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
+            ZK_LAUNCH(zkdev::k_inputs_mul<4>, dim3((unsigned)((4 * n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
                       (const DG1A*)V->ic_table.as<DG1A>(), (const uint32_t*)V->scal.as<uint32_t>(), V->part.as<DG1>(), V->n_ic,
                       (uint32_t)n);
-        ZK_LAUNCH_SYNC(zkdev::k_inputs_sum, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
+        ZK_LAUNCH_SYNC((zkdev::k_inputs_sum<4, 8>), dim3((unsigned)((n + 7) / 8)), dim3(64), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
                   (const DG1*)V->part.as<DG1>(), V->acc.as<uint32_t>(), V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n);
+        }
         }
     }
     HIP_TRY(hipEventRecord(V->ev_join[1], g_copy_stream));
