@@ -1036,7 +1036,7 @@ def verifier_forms_agree(lib, seed=6, n_in=4, n_aux=10, n_con=13):
     r1, asg, P, pk = helpers.small_case(seed, n_in, n_aux, n_con)
     params = zk.Parameters.read(pk, checked=False, lib=lib)
     pvk = zk.prepare_verifying_key(params)
-    keys = ("ZKAMD_COOP_PAIRING", "ZKAMD_COOP_VERIFY", "ZKAMD_COOP_INPUTS_MAX", "ZKAMD_INPUTS_FINE_MIN")
+    keys = ("ZKAMD_COOP_PAIRING", "ZKAMD_COOP_VERIFY", "ZKAMD_COOP_INPUTS_MAX", "ZKAMD_INPUTS_FINE_MIN", "ZKAMD_COOP_PREPARE_ROWS")
     saved = {k: os.environ.get(k) for k in keys}
     try:
         good = [helpers.expected_proof_trapdoor(P, asg, r, s) for r, s in ((1, 2), (bls.R_MOD - 2, 0), (99, 2 ** 200 + 1))]
@@ -1048,7 +1048,8 @@ def verifier_forms_agree(lib, seed=6, n_in=4, n_aux=10, n_con=13):
         ins = [inputs, inputs, inputs, inputs, inputs, bad_in, inputs]
         want = [True, False, True, False, True, False, True]
         # (the last form: the one-lane accumulator of a large chunk - sixteen pieces per scalar, a wave per proof for the sum)
-        for form in ({}, {"ZKAMD_COOP_PAIRING": "0"}, {"ZKAMD_COOP_VERIFY": "0"}, {"ZKAMD_COOP_INPUTS_MAX": "0", "ZKAMD_INPUTS_FINE_MIN": "1"}):
+        for form in ({}, {"ZKAMD_COOP_PAIRING": "0"}, {"ZKAMD_COOP_VERIFY": "0"}, {"ZKAMD_COOP_INPUTS_MAX": "0", "ZKAMD_INPUTS_FINE_MIN": "1"},
+                     {"ZKAMD_COOP_PREPARE_ROWS": "1"}):
             for k in keys:
                 os.environ.pop(k, None)
             os.environ.update(form)

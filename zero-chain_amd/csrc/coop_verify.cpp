@@ -12,6 +12,7 @@
 //
 // Reference: core/bellman-verifier/src/verifier.rs:32-63 (the accumulator), core/pairing/src/bls12_381/mod.rs:335-359,
 // :98-160 (G2Prepared::from_affine: the doubling / addition steps and their coefficient scaling), ec.rs:296-526.
+#include <stdlib.h>
 #include "gpu_rt.h"
 #include "coop_curve.h"
 #include "coop_verify.h"
@@ -287,6 +288,160 @@ k_cv_g2_prepare(const uint32_t* __restrict__ q, Fq28* __restrict__ stage, uint32
             if (!in) st[i] = 2;
     }
 }
+// ---- the same preparation with FOUR rows (one wave) per point.  A step of the chain above is four (doubling) or seven
+// (addition) groups of independent products, each group ~1100 instructions for its one row - a lone wave is bound by issue,
+// so the 63 + 5 steps were 0.66 ms.  Here the four rows of a wave hold the running point replicated, every row computes ONE
+// square / product / reduction of a group (two accumulators instead of eight) and the group ends with an exchange through LDS
+// from which every row reads all four results; the linear steps in between are computed by all four rows alike (they run in
+// lockstep: it costs nothing).  Same formulas, same bounds, the same stage words.
+ZK_DI void cv_status(uint32_t* st, uint32_t i, uint32_t v) {
+#ifndef ZK_EMU
+    if (coop_lane() == 0)
+#endif
+        st[i] = v;
+}
+struct QuadLds {
+    CLanes w[4][2][COOP_W];
+};
+ZK_DI uint32_t cvq_l() {
+#ifndef ZK_EMU
+    return coop_lane();
+#else
+    return 0u;
+#endif
+}
+ZK_DI CFq2 cvq_sel(uint32_t r, const CFq2& a0, const CFq2& a1, const CFq2& a2, const CFq2& a3) {
+    CFq2 o;
+    ZK_COOP_EACH(j) {
+        o.c0.l.v[j] = r == 0 ? a0.c0.l.v[j] : r == 1 ? a1.c0.l.v[j] : r == 2 ? a2.c0.l.v[j] : a3.c0.l.v[j];
+        o.c1.l.v[j] = r == 0 ? a0.c1.l.v[j] : r == 1 ? a1.c1.l.v[j] : r == 2 ? a2.c1.l.v[j] : a3.c1.l.v[j];
+    }
+    return o;
+}
+ZK_DI void cvq_gather(QuadLds& q, uint32_t r, const CFq2& mine, CFq2 (&all)[4]) {
+    q.w[r][0][cvq_l()] = mine.c0.l;
+    q.w[r][1][cvq_l()] = mine.c1.l;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) all[k] = CFq2{CFq{q.w[k][0][cvq_l()]}, CFq{q.w[k][1][cvq_l()]}};
+    __syncthreads();
+}
+// out[k] = a_k^2 (components of every a_k below B p)
+template <int B>
+ZK_DI void cvq_sqr(QuadLds& q, uint32_t r, const CFq2& a0, const CFq2& a1, const CFq2& a2, const CFq2& a3, CFq2 (&out)[4]) {
+    CLanes x[2][1], y[2][1];
+    coop_slot_sqr<B>(x, y, 0, cvq_sel(r, a0, a1, a2, a3));
+    CFq g[2];
+    coop_products<2, 1>(x, y, g);
+    cvq_gather(q, r, CFq2{g[0], g[1]}, out);
+}
+// out[k] = a_k b_k (c1 of every a_k below 15 p)
+ZK_DI void cvq_mul(QuadLds& q, uint32_t r, const CFq2& a0, const CFq2& b0, const CFq2& a1, const CFq2& b1, const CFq2& a2, const CFq2& b2,
+                   const CFq2& a3, const CFq2& b3, CFq2 (&out)[4]) {
+    CLanes x[2][2], y[2][2];
+    coop_slot_mul(x, y, 0, cvq_sel(r, a0, a1, a2, a3), cvq_sel(r, b0, b1, b2, b3));
+    CFq g[2];
+    coop_products<2, 2>(x, y, g);
+    cvq_gather(q, r, CFq2{g[0], g[1]}, out);
+}
+// out[k] = a_k below 2p (a product with one)
+ZK_DI void cvq_red(QuadLds& q, uint32_t r, const CFq2& a0, const CFq2& a1, const CFq2& a2, CFq2 (&out)[4]) {
+    const CFq2 a = cvq_sel(r, a0, a1, a2, a2);
+    const CLanes one = CFq::one().l;
+    const CLanes x[2][1] = {{a.c0.l}, {a.c1.l}}, y[2][1] = {{one}, {one}};
+    CFq g[2];
+    coop_products<2, 1>(x, y, g);
+    cvq_gather(q, r, CFq2{g[0], g[1]}, out);
+}
+ZK_DI void cvq_double_step(QuadLds& q, uint32_t r, CFq2& X, CFq2& Y, CFq2& Z, CvLine& l) {
+    CFq2 s1[4], s2[4], m[4], rd[4];
+    cvq_sqr<4>(q, r, X, Y, Z, add(Y, Z), s1);                              // X^2, Y^2, Z^2, (Y + Z)^2
+    const CFq2 A = s1[0], B = s1[1], zz = s1[2], t2 = s1[3];
+    const CFq2 E = add(dbl(A), A);                                         // 3 A            < 6
+    cvq_sqr<8>(q, r, B, add(X, B), E, add(X, E), s2);                      // B^2, (X + B)^2, E^2, (X + E)^2
+    const CFq2 C = s2[0], t1 = s2[1], G = s2[2], t3 = s2[3];
+    const CFq2 D = dbl(sub_b<2>(sub_b<2>(t1, A), C));                      // 4 X Y^2        < 16
+    const CFq2 x3 = sub_b<32>(G, dbl(D));                                  //                < 35
+    const CFq2 z3 = sub_b<2>(sub_b<2>(t2, B), zz);                         // 2 Y Z          < 8
+    const CFq2 c8 = dbl(dbl(dbl(C)));                                      //                < 16
+    cvq_mul(q, r, E, sub_b<35>(D, x3), z3, zz, E, zz, E, zz, m);           // E (D - x3), z3 zz, E zz
+    const CFq2 y3 = sub_b<16>(m[0], c8);                                   //                < 19
+    l.a = dbl(m[1]);
+    l.b = neg_b<4>(dbl(m[2]));
+    l.c = sub_b<8>(sub_b<2>(sub_b<2>(t3, A), G), dbl(dbl(B)));
+    cvq_red(q, r, x3, y3, z3, rd);
+    X = rd[0];
+    Y = rd[1];
+    Z = rd[2];
+}
+ZK_DI void cvq_add_step(QuadLds& q, uint32_t r, CFq2& X, CFq2& Y, CFq2& Z, const CFq2& qx, const CFq2& qy, const CFq2& yy, CvLine& l) {
+    CFq2 g1[4], g2[4], g3[4], g4[4], g5[4], g6[4], rd[4];
+    cvq_sqr<4>(q, r, Z, add(qy, Z), Z, Z, g1);                             // Z^2, (y_Q + Z)^2
+    const CFq2 zz = g1[0], t1 = g1[1];
+    const CFq2 e = sub_b<2>(sub_b<2>(t1, yy), zz);                         // 2 y_Q Z        < 8
+    cvq_mul(q, r, zz, qx, e, zz, zz, qx, zz, qx, g2);                      // x_Q Z^2, 2 y_Q Z^3
+    const CFq2 u2 = g2[0], s2x2 = g2[1];
+    const CFq2 H = sub_b<2>(u2, X);                                        //                < 5
+    const CFq2 r2 = sub_b<4>(s2x2, dbl(Y));                                //                < 7
+    cvq_sqr<7>(q, r, H, r2, add(Z, H), H, g3);                             // H^2, r2^2, (Z + H)^2
+    const CFq2 HH = g3[0], r2sq = g3[1], zh = g3[2];
+    const CFq2 H4 = dbl(dbl(HH));                                          //                < 8
+    cvq_mul(q, r, H4, H, H4, X, r2, qx, r2, qx, g4);                       // 4 H^3, 4 X H^2, r2 x_Q
+    const CFq2 H3x4 = g4[0], V = g4[1], rq = g4[2];
+    const CFq2 x3 = sub_sub2<2, 2>(r2sq, H3x4, V);                         // r2^2 - 4 H^3 - 8 X H^2  < 9
+    const CFq2 z3 = sub_b<2>(sub_b<2>(zh, zz), HH);                        // 2 Z H          < 8
+    cvq_mul(q, r, r2, sub_b<9>(V, x3), Y, H3x4, Y, H3x4, Y, H3x4, g5);     // r2 (V - x3), Y 4 H^3
+    const CFq2 y3 = sub_b<4>(g5[0], dbl(g5[1]));                           //                < 7
+    cvq_sqr<10>(q, r, add(qy, z3), z3, z3, z3, g6);                        // (y_Q + Z3)^2, Z3^2
+    const CFq2 yz2 = sub_b<2>(sub_b<2>(g6[0], yy), g6[1]);                 // 2 y_Q Z3       < 8
+    l.a = dbl(z3);
+    l.b = neg_b<14>(dbl(r2));
+    l.c = sub_b<8>(dbl(rq), yz2);
+    cvq_red(q, r, x3, y3, z3, rd);
+    X = rd[0];
+    Y = rd[1];
+    Z = rd[2];
+}
+// q, stage, st as k_cv_g2_prepare; one workgroup of four rows per point
+static __global__ void __launch_bounds__(4 * COOP_W)
+k_cv_g2_prepare_quad(const uint32_t* __restrict__ q, Fq28* __restrict__ stage, uint32_t n, uint32_t* st) {
+    ZK_SHARED QuadLds lds;
+    const uint32_t i = blockIdx.x, r = coop_row_in_block();
+    if (st && st[i] != 0) return;   // nothing was decoded
+    const CFq2 qx = cv_import2(q + (size_t)i * 48), qy = cv_import2(q + (size_t)i * 48 + 24);
+    CFq2 yy, unused;
+    cv_sqr2<2, 2>(qy, qy, yy, unused);
+    CFq2 X = qx, Y = qy, Z = CFq2::one();
+    Fq28* o = stage + (size_t)i * PAIRING_NCOEF * 6;
+    CvLine l;
+    int idx = 0;
+#pragma unroll 1
+    for (int b = 61; b >= 0; b--) {
+        cvq_double_step(lds, r, X, Y, Z, l);
+        if (r == 0) cv_put(o + idx * 6, l);
+        idx++;
+        if ((PAIRING_LOOP >> b) & 1ull) {
+            cvq_add_step(lds, r, X, Y, Z, qx, qy, yy, l);
+            if (r == 0) cv_put(o + idx * 6, l);
+            idx++;
+        }
+    }
+    cvq_double_step(lds, r, X, Y, Z, l);
+    if (r == 0) cv_put(o + idx * 6, l);
+    if (st) {
+        const uint32_t cx1[12] = ZK_G2_PSI_CX1_MONT_32, cy0[12] = ZK_G2_PSI_CY0_MONT_32, cy1[12] = ZK_G2_PSI_CY1_MONT_32;
+        const CFq2 kx{CFq::zero(), coop_import(cx1)}, ky{coop_import(cy0), coop_import(cy1)};
+        const CFq2 cqx{qx.c0, neg_b<2>(qx.c1)}, cqy{qy.c0, neg_b<2>(qy.c1)};
+        CFq2 px, py, zz, unused2;
+        cv_mul2(kx, cqx, ky, cqy, px, py);
+        cv_sqr2<2, 2>(Z, Z, zz, unused2);
+        CFq2 pz, zzz;
+        cv_mul2(px, zz, zz, Z, pz, zzz);
+        const CFq2 pyz = mul(py, zzz);
+        const bool in = !is_zero_full(Z) && is_zero_full(sub_b<2>(X, pz)) && is_zero_full(add(Y, pyz));
+        if (!in && r == 0) cv_status(st, i, 2);
+    }
+}
 // stage -> the tables the Miller loop reads: out[(item 68 + step) 72 + which 24 + comp 12 ...], canonical words.  One lane
 // per field element: 408 per point, all side by side.
 static __global__ void __launch_bounds__(64)
@@ -321,12 +476,6 @@ ZK_DI XYZZ<CFq> cv_mul_x_abs(const XYZZ<CFq>& p) {
         if ((ZK_BLS_X_ABS >> b) & 1ull) acc = xadd(acc, p);
     }
     return acc;
-}
-ZK_DI void cv_status(uint32_t* st, uint32_t i, uint32_t v) {
-#ifndef ZK_EMU
-    if (coop_lane() == 0)
-#endif
-        st[i] = v;
 }
 static __global__ void __launch_bounds__(CV_THIN * COOP_W)
 k_cv_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out, uint32_t* __restrict__ st,
@@ -440,8 +589,12 @@ void verify_decode_g2(const uint32_t* in, const uint32_t* flags, uint32_t* out, 
 }
 size_t g2_prepare_stage_bytes(uint32_t n) { return (size_t)n * zkdev::PAIRING_NCOEF * 6 * sizeof(zkdev::Fq28); }
 void verify_g2_prepare(const uint32_t* q, void* stage, uint32_t* out, uint32_t n, uint32_t* st_flags, hipStream_t st) {
-    ZK_LAUNCH(zkdev::k_cv_g2_prepare, dim3((n + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, q, (zkdev::Fq28*)stage,
-              n, st_flags);
+    const bool one_row = getenv("ZKAMD_COOP_PREPARE_ROWS") && atoi(getenv("ZKAMD_COOP_PREPARE_ROWS")) == 1;   // A/B: a row per point
+    if (one_row)
+        ZK_LAUNCH(zkdev::k_cv_g2_prepare, dim3((n + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, q,
+                  (zkdev::Fq28*)stage, n, st_flags);
+    else
+        ZK_LAUNCH_SYNC(zkdev::k_cv_g2_prepare_quad, dim3(n), dim3(4 * COOP_W), 0, st, q, (zkdev::Fq28*)stage, n, st_flags);
     if (!out) return;
     const uint32_t cnt = n * (uint32_t)zkdev::PAIRING_NCOEF * 6;
     ZK_LAUNCH(zkdev::k_cv_export_coefs, dim3((cnt + 63) / 64), dim3(64), 0, st, (const zkdev::Fq28*)stage, out, n, (const uint32_t*)st_flags);
