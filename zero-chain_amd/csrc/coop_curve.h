@@ -266,28 +266,58 @@ ZK_DI void coop_export(const CFq& a, uint32_t* h) {
         for (int i = 0; i < 12; i++) h[i] = w[i];
     }
 }
-// a^e for a public 12-word exponent, MSB first: ~380 squarings and ~190 products in a row, 0.19 ms for a lone row
-ZK_DI CFq coop_pow(const CFq& a, const uint32_t (&e)[12]) {
-    CFq r = a;
+// a^e for a public 12-word exponent: sliding windows of four bits over a table of the odd powers a, a^3, ..., a^15 that
+// the row keeps in LDS (tab: this row's eight entries; every lane reads back only what it wrote itself, so no barrier) -
+// ~376 squarings and ~84 products in a row for a 381-bit exponent of weight ~190 (square-and-multiply: 570): 0.15 ms.
+constexpr int COOP_POW_TAB = 8;
+typedef CLanes CoopPowTab[COOP_POW_TAB][COOP_W];
+ZK_DI CFq coop_pow(const CFq& a, const uint32_t (&e)[12], CoopPowTab& tab) {
+#ifndef ZK_EMU
+    const uint32_t l = coop_lane();
+#else
+    const uint32_t l = 0;
+#endif
+    const CFq a2 = mul(a, a);
+    CFq p = a;
+    tab[0][l] = a.l;
+#pragma unroll 1
+    for (int i = 1; i < COOP_POW_TAB; i++) {
+        p = mul(p, a2);
+        tab[i][l] = p.l;
+    }
+    auto bit_at = [&](int i) { return (e[i >> 5] >> (i & 31)) & 1u; };
+    int bit = 383;
+    while (bit >= 0 && !bit_at(bit)) bit--;
+    CFq r = CFq::one();   // (e == 0)
     bool started = false;
 #pragma unroll 1
-    for (int i = 11; i >= 0; i--) {
-        const uint32_t w = e[i];
-#pragma unroll 1
-        for (int b = 31; b >= 0; b--) {
-            if (started) r = mul(r, r);
-            if ((w >> b) & 1u) {
-                if (started) r = mul(r, a);
-                started = true;
-            }
+    while (bit >= 0) {
+        if (!bit_at(bit)) {
+            r = mul(r, r);
+            bit--;
+            continue;
         }
+        int len = bit >= 3 ? 4 : bit + 1;
+        uint32_t v = 0;
+        for (int k = 0; k < len; k++) v = (v << 1) | bit_at(bit - k);
+        while (!(v & 1u)) {
+            v >>= 1;
+            len--;
+        }
+        if (started)
+#pragma unroll 1
+            for (int k = 0; k < len; k++) r = mul(r, r);
+        const CFq t{tab[v >> 1][l]};
+        r = started ? mul(r, t) : t;
+        started = true;
+        bit -= len;
     }
     return r;
 }
 // a^(q - 2) (the one-lane Euclidean inversion - divergent word loops - takes ~0.3 ms)
-ZK_DI CFq inv(const CFq& a) {
+ZK_DI CFq inv(const CFq& a, CoopPowTab& tab) {
     const uint32_t e[12] = ZK_FQ_EXP_QM2_32;
-    return coop_pow(a, e);
+    return coop_pow(a, e, tab);
 }
 // is the PLAIN value of a (any stored magnitude) above (q - 1) / 2, i.e. y > -y in the reference's ordering (fq.rs:707-713)?
 // The Montgomery reduction of a x 1 leaves the plain residue below 2p; it is gathered, brought below p and compared.

@@ -39,6 +39,9 @@ struct C12Lds {
     C12Slot f, g;           // the two operands of a product
     uint32_t flag;
 };
+struct C12LdsInv : C12Lds {
+    CoopPowTab powtab[12];  // the rows' tables of the one inversion in Fq
+};
 ZK_DI uint32_t c12_l() {
 #ifndef ZK_EMU
     return coop_lane();
@@ -243,7 +246,7 @@ ZK_C12_FN CFq c12_exp_x(C12Lds& lds, uint32_t k, uint32_t c, const CFq& a) {
 // 1 / f = conj(f) h / N with g = f conj(f) in Fq6 (w -> -w is the conjugation over Fq6), h = g^(q^2) g^(q^4) and
 // N = g h in Fq2 (the norm of Fq6 over Fq2: q^2 generates that Galois group); 1 / N = conj(N) / (N0^2 + N1^2), and the one
 // inversion in Fq is a^(q - 2) on the row (every row computes it: the rows run the same instructions anyway)
-ZK_C12_FN CFq c12_inv(C12Lds& lds, uint32_t k, uint32_t c, const CFq& f, const C12Frob& fr) {
+ZK_C12_FN CFq c12_inv(C12LdsInv& lds, uint32_t k, uint32_t c, const CFq& f, const C12Frob& fr) {
     const CFq fb = c12_conj(k, f);
     const CFq g = c12_mul(lds, k, c, f, fb);
     const CFq gq2 = c12_frob(lds, k, c, g, 2, fr), gq4 = c12_frob(lds, k, c, gq2, 2, fr);
@@ -256,7 +259,7 @@ ZK_C12_FN CFq c12_inv(C12Lds& lds, uint32_t k, uint32_t c, const CFq& f, const C
     const CLanes xs[1][2] = {{N0.l, N1.l}}, ys[1][2] = {{N0.l, N1.l}};
     CFq nn[1];
     coop_products<1, 2>(xs, ys, nn);
-    const CFq ni = inv(nn[0]);
+    const CFq ni = inv(nn[0], lds.powtab[2 * k + c]);
     CFq i0, i1;
     mul2(N0, ni, neg_b<2>(N1), ni, i0, i1);
     const CFq fh = c12_mul(lds, k, c, fb, h);
@@ -265,7 +268,7 @@ ZK_C12_FN CFq c12_inv(C12Lds& lds, uint32_t k, uint32_t c, const CFq& f, const C
 static __global__ void __launch_bounds__(C12_ROWS * COOP_W)
 k_c12_final_exp(const uint32_t* __restrict__ f_in, const uint32_t* __restrict__ gam, const uint32_t* __restrict__ want,
                 const uint32_t* __restrict__ valid, uint32_t* __restrict__ ok, uint32_t* value_out, uint32_t n) {
-    ZK_SHARED C12Lds lds;
+    ZK_SHARED C12LdsInv lds;
     const uint32_t row = coop_row_in_block(), k = row >> 1, c = row & 1u, item = blockIdx.x;
     if (valid && !valid[item]) {
         if (ok && threadIdx.x == 0) ok[item] = 0;

@@ -71,6 +71,7 @@ static __global__ void __launch_bounds__(CV_ROWS * COOP_W)
 k_cv_inputs_sum(const Affine<Fq28>* __restrict__ table, const XYZZ<Fq28>* __restrict__ part, uint32_t* __restrict__ out,
                 uint32_t* __restrict__ inf, uint32_t n_ic) {
     ZK_SHARED XYZZ<CFq> sm[CV_ROWS * COOP_W];
+    ZK_SHARED CoopPowTab powtab;
     const uint32_t r = coop_row_in_block(), tid = threadIdx.x, p = blockIdx.x, np = 4 * (n_ic - 1);
     XYZZ<CFq> acc = XYZZ<CFq>::inf();
     if (r < np) {
@@ -97,7 +98,7 @@ k_cv_inputs_sum(const Affine<Fq28>* __restrict__ table, const XYZZ<Fq28>* __rest
         inf[p] = is_inf ? 1u : 0u;
     CFq ax = CFq::zero(), ay = CFq::zero();
     if (!is_inf) {
-        const CFq izzz = inv(acc.zzz);
+        const CFq izzz = inv(acc.zzz, powtab);
         CFq sq[2];
         mul2(acc.zz, acc.zz, izzz, izzz, sq[0], sq[1]);
         const CFq izz = mul(sq[0], sq[1]);   // zz^2 / zzz^2 = 1 / zz
@@ -480,6 +481,8 @@ ZK_DI XYZZ<CFq> cv_mul_x_abs(const XYZZ<CFq>& p) {
 static __global__ void __launch_bounds__(CV_THIN * COOP_W)
 k_cv_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out, uint32_t* __restrict__ st,
                uint32_t n, uint32_t check_subgroup) {
+    ZK_SHARED CoopPowTab powtab[CV_THIN];
+    CoopPowTab& tab = powtab[coop_row_in_block()];
     const uint32_t i = coop_row();
     if (i >= n) return;
     if (flags[i] & 1u) {
@@ -489,7 +492,7 @@ k_cv_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ fla
     const uint32_t e[12] = ZK_FQ_EXP_QP1D4_32;
     const CFq x = coop_import_plain(in + (size_t)i * 12);
     const CFq rhs = add(mul(mul(x, x), x), CFq::from_const(Fq28Consts::B));   // < 3
-    CFq y = coop_pow(rhs, e);                                                 // q = 3 mod 4
+    CFq y = coop_pow(rhs, e, tab);                                                 // q = 3 mod 4
     if (!is_zero_full(sub_b<4>(mul(y, y), rhs))) {
         cv_status(st, i, 1);
         return;
@@ -515,7 +518,7 @@ k_cv_decode_g1(const uint32_t* __restrict__ in, const uint32_t* __restrict__ fla
     cv_status(st, i, 0);
 }
 // some square root in Fq2 by the norm route of pairing.h f2_sqrt (two exponentiations in Fq); a below 4
-ZK_DI bool cv_f2_sqrt(const CFq2& a, CFq2& out) {
+ZK_DI bool cv_f2_sqrt(const CFq2& a, CFq2& out, CoopPowTab& tab) {
     if (is_zero_full(a)) {
         out = CFq2::zero();
         return true;
@@ -525,9 +528,9 @@ ZK_DI bool cv_f2_sqrt(const CFq2& a, CFq2& out) {
     const CLanes xs[1][2] = {{a.c0.l, a.c1.l}}, ys[1][2] = {{a.c0.l, a.c1.l}};
     CFq nn[1];
     coop_products<1, 2>(xs, ys, nn);                          // a0^2 + a1^2
-    const CFq s = coop_pow(nn[0], e_s);
+    const CFq s = coop_pow(nn[0], e_s, tab);
     const CFq delta = is_zero_full(a.c1) ? mul(a.c0, CFq::one()) : mul(add(a.c0, s), h);
-    const CFq t = coop_pow(delta, e_t);
+    const CFq t = coop_pow(delta, e_t, tab);
     CFq x0, a1h, tt;
     mul2(t, delta, a.c1, h, x0, a1h);
     CFq x0sq, w0;
@@ -540,6 +543,8 @@ ZK_DI bool cv_f2_sqrt(const CFq2& a, CFq2& out) {
 static __global__ void __launch_bounds__(CV_THIN * COOP_W)
 k_cv_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out, uint32_t* __restrict__ st,
                uint32_t n) {
+    ZK_SHARED CoopPowTab powtab[CV_THIN];
+    CoopPowTab& tab = powtab[coop_row_in_block()];
     const uint32_t i = coop_row();
     if (i >= n) return;
     if (flags[i] & 1u) {
@@ -550,7 +555,7 @@ k_cv_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ fla
     const CFq b = CFq::from_const(Fq28Consts::B);
     const CFq2 rhs = add(mul(sqr(x), x), CFq2{b, b});          // 4 (u + 1), ec.rs:1567-1572
     CFq2 y;
-    if (!cv_f2_sqrt(rhs, y)) {
+    if (!cv_f2_sqrt(rhs, y, tab)) {
         cv_status(st, i, 1);
         return;
     }
