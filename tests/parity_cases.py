@@ -1028,6 +1028,34 @@ def verifier_small_circuit(lib, seed=5, n_in=3, n_aux=12, n_con=14):
         params.close()
 
 
+def fq_inverse_on_rows(lib, n=600, seed=77):
+    """The inversion in Fq of the verification kernels on rows - a half-GCD on 30-bit limbs (csrc/coop_inv.h) - against
+    pow(x, q - 2, q) on edge values (0, 1, q - 1, 2, small and large powers of two, values around 2^30 k limb boundaries,
+    values whose inverse is small) and on random ones; through the test hook zk_hook_fq_inverse (hooks / emulation builds)."""
+    import ctypes as C2
+    Q = bls.Q_MOD
+    rng = synth.SplitMix64(seed)
+    xs = [0, 1, Q - 1, 2, Q - 2, 3, (Q + 1) // 2, (Q - 1) // 2, 1 << 30, (1 << 30) - 1, (1 << 60) + 1, 1 << 380, Q >> 1, Q - (1 << 200)]
+    xs += [pow(k, Q - 2, Q) for k in (2, 3, 5, 7, 1 << 29, (1 << 31) - 1, 1 << 62)]
+    xs += [(1 << (30 * k)) % Q for k in range(1, 13)] + [((1 << (30 * k)) - 1) % Q for k in range(1, 13)]
+    while len(xs) < n:
+        xs.append(rng.field(Q))
+    R = pow(2, 384, Q)
+    words = np.zeros((len(xs), 12), dtype=np.uint32)
+    for i, x in enumerate(xs):
+        m = x * R % Q
+        words[i] = [(m >> (32 * j)) & 0xffffffff for j in range(12)]
+    out = np.zeros_like(words)
+    fn = lib.dll.zk_hook_fq_inverse
+    fn.restype = C2.c_int
+    fn.argtypes = [C2.c_void_p, C2.c_void_p, C2.c_size_t]
+    lib.check(fn(words.ctypes.data, out.ctypes.data, len(xs)))
+    Rinv = pow(R, Q - 2, Q)
+    for i, x in enumerate(xs):
+        got = sum(int(out[i, j]) << (32 * j) for j in range(12)) * Rinv % Q
+        assert got == pow(x, Q - 2, Q), "1 / %x" % x
+
+
 def verifier_forms_agree(lib, seed=6, n_in=4, n_aux=10, n_con=13):
     """A handful of proofs is verified on rows (coop_verify.cpp: the accumulator and the lines of B; coop_pairing.cpp: the
     Miller loops and the final exponentiation with an Fq12 value on six rows): the verdicts are those of the eighteen-lane

@@ -199,6 +199,10 @@ def test_verifier_small_circuit(emu_lib):
     pc.verifier_small_circuit(emu_lib)
 
 
+def test_fq_inverse_on_rows(emu_lib):
+    pc.fq_inverse_on_rows(emu_lib)
+
+
 def test_verifier_forms_agree(emu_lib):
     pc.verifier_forms_agree(emu_lib)
 

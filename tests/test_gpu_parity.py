@@ -337,6 +337,10 @@ def test_verifier_small_circuit(gpu_lib):
     pc.verifier_small_circuit(gpu_lib)
 
 
+def test_fq_inverse_on_rows(gpu_hooks_lib):
+    pc.fq_inverse_on_rows(gpu_hooks_lib, n=4000)
+
+
 def test_verifier_forms_agree(gpu_lib):
     pc.verifier_forms_agree(gpu_lib)
 

@@ -56,7 +56,10 @@ def _deps(path, seen=None):
 
 
 def _uses_hooks(tu):
-    return any("hook_env(" in open(d).read() for d in _deps(os.path.join(CSRC, tu)) if not d.endswith("host_common.h"))
+    def marked(path):
+        text = open(path).read()
+        return "hook_env(" in text or "ZK_TEST_HOOKS" in text
+    return any(marked(d) for d in _deps(os.path.join(CSRC, tu)) if not d.endswith("host_common.h"))
 
 
 def build_lib(force=False, hooks=False):

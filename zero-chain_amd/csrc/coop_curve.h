@@ -8,6 +8,7 @@
 #pragma once
 #include "dev_curve.h"
 #include "coop_field.h"
+#include "coop_inv.h"
 
 namespace zkdev {
 
@@ -314,10 +315,30 @@ ZK_DI CFq coop_pow(const CFq& a, const uint32_t (&e)[12], CoopPowTab& tab) {
     }
     return r;
 }
-// a^(q - 2) (the one-lane Euclidean inversion - divergent word loops - takes ~0.3 ms)
-ZK_DI CFq inv(const CFq& a, CoopPowTab& tab) {
+// a^(q - 2): 0.15 ms on a row
+ZK_DI CFq inv_fermat(const CFq& a, CoopPowTab& tab) {
     const uint32_t e[12] = ZK_FQ_EXP_QM2_32;
     return coop_pow(a, e, tab);
+}
+// 1 / a (0 for 0) by the half-GCD of coop_inv.h: the row's value is gathered as the plain integer below q, every lane runs
+// the 13-limb algorithm on it, and the result comes back through the row's LDS scratch (tab) as a row in Montgomery form.
+ZK_DI CFq inv(const CFq& a, CoopPowTab& tab) {
+    const uint32_t one[14] = {1u, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const Fq28 t = coop_gather(coop_exact(mul(a, CFq::from_const(one))));   // the plain residue, below 2p
+    uint32_t x[12], y[12];
+    fq28_export_tail(t, x);
+    gcd_inverse_words(x, y);
+    uint32_t* w = &tab[0][0].v[0];
+#pragma unroll
+    for (int i = 0; i < 12; i++) w[i] = y[i];   // (every lane of the row writes the same twelve words and reads back its two)
+    const CFq r = mul(coop_unpack(w), CFq::from_const(Fq28Consts::R2));
+#ifdef ZK_EMU
+    if (!is_zero_full(sub_b<2>(r, inv_fermat(a, tab)))) {
+        fprintf(stderr, "coop inv: the half-GCD and a^(q-2) disagree\n");
+        abort();
+    }
+#endif
+    return r;
 }
 // is the PLAIN value of a (any stored magnitude) above (q - 1) / 2, i.e. y > -y in the reference's ordering (fq.rs:707-713)?
 // The Montgomery reduction of a x 1 leaves the plain residue below 2p; it is gathered, brought below p and compared.

@@ -569,6 +569,17 @@ k_cv_decode_g2(const uint32_t* __restrict__ in, const uint32_t* __restrict__ fla
     cv_status(st, i, 0);
 }
 
+#ifdef ZK_TEST_HOOKS
+// test hook: out[i] = 1 / in[i] through inv() of coop_curve.h; both in the host's Montgomery words
+static __global__ void __launch_bounds__(CV_THIN * COOP_W)
+k_cv_test_inverse(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n) {
+    ZK_SHARED CoopPowTab powtab[CV_THIN];
+    const uint32_t i = coop_row();
+    if (i >= n) return;
+    coop_export(inv(coop_import(in + (size_t)i * 12), powtab[coop_row_in_block()]), out + (size_t)i * 12);
+}
+#endif
+
 }  // namespace zkdev
 
 namespace zkcoop {
@@ -592,6 +603,11 @@ void verify_decode_g1(const uint32_t* in, const uint32_t* flags, uint32_t* out, 
 void verify_decode_g2(const uint32_t* in, const uint32_t* flags, uint32_t* out, uint32_t* status, uint32_t n, hipStream_t st) {
     ZK_LAUNCH(zkdev::k_cv_decode_g2, dim3((n + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, in, flags, out, status, n);
 }
+#ifdef ZK_TEST_HOOKS
+void test_inverse(const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t st) {
+    ZK_LAUNCH(zkdev::k_cv_test_inverse, dim3((n + zkdev::CV_THIN - 1) / zkdev::CV_THIN), dim3(zkdev::CV_THIN * COOP_W), 0, st, in, out, n);
+}
+#endif
 size_t g2_prepare_stage_bytes(uint32_t n) { return (size_t)n * zkdev::PAIRING_NCOEF * 6 * sizeof(zkdev::Fq28); }
 void verify_g2_prepare(const uint32_t* q, void* stage, uint32_t* out, uint32_t n, uint32_t* st_flags, hipStream_t st) {
     const bool one_row = getenv("ZKAMD_COOP_PREPARE_ROWS") && atoi(getenv("ZKAMD_COOP_PREPARE_ROWS")) == 1;   // A/B: a row per point

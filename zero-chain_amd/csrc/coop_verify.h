@@ -38,4 +38,9 @@ void verify_miller(const uint32_t* p0, const void* lines0, const uint32_t* p1, c
 void verify_final_exp(const void* f_in, const uint32_t* gam, const void* want, const uint32_t* valid, uint32_t* ok, void* value_out, uint32_t n,
                       hipStream_t st);
 
+#ifdef ZK_TEST_HOOKS
+// test hook (libzkamd_hooks.so, the emulation): element-wise inverses in Fq by the rows' inversion routine; in / out: n x 12 words
+void test_inverse(const uint32_t* in, uint32_t* out, uint32_t n, hipStream_t st);
+#endif
+
 }  // namespace zkcoop

@@ -1065,4 +1065,22 @@ zk_status zk_verify_proof(zk_vk* vk, const uint8_t proof[192], const uint8_t* pu
     return st;
 } ZK_ABI_CATCH
 
+#ifdef ZK_TEST_HOOKS
+// Test hook, NOT part of the ABI (absent from libzkamd.so): 1 / x for n field elements of Fq in the host's Montgomery words,
+// through the inversion routine of the verification kernels on rows (coop_inv.h).
+zk_status zk_hook_fq_inverse(const uint32_t* in, uint32_t* out, size_t n) try {
+    if (!in || !out) return fail(ZK_ERR_INVALID_ARGUMENT, "null argument");
+    ZK_TRY(use_device(0));
+    DevBuf a, b;
+    a.is_public = b.is_public = true;
+    ZK_TRY(a.ensure(n * 48));
+    ZK_TRY(b.ensure(n * 48));
+    HIP_TRY(hipMemcpy(a.p, in, n * 48, hipMemcpyHostToDevice));
+    zkcoop::test_inverse((const uint32_t*)a.p, (uint32_t*)b.p, (uint32_t)n, g_stream);
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipMemcpy(out, b.p, n * 48, hipMemcpyDeviceToHost));
+    return ZK_OK;
+} ZK_ABI_CATCH
+#endif
+
 }  // extern "C"
