@@ -286,32 +286,36 @@ ZK_DI CFq coop_pow(const CFq& a, const uint32_t (&e)[12], CoopPowTab& tab) {
         p = mul(p, a2);
         tab[i][l] = p.l;
     }
-    auto bit_at = [&](int i) { return (e[i >> 5] >> (i & 31)) & 1u; };
-    int bit = 383;
-    while (bit >= 0 && !bit_at(bit)) bit--;
+    // The exponent is read a word at a time (a scalar load per BIT sat in the chain of products): buf = [word i | word i - 1],
+    // the bits of word i are consumed from position 63 down to 32 and a window may reach up to three bits into word i - 1.
     CFq r = CFq::one();   // (e == 0)
     bool started = false;
+    int pos = 63;
 #pragma unroll 1
-    while (bit >= 0) {
-        if (!bit_at(bit)) {
-            r = mul(r, r);
-            bit--;
-            continue;
-        }
-        int len = bit >= 3 ? 4 : bit + 1;
-        uint32_t v = 0;
-        for (int k = 0; k < len; k++) v = (v << 1) | bit_at(bit - k);
-        while (!(v & 1u)) {
-            v >>= 1;
-            len--;
-        }
-        if (started)
+    for (int i = 11; i >= 0; i--) {
+        const uint64_t buf = ((uint64_t)e[i] << 32) | (i ? e[i - 1] : 0u);
 #pragma unroll 1
-            for (int k = 0; k < len; k++) r = mul(r, r);
-        const CFq t{tab[v >> 1][l]};
-        r = started ? mul(r, t) : t;
-        started = true;
-        bit -= len;
+        while (pos >= 32) {
+            if (!((buf >> pos) & 1u)) {
+                if (started) r = mul(r, r);
+                pos--;
+                continue;
+            }
+            int len = (i == 0 && pos - 31 < 4) ? pos - 31 : 4;   // (the last word: nothing below bit 0 of the exponent)
+            uint32_t v = (uint32_t)(buf >> (pos - len + 1)) & ((1u << len) - 1u);
+            while (!(v & 1u)) {
+                v >>= 1;
+                len--;
+            }
+            if (started)
+#pragma unroll 1
+                for (int k = 0; k < len; k++) r = mul(r, r);
+            const CFq t{tab[v >> 1][l]};
+            r = started ? mul(r, t) : t;
+            started = true;
+            pos -= len;
+        }
+        pos += 32;   // the bits a window took from word i - 1 are gone from its turn
     }
     return r;
 }
