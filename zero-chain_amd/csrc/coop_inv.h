@@ -11,7 +11,7 @@
 // Division steps (eta = -delta): (eta, f, g) -> g even: (eta - 1, f, g / 2);  g odd, eta < 0: (-eta - 1, g, (g - f) / 2) ...
 // kept with f odd throughout; after the last batch g = 0, f = +-1 and d = +-1/x mod q.
 #pragma once
-#include "coop_field.h"
+#include "dev_field.h"
 
 namespace zkdev {
 

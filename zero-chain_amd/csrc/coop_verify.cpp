@@ -354,37 +354,54 @@ ZK_DI void cvq_red(QuadLds& q, uint32_t r, const CFq2& a0, const CFq2& a1, const
     coop_products<2, 1>(x, y, g);
     cvq_gather(q, r, CFq2{g[0], g[1]}, out);
 }
+// out[k] = a_k b_k + e_k (c1 of every a_k below 15 p; e_k: any stored value, it enters as e_k times one)
+ZK_DI void cvq_mul_add(QuadLds& q, uint32_t r, const CFq2& a0, const CFq2& b0, const CFq2& a1, const CFq2& b1, const CFq2& a2, const CFq2& b2,
+                       const CFq2& a3, const CFq2& b3, const CFq2& e0, CFq2 (&out)[4]) {
+    CLanes x[2][3], y[2][3];
+    coop_slot_mul(x, y, 0, cvq_sel(r, a0, a1, a2, a3), cvq_sel(r, b0, b1, b2, b3));
+    const CFq2 e = cvq_sel(r, e0, CFq2::zero(), CFq2::zero(), CFq2::zero());
+    const CLanes one = CFq::one().l;
+    x[0][2] = e.c0.l;
+    y[0][2] = one;
+    x[1][2] = e.c1.l;
+    y[1][2] = one;
+    CFq g[2];
+    coop_products<2, 3>(x, y, g);
+    cvq_gather(q, r, CFq2{g[0], g[1]}, out);
+}
+// R <- 2 R; tangent at R.  In: X, Y < 2, Z < 4.  Three groups: the products X^2, Y^2, Z^2, Y Z (Z3 = 2 Y Z directly - on rows a
+// product costs what the square of the reference's (Y + Z)^2 - Y^2 - Z^2 costs, and the value needs no reduction), four
+// squares, then E (D - X3) - 8 C with the subtrahend inside the accumulation, the two line products, and X3 times one.
 ZK_DI void cvq_double_step(QuadLds& q, uint32_t r, CFq2& X, CFq2& Y, CFq2& Z, CvLine& l) {
-    CFq2 s1[4], s2[4], m[4], rd[4];
-    cvq_sqr<4>(q, r, X, Y, Z, add(Y, Z), s1);                              // X^2, Y^2, Z^2, (Y + Z)^2
-    const CFq2 A = s1[0], B = s1[1], zz = s1[2], t2 = s1[3];
+    CFq2 s1[4], s2[4], m[4];
+    cvq_mul(q, r, X, X, Y, Y, Z, Z, Y, Z, s1);                             // X^2, Y^2, Z^2, Y Z
+    const CFq2 A = s1[0], B = s1[1], zz = s1[2];
+    const CFq2 z3 = dbl(s1[3]);                                            // 2 Y Z          < 4
     const CFq2 E = add(dbl(A), A);                                         // 3 A            < 6
     cvq_sqr<8>(q, r, B, add(X, B), E, add(X, E), s2);                      // B^2, (X + B)^2, E^2, (X + E)^2
     const CFq2 C = s2[0], t1 = s2[1], G = s2[2], t3 = s2[3];
     const CFq2 D = dbl(sub_b<2>(sub_b<2>(t1, A), C));                      // 4 X Y^2        < 16
     const CFq2 x3 = sub_b<32>(G, dbl(D));                                  //                < 35
-    const CFq2 z3 = sub_b<2>(sub_b<2>(t2, B), zz);                         // 2 Y Z          < 8
     const CFq2 c8 = dbl(dbl(dbl(C)));                                      //                < 16
-    cvq_mul(q, r, E, sub_b<35>(D, x3), z3, zz, E, zz, E, zz, m);           // E (D - x3), z3 zz, E zz
-    const CFq2 y3 = sub_b<16>(m[0], c8);                                   //                < 19
+    // E (D - x3) - 8 C, z3 zz, E zz, x3 (as one times x3: the first operand's c1 must stay below 15)
+    cvq_mul_add(q, r, E, sub_b<35>(D, x3), z3, zz, E, zz, CFq2::one(), x3, neg_b<16>(c8), m);
     l.a = dbl(m[1]);
     l.b = neg_b<4>(dbl(m[2]));
     l.c = sub_b<8>(sub_b<2>(sub_b<2>(t3, A), G), dbl(dbl(B)));
-    cvq_red(q, r, x3, y3, z3, rd);
-    X = rd[0];
-    Y = rd[1];
-    Z = rd[2];
+    X = m[3];
+    Y = m[0];
+    Z = z3;
 }
 ZK_DI void cvq_add_step(QuadLds& q, uint32_t r, CFq2& X, CFq2& Y, CFq2& Z, const CFq2& qx, const CFq2& qy, const CFq2& yy, CvLine& l) {
     CFq2 g1[4], g2[4], g3[4], g4[4], g5[4], g6[4], rd[4];
-    cvq_sqr<4>(q, r, Z, add(qy, Z), Z, Z, g1);                             // Z^2, (y_Q + Z)^2
+    cvq_sqr<6>(q, r, Z, add(qy, Z), Z, Z, g1);                             // Z^2, (y_Q + Z)^2       (Z < 4)
     const CFq2 zz = g1[0], t1 = g1[1];
     const CFq2 e = sub_b<2>(sub_b<2>(t1, yy), zz);                         // 2 y_Q Z        < 8
     cvq_mul(q, r, zz, qx, e, zz, zz, qx, zz, qx, g2);                      // x_Q Z^2, 2 y_Q Z^3
     const CFq2 u2 = g2[0], s2x2 = g2[1];
     const CFq2 H = sub_b<2>(u2, X);                                        //                < 5
     const CFq2 r2 = sub_b<4>(s2x2, dbl(Y));                                //                < 7
-    cvq_sqr<7>(q, r, H, r2, add(Z, H), H, g3);                             // H^2, r2^2, (Z + H)^2
+    cvq_sqr<9>(q, r, H, r2, add(Z, H), H, g3);                             // H^2, r2^2, (Z + H)^2
     const CFq2 HH = g3[0], r2sq = g3[1], zh = g3[2];
     const CFq2 H4 = dbl(dbl(HH));                                          //                < 8
     cvq_mul(q, r, H4, H, H4, X, r2, qx, r2, qx, g4);                       // 4 H^3, 4 X H^2, r2 x_Q
@@ -435,7 +452,7 @@ k_cv_g2_prepare_quad(const uint32_t* __restrict__ q, Fq28* __restrict__ stage, u
         const CFq2 cqx{qx.c0, neg_b<2>(qx.c1)}, cqy{qy.c0, neg_b<2>(qy.c1)};
         CFq2 px, py, zz, unused2;
         cv_mul2(kx, cqx, ky, cqy, px, py);
-        cv_sqr2<2, 2>(Z, Z, zz, unused2);
+        cv_sqr2<4, 4>(Z, Z, zz, unused2);   // (Z < 4 after the last doubling)
         CFq2 pz, zzz;
         cv_mul2(px, zz, zz, Z, pz, zzz);
         const CFq2 pyz = mul(py, zzz);

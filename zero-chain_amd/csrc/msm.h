@@ -24,6 +24,7 @@
 // same group share every launch; `MsmJob` carries the per-job pointers.
 #pragma once
 #include "dev_curve.h"
+#include "coop_inv.h"
 
 namespace zkdev {
 
@@ -1471,7 +1472,7 @@ ZK_DI F fq_pow_qm2_unrolled(const F& a) {
 // Fermat form is the whole run time (the final into_affine of a proof made alone: 0.66 -> 0.1 ms).  Divergent
 // loops: not for kernels with a full machine of lanes.  inv_gcd(0) = 0.
 // y = u^-1 mod q for a canonical integer 0 < u < q (12 little-endian words); u is consumed
-ZK_DI void gcd_inv_words(uint32_t (&u)[12], uint32_t (&y)[12]) {
+ZK_DI void gcd_inv_words_binary(uint32_t (&u)[12], uint32_t (&y)[12]) {
     uint32_t v[12], x1[12], x2[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) {
@@ -1549,6 +1550,21 @@ ZK_DI void gcd_inv_words(uint32_t (&u)[12], uint32_t (&y)[12]) {
     const bool first = is_one(u);
 #pragma unroll
     for (int i = 0; i < 12; i++) y[i] = first ? x1[i] : x2[i];
+}
+// ... and since round 6 by the half-GCD of coop_inv.h (batches of 30 division steps on the low limbs, transition matrices
+// applied with 64-bit accumulators: ~25 batches of ~500 instructions instead of ~760 twelve-word shift / subtract steps);
+// the binary form above stays as the emulation's cross-check.
+ZK_DI void gcd_inv_words(uint32_t (&u)[12], uint32_t (&y)[12]) {
+    gcd_inverse_words(u, y);
+#ifdef ZK_EMU
+    uint32_t y2[12];
+    gcd_inv_words_binary(u, y2);
+    for (int i = 0; i < 12; i++)
+        if (y[i] != y2[i]) {
+            fprintf(stderr, "gcd_inv_words: the half-GCD and the binary algorithm disagree\n");
+            abort();
+        }
+#endif
 }
 ZK_DI Fq28 inv_gcd(const Fq28& a) {
     uint32_t u[12], y[12];
