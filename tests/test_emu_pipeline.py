@@ -232,6 +232,18 @@ def test_msm_variable_base(emu_lib):
     pc.msm_variable_base(emu_lib, windows=(9,), n=60, g2_n=24, auto_n=40, g2_w=9, one_w=6)
 
 
+def test_msm_variable_base_lane_merges(emu_lib, monkeypatch):
+    """ZKAMD_COOP_L1_MAX=0: the launch sets of a variable-base multiexp merge their task partials with the lanes' kernels -
+    eight lanes per listed bucket (k_msm_merge_medium), a workgroup (of rows) for the few with more than 64 partials, one lane
+    for the unlisted - as the sets with many buckets do by default; narrow windows make every bucket heavy."""
+    monkeypatch.setenv("ZKAMD_MERGE_SPLIT_MIN", "16")   # ... and the listed buckets with more than 16 partials by sixteen workgroups of rows
+    pc.msm_variable_base(emu_lib, windows=(3,), n=700, g2_n=300, auto_n=40, g2_w=3, one_w=6)     # merge and level 1 on rows
+    monkeypatch.setenv("ZKAMD_COOP_L1_MAX", "0")
+    pc.msm_variable_base(emu_lib, windows=(3, 9), n=700, g2_n=300, auto_n=40, g2_w=3, one_w=6)
+    monkeypatch.setenv("ZKAMD_COOP_TAIL", "0")
+    pc.msm_variable_base(emu_lib, windows=(3,), n=700, g2_n=200, auto_n=40, g2_w=3, one_w=6)
+
+
 def test_proof_reader_subgroup_tests(emu_lib):
     pc.proof_reader(emu_lib)
 

@@ -664,6 +664,15 @@ def test_msm_variable_base(gpu_lib):
     pc.msm_variable_base(gpu_lib)
 
 
+def test_msm_variable_base_lane_merges(gpu_lib, monkeypatch):
+    """ZKAMD_COOP_L1_MAX=0: the merges of the lanes' kernels (eight lanes per listed bucket, a workgroup of rows for the
+    heaviest) also for the small sets that take merge and level 1 on rows by default."""
+    monkeypatch.setenv("ZKAMD_MERGE_SPLIT_MIN", "16")   # (the split form of the heaviest buckets from 17 partials)
+    pc.msm_variable_base(gpu_lib, windows=(3,), n=3000, g2_n=900, auto_n=700, g2_w=3, one_w=3)
+    monkeypatch.setenv("ZKAMD_COOP_L1_MAX", "0")
+    pc.msm_variable_base(gpu_lib, windows=(3, 8, 13), n=3000, g2_n=900, auto_n=700, g2_w=3, one_w=3)
+
+
 def test_msm_variable_base_2p17_vs_table(gpu_lib):
     """2^17 distinct bases: the variable-base multiexp (no table of doublings) and the resident-table multiexp give the
     same point (and the C restatement of bellman's algorithm agrees)."""

@@ -5,6 +5,8 @@
 // rows; the rows of a wave may take different branches (a row's conditions are uniform over its lanes).  Points cross
 // between rows through LDS ([row][lane] slots, one barrier per tree level); a point in HBM is the one-lane layout
 // (XYZZ<Fq28> / XYZZ<Fq2x>: 14 limbs per coordinate), read and written 56 contiguous bytes per row and coordinate.
+#include <algorithm>
+#include <stdlib.h>
 #include "gpu_rt.h"
 #include "coop_curve.h"
 #include "coop_tail.h"
@@ -59,16 +61,18 @@ template <class F>
 static __global__ void __launch_bounds__(CT_ROWS * COOP_W)
 k_ct_merge(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
            const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb, uint32_t seg,
-           uint32_t n_buckets, uint32_t heavy_blocks, uint32_t merge_inline, uint32_t rb) {
+           uint32_t n_buckets, uint32_t heavy_blocks, uint32_t merge_inline, uint32_t rb, uint32_t min_heavy, uint32_t max_heavy) {
     typedef CoopT<F> C;
     ZK_SHARED XYZZ<C> sm[CT_ROWS * COOP_W];
     const uint32_t r = coop_row_in_block();
     if (blockIdx.x < heavy_blocks) {
         // a fixed grid walks the list of buckets with more than merge_inline partials: all rows on one bucket
+        // (min_heavy: listed buckets with at most that many partials belong to another kernel)
         const uint32_t nh = n_heavy[0];
         for (uint32_t hb = blockIdx.x; hb < nh; hb += heavy_blocks) {
             const uint32_t gb = heavy[hb];
             const uint32_t nt = (cnt[gb] + seg - 1) / seg;
+            if (nt <= min_heavy || nt > max_heavy) continue;
             XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
             const XYZZ<C> acc = ct_group_sum(ct_strided_sum<F>(ts, r, nt, CT_ROWS), sm, CT_ROWS);
             if (r == 0) coop_store(ts[0], acc);
@@ -86,6 +90,38 @@ k_ct_merge(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_he
     }
     const XYZZ<C> acc = ct_group_sum(ct_strided_sum<F>(ts, sub, nt, rb), sm, rb);
     if (nt && sub == 0) coop_store(ts[0], acc);
+}
+
+// A listed bucket with MANY partials (the top digit position of a variable-base multiexp holds a handful of buckets: the
+// 2^17-point G2 multiexp at w = 12 has four of them with 2 000 - 2 400 partials each, 1.4 ms for the one workgroup that
+// k_ct_merge gives a bucket): CT_SPLIT workgroups sum a slice each into the slice's first partial (phase 0), one workgroup
+// sums the slice heads into ts[0] (phase 1).  Buckets with at most split_min partials are k_ct_merge's.
+constexpr uint32_t CT_SPLIT = 16;
+template <class F>
+static __global__ void __launch_bounds__(CT_ROWS * COOP_W)
+k_ct_merge_split(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
+                 const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb, uint32_t seg,
+                 uint32_t split_min, uint32_t phase) {
+    typedef CoopT<F> C;
+    ZK_SHARED XYZZ<C> sm[CT_ROWS * COOP_W];
+    const uint32_t r = coop_row_in_block(), c = blockIdx.y, nh = n_heavy[0];
+    for (uint32_t hb = blockIdx.x; hb < nh; hb += gridDim.x) {
+        const uint32_t gb = heavy[hb];
+        const uint32_t nt = (cnt[gb] + seg - 1) / seg;
+        if (nt <= split_min) continue;
+        XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
+        if (phase == 0) {
+            const uint32_t lo = (uint32_t)((uint64_t)c * nt / CT_SPLIT), hi = (uint32_t)((uint64_t)(c + 1) * nt / CT_SPLIT);
+            const XYZZ<C> acc = ct_group_sum(ct_strided_sum<F>(ts + lo, r, hi - lo, CT_ROWS), sm, CT_ROWS);
+            if (r == 0 && hi > lo) coop_store(ts[lo], acc);
+        } else {
+            // slice r's head (nt > split_min >= CT_SPLIT: every slice holds a partial)
+            XYZZ<C> v = XYZZ<C>::inf();
+            if (r < CT_SPLIT) v = coop_load(ts[(uint32_t)((uint64_t)r * nt / CT_SPLIT)]);
+            const XYZZ<C> acc = ct_group_sum(v, sm, CT_ROWS);
+            if (r == 0) coop_store(ts[0], acc);
+        }
+    }
 }
 
 // one row per node of L buckets, walked from the top down with both running sums in registers:
@@ -181,14 +217,26 @@ using zkdev::CT_ROWS;
 using zkdev::CT_THIN;
 using zkdev::XYZZ;
 
+// (a test may lower the threshold of the split form: ZKAMD_MERGE_SPLIT_MIN; at least CT_SPLIT)
+uint32_t merge_split_min() {
+    const char* e = getenv("ZKAMD_MERGE_SPLIT_MIN");
+    return std::max<uint32_t>(zkdev::CT_SPLIT, e ? (uint32_t)atoi(e) : 256u);
+}
 template <class F>
 void merge(const uint32_t* heavy, const uint32_t* n_heavy, const uint32_t* cnt, const uint32_t* toff, const uint32_t* task_base,
            XYZZ<F>* tsums, uint32_t nb, uint32_t seg, size_t n_buckets, uint32_t heavy_blocks, uint32_t merge_inline,
-           uint32_t rows_per_bucket, hipStream_t st) {
+           uint32_t rows_per_bucket, hipStream_t st, uint32_t min_heavy) {
     const uint32_t per = CT_ROWS / rows_per_bucket;
+    const uint32_t split_min = merge_split_min();
+    if (heavy_blocks) {
+        const uint32_t gx = std::min<uint32_t>(heavy_blocks, 64u);
+        for (uint32_t phase = 0; phase < 2; phase++)
+            ZK_LAUNCH_SYNC(zkdev::k_ct_merge_split<F>, dim3(gx, phase ? 1 : zkdev::CT_SPLIT), dim3(CT_ROWS * COOP_W), 0, st, heavy, n_heavy, cnt, toff,
+                           task_base, tsums, nb, seg, split_min, phase);
+    }
     ZK_LAUNCH_SYNC(zkdev::k_ct_merge<F>, dim3(heavy_blocks + (unsigned)((n_buckets + per - 1) / per)), dim3(CT_ROWS * COOP_W), 0, st,
                    heavy, n_heavy, cnt, toff, task_base, tsums, nb, seg, (uint32_t)n_buckets, heavy_blocks, merge_inline,
-                   rows_per_bucket);
+                   rows_per_bucket, min_heavy, split_min);
 }
 template <class F>
 void level1(const XYZZ<F>* tsums, const uint32_t* cnt, const uint32_t* toff, const uint32_t* task_base, XYZZ<F>* S, XYZZ<F>* W,
@@ -218,7 +266,7 @@ void combine(const XYZZ<F>* Y, XYZZ<F>* out, uint32_t nbits, uint32_t log2_2l, u
 
 #define ZK_COOP_TAIL_INSTANTIATE(F)                                                                                                   \
     template void merge<F>(const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, XYZZ<F>*, uint32_t,   \
-                           uint32_t, size_t, uint32_t, uint32_t, uint32_t, hipStream_t);                                              \
+                           uint32_t, size_t, uint32_t, uint32_t, uint32_t, hipStream_t, uint32_t);                                              \
     template void level1<F>(const XYZZ<F>*, const uint32_t*, const uint32_t*, const uint32_t*, XYZZ<F>*, XYZZ<F>*, uint32_t, uint32_t, \
                             uint32_t, hipStream_t);                                                                                   \
     template void planes<F>(const XYZZ<F>*, uint32_t, const XYZZ<F>*, XYZZ<F>*, XYZZ<F>*, uint32_t, uint32_t, uint32_t, hipStream_t);                    \

@@ -15,10 +15,12 @@ constexpr uint32_t LEVEL1_FAN = 4;   // buckets per level-1 node
 
 // ts[0] of every bucket with 2 or more task partials = their sum.  Buckets on the `heavy` list (more than merge_inline
 // partials, listed by k_msm_task_place) take a whole workgroup each, the others `rows_per_bucket` rows (a power of two <= 16).
+// partials from which a listed bucket is summed by sixteen workgroups (k_ct_merge_split) instead of one
+uint32_t merge_split_min();
 template <class F>
 void merge(const uint32_t* heavy, const uint32_t* n_heavy, const uint32_t* cnt, const uint32_t* toff, const uint32_t* task_base,
            zkdev::XYZZ<F>* tsums, uint32_t nb, uint32_t seg, size_t n_buckets, uint32_t heavy_blocks, uint32_t merge_inline,
-           uint32_t rows_per_bucket, hipStream_t st);
+           uint32_t rows_per_bucket, hipStream_t st, uint32_t min_heavy = 0);   // min_heavy: listed buckets with at most that many partials are left alone
 
 // level 1: node t of job j covers the buckets [t L, (t + 1) L): S[j T + t] = their sum, W[j T + t] = sum_k (2 k + 1) B_(t L + k)
 template <class F>

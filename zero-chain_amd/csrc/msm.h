@@ -1196,7 +1196,7 @@ template <class F>
 static __global__ void __launch_bounds__(MSM_MERGE_THREADS)
 k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
                   const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb,
-                  uint32_t seg, uint32_t heavy_blocks, uint32_t light_buckets, uint32_t merge_inline) {
+                  uint32_t seg, uint32_t heavy_blocks, uint32_t light_buckets, uint32_t merge_inline, uint32_t min_tasks = 0) {
     ZK_SHARED XYZZ<F> sm[MSM_MERGE_THREADS];
     const uint32_t tid = threadIdx.x;
     if (blockIdx.x >= heavy_blocks) {
@@ -1217,6 +1217,7 @@ k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict
     for (uint32_t hb = blockIdx.x; hb < n_heavy[0]; hb += heavy_blocks) {
         const uint32_t gb = heavy[hb];
         const uint32_t nt = (cnt[gb] + seg - 1) / seg;
+        if (nt <= min_tasks) continue;   // (k_msm_merge_medium's; uniform over the workgroup)
         XYZZ<F>* ts = tsums + task_base[gb / nb] + toff[gb];
         XYZZ<F> acc = XYZZ<F>::inf();
         for (uint32_t u = tid; u < nt; u += MSM_MERGE_THREADS) acc = xadd(acc, ts[u]);
@@ -1231,6 +1232,41 @@ k_msm_merge_heavy(const uint32_t* __restrict__ heavy, const uint32_t* __restrict
     }
 }
 
+
+// Pass 5c, few-jobs sets whose heavy list is LONG (a variable-base multiexp with ~as many points per bucket as a task
+// holds times merge_inline: half of the 24 k buckets of the 2^17-point G2 multiexp are "heavy" with 9 - 16 partials): a
+// workgroup per bucket walks such a list for a millisecond - eight levels of a 256-wide tree for a dozen partials - so the
+// listed buckets with at most max_tasks partials take EIGHT lanes each here (one or two partials per lane, three levels), eight
+// buckets per workgroup and step; the few with more (the top digit position) keep the workgroup form / a workgroup of rows.
+template <class F>
+static __global__ void __launch_bounds__(64, MsmOcc<F>::red)
+k_msm_merge_medium(const uint32_t* __restrict__ heavy, const uint32_t* __restrict__ n_heavy, const uint32_t* __restrict__ cnt,
+                   const uint32_t* __restrict__ toff, const uint32_t* __restrict__ task_base, XYZZ<F>* tsums, uint32_t nb, uint32_t seg,
+                   uint32_t max_tasks) {
+    ZK_SHARED XYZZ<F> sm[64];
+    const uint32_t tid = threadIdx.x, g = tid >> 3, r = tid & 7u, nh = n_heavy[0];
+    for (uint32_t base = blockIdx.x * 8; base < nh; base += gridDim.x * 8) {
+        const uint32_t hb = base + g;
+        uint32_t nt = 0;
+        XYZZ<F>* ts = nullptr;
+        if (hb < nh) {
+            const uint32_t gb = heavy[hb];
+            nt = (cnt[gb] + seg - 1) / seg;
+            if (nt > max_tasks) nt = 0;
+            ts = tsums + task_base[gb / nb] + toff[gb];
+        }
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t u = r; u < nt; u += 8) acc = xadd(acc, ts[u]);
+        sm[tid] = acc;
+        __syncthreads();
+        for (uint32_t st = 4; st >= 1; st >>= 1) {
+            if (r < st && nt) sm[tid] = xadd(sm[tid], sm[tid + st]);
+            __syncthreads();
+        }
+        if (r == 0 && nt) ts[0] = sm[tid];
+        __syncthreads();
+    }
+}
 
 // Pass 5c for the many-jobs launches: the buckets with 2 .. merge_inline partials (the small magnitudes that collect the
 // top digits of the recoding: ~30 of a job's 8 192 buckets, ~60 000 per launch set) are LISTED by k_msm_task_place and

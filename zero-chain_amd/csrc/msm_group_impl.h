@@ -137,7 +137,11 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
     // 4 - 5 x shorter than a lane's but a wave holds four rows instead of sixty-four lanes, so a set of 278 528 buckets (the
     // seventeen digit positions of a 2^20-point variable-base multiexp) keeps the one-lane kernels for these two steps and
     // goes onto rows where the tree gets narrow (msm_reduce_g1 1.33 ms one-lane, 1.23 all on rows, profiles/r06m_*)
-    const bool coop_l1 = coop && (uint64_t)nj * nb <= 131072;
+    // (G2: 16 384 - an addition on a row is 2.4 x G1's, and the 80 k buckets of the 2^17-point variable-base G2 multiexp took
+    //  1.73 ms for merge + level 1 on rows against 0.8 ms with the lanes' kernels and only the heavy buckets on rows)
+    const uint64_t coop_l1_max = getenv("ZKAMD_COOP_L1_MAX") ? (uint64_t)atoll(getenv("ZKAMD_COOP_L1_MAX"))
+                                                                      : (zkdev::HostWords<DF>::N == 24 ? 16384ull : 131072ull);
+    const bool coop_l1 = coop && (uint64_t)nj * nb <= coop_l1_max;
     // rows per bucket of the cooperative merge: a power of two near a quarter of the average number of partials
     uint32_t coop_rb = 1;
     if (coop_l1) {
@@ -170,8 +174,10 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
     };
     // launches large enough for the assembly loops (accumulation and level 1 of the reduction); tests set 0: every
     // launch, however small, goes through them
+    // (G2 additions are three times as long: its loop pays from a quarter of the pairs - the 2^17-point variable-base G2
+    //  multiexp, 2.5 M pairs: accumulation 1.89 -> 1.37 ms, profiles/r06z_*)
     const char* min_env = getenv("ZKAMD_ASM_MIN_PAIRS");
-    const bool big_launch = total >= (min_env ? (uint64_t)atoll(min_env) : 4000000ull);
+    const bool big_launch = total >= (min_env ? (uint64_t)atoll(min_env) : (zkdev::HostWords<DF>::N == 24 ? 1000000ull : 4000000ull));
     // level 1 of the reduction in assembly: many-jobs launches only (the few-jobs tail folds level 1 differently)
     const bool red_asm = asm_reduce<DF>() && big_launch && !few;
     uint32_t L = coop_l1 ? zkcoop::LEVEL1_FAN : pick_fan((uint64_t)nj * nb);
@@ -328,12 +334,53 @@ zk_status MsmGroup<HF, DF>::enqueue(std::vector<MsmJob>& jobs, std::vector<typen
             }
         }
         if (!coop_l1) {
+        // the buckets with many partials (the top digit position of a variable-base multiexp: 2^(c-6) buckets with dozens of
+        // tasks each) take a workgroup of rows each when the set has the cooperative tail: 64 partials are 8 additions of 9 us
+        // there, 7 of 43+ us on lanes (the 2^17-point G2 multiexp: profiles/r06z_*); the buckets with 2 .. merge_inline
+        // partials stay with one lane each
+        // ... and the listed buckets with up to MEDIUM_MAX partials eight lanes each (k_msm_merge_medium: the list of a
+        // variable-base multiexp can hold half of its buckets)
+        // (never beyond the threshold from which the split form of coop_tail.cpp takes a bucket: a test lowers that one)
+        const uint32_t MEDIUM_MAX = std::min<uint32_t>(64u, zkcoop::merge_split_min());
+        bool heavy_on_rows = false;
+        if (hook_env("ZKAMD_DEBUG_HEAVY")) {   // diagnostics: the heavy list of the set and the partials of its buckets
+            (void)hipStreamSynchronize(st);
+            uint32_t nh = 0;
+            (void)hipMemcpy(&nh, d_nheavy, 4, hipMemcpyDeviceToHost);
+            std::vector<uint32_t> hl(nh), ch(n_buckets);
+            if (nh) (void)hipMemcpy(hl.data(), heavy.as<uint32_t>(), nh * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(ch.data(), cnt.as<uint32_t>(), n_buckets * 4, hipMemcpyDeviceToHost);
+            uint32_t mx = 0, le = 0;
+            uint64_t sum = 0;
+            for (uint32_t q = 0; q < nh; q++) {
+                const uint32_t nt = (ch[hl[q]] + seg - 1) / seg;
+                mx = std::max(mx, nt);
+                le += nt <= MEDIUM_MAX;
+                sum += nt;
+            }
+            fprintf(stderr, "[heavy] nj %zu nb %u seg %u merge_inline %u: %u listed buckets (%u with <= %u partials), %llu partials, largest %u\n", nj, nb,
+                    seg, merge_inline, nh, le, MEDIUM_MAX, (unsigned long long)sum, mx);
+        }
+        if (few)
+            ZK_LAUNCH_SYNC(zkdev::k_msm_merge_medium<DF>, dim3((unsigned)std::min<size_t>((heavy_cap + 7) / 8, 4096)), dim3(64), 0, st,
+                           (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy, (const uint32_t*)cnt.as<uint32_t>(),
+                           (const uint32_t*)toff.as<uint32_t>(), (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg, MEDIUM_MAX);
+        const uint32_t min_heavy = few ? MEDIUM_MAX : 0u;
+        if constexpr (HasCoopTail<DF>::value) {
+            if (coop) {
+                zkcoop::merge<DF>(heavy.as<uint32_t>(), d_nheavy, cnt.as<uint32_t>(), toff.as<uint32_t>(), tbase.as<uint32_t>(),
+                                  tsums.as<DPoint>(), nb, seg, 0, heavy_blocks, merge_inline, 1, st, min_heavy);
+                heavy_on_rows = true;
+            }
+        }
+        const uint32_t lane_heavy_blocks = heavy_on_rows ? 0u : heavy_blocks;
+        if (lane_heavy_blocks + light_buckets)
         ZK_LAUNCH_SYNC(zkdev::k_msm_merge_heavy<DF>,
-                       dim3(heavy_blocks + (light_buckets + zkdev::MSM_MERGE_THREADS - 1) / zkdev::MSM_MERGE_THREADS),
+                       dim3(lane_heavy_blocks + (light_buckets + zkdev::MSM_MERGE_THREADS - 1) / zkdev::MSM_MERGE_THREADS),
                        dim3(zkdev::MSM_MERGE_THREADS), 0, st, (const uint32_t*)heavy.as<uint32_t>(), (const uint32_t*)d_nheavy,
                        (const uint32_t*)cnt.as<uint32_t>(), (const uint32_t*)toff.as<uint32_t>(),
-                       (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg, heavy_blocks, light_buckets,
-                       merge_inline);
+                       (const uint32_t*)tbase.as<uint32_t>(), tsums.as<DPoint>(), nb, seg, lane_heavy_blocks, light_buckets,
+                       merge_inline, min_heavy);
         // the listed buckets with 2 .. merge_inline partials, one thread each (the heavier ones above): level 1 then
         // meets ONE partial per bucket
         if (use_light)
