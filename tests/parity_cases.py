@@ -1093,6 +1093,41 @@ def verifier_forms_agree(lib, seed=6, n_in=4, n_aux=10, n_con=13):
         params.close()
 
 
+def verifier_chunk_sizes(lib, sizes=(65, 300), seed=6, n_in=4, n_aux=10, n_con=13):
+    """Chunk sizes on either side of the thresholds of verify_chunk (input accumulator on rows up to 64 proofs, four or sixteen
+    pieces per scalar on lanes from 65 / 256, everything else on rows up to 2048): a batch of valid proofs with ONE damaged
+    proof and ONE wrong public input is judged proof by proof, on the default forms and on the eighteen-lane kernels."""
+    r1, asg, P, pk = helpers.small_case(seed, n_in, n_aux, n_con)
+    params = zk.Parameters.read(pk, checked=False, lib=lib)
+    pvk = zk.prepare_verifying_key(params)
+    keys = ("ZKAMD_COOP_VERIFY",)
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        good = [helpers.expected_proof_trapdoor(P, asg, r, s) for r, s in ((1, 2), (7, 0), (99, 2 ** 200 + 1), (5, 5))]
+        inputs = list(asg.inputs[1:])
+        bad_in = inputs[:-1] + [(inputs[-1] + 1) % bls.R_MOD]
+        for n in sizes:
+            batch = [good[i % 4] for i in range(n)]
+            ins = [inputs] * n
+            want = [True] * n
+            batch[n // 2] = good[0][:144] + good[1][144:]
+            want[n // 2] = False
+            ins[n - 1] = bad_in
+            want[n - 1] = False
+            for form in ({}, {"ZKAMD_COOP_VERIFY": "0"}):
+                for k in keys:
+                    os.environ.pop(k, None)
+                os.environ.update(form)
+                assert zk.verify_proofs(pvk, batch, ins) == want, (n, form)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        pvk.close()
+        params.close()
+
+
 def verifier_rlc(lib, n=20, seed=8, capfd=None):
     """zk_verify_batch_rlc (one combined check per chunk: rho_i-weighted Miller loops, ONE final exponentiation, the per-proof
     verifier behind it) gives EXACTLY zk_verify_batch's verdicts: a batch of proofs of different statements, all good; one /

@@ -199,6 +199,10 @@ def test_verifier_small_circuit(emu_lib):
     pc.verifier_small_circuit(emu_lib)
 
 
+def test_verifier_chunk_sizes(emu_lib):
+    pc.verifier_chunk_sizes(emu_lib, sizes=(65,))
+
+
 def test_fq_inverse_on_rows(emu_lib):
     pc.fq_inverse_on_rows(emu_lib)
 

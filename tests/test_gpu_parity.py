@@ -337,6 +337,10 @@ def test_verifier_small_circuit(gpu_lib):
     pc.verifier_small_circuit(gpu_lib)
 
 
+def test_verifier_chunk_sizes(gpu_lib):
+    pc.verifier_chunk_sizes(gpu_lib, sizes=(65, 300, 1100))
+
+
 def test_fq_inverse_on_rows(gpu_hooks_lib):
     pc.fq_inverse_on_rows(gpu_hooks_lib, n=4000)
 
