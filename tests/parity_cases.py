@@ -1084,6 +1084,21 @@ def verifier_forms_agree(lib, seed=6, n_in=4, n_aux=10, n_con=13):
             assert zk.verify_proofs(pvk, batch, ins) == want, form
             assert zk.verify_proof(pvk, zk.Proof(good[2]), inputs) is True, form
             assert zk.verify_proof(pvk, zk.Proof(mixed), inputs) is False, form
+        # a key WITHOUT public inputs (ic = [ic_0]: the accumulator is ic_0 itself) on the same forms
+        r1b, asgb, Pb, pkb = helpers.small_case(seed + 3, 1, n_aux, n_con)
+        params0 = zk.Parameters.read(pkb, checked=False, lib=lib)
+        pvk0 = zk.prepare_verifying_key(params0)
+        try:
+            assert pvk0.n_inputs == 0
+            g0 = [helpers.expected_proof_trapdoor(Pb, asgb, r, s) for r, s in ((3, 5), (0, 0))]
+            for form in ({}, {"ZKAMD_COOP_VERIFY": "0"}, {"ZKAMD_COOP_INPUTS_MAX": "0", "ZKAMD_INPUTS_FINE_MIN": "1"}):
+                for k in keys:
+                    os.environ.pop(k, None)
+                os.environ.update(form)
+                assert zk.verify_proofs(pvk0, [g0[0], g0[0][:144] + g0[1][144:], g0[1]], [[], [], []]) == [True, False, True], form
+        finally:
+            pvk0.close()
+            params0.close()
     finally:
         for k, v in saved.items():
             os.environ.pop(k, None)
