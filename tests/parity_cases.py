@@ -1064,7 +1064,7 @@ def verifier_forms_agree(lib, seed=6, n_in=4, n_aux=10, n_con=13):
     r1, asg, P, pk = helpers.small_case(seed, n_in, n_aux, n_con)
     params = zk.Parameters.read(pk, checked=False, lib=lib)
     pvk = zk.prepare_verifying_key(params)
-    keys = ("ZKAMD_COOP_PAIRING", "ZKAMD_COOP_VERIFY", "ZKAMD_COOP_INPUTS_MAX", "ZKAMD_INPUTS_FINE_MIN", "ZKAMD_COOP_PREPARE_ROWS")
+    keys = ("ZKAMD_COOP_PAIRING", "ZKAMD_COOP_VERIFY", "ZKAMD_COOP_INPUTS_MAX", "ZKAMD_INPUTS_FINE_MIN", "ZKAMD_COOP_PREPARE_ROWS", "ZKAMD_INPUTS_WINDOWS")
     saved = {k: os.environ.get(k) for k in keys}
     try:
         good = [helpers.expected_proof_trapdoor(P, asg, r, s) for r, s in ((1, 2), (bls.R_MOD - 2, 0), (99, 2 ** 200 + 1))]
@@ -1075,9 +1075,10 @@ def verifier_forms_agree(lib, seed=6, n_in=4, n_aux=10, n_con=13):
         batch = [good[0], mixed, good[1], other_b, good[2], good[1], good[0]]
         ins = [inputs, inputs, inputs, inputs, inputs, bad_in, inputs]
         want = [True, False, True, False, True, False, True]
-        # (the last form: the one-lane accumulator of a large chunk - sixteen pieces per scalar, a wave per proof for the sum)
+        # (the one-lane accumulators of a large chunk: from the table of 8-bit windows, and from the doubling table with sixteen
+        #  pieces per scalar and a wave per proof for the sum)
         for form in ({}, {"ZKAMD_COOP_PAIRING": "0"}, {"ZKAMD_COOP_VERIFY": "0"}, {"ZKAMD_COOP_INPUTS_MAX": "0", "ZKAMD_INPUTS_FINE_MIN": "1"},
-                     {"ZKAMD_COOP_PREPARE_ROWS": "1"}):
+                     {"ZKAMD_COOP_INPUTS_MAX": "0", "ZKAMD_INPUTS_FINE_MIN": "1", "ZKAMD_INPUTS_WINDOWS": "0"}, {"ZKAMD_COOP_PREPARE_ROWS": "1"}):
             for k in keys:
                 os.environ.pop(k, None)
             os.environ.update(form)

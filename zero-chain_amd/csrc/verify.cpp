@@ -121,6 +121,7 @@ struct zk_vk {
     // per-batch workspaces
     DevBuf in_g1, in_g2, fl_g1, fl_g2, aff_g1, aff_g2, st_g1, st_g2, scal, part, acc, acc_inf, host_bad, skip, valid, f, ok;
     DevBuf coop_stage;   // the cooperative line preparation's un-reduced coefficients (coop_verify.cpp)
+    DevBuf ic_win;       // the 8-bit window table of the ic bases (pairing.h k_inputs_window_table), built on first use
     DevBuf lines28[2];   // prep[] in the multiexps' representation, for the Miller loop on rows (coop_pairing.cpp); built on first use
     DevBuf prep_b;   // line coefficients of the batch's own B points (the lane-parallel Miller loop reads every pair prepared)
     // the random-linear-combination check (verify_chunk_rlc): rho_i, the n_ic input scalars, rho_i A_i | acc | C sum, rho_i C_i and
@@ -560,7 +561,19 @@ zk_status verify_chunk(zk_vk* V, size_t n, const uint8_t* proofs, const uint8_t*
             zkcoop::verify_inputs(V->ic_table.p, (const uint32_t*)V->scal.as<uint32_t>(), V->part.p, V->acc.as<uint32_t>(),
                                   V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n, g_copy_stream);
         else {
-        if (n >= env_n("ZKAMD_INPUTS_FINE_MIN", zkdev::INPUTS_FINE_MIN)) {   // sixteen pieces per scalar, a wave per proof for the sum
+        if (ni && n >= env_n("ZKAMD_INPUTS_FINE_MIN", zkdev::INPUTS_FINE_MIN) && env_n("ZKAMD_INPUTS_WINDOWS", 1) != 0) {
+            // products from the table of 8-bit windows: four chains of eight additions per scalar
+            if (!V->ic_win.cap) {
+                V->ic_win.is_public = true;
+                ZK_TRY(V->ic_win.ensure((size_t)V->n_ic * 32 * 256 * sizeof(DG1A)));
+                ZK_LAUNCH(zkdev::k_inputs_window_table, dim3((unsigned)(V->n_ic * 32 * 256 / 64)), dim3(64), 0, g_copy_stream,
+                          (const DG1A*)V->ic_table.as<DG1A>(), V->ic_win.as<DG1A>(), V->n_ic);
+            }
+            ZK_LAUNCH(zkdev::k_inputs_mul_win<4>, dim3((unsigned)((4 * n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
+                      (const DG1A*)V->ic_win.as<DG1A>(), (const uint32_t*)V->scal.as<uint32_t>(), V->part.as<DG1>(), V->n_ic, (uint32_t)n);
+            ZK_LAUNCH_SYNC((zkdev::k_inputs_sum<4, 8>), dim3((unsigned)((n + 7) / 8)), dim3(64), 0, g_copy_stream, (const DG1A*)V->ic_table.as<DG1A>(),
+                           (const DG1*)V->part.as<DG1>(), V->acc.as<uint32_t>(), V->acc_inf.as<uint32_t>(), V->n_ic, (uint32_t)n);
+        } else if (n >= env_n("ZKAMD_INPUTS_FINE_MIN", zkdev::INPUTS_FINE_MIN)) {   // sixteen pieces per scalar, a wave per proof for the sum
             if (ni)
                 ZK_LAUNCH(zkdev::k_inputs_mul<16>, dim3((unsigned)((16 * n * ni + 63) / 64)), dim3(64), 0, g_copy_stream,
                           (const DG1A*)V->ic_table.as<DG1A>(), (const uint32_t*)V->scal.as<uint32_t>(), V->part.as<DG1>(), V->n_ic, (uint32_t)n);
